@@ -1,0 +1,224 @@
+"""Synthetic PDBBind-shaped complexes (no dataset / checkpoints are available offline).
+
+Emits plain numpy arrays in the layout ``datasets_utils/process_mols.py`` produces for one
+complex, following the recipe of SURVEY.md §8(d):
+
+* receptor: N_r C-alpha points rejection-sampled in a ball at protein density
+  (135 A^3 / residue, min separation 3.8 A), centred; kNN contact edges with the rule of
+  ``get_calpha_graph`` (reference datasets_utils/process_mols.py:337-353: all residues
+  closer than ``cutoff``; the ``max_neighbor`` nearest if there are more; at least one);
+  features [residue id in 0..37 | ESM-like N(0,1)^1280].
+* ligand: two six-rings joined by a linker plus a tail and single-atom substituents,
+  1.5 A bonds, N_l in 20..40 atoms, 4..8 rotatable bonds; 16 categorical atom features
+  within ``LIG_FEATURE_DIMS``; bond-type one-hots; ``edge_mask`` / ``mask_rotate`` by the
+  rule of ``get_transformation_mask`` (reference utils/torsion.py:15-45).
+"""
+import numpy as np
+
+# lengths of the categorical feature vocabularies (reference datasets_utils/process_mols.py:62-79, 88-90)
+LIG_FEATURE_DIMS = (119, 4, 12, 12, 8, 10, 6, 6, 2, 8, 2, 2, 2, 2, 2, 2)
+REC_RESIDUE_FEATURE_DIMS = (38,)
+ESM_DIM = 1280
+
+
+def _rand_unit(rng):
+    v = rng.normal(size=3)
+    return v / np.linalg.norm(v)
+
+
+def make_receptor(rng, n_res, cutoff=15.0, max_neighbor=24, esm_dim=ESM_DIM):
+    radius = (3.0 * 135.0 * n_res / (4.0 * np.pi)) ** (1.0 / 3.0)
+    pts = np.zeros((0, 3))
+    cell = 3.8
+    grid = {}
+
+    def key(p):
+        return tuple(np.floor(p / cell).astype(int))
+
+    tries = 0
+    out = []
+    while len(out) < n_res:
+        tries += 1
+        if tries > 400 * n_res:
+            radius *= 1.05
+            tries = 0
+        p = rng.uniform(-radius, radius, size=3)
+        if p @ p > radius * radius:
+            continue
+        k = key(p)
+        ok = True
+        for dx in (-1, 0, 1):
+            for dy in (-1, 0, 1):
+                for dz in (-1, 0, 1):
+                    for q in grid.get((k[0] + dx, k[1] + dy, k[2] + dz), ()):
+                        if np.sum((out[q] - p) ** 2) < 3.8 ** 2:
+                            ok = False
+        if ok:
+            grid.setdefault(k, []).append(len(out))
+            out.append(p)
+    pos = np.asarray(out)
+    pos = pos - pos.mean(0, keepdims=True)
+    d = np.linalg.norm(pos[:, None] - pos[None], axis=-1)
+    src, dst = [], []
+    for i in range(n_res):
+        nb = list(np.where(d[i] < cutoff)[0])
+        nb.remove(i)
+        if max_neighbor is not None and len(nb) > max_neighbor:
+            nb = list(np.argsort(d[i]))[1:max_neighbor + 1]
+        if len(nb) == 0:
+            nb = list(np.argsort(d[i]))[1:2]
+        src += [i] * len(nb)
+        dst += [int(j) for j in nb]
+    x = np.concatenate([rng.integers(0, REC_RESIDUE_FEATURE_DIMS[0], size=(n_res, 1)).astype(np.float32),
+                        rng.normal(size=(n_res, esm_dim)).astype(np.float32)], axis=1)
+    return dict(rec_x=x, rec_pos=pos.astype(np.float32), rec_edge_index=np.asarray([src, dst], dtype=np.int64))
+
+
+def _components_without(n, bonds, skip):
+    adj = [[] for _ in range(n)]
+    for bi, (a, b) in enumerate(bonds):
+        if bi == skip:
+            continue
+        adj[a].append(b)
+        adj[b].append(a)
+    seen = [-1] * n
+    comps = []
+    for s in range(n):
+        if seen[s] >= 0:
+            continue
+        stack, comp = [s], []
+        seen[s] = len(comps)
+        while stack:
+            u = stack.pop()
+            comp.append(u)
+            for v in adj[u]:
+                if seen[v] < 0:
+                    seen[v] = len(comps)
+                    stack.append(v)
+        comps.append(comp)
+    return comps
+
+
+def transformation_mask(n_atoms, bonds):
+    """edge_mask over the 2*len(bonds) directed bonds and mask_rotate [R, n_atoms]
+    (rule of reference utils/torsion.py:15-45: directed pair (u->v, v->u) per bond; the direction
+    whose head v lies on the smaller, >1 atom, side is the rotatable one)."""
+    to_rotate = []
+    for bi, (u, v) in enumerate(bonds):
+        comps = _components_without(n_atoms, bonds, bi)
+        if len(comps) > 1:
+            l = sorted(comps, key=len)[0]
+            if len(l) > 1:
+                if u in l:
+                    to_rotate += [[], l]
+                else:
+                    to_rotate += [l, []]
+                continue
+        to_rotate += [[], []]
+    mask_edges = np.asarray([len(l) > 0 for l in to_rotate], dtype=bool)
+    mask_rotate = np.zeros((int(mask_edges.sum()), n_atoms), dtype=bool)
+    idx = 0
+    for i, l in enumerate(to_rotate):
+        if mask_edges[i]:
+            mask_rotate[idx][np.asarray(l, dtype=int)] = True
+            idx += 1
+    return mask_edges, mask_rotate
+
+
+def make_ligand(rng, n_atoms=None):
+    if n_atoms is None:
+        n_atoms = int(rng.integers(20, 41))
+    k1, k2 = int(rng.integers(2, 5)), int(rng.integers(2, 5))
+    n_atoms = max(n_atoms, 12 + k1 + k2)
+    pos, bonds = [], []
+
+    def clash(p, exclude=()):
+        for j, q in enumerate(pos):
+            if j in exclude:
+                continue
+            if np.linalg.norm(q - p) < 2.0:
+                return True
+        return False
+
+    def grow(parent, prev_dir):
+        for _ in range(2000):
+            d = _rand_unit(rng)
+            if prev_dir is not None and d @ prev_dir < -0.2:  # avoid folding straight back
+                continue
+            p = pos[parent] + 1.5 * d
+            if not clash(p, exclude=(parent,)):
+                pos.append(p)
+                bonds.append((parent, len(pos) - 1))
+                return len(pos) - 1, d
+        raise RuntimeError('ligand growth failed')
+
+    def ring(parent, prev_dir):
+        """planar hexagon a0..a5 (side 1.5) attached to `parent` through a0; returns (a3, out dir)."""
+        for attempt in range(2000):
+            d = prev_dir if (attempt == 0 and prev_dir is not None) else _rand_unit(rng)
+            n = np.cross(d, _rand_unit(rng))
+            n /= np.linalg.norm(n)
+            e2 = np.cross(n, d)
+            a0 = (pos[parent] + 1.5 * d) if parent is not None else np.zeros(3)
+            centre = a0 + 1.5 * d
+            verts = [centre + 1.5 * (np.cos(np.pi + k * np.pi / 3) * d + np.sin(np.pi + k * np.pi / 3) * e2)
+                     for k in range(6)]
+            if any(clash(v, exclude=(parent,) if parent is not None else ()) for v in verts):
+                continue
+            base = len(pos)
+            pos.extend(verts)
+            if parent is not None:
+                bonds.append((parent, base))
+            for k in range(6):
+                bonds.append((base + k, base + (k + 1) % 6))
+            return base + 3, d
+        raise RuntimeError('ring placement failed')
+
+    cur, d = ring(None, None)
+    for _ in range(k1):
+        cur, d = grow(cur, d)
+    cur, d = ring(cur, d)
+    for _ in range(k2):
+        cur, d = grow(cur, d)
+    heavy = list(range(len(pos)))
+    while len(pos) < n_atoms:
+        parent = int(rng.choice(heavy))
+        try:
+            grow(parent, None)
+        except RuntimeError:
+            continue
+    n = len(pos)
+    pos = np.asarray(pos)
+    # randomise the atom order so that topology is not index-sorted
+    perm = rng.permutation(n)
+    inv = np.argsort(perm)
+    pos = pos[perm]
+    bonds = [(int(inv[a]), int(inv[b])) for a, b in bonds]
+    edge_mask, mask_rotate = transformation_mask(n, bonds)
+    ei = np.zeros((2, 2 * len(bonds)), dtype=np.int64)
+    ea = np.zeros((2 * len(bonds), 4), dtype=np.float32)
+    for bi, (a, b) in enumerate(bonds):
+        ei[:, 2 * bi] = (a, b)
+        ei[:, 2 * bi + 1] = (b, a)
+        t = int(rng.integers(0, 4))
+        ea[2 * bi, t] = 1.0
+        ea[2 * bi + 1, t] = 1.0
+    x = np.stack([rng.integers(0, dmax, size=n) for dmax in LIG_FEATURE_DIMS], axis=1).astype(np.int64)
+    return dict(lig_x=x, lig_pos=pos.astype(np.float32), bond_index=ei, bond_attr=ea,
+                edge_mask=edge_mask, mask_rotate=mask_rotate)
+
+
+def make_complex(seed, n_res=300, n_lig=None, cutoff=15.0, max_neighbor=24, esm_dim=ESM_DIM):
+    """One synthetic complex as a dict of numpy arrays; ligand centred on a random pocket point
+    inside the receptor ball (coordinates are receptor-centred like pdbbind.py:341-347)."""
+    rng = np.random.default_rng(seed)
+    rec = make_receptor(rng, n_res, cutoff, max_neighbor, esm_dim)
+    lig = make_ligand(rng, n_lig)
+    rad = np.linalg.norm(rec['rec_pos'], axis=1).max()
+    pocket = _rand_unit(rng) * rng.uniform(0.3, 0.8) * rad
+    lig['lig_pos'] = (lig['lig_pos'] - lig['lig_pos'].mean(0, keepdims=True) + pocket).astype(np.float32)
+    out = dict(rec)
+    out.update(lig)
+    out['original_center'] = np.zeros((1, 3), dtype=np.float32)
+    out['name'] = f'synthetic_{seed}'
+    return out

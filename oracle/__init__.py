@@ -1,0 +1,30 @@
+"""ddk oracle — TEST INFRASTRUCTURE ONLY.
+
+A CPU restatement (PyTorch-CPU, fp32 or fp64) of the DisCo-DiffDock hot path
+(reference: models/score_model.py, models/tensor_layers.py, models/layers.py,
+utils/sampling.py, utils/diffusion_utils.py, utils/geometry.py, utils/torsion.py,
+utils/so3.py, utils/torus.py under /root/reference).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this package, and only as the checker / the timed CPU baseline.  The product
+(``disco_diffdock_amd``) never imports it and has no CPU fallback.
+
+Pinning status
+--------------
+* Tier A (pinned): everything whose arithmetic lives in the reference repo itself
+  (FasterTensorProduct, TensorProductConvLayer, GaussianSmearing, AtomEncoder, FCBlock,
+  sinusoidal embedding, t_to_sigma, SDE step, axis-angle, Kabsch, torsion updates,
+  modify_conformer_batch, so3/torus score-norm tables) is checked against golden vectors
+  produced by the UNMODIFIED reference code (tests/golden/make_golden.py, run in the build
+  container where /root/reference is mounted).
+* Tier B (PARITY UNPINNED): ops whose arithmetic lives in third-party wheels that are not
+  vendored in the reference and not installable here (e3nn: spherical_harmonics,
+  FullyConnectedTensorProduct, FullTensorProduct, BatchNorm; torch_cluster: radius,
+  radius_graph; torch_scatter: scatter; versions unpinned by the reference — it has no
+  requirements file).  ``oracle/e3nn_lite.py``, ``oracle/cluster_lite.py`` and
+  ``oracle/scatter_lite.py`` restate their published algorithms from memory; the full
+  score-model goldens are produced by the reference's own ``models/score_model.py`` running
+  on top of these stand-ins.  They are cross-checked by equivariance and self-consistency
+  tests (e.g. FasterTensorProduct == FCTP with re-laid-out weights) but no reference-owned
+  test vector pins them.
+"""

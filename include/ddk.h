@@ -1,0 +1,135 @@
+/* ddk — C ABI of the MI355X-native DiffDock-S / DisCo-DiffDock-S score-model + sampler hot path.
+ *
+ * This is the drop-in boundary.  Every entry point names the reference
+ * interface it replaces (paths relative to the reference checkout).  Conventions:
+ *   - plain C, no torch types; all array arguments are CALLER-OWNED DEVICE pointers to
+ *     contiguous row-major fp32 / int32 arrays unless the parameter is documented "host";
+ *   - functions enqueue work on the given hipStream_t (passed as void*) and do not synchronise;
+ *   - return 0 on success, a negative ddk_status otherwise; never throw across the ABI;
+ *     ddk_last_error(ctx) returns a message for the last failure on that context;
+ *   - a context is bound to one device, owns only its weight copies and workspaces, is not
+ *     thread-safe, and holds no global state (one context per GPU / process).
+ */
+#ifndef DDK_H
+#define DDK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ddk_ctx ddk_ctx;
+typedef struct ddk_complex ddk_complex;
+
+enum ddk_status {
+  DDK_OK = 0,
+  DDK_ERR_INVALID = -1,   /* bad argument / unsupported configuration */
+  DDK_ERR_HIP = -2,       /* a HIP runtime call failed */
+  DDK_ERR_STATE = -3,     /* call order (e.g. weights not finalised) */
+  DDK_ERR_NOMEM = -4
+};
+
+/* Constructor arguments of TensorProductScoreModel as utils/model_utils.py:25-68 (get_model) maps
+ * them from model_parameters.yml, plus the ctor defaults it leaves alone (models/score_model.py:15-24)
+ * and the diffusion constants t_to_sigma needs (utils/diffusion_utils.py:12-16). */
+typedef struct ddk_config {
+  int32_t ns, nv, num_conv_layers;
+  int32_t sigma_embed_dim, distance_embed_dim, cross_distance_embed_dim;
+  float lig_max_radius, rec_max_radius, cross_max_distance, center_max_distance;
+  int32_t dynamic_max_cross;
+  float embedding_scale;
+  int32_t scale_by_sigma, no_torsion, batch_norm;
+  int32_t latent_dim, latent_vocab;
+  float latent_droprate;
+  int32_t lm_embedding_dim;            /* 1280 when esm_embeddings_path is set, else 0 */
+  float tr_sigma_min, tr_sigma_max, rot_sigma_min, rot_sigma_max, tor_sigma_min, tor_sigma_max;
+  int32_t device;                      /* HIP device ordinal */
+} ddk_config;
+
+/* ---- lifetime ---------------------------------------------------------------------------- */
+int ddk_create(const ddk_config* cfg, ddk_ctx** out);
+void ddk_destroy(ddk_ctx* ctx);
+const char* ddk_last_error(ddk_ctx* ctx);
+const char* ddk_version(void);
+
+/* ---- checkpoint: replaces model.score_model.load_state_dict(state_dict, strict=True)
+ *      (evaluate.py:169-171).  One call per state_dict tensor, HOST pointer, reference key name
+ *      (e.g. "conv_layers.3.fc.2.4.weight").  Unknown "*.tp.*" buffer keys are ignored.
+ *      ddk_finalize_weights checks that every required key arrived with the right shape and packs
+ *      the radial-MLP weights into the MFMA fragment order the fused kernel streams. */
+int ddk_load_weights(ddk_ctx* ctx, const char* name, const float* host_ptr, const int64_t* shape, int32_t ndim);
+int ddk_finalize_weights(ddk_ctx* ctx);
+
+/* Host tables of utils/so3.py:91-95 (_exp_score_norms, 1000 doubles) and utils/torus.py:79-83
+ * (score_norm_, 5001 doubles; Monte-Carlo in the reference, shipped as data here). */
+int ddk_set_score_norm_tables(ddk_ctx* ctx, const double* so3_exp_score_norms, int32_t n_so3,
+                              const double* torus_score_norm, int32_t n_torus);
+
+/* ---- a12: FasterTensorProduct.forward(in_, sh, weight)  models/tensor_layers.py:65-116.
+ *      x_dst [E, Din] (already gathered node_attr[edge_dst]), sh [E,4], w [E, W] -> out [E, Dout]
+ *      with the irreps of conv layer `layer` (0..num_conv_layers-1).  HBM-bound (streams w). */
+int ddk_tp_forward(ddk_ctx* ctx, int32_t layer, const float* x_dst, const float* sh, const float* w,
+                   int64_t E, float* out, void* stream);
+
+/* ---- a11: TensorProductConvLayer.forward(node_attr, edge_index, edge_attr, edge_sh)
+ *      models/tensor_layers.py:147-168 for conv layer `layer`, fused: radial MLP (fp32 MFMA) +
+ *      tensor product + segmented scatter-sum + mean + BatchNorm(eval) + residual, without ever
+ *      materialising the [E, W] weight tensor.
+ *      x [N, Din]; edge_src/edge_dst [E] int32 (edge_index rows 0/1); group_offsets[5] HOST array
+ *      (edge ranges of the 4 edge groups, group g uses fc[g]); edge_attr [E, 3*ns] (the
+ *      concatenated per-group edge_attr list); sh [E,4]; out [N, Dout]. */
+int ddk_conv_forward(ddk_ctx* ctx, int32_t layer, const float* x, int64_t N, const int32_t* edge_src,
+                     const int32_t* edge_dst, const int64_t* group_offsets, const float* edge_attr,
+                     const float* sh, float* out, void* stream);
+
+/* ---- one complex: the graph tensors datasets_utils/process_mols.py emits.
+ *      All pointers are HOST pointers; the library uploads them and precomputes everything that is
+ *      constant over the reverse-diffusion steps and over the samples (receptor embedding without
+ *      its sigma part, receptor-receptor geometry). */
+typedef struct ddk_complex_desc {
+  int32_t n_lig, n_rec, n_bond_edges /* directed, = 2*bonds */, n_rot, n_rec_edges, rec_feat_dim /* 1 + lm dim */;
+  const int32_t* lig_x;          /* [n_lig, 16]   data['ligand'].x */
+  const int32_t* bond_index;     /* [2, n_bond_edges]   data['ligand','ligand'].edge_index */
+  const float* bond_attr;        /* [n_bond_edges, 4]   .edge_attr */
+  const uint8_t* edge_mask;      /* [n_bond_edges]      data['ligand'].edge_mask */
+  const uint8_t* mask_rotate;    /* [n_rot, n_lig]      data['ligand'].mask_rotate */
+  const float* rec_x;            /* [n_rec, rec_feat_dim] data['receptor'].x */
+  const float* rec_pos;          /* [n_rec, 3] */
+  const int32_t* rec_edge_index; /* [2, n_rec_edges]    data['receptor','receptor'].edge_index */
+} ddk_complex_desc;
+
+int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* desc, int32_t max_batch, ddk_complex** out);
+void ddk_complex_destroy(ddk_ctx* ctx, ddk_complex* cx);
+
+/* ---- a5-a17: model.score_model(batch) -> (tr[B,3], rot[B,3], tor[B*R])  models/score_model.py:259-308
+ *      for B copies of one complex at a common time (utils/sampling.py:113-117).
+ *      lig_pos [B, n_lig, 3]; outputs tr [B,3], rot [B,3], tor [B*n_rot]. */
+int ddk_score_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* lig_pos, float t_tr, float t_rot,
+                      float t_tor, float* tr_out, float* rot_out, float* tor_out, void* stream);
+
+/* ---- a18-a21: modify_conformer_batch(pos, data, tr_update, rot_update, torsion_updates, mask_rotate)
+ *      utils/diffusion_utils.py:37-55 (axis-angle rotation, sequential torsion updates, Kabsch re-alignment).
+ *      pos [B,n_lig,3], tr [B,3], rot [B,3], tor [B*n_rot] (may be NULL: rigid only) -> pos_out [B,n_lig,3]. */
+int ddk_se3_update(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* pos, const float* tr, const float* rot,
+                   const float* tor, float* pos_out, void* stream);
+
+/* ---- a1-a2: the reverse-diffusion loop of sampling()  utils/sampling.py:105-198 for one batch:
+ *      per step  perturb = score_coeff*score + noise_coeff*z  (coefficients are the host scalars of
+ *      sampling.py:137-192, including the low-temperature variant), then ddk_se3_update.
+ *      t [steps,3]; score_coeff / noise_coeff [steps,3] HOST arrays (tr,rot,tor);
+ *      noise: DEVICE array [steps, B, 6 + n_rot] of N(0,1) draws (tr xyz, rot xyz, tor...), or NULL = zeros.
+ *      pos [B,n_lig,3] is updated in place.  No host synchronisation inside. */
+int ddk_sample(ddk_ctx* ctx, ddk_complex* cx, int32_t B, int32_t steps, const float* t, const float* score_coeff,
+               const float* noise_coeff, const float* noise, float* pos, void* stream);
+
+/* ---- introspection for tests / benches ------------------------------------------------------ */
+/* Copies the last forward's per-stage edge counts into out[8] (HOST): E_ll, E_lr, E_rr, E_rl, tiles, ... */
+int ddk_last_graph_stats(ddk_ctx* ctx, ddk_complex* cx, int64_t* out, void* stream);
+/* Node features after the conv stack of the last forward: lig [B*n_lig, 84], rec [B*n_rec, 84] (device ptrs, may be NULL). */
+int ddk_last_node_features(ddk_ctx* ctx, ddk_complex* cx, int32_t B, float* lig_out, float* rec_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDK_H */

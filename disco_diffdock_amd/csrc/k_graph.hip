@@ -1,0 +1,342 @@
+// Graph construction and edge / node featurisation for one batch of B samples of one complex
+// (reference models/score_model.py:310-408 + 218-225): ligand radius graph + bonds, ligand<->receptor cross
+// edges with the time-dependent cutoff, the static receptor kNN edges, merged into ONE edge list
+//   [ lig-lig | lig->rec | rec-rec | rec->lig ]   (group order of score_model.py:220-224)
+// with every group sorted by edge_src so that the fused conv kernel's segmented reduction sees long runs.
+// One workgroup per sample; ligand and receptor coordinates live in LDS (n_rec*12 B: 3.6 KB for 300 residues,
+// 24 KB for 2000), neighbour tests are brute force over the sample (30 x 300 .. 30 x 2000 pairs).
+#include "model.h"
+
+namespace ddk {
+
+struct GraphArgs {
+  const float* lig_pos;     // [B, n_lig, 3]
+  const float* rec_pos;     // [n_rec, 3]
+  const int32_t* bond_src;  // [M]
+  const int32_t* bond_dst;
+  const int32_t* rr_src;    // [E_rr]
+  const int32_t* rr_dst;
+  const int32_t* rr_outdeg; // [n_rec]
+  int B, n_lig, n_rec, M, E_rr;
+  float lig_r2;             // lig_max_radius^2
+  float cross_cutoff;
+  int32_t* counts;          // [B, 2]: ll radius edges, lr edges
+  int32_t* offs;            // [B, 2]: exclusive prefix of counts
+  int32_t* info;            // tile_info (see graph_scan_kernel)
+  int32_t* e_src;
+  int32_t* e_dst;
+  int32_t* e_aux;
+  int32_t* deg;             // [B*(n_lig+n_rec)]
+};
+
+// torch_cluster.radius on coordinates rescaled by the per-graph cutoff (score_model.py:379-381): |x/c - y/c|^2 < 1
+__device__ __forceinline__ bool cross_within(const float* lp, const float* rp, float c) {
+  const float dx = rp[0] / c - lp[0] / c, dy = rp[1] / c - lp[1] / c, dz = rp[2] / c - lp[2] / c;
+  return dx * dx + dy * dy + dz * dz < 1.0f;
+}
+
+__device__ __forceinline__ float dist2(const float* a, const float* b) {
+  const float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+  return dx * dx + dy * dy + dz * dz;
+}
+
+// adjacency of the capped radius graph: bit (i, j) set <=> j is among the first LIG_CAP (incl. self) atoms within
+// lig_max_radius of centre i, j != i  (radius_graph -> edge (src=j, dst=i), score_model.py:315)
+__device__ void build_lig_adj(const float* lp, int n_lig, float r2, unsigned (*adj)[MAX_LIG / 32]) {
+  for (int i = threadIdx.x; i < n_lig; i += blockDim.x) {
+    int cnt = 0;
+    for (int w = 0; w < MAX_LIG / 32; ++w) adj[i][w] = 0u;
+    for (int j = 0; j < n_lig && cnt < LIG_CAP; ++j) {
+      if (dist2(lp + 3 * i, lp + 3 * j) < r2) {
+        ++cnt;
+        if (j != i) adj[i][j >> 5] |= 1u << (j & 31);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void graph_count_kernel(GraphArgs G) {
+  extern __shared__ float smem[];
+  float* lp = smem;                              // [MAX_LIG*3]
+  float* rp = lp + MAX_LIG * 3;                  // [n_rec*3]
+  __shared__ unsigned adj[MAX_LIG][MAX_LIG / 32];
+  __shared__ int s_cnt[2];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < G.n_lig * 3; i += 256) lp[i] = G.lig_pos[(size_t)b * G.n_lig * 3 + i];
+  for (int i = tid; i < G.n_rec * 3; i += 256) rp[i] = G.rec_pos[i];
+  if (tid < 2) s_cnt[tid] = 0;
+  __syncthreads();
+  build_lig_adj(lp, G.n_lig, G.lig_r2, adj);
+  __syncthreads();
+  int c_ll = 0, c_lr = 0;
+  for (int i = tid; i < G.n_lig; i += 256)
+    for (int w = 0; w < MAX_LIG / 32; ++w) c_ll += __popc(adj[i][w]);
+  for (int idx = tid; idx < G.n_lig * G.n_rec; idx += 256) {
+    const int i = idx / G.n_rec, j = idx - i * G.n_rec;
+    c_lr += cross_within(lp + 3 * i, rp + 3 * j, G.cross_cutoff) ? 1 : 0;
+  }
+  atomicAdd(&s_cnt[0], c_ll);
+  atomicAdd(&s_cnt[1], c_lr);
+  __syncthreads();
+  if (tid < 2) G.counts[2 * b + tid] = s_cnt[tid];
+}
+
+// info layout (int32): [0..4] conv tile_start, [5..9] group_off, [10..17] per-layer tile counters,
+// [18..22] edge-feature block_start (256 edges per block), [23] total edges, [24] overflow flag
+__global__ void graph_scan_kernel(GraphArgs G, int64_t edge_cap) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int ll = 0, lr = 0;
+  for (int b = 0; b < G.B; ++b) {
+    G.offs[2 * b] = ll;
+    G.offs[2 * b + 1] = lr;
+    ll += G.M + G.counts[2 * b];
+    lr += G.counts[2 * b + 1];
+  }
+  int go[5];
+  go[0] = 0; go[1] = ll; go[2] = ll + lr; go[3] = go[2] + G.B * G.E_rr; go[4] = go[3] + lr;
+  int ts = 0, bs = 0;
+  G.info[0] = 0;
+  G.info[18] = 0;
+  for (int g = 0; g < 4; ++g) {
+    ts += (go[g + 1] - go[g] + 31) / 32;
+    bs += (go[g + 1] - go[g] + 255) / 256;
+    G.info[g + 1] = ts;
+    G.info[19 + g] = bs;
+  }
+  for (int g = 0; g < 5; ++g) G.info[5 + g] = go[g];
+  for (int k = 0; k < 8; ++k) G.info[10 + k] = 0;
+  G.info[23] = go[4];
+  G.info[24] = ((int64_t)go[4] > edge_cap) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void graph_fill_kernel(GraphArgs G) {
+  extern __shared__ float smem[];
+  float* lp = smem;                                   // [MAX_LIG*3]
+  float* rp = lp + MAX_LIG * 3;                       // [n_rec*3]
+  int* c_rl = reinterpret_cast<int*>(rp + 3 * G.n_rec);   // [n_rec] -> exclusive prefix
+  __shared__ unsigned adj[MAX_LIG][MAX_LIG / 32];
+  __shared__ int bdeg[MAX_LIG], odeg[MAX_LIG], c_lr[MAX_LIG], ll_pre[MAX_LIG], lr_pre[MAX_LIG];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (G.info[24]) return;   // capacity overflow: reported by the host wrapper
+  const int n_lig = G.n_lig, n_rec = G.n_rec;
+  for (int i = tid; i < n_lig * 3; i += 256) lp[i] = G.lig_pos[(size_t)b * n_lig * 3 + i];
+  for (int i = tid; i < n_rec * 3; i += 256) rp[i] = G.rec_pos[i];
+  for (int i = tid; i < MAX_LIG; i += 256) { bdeg[i] = 0; c_lr[i] = 0; }
+  for (int j = tid; j < n_rec; j += 256) c_rl[j] = 0;
+  __syncthreads();
+  build_lig_adj(lp, n_lig, G.lig_r2, adj);
+  for (int m = tid; m < G.M; m += 256) atomicAdd(&bdeg[G.bond_src[m]], 1);
+  for (int idx = tid; idx < n_lig * n_rec; idx += 256) {
+    const int i = idx / n_rec, j = idx - i * n_rec;
+    if (cross_within(lp + 3 * i, rp + 3 * j, G.cross_cutoff)) {
+      atomicAdd(&c_lr[i], 1);
+      atomicAdd(&c_rl[j], 1);
+    }
+  }
+  __syncthreads();
+  for (int j = tid; j < n_lig; j += 256) {
+    int od = 0;
+    for (int i = 0; i < n_lig; ++i) od += (adj[i][j >> 5] >> (j & 31)) & 1u;
+    odeg[j] = od;
+  }
+  __syncthreads();
+  const int lig0 = b * n_lig, rec0 = G.B * n_lig + b * n_rec;
+  // degrees (scatter 'mean' divisor: all incoming groups together, tensor_layers.py:159)
+  for (int i = tid; i < n_lig; i += 256) G.deg[lig0 + i] = bdeg[i] + odeg[i] + c_lr[i];
+  for (int j = tid; j < n_rec; j += 256) G.deg[rec0 + j] = G.rr_outdeg[j] + c_rl[j];
+  __syncthreads();
+  if (tid == 0) {
+    int a = 0, c = 0;
+    for (int i = 0; i < n_lig; ++i) {
+      ll_pre[i] = a; a += bdeg[i] + odeg[i];
+      lr_pre[i] = c; c += c_lr[i];
+    }
+  }
+  if (tid == 64) {   // exclusive prefix of the per-residue rec->lig counts (in place)
+    int a = 0;
+    for (int j = 0; j < n_rec; ++j) { const int t = c_rl[j]; c_rl[j] = a; a += t; }
+  }
+  __syncthreads();
+  const int g1 = G.info[6], g2 = G.info[7], g3 = G.info[8];
+  // ---- group 0: lig-lig, sorted by src: bonds of the atom (bond order) then radius edges (ascending dst)
+  for (int j = tid; j < n_lig; j += 256) {
+    int pos = G.offs[2 * b] + ll_pre[j];
+    for (int m = 0; m < G.M; ++m)
+      if (G.bond_src[m] == j) {
+        G.e_src[pos] = lig0 + j; G.e_dst[pos] = lig0 + G.bond_dst[m]; G.e_aux[pos] = m; ++pos;
+      }
+    for (int i = 0; i < n_lig; ++i)
+      if ((adj[i][j >> 5] >> (j & 31)) & 1u) {
+        G.e_src[pos] = lig0 + j; G.e_dst[pos] = lig0 + i; G.e_aux[pos] = -1; ++pos;
+      }
+  }
+  // ---- group 1: lig->rec, sorted by ligand atom then residue: one wave per ligand atom, ballot compaction
+  for (int i = wave; i < n_lig; i += 4) {
+    int pos = g1 + G.offs[2 * b + 1] + lr_pre[i];
+    for (int j0 = 0; j0 < n_rec; j0 += 64) {
+      const int j = j0 + lane;
+      const bool in = j < n_rec && cross_within(lp + 3 * i, rp + 3 * j, G.cross_cutoff);
+      const unsigned long long mask = __ballot(in);
+      if (in) {
+        const int p = pos + __popcll(mask & ((1ull << lane) - 1ull));
+        G.e_src[p] = lig0 + i; G.e_dst[p] = rec0 + j; G.e_aux[p] = -1;
+      }
+      pos += __popcll(mask);
+    }
+  }
+  // ---- group 3: rec->lig (flipped cross edges), sorted by residue then ligand atom
+  for (int j = tid; j < n_rec; j += 256) {
+    int pos = g3 + G.offs[2 * b + 1] + c_rl[j];
+    for (int i = 0; i < n_lig; ++i)
+      if (cross_within(lp + 3 * i, rp + 3 * j, G.cross_cutoff)) {
+        G.e_src[pos] = rec0 + j; G.e_dst[pos] = lig0 + i; G.e_aux[pos] = -1; ++pos;
+      }
+  }
+  // ---- group 2: static receptor edges of this sample
+  for (int k = tid; k < G.E_rr; k += 256) {
+    const int pos = g2 + b * G.E_rr + k;
+    G.e_src[pos] = rec0 + G.rr_src[k]; G.e_dst[pos] = rec0 + G.rr_dst[k]; G.e_aux[pos] = k;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Edge features: spherical harmonics (component normalised, lmax=1: [1, sqrt3*v^]) and the edge-embedding MLPs
+// lig/rec/cross_edge_embedding (score_model.py:51-56,193,199,207) on [bond one-hot | sigma_emb | gaussians].
+// The sigma_emb columns are the same for every edge of a forward -> folded into the first-layer bias on the host.
+// ---------------------------------------------------------------------------------------------------
+struct EdgeFeatArgs {
+  const float* lig_pos;    // [B*n_lig,3]
+  const float* rec_pos;    // [n_rec,3]
+  const float* bond_attr;  // [M,4]
+  const float* rr_pre1;    // [E_rr,NS]  W1d.gauss for the static receptor edges
+  const float* rr_sh;      // [E_rr,4]
+  const int32_t* e_src;
+  const int32_t* e_dst;
+  const int32_t* e_aux;
+  const int32_t* info;
+  float* e_emb;            // [E,NS]
+  float* e_sh;             // [E,4]
+  EdgeMlpDev lig, rec, cross;
+  StepParams sp;
+  int n_lig_total;         // B*n_lig
+  int n_rec;
+};
+
+__device__ __forceinline__ void gaussians(float d, const EdgeMlpDev& m, float* gs) {
+#pragma unroll
+  for (int k = 0; k < DE; ++k) {
+    const float t = d - m.offset[k];
+    gs[k] = __expf(0.0f) * expf(m.coeff * (t * t));
+  }
+}
+
+__global__ __launch_bounds__(256) void edge_features_kernel(EdgeFeatArgs A) {
+  const int blk = blockIdx.x;
+  const int bs1 = A.info[19], bs2 = A.info[20], bs3 = A.info[21], bs4 = A.info[22];
+  if (blk >= bs4) return;
+  const int g = (blk >= bs1) + (blk >= bs2) + (blk >= bs3);
+  const int bstart = g == 0 ? 0 : (g == 1 ? bs1 : (g == 2 ? bs2 : bs3));
+  const int e = A.info[5 + g] + 256 * (blk - bstart) + threadIdx.x;
+  if (e >= A.info[6 + g]) return;
+  const int sn = A.e_src[e], dn = A.e_dst[e], aux = A.e_aux[e];
+  const EdgeMlpDev& M = g == 0 ? A.lig : (g == 2 ? A.rec : A.cross);
+  const float* sigb = g == 0 ? A.sp.lig_edge_sigb : (g == 2 ? A.sp.rec_edge_sigb : A.sp.cross_edge_sigb);
+  float h[NS];
+  float4 shv;
+  if (g == 2) {
+    shv = *reinterpret_cast<const float4*>(A.rr_sh + 4 * (size_t)aux);
+#pragma unroll
+    for (int o = 0; o < NS; ++o) h[o] = A.rr_pre1[(size_t)aux * NS + o] + sigb[o];
+  } else {
+    float vx, vy, vz;
+    if (g == 0) {
+      const float *ps = A.lig_pos + 3 * (size_t)sn, *pd = A.lig_pos + 3 * (size_t)dn;
+      vx = pd[0] - ps[0]; vy = pd[1] - ps[1]; vz = pd[2] - ps[2];
+    } else {   // cross edges: vec = rec - lig for BOTH directions (score_model.py:387, 220-223)
+      const int ln = g == 1 ? sn : dn, rn = g == 1 ? dn : sn;
+      const float* pl = A.lig_pos + 3 * (size_t)ln;
+      const float* pr = A.rec_pos + 3 * (size_t)((rn - A.n_lig_total) % A.n_rec);
+      vx = pr[0] - pl[0]; vy = pr[1] - pl[1]; vz = pr[2] - pl[2];
+    }
+    const float d = sqrtf(vx * vx + vy * vy + vz * vz);
+    const float inv = 1.7320508075688772f / fmaxf(d, 1e-12f);
+    shv = make_float4(1.0f, vx * inv, vy * inv, vz * inv);
+    float gs[DE];
+#pragma unroll
+    for (int k = 0; k < DE; ++k) {
+      const float t = d - M.offset[k];
+      gs[k] = expf(M.coeff * (t * t));
+    }
+#pragma unroll
+    for (int o = 0; o < NS; ++o) {
+      float a = sigb[o];
+#pragma unroll
+      for (int k = 0; k < DE; ++k) a += M.w1d[o * DE + k] * gs[k];
+      h[o] = a;
+    }
+    if (g == 0 && aux >= 0) {
+      const float4 ba = *reinterpret_cast<const float4*>(A.bond_attr + 4 * (size_t)aux);
+#pragma unroll
+      for (int o = 0; o < NS; ++o)
+        h[o] += M.w1b[o * 4] * ba.x + M.w1b[o * 4 + 1] * ba.y + M.w1b[o * 4 + 2] * ba.z + M.w1b[o * 4 + 3] * ba.w;
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < NS; ++o) h[o] = fmaxf(h[o], 0.0f);
+  float* out = A.e_emb + (size_t)e * NS;
+#pragma unroll
+  for (int o4 = 0; o4 < NS / 4; ++o4) {
+    float r[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int o = 4 * o4 + q;
+      float a = M.b2[o];
+#pragma unroll
+      for (int k = 0; k < NS; ++k) a += M.w2[o * NS + k] * h[k];
+      r[q] = a;
+    }
+    *reinterpret_cast<float4*>(out + 4 * o4) = make_float4(r[0], r[1], r[2], r[3]);
+  }
+  *reinterpret_cast<float4*>(A.e_sh + 4 * (size_t)e) = shv;
+}
+
+// node embeddings: static part (categorical embeddings, ESM projection, bias) + the per-step sigma part
+// (AtomEncoder, models/layers.py:140-149), written zero-padded to XW floats per node
+__global__ void node_embed_kernel(const float* lig_static, const float* rec_static, StepParams sp, int B, int n_lig,
+                                  int n_rec, float* x) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n_l = (int64_t)B * n_lig, n = n_l + (int64_t)B * n_rec;
+  if (i >= n * XW) return;
+  const int64_t node = i / XW;
+  const int c = (int)(i % XW);
+  float v = 0.0f;
+  if (c < NS) {
+    if (node < n_l) v = lig_static[(node % n_lig) * NS + c] + sp.lig_node_sig[c];
+    else v = rec_static[((node - n_l) % n_rec) * NS + c] + sp.rec_node_sig[c];
+  }
+  x[i] = v;
+}
+
+hipError_t launch_graph(const GraphArgs& G, int64_t edge_cap, hipStream_t s) {
+  const size_t lds = (size_t)(MAX_LIG * 3 + G.n_rec * 3) * 4 + (size_t)G.n_rec * 4;
+  hipLaunchKernelGGL(graph_count_kernel, dim3(G.B), dim3(256), lds, s, G);
+  hipLaunchKernelGGL(graph_scan_kernel, dim3(1), dim3(64), 0, s, G, edge_cap);
+  hipLaunchKernelGGL(graph_fill_kernel, dim3(G.B), dim3(256), lds, s, G);
+  return hipGetLastError();
+}
+
+hipError_t launch_edge_features(const EdgeFeatArgs& A, int64_t edge_cap, hipStream_t s) {
+  const unsigned blocks = (unsigned)((edge_cap + 255) / 256 + 4);
+  hipLaunchKernelGGL(edge_features_kernel, dim3(blocks), dim3(256), 0, s, A);
+  return hipGetLastError();
+}
+
+hipError_t launch_node_embed(const float* lig_static, const float* rec_static, const StepParams& sp, int B, int n_lig,
+                             int n_rec, float* x, hipStream_t s) {
+  const int64_t tot = (int64_t)B * (n_lig + n_rec) * XW;
+  hipLaunchKernelGGL(node_embed_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, lig_static, rec_static, sp, B,
+                     n_lig, n_rec, x);
+  return hipGetLastError();
+}
+
+}  // namespace ddk

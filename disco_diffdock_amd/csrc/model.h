@@ -1,0 +1,88 @@
+// Score-model level device structures (internal; see include/ddk.h for the ABI).
+#pragma once
+#include "ddk_internal.h"
+
+namespace ddk {
+
+constexpr int SIG = 32;        // sigma_embed_dim
+constexpr int DE = 32;         // distance_embed_dim
+constexpr int MAX_LIG = 256;   // ligand atoms per sample the graph kernels support
+constexpr int MAX_REC = 8192;  // residues per sample
+constexpr int LIG_CAP = 33;    // radius_graph(max_num_neighbors=32) -> radius(..., 33) including self
+constexpr int BOND_CAP = 32;   // radius(..., max_num_neighbors=32) of the bond-centre graph
+
+// Everything that depends only on the diffusion time of a forward (computed on the HOST from t, which the
+// sampler knows without reading the device: utils/sampling.py:106-113, diffusion_utils.py:12-16,58-69).
+struct StepParams {
+  float lig_node_sig[NS], rec_node_sig[NS];                   // W[:, sigma cols] . sigma_emb(t)  (+ nothing: bias is in the static part)
+  float lig_edge_sigb[NS], rec_edge_sigb[NS], cross_edge_sigb[NS], center_edge_sigb[NS];   // first-layer bias incl. the sigma part
+  float tr_sigb[NS], rot_sigb[NS];                            // tr/rot_final_layer.0: W[:,1:33].sigma_emb + b
+  float tr_sigma, rot_sigma, tor_sigma;
+  float so3_norm;          // so3.score_norm(rot_sigma)
+  float torus_norm_sqrt;   // sqrt(torus.score_norm(tor_sigma))
+  float cross_cutoff;      // 3*tr_sigma + 20 (dynamic_max_cross) or cross_max_distance
+};
+
+// 2-layer edge-embedding MLP: h = relu(W1d.gauss(+W1b.bond) + sigb) ; out = W2.h + b2
+struct EdgeMlpDev {
+  const float* w1d;   // [NS][DE]  columns that multiply the Gaussian distance expansion
+  const float* w1b;   // [NS][4]   bond one-hot columns (ligand edges) or null
+  const float* w2;    // [NS][NS]
+  const float* b2;    // [NS]
+  float coeff;        // GaussianSmearing coeff
+  float step;         // offset spacing (offset_k = k*step)
+  const float* offset;  // [DE]
+};
+
+struct ModelDev {
+  EdgeMlpDev lig_edge, rec_edge, cross_edge, center_edge, final_edge;
+  const float* final_edge_b1;   // [NS] (final_edge_embedding has no sigma part)
+  // final_conv (tr/rot head)
+  const float *fc_w0, *fc_b0, *fc_w4, *fc_b4;   // [2ns][2ns],[2ns],[144][2ns],[144]
+  float fc_bn_scale[4];
+  const float *tr_w0n, *tr_w3, *rot_w0n, *rot_w3;  // [NS] each
+  float tr_b3, rot_b3;
+  // torsion head
+  const float *tb_w0, *tb_b0, *tb_w4, *tb_b4;   // [72][72],[72],[288][72],[288]
+  const float *tb_bn_scale, *tb_bn_mean, *tb_bn_bias;  // [48] (mean/bias non-zero only on the 0e half)
+  const float *tf_w0, *tf_w3;                    // [NS][2NS], [NS]
+};
+
+struct ModelHost {   // host copies needed per forward / per complex
+  std::vector<float> lig_tables;        // concatenated embedding tables [sum(dims)][NS]
+  std::vector<int> lig_table_off;       // row offset of each categorical feature
+  std::vector<float> lig_w_emb, lig_w_sig, lig_b;      // [NS][NS], [NS][SIG], [NS]
+  std::vector<float> rec_table, rec_w_emb, rec_w_esm, rec_w_sig, rec_b;
+  std::vector<float> le_w1s, le_b1, re_w1s, re_b1, ce_w1s, ce_b1, cen_w1s, cen_b1;   // sigma columns + bias of the edge MLP first layers
+  std::vector<float> re_w1d;            // rec edge distance columns (static precompute per complex)
+  std::vector<float> tr_w0s, tr_b0, rot_w0s, rot_b0;   // [NS][SIG], [NS]
+  float rec_coeff = 0.f;
+  std::vector<float> rec_offset;
+  bool ready = false;
+};
+
+struct Model {
+  ModelDev dev;
+  ModelHost host;
+};
+
+}  // namespace ddk
+
+struct ddk_complex {
+  int n_lig = 0, n_rec = 0, M = 0, R = 0, E_rr = 0, max_batch = 0;
+  // static device data
+  int32_t *bond_src = nullptr, *bond_dst = nullptr, *rot_u = nullptr, *rot_v = nullptr, *rot_bond = nullptr;
+  float* bond_attr = nullptr;
+  uint8_t* mask_rotate = nullptr;
+  float *rec_pos = nullptr, *lig_node_static = nullptr, *rec_node_static = nullptr;
+  int32_t *rr_src = nullptr, *rr_dst = nullptr, *rr_outdeg = nullptr;
+  float *rr_pre1 = nullptr, *rr_sh = nullptr;
+  // per-forward workspaces (sized for max_batch)
+  int64_t edge_cap = 0;
+  int32_t *e_src = nullptr, *e_dst = nullptr, *e_aux = nullptr, *deg = nullptr, *counts = nullptr, *offs = nullptr, *info = nullptr;
+  float *e_emb = nullptr, *e_sh = nullptr, *xa = nullptr, *xb = nullptr, *sum = nullptr;
+  float *pos_tmp = nullptr, *scores = nullptr;
+  float* x_last = nullptr;    // node features after the conv stack of the last forward
+  int last_B = 0;
+  std::vector<void*> allocs;
+};

@@ -65,5 +65,12 @@ def lib():
     L.ddk_last_node_features.argtypes = [vp, vp, i32, vp, vp, vp]
     L.ddk_debug_export.argtypes = [vp, C.c_char_p, vp, i64]
     L.ddk_debug_export.restype = i64
+    _declare_debug(L)
     _lib = L
     return L
+
+
+def _declare_debug(L):
+    import ctypes as C
+    L.ddk_debug_read_edges.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_int64]

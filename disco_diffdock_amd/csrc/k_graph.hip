@@ -9,25 +9,6 @@
 
 namespace ddk {
 
-struct GraphArgs {
-  const float* lig_pos;     // [B, n_lig, 3]
-  const float* rec_pos;     // [n_rec, 3]
-  const int32_t* bond_src;  // [M]
-  const int32_t* bond_dst;
-  const int32_t* rr_src;    // [E_rr]
-  const int32_t* rr_dst;
-  const int32_t* rr_outdeg; // [n_rec]
-  int B, n_lig, n_rec, M, E_rr;
-  float lig_r2;             // lig_max_radius^2
-  float cross_cutoff;
-  int32_t* counts;          // [B, 2]: ll radius edges, lr edges
-  int32_t* offs;            // [B, 2]: exclusive prefix of counts
-  int32_t* info;            // tile_info (see graph_scan_kernel)
-  int32_t* e_src;
-  int32_t* e_dst;
-  int32_t* e_aux;
-  int32_t* deg;             // [B*(n_lig+n_rec)]
-};
 
 // torch_cluster.radius on coordinates rescaled by the per-graph cutoff (score_model.py:379-381): |x/c - y/c|^2 < 1
 __device__ __forceinline__ bool cross_within(const float* lp, const float* rp, float c) {
@@ -204,31 +185,6 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(GraphArgs G) {
 // lig/rec/cross_edge_embedding (score_model.py:51-56,193,199,207) on [bond one-hot | sigma_emb | gaussians].
 // The sigma_emb columns are the same for every edge of a forward -> folded into the first-layer bias on the host.
 // ---------------------------------------------------------------------------------------------------
-struct EdgeFeatArgs {
-  const float* lig_pos;    // [B*n_lig,3]
-  const float* rec_pos;    // [n_rec,3]
-  const float* bond_attr;  // [M,4]
-  const float* rr_pre1;    // [E_rr,NS]  W1d.gauss for the static receptor edges
-  const float* rr_sh;      // [E_rr,4]
-  const int32_t* e_src;
-  const int32_t* e_dst;
-  const int32_t* e_aux;
-  const int32_t* info;
-  float* e_emb;            // [E,NS]
-  float* e_sh;             // [E,4]
-  EdgeMlpDev lig, rec, cross;
-  StepParams sp;
-  int n_lig_total;         // B*n_lig
-  int n_rec;
-};
-
-__device__ __forceinline__ void gaussians(float d, const EdgeMlpDev& m, float* gs) {
-#pragma unroll
-  for (int k = 0; k < DE; ++k) {
-    const float t = d - m.offset[k];
-    gs[k] = __expf(0.0f) * expf(m.coeff * (t * t));
-  }
-}
 
 __global__ __launch_bounds__(256) void edge_features_kernel(EdgeFeatArgs A) {
   const int blk = blockIdx.x;

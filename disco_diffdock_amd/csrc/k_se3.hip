@@ -1,0 +1,155 @@
+// SE(3) x torus conformer update of one reverse-diffusion step, one workgroup per sample
+// (reference utils/diffusion_utils.py:37-55 modify_conformer_batch, utils/geometry.py:6-85,126-156,
+//  utils/torsion.py:71-86, and the perturbation arithmetic of utils/sampling.py:137-192):
+//   upd   = score_coeff * score + noise_coeff * z                       (tr, rot, tor)
+//   rigid = (pos - centroid) R(rot)^T + tr + centroid
+//   flex  = sequential torsion rotations (in bond order, on already-updated coordinates)
+//   out   = Kabsch-align(flex -> rigid)
+// The 3x3 SVD of the reference is replaced by Horn's closed form (largest eigenvector of a 4x4 symmetric
+// matrix, Jacobi in fp64 on one lane): same optimal proper rotation, reflection case included.
+#include "model.h"
+
+namespace ddk {
+
+
+__device__ void axis_angle_to_matrix_dev(float ax, float ay, float az, float* R) {
+  // utils/geometry.py:38-85 (quaternion route, small-angle series below 1e-6)
+  const float ang = sqrtf(ax * ax + ay * ay + az * az);
+  const float half = 0.5f * ang;
+  const float s = fabsf(ang) < 1e-6f ? 0.5f - ang * ang / 48.0f : sinf(half) / ang;
+  const float qr = cosf(half), qi = ax * s, qj = ay * s, qk = az * s;
+  const float two_s = 2.0f / (qr * qr + qi * qi + qj * qj + qk * qk);
+  R[0] = 1 - two_s * (qj * qj + qk * qk); R[1] = two_s * (qi * qj - qk * qr); R[2] = two_s * (qi * qk + qj * qr);
+  R[3] = two_s * (qi * qj + qk * qr); R[4] = 1 - two_s * (qi * qi + qk * qk); R[5] = two_s * (qj * qk - qi * qr);
+  R[6] = two_s * (qi * qk - qj * qr); R[7] = two_s * (qj * qk + qi * qr); R[8] = 1 - two_s * (qi * qi + qj * qj);
+}
+
+// rotation R minimising sum |R a_i - b_i|^2 given S[a][b] = sum a_i[a] b_i[b]  (Horn 1987)
+__device__ void horn_rotation(const double* S, float* R) {
+  double N[4][4] = {
+      {S[0] + S[4] + S[8], S[5] - S[7], S[6] - S[2], S[1] - S[3]},
+      {S[5] - S[7], S[0] - S[4] - S[8], S[1] + S[3], S[6] + S[2]},
+      {S[6] - S[2], S[1] + S[3], -S[0] + S[4] - S[8], S[5] + S[7]},
+      {S[1] - S[3], S[6] + S[2], S[5] + S[7], -S[0] - S[4] + S[8]}};
+  double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    double off = 0;
+    for (int p = 0; p < 4; ++p)
+      for (int q = p + 1; q < 4; ++q) off += N[p][q] * N[p][q];
+    if (off < 1e-30) break;
+    for (int p = 0; p < 4; ++p)
+      for (int q = p + 1; q < 4; ++q) {
+        if (fabs(N[p][q]) < 1e-300) continue;
+        const double theta = (N[q][q] - N[p][p]) / (2.0 * N[p][q]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 4; ++k) {
+          const double a = N[k][p], b = N[k][q];
+          N[k][p] = c * a - s * b; N[k][q] = s * a + c * b;
+        }
+        for (int k = 0; k < 4; ++k) {
+          const double a = N[p][k], b = N[q][k];
+          N[p][k] = c * a - s * b; N[q][k] = s * a + c * b;
+        }
+        for (int k = 0; k < 4; ++k) {
+          const double a = V[k][p], b = V[k][q];
+          V[k][p] = c * a - s * b; V[k][q] = s * a + c * b;
+        }
+      }
+  }
+  int best = 0;
+  for (int k = 1; k < 4; ++k)
+    if (N[k][k] > N[best][best]) best = k;
+  const double w = V[0][best], x = V[1][best], y = V[2][best], z = V[3][best];
+  const double nn = w * w + x * x + y * y + z * z, s2 = 2.0 / nn;
+  R[0] = (float)(1 - s2 * (y * y + z * z)); R[1] = (float)(s2 * (x * y - z * w)); R[2] = (float)(s2 * (x * z + y * w));
+  R[3] = (float)(s2 * (x * y + z * w)); R[4] = (float)(1 - s2 * (x * x + z * z)); R[5] = (float)(s2 * (y * z - x * w));
+  R[6] = (float)(s2 * (x * z - y * w)); R[7] = (float)(s2 * (y * z + x * w)); R[8] = (float)(1 - s2 * (x * x + y * y));
+}
+
+__global__ __launch_bounds__(256) void se3_update_kernel(Se3Args A) {
+  __shared__ float rig[MAX_LIG * 3], flx[MAX_LIG * 3];
+  __shared__ float upd[6], ctr[3], Rm[9], Rt[9], piv[3], cA[3], cB[3], Rk[9], tk[3];
+  __shared__ double S[9];
+  const int b = blockIdx.x, tid = threadIdx.x, n = A.n_lig, R = A.R;
+  const float* nz = A.noise ? A.noise + (size_t)b * (6 + R) : nullptr;
+  for (int i = tid; i < n * 3; i += 256) rig[i] = A.pos[(size_t)b * n * 3 + i];
+  if (tid < 6) {
+    const int k = tid / 3;
+    const float sc = (tid < 3 ? A.tr : A.rot)[3 * b + tid % 3];
+    upd[tid] = A.sc[k] * sc + (nz ? A.nc[k] * nz[tid] : 0.0f);
+  }
+  __syncthreads();
+  if (tid < 3) {
+    float s = 0.0f;
+    for (int i = 0; i < n; ++i) s += rig[3 * i + tid];
+    ctr[tid] = s / (float)n;
+  }
+  if (tid == 32) axis_angle_to_matrix_dev(upd[3], upd[4], upd[5], Rm);
+  __syncthreads();
+  if (tid < n) {
+    const float x = rig[3 * tid] - ctr[0], y = rig[3 * tid + 1] - ctr[1], z = rig[3 * tid + 2] - ctr[2];
+    const float rx = Rm[0] * x + Rm[1] * y + Rm[2] * z + upd[0] + ctr[0];
+    const float ry = Rm[3] * x + Rm[4] * y + Rm[5] * z + upd[1] + ctr[1];
+    const float rz = Rm[6] * x + Rm[7] * y + Rm[8] * z + upd[2] + ctr[2];
+    // every thread owns its atom: safe to overwrite in place after the barrier above
+    rig[3 * tid] = rx; rig[3 * tid + 1] = ry; rig[3 * tid + 2] = rz;
+    flx[3 * tid] = rx; flx[3 * tid + 1] = ry; flx[3 * tid + 2] = rz;
+  }
+  __syncthreads();
+  if (A.tor == nullptr || R == 0) {
+    for (int i = tid; i < n * 3; i += 256) A.pos_out[(size_t)b * n * 3 + i] = rig[i];
+    return;
+  }
+  for (int r = 0; r < R; ++r) {
+    if (tid == 0) {
+      const int u = A.rot_u[r], v = A.rot_v[r];
+      const float th = A.sc[2] * A.tor[(size_t)b * R + r] + (nz ? A.nc[2] * nz[6 + r] : 0.0f);
+      float ax = flx[3 * u] - flx[3 * v], ay = flx[3 * u + 1] - flx[3 * v + 1], az = flx[3 * u + 2] - flx[3 * v + 2];
+      const float nn = sqrtf(ax * ax + ay * ay + az * az);
+      axis_angle_to_matrix_dev(ax / nn * th, ay / nn * th, az / nn * th, Rt);
+      piv[0] = flx[3 * v]; piv[1] = flx[3 * v + 1]; piv[2] = flx[3 * v + 2];
+    }
+    __syncthreads();
+    if (tid < n && A.mask_rotate[(size_t)r * n + tid]) {
+      const float x = flx[3 * tid] - piv[0], y = flx[3 * tid + 1] - piv[1], z = flx[3 * tid + 2] - piv[2];
+      flx[3 * tid] = Rt[0] * x + Rt[1] * y + Rt[2] * z + piv[0];
+      flx[3 * tid + 1] = Rt[3] * x + Rt[4] * y + Rt[5] * z + piv[1];
+      flx[3 * tid + 2] = Rt[6] * x + Rt[7] * y + Rt[8] * z + piv[2];
+    }
+    __syncthreads();
+  }
+  // Kabsch: align flex (A) onto rigid (B)
+  if (tid < 3) {
+    float sa = 0.0f, sb = 0.0f;
+    for (int i = 0; i < n; ++i) { sa += flx[3 * i + tid]; sb += rig[3 * i + tid]; }
+    cA[tid] = sa / (float)n; cB[tid] = sb / (float)n;
+  }
+  __syncthreads();
+  if (tid < 9) {
+    const int a = tid / 3, c = tid % 3;
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += (double)(flx[3 * i + a] - cA[a]) * (double)(rig[3 * i + c] - cB[c]);
+    S[tid] = s;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    horn_rotation(S, Rk);
+    for (int k = 0; k < 3; ++k) tk[k] = -(Rk[3 * k] * cA[0] + Rk[3 * k + 1] * cA[1] + Rk[3 * k + 2] * cA[2]) + cB[k];
+  }
+  __syncthreads();
+  if (tid < n) {
+    const float x = flx[3 * tid], y = flx[3 * tid + 1], z = flx[3 * tid + 2];
+    float* o = A.pos_out + ((size_t)b * n + tid) * 3;
+    o[0] = Rk[0] * x + Rk[1] * y + Rk[2] * z + tk[0];
+    o[1] = Rk[3] * x + Rk[4] * y + Rk[5] * z + tk[1];
+    o[2] = Rk[6] * x + Rk[7] * y + Rk[8] * z + tk[2];
+  }
+}
+
+hipError_t launch_se3(const Se3Args& A, hipStream_t s) {
+  hipLaunchKernelGGL(se3_update_kernel, dim3(A.B), dim3(256), 0, s, A);
+  return hipGetLastError();
+}
+
+}  // namespace ddk

@@ -66,6 +66,82 @@ struct Model {
   ModelHost host;
 };
 
+
+// ---- kernel argument blocks + launchers (k_graph.hip / k_heads.hip / k_se3.hip) ---------------------------
+struct GraphArgs {
+  const float* lig_pos;     // [B, n_lig, 3]
+  const float* rec_pos;     // [n_rec, 3]
+  const int32_t* bond_src;  // [M]
+  const int32_t* bond_dst;
+  const int32_t* rr_src;    // [E_rr]
+  const int32_t* rr_dst;
+  const int32_t* rr_outdeg; // [n_rec]
+  int B, n_lig, n_rec, M, E_rr;
+  float lig_r2;             // lig_max_radius^2
+  float cross_cutoff;
+  int32_t* counts;          // [B, 2]: ll radius edges, lr edges
+  int32_t* offs;            // [B, 2]: exclusive prefix of counts
+  int32_t* info;            // tile_info (see graph_scan_kernel)
+  int32_t* e_src;
+  int32_t* e_dst;
+  int32_t* e_aux;
+  int32_t* deg;             // [B*(n_lig+n_rec)]
+};
+
+struct EdgeFeatArgs {
+  const float* lig_pos;    // [B*n_lig,3]
+  const float* rec_pos;    // [n_rec,3]
+  const float* bond_attr;  // [M,4]
+  const float* rr_pre1;    // [E_rr,NS]  W1d.gauss for the static receptor edges
+  const float* rr_sh;      // [E_rr,4]
+  const int32_t* e_src;
+  const int32_t* e_dst;
+  const int32_t* e_aux;
+  const int32_t* info;
+  float* e_emb;            // [E,NS]
+  float* e_sh;             // [E,4]
+  EdgeMlpDev lig, rec, cross;
+  StepParams sp;
+  int n_lig_total;         // B*n_lig
+  int n_rec;
+};
+
+struct HeadArgs {
+  const float* lig_pos;   // [B, n_lig, 3]
+  const float* x;         // [N, XW] node features after the conv stack (ligand nodes first)
+  ModelDev md;
+  StepParams sp;
+  int B, n_lig, R;
+  int scale_by_sigma;
+  const int32_t* rot_u;   // [R]
+  const int32_t* rot_v;
+  float lig_r2;
+  float* tr_out;          // [B,3]
+  float* rot_out;         // [B,3]
+  float* tor_out;         // [B*R]
+};
+
+struct Se3Args {
+  const float* pos;      // [B, n_lig, 3]
+  const float* tr;       // [B,3] scores (or updates when coeff = (1,0))
+  const float* rot;      // [B,3]
+  const float* tor;      // [B*R] or null
+  const float* noise;    // [B, 6+R] or null
+  float sc[3], nc[3];
+  const int32_t* rot_u;
+  const int32_t* rot_v;
+  const uint8_t* mask_rotate;   // [R, n_lig]
+  int B, n_lig, R;
+  float* pos_out;
+};
+
+hipError_t launch_graph(const GraphArgs& G, int64_t edge_cap, hipStream_t s);
+hipError_t launch_edge_features(const EdgeFeatArgs& A, int64_t edge_cap, hipStream_t s);
+hipError_t launch_node_embed(const float* lig_static, const float* rec_static, const StepParams& sp, int B, int n_lig,
+                             int n_rec, float* x, hipStream_t s);
+hipError_t launch_heads(const HeadArgs& A, bool torsion, hipStream_t s);
+hipError_t launch_se3(const Se3Args& A, hipStream_t s);
+
 }  // namespace ddk
 
 struct ddk_complex {

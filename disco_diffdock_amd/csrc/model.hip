@@ -1,16 +1,513 @@
-// placeholder: filled in by the pipeline milestone
-#include "ddk_internal.h"
+// Score-model level host code: small-weight upload, per-complex static precompute, per-forward host scalars,
+// kernel orchestration for ddk_score_forward / ddk_se3_update / ddk_sample (include/ddk.h).
+#include <math.h>
+#include <string.h>
+
+#include "model.h"
+
 namespace ddk {
-int model_finalize(ddk_ctx* ctx) { (void)ctx; return DDK_OK; }
-void model_destroy(ddk_ctx* ctx) { (void)ctx; }
+
+static const int LIG_DIMS[16] = {119, 4, 12, 12, 8, 10, 6, 6, 2, 8, 2, 2, 2, 2, 2, 2};   // process_mols.py:62-79
+static const int REC_DIM = 38;                                                             // process_mols.py:88-90
+
+static const HostTensor* getw(ddk_ctx* ctx, const std::string& name, std::initializer_list<int64_t> shape) {
+  auto it = ctx->weights.find(name);
+  if (it == ctx->weights.end()) { ctx->err = "missing state_dict key: " + name; return nullptr; }
+  if (it->second.shape != std::vector<int64_t>(shape)) { ctx->err = "shape mismatch for " + name; return nullptr; }
+  return &it->second;
 }
+
+// columns [c0, c1) of a row-major [rows, cols] matrix
+static std::vector<float> cols(const HostTensor* t, int c0, int c1) {
+  const int rows = (int)t->shape[0], nc = (int)t->shape[1];
+  std::vector<float> o((size_t)rows * (c1 - c0));
+  for (int r = 0; r < rows; ++r)
+    for (int c = c0; c < c1; ++c) o[(size_t)r * (c1 - c0) + (c - c0)] = t->data[(size_t)r * nc + c];
+  return o;
+}
+
+static bool smearing(ddk_ctx* ctx, const char* name, float stop, EdgeMlpDev& m, std::vector<float>* host_off, float* host_coeff) {
+  // GaussianSmearing (tensor_layers.py:171-181): offset buffer from the checkpoint, coeff = -0.5/(offset[1]-offset[0])^2
+  std::vector<float> off(DE);
+  auto it = ctx->weights.find(std::string(name) + "_distance_expansion.offset");
+  if (it != ctx->weights.end() && it->second.data.size() == (size_t)DE) off = it->second.data;
+  else for (int k = 0; k < DE; ++k) off[k] = stop * (float)k / (float)(DE - 1);
+  const double d = (double)(off[1] - off[0]);
+  m.coeff = (float)(-0.5 / (d * d));
+  m.step = off[1] - off[0];
+  m.offset = dev_upload(ctx, off);
+  if (host_off) *host_off = off;
+  if (host_coeff) *host_coeff = m.coeff;
+  return m.offset != nullptr;
+}
+
+int model_finalize(ddk_ctx* ctx) {
+  if (ctx->model) { delete (Model*)ctx->model; ctx->model = nullptr; }
+  if (ctx->weights.find("lig_node_embedding.additional_features_embedder.weight") == ctx->weights.end())
+    return DDK_OK;   // operator-only context (no score model loaded)
+  const ddk_config& c = ctx->cfg;
+  if (c.latent_dim != 0)
+    return fail(ctx, DDK_ERR_INVALID, "latent_dim > 0 (DisCo latent conditioning) is not implemented on the device yet");
+  Model* M = new Model();
+  ctx->model = M;
+  ModelHost& H = M->host;
+  ModelDev& D = M->dev;
+  const int lm = c.lm_embedding_dim;
+#define GET(var, name, ...) const HostTensor* var = getw(ctx, name, {__VA_ARGS__}); if (!var) return DDK_ERR_INVALID
+  // ---- node encoders -----------------------------------------------------------------------
+  int off = 0;
+  for (int i = 0; i < 16; ++i) {
+    GET(t, "lig_node_embedding.atom_embedding_list." + std::to_string(i) + ".weight", LIG_DIMS[i], NS);
+    H.lig_table_off.push_back(off);
+    H.lig_tables.insert(H.lig_tables.end(), t->data.begin(), t->data.end());
+    off += LIG_DIMS[i];
+  }
+  GET(lw, "lig_node_embedding.additional_features_embedder.weight", NS, NS + SIG);
+  GET(lb, "lig_node_embedding.additional_features_embedder.bias", NS);
+  H.lig_w_emb = cols(lw, 0, NS); H.lig_w_sig = cols(lw, NS, NS + SIG); H.lig_b = lb->data;
+  GET(rt, "rec_node_embedding.atom_embedding_list.0.weight", REC_DIM, NS);
+  GET(rw, "rec_node_embedding.additional_features_embedder.weight", NS, NS + lm + SIG);
+  GET(rb, "rec_node_embedding.additional_features_embedder.bias", NS);
+  H.rec_table = rt->data; H.rec_w_emb = cols(rw, 0, NS); H.rec_w_esm = cols(rw, NS, NS + lm);
+  H.rec_w_sig = cols(rw, NS + lm, NS + lm + SIG); H.rec_b = rb->data;
+  // ---- edge embedding MLPs -------------------------------------------------------------------
+  auto edge_mlp = [&](const char* name, int n_bond, bool sigma_first, EdgeMlpDev& m, std::vector<float>* w1s,
+                      std::vector<float>* b1, std::vector<float>* w1d_host) -> bool {
+    const int in = n_bond + (w1s ? SIG : 0) + DE;
+    const HostTensor* w0 = getw(ctx, std::string(name) + ".0.weight", {NS, in});
+    const HostTensor* b0 = getw(ctx, std::string(name) + ".0.bias", {NS});
+    const HostTensor* w3 = getw(ctx, std::string(name) + ".3.weight", {NS, NS});
+    const HostTensor* b3 = getw(ctx, std::string(name) + ".3.bias", {NS});
+    if (!w0 || !b0 || !w3 || !b3) return false;
+    int c_sig, c_d;
+    if (!w1s) { c_sig = -1; c_d = n_bond; }
+    else if (sigma_first) { c_sig = n_bond; c_d = n_bond + SIG; }       // [bond | sigma | dist]
+    else { c_d = n_bond; c_sig = n_bond + DE; }                           // [dist | sigma]
+    std::vector<float> w1d = cols(w0, c_d, c_d + DE);
+    if (w1d_host) *w1d_host = w1d;
+    m.w1d = dev_upload(ctx, w1d);
+    m.w1b = n_bond ? dev_upload(ctx, cols(w0, 0, n_bond)) : nullptr;
+    m.w2 = dev_upload(ctx, w3->data);
+    m.b2 = dev_upload(ctx, b3->data);
+    if (w1s) *w1s = cols(w0, c_sig, c_sig + SIG);
+    *b1 = b0->data;
+    return m.w1d && m.w2 && m.b2;
+  };
+  std::vector<float> fe_b1;
+  if (!edge_mlp("lig_edge_embedding", 4, true, D.lig_edge, &H.le_w1s, &H.le_b1, nullptr)) return DDK_ERR_INVALID;
+  if (!edge_mlp("rec_edge_embedding", 0, true, D.rec_edge, &H.re_w1s, &H.re_b1, &H.re_w1d)) return DDK_ERR_INVALID;
+  if (!edge_mlp("cross_edge_embedding", 0, true, D.cross_edge, &H.ce_w1s, &H.ce_b1, nullptr)) return DDK_ERR_INVALID;
+  if (!edge_mlp("center_edge_embedding", 0, false, D.center_edge, &H.cen_w1s, &H.cen_b1, nullptr)) return DDK_ERR_INVALID;
+  if (!smearing(ctx, "lig", c.lig_max_radius, D.lig_edge, nullptr, nullptr)) return fail(ctx, DDK_ERR_NOMEM, "alloc");
+  if (!smearing(ctx, "rec", c.rec_max_radius, D.rec_edge, &H.rec_offset, &H.rec_coeff)) return fail(ctx, DDK_ERR_NOMEM, "alloc");
+  if (!smearing(ctx, "cross", c.cross_max_distance, D.cross_edge, nullptr, nullptr)) return fail(ctx, DDK_ERR_NOMEM, "alloc");
+  if (!smearing(ctx, "center", c.center_max_distance, D.center_edge, nullptr, nullptr)) return fail(ctx, DDK_ERR_NOMEM, "alloc");
+  // ---- tr / rot head -------------------------------------------------------------------------
+  {
+    GET(w0, "final_conv.fc.0.weight", 2 * NS, 2 * NS);
+    GET(b0, "final_conv.fc.0.bias", 2 * NS);
+    GET(w4, "final_conv.fc.4.weight", 144, 2 * NS);
+    GET(b4, "final_conv.fc.4.bias", 144);
+    D.fc_w0 = dev_upload(ctx, w0->data); D.fc_b0 = dev_upload(ctx, b0->data);
+    D.fc_w4 = dev_upload(ctx, w4->data); D.fc_b4 = dev_upload(ctx, b4->data);
+    for (int k = 0; k < 4; ++k) D.fc_bn_scale[k] = 1.0f;
+    if (c.batch_norm) {
+      GET(bw, "final_conv.batch_norm.weight", 4);
+      GET(bv, "final_conv.batch_norm.running_var", 4);
+      for (int k = 0; k < 4; ++k) D.fc_bn_scale[k] = powf(bv->data[k] + 1e-5f, -0.5f) * bw->data[k];
+    }
+    GET(t0, "tr_final_layer.0.weight", NS, 1 + SIG);
+    GET(tb0, "tr_final_layer.0.bias", NS);
+    GET(t3, "tr_final_layer.3.weight", 1, NS);
+    GET(tb3, "tr_final_layer.3.bias", 1);
+    GET(r0, "rot_final_layer.0.weight", NS, 1 + SIG);
+    GET(rb0, "rot_final_layer.0.bias", NS);
+    GET(r3, "rot_final_layer.3.weight", 1, NS);
+    GET(rb3, "rot_final_layer.3.bias", 1);
+    D.tr_w0n = dev_upload(ctx, cols(t0, 0, 1)); D.tr_w3 = dev_upload(ctx, t3->data); D.tr_b3 = tb3->data[0];
+    D.rot_w0n = dev_upload(ctx, cols(r0, 0, 1)); D.rot_w3 = dev_upload(ctx, r3->data); D.rot_b3 = rb3->data[0];
+    H.tr_w0s = cols(t0, 1, 1 + SIG); H.tr_b0 = tb0->data; H.rot_w0s = cols(r0, 1, 1 + SIG); H.rot_b0 = rb0->data;
+  }
+  // ---- torsion head --------------------------------------------------------------------------
+  if (!c.no_torsion) {
+    if (!edge_mlp("final_edge_embedding", 0, false, D.final_edge, nullptr, &fe_b1, nullptr)) return DDK_ERR_INVALID;
+    D.final_edge.coeff = D.lig_edge.coeff; D.final_edge.step = D.lig_edge.step; D.final_edge.offset = D.lig_edge.offset;
+    D.final_edge_b1 = dev_upload(ctx, fe_b1);
+    GET(w0, "tor_bond_conv.fc.0.weight", NE, NE);
+    GET(b0, "tor_bond_conv.fc.0.bias", NE);
+    GET(w4, "tor_bond_conv.fc.4.weight", 2 * NV * NS, NE);
+    GET(b4, "tor_bond_conv.fc.4.bias", 2 * NV * NS);
+    D.tb_w0 = dev_upload(ctx, w0->data); D.tb_b0 = dev_upload(ctx, b0->data);
+    D.tb_w4 = dev_upload(ctx, w4->data); D.tb_b4 = dev_upload(ctx, b4->data);
+    std::vector<float> sc(2 * NS, 1.f), mn(2 * NS, 0.f), bi(2 * NS, 0.f);
+    if (c.batch_norm) {   // irreps 24x0o + 24x0e: only the 0e half (channels 24..47) has mean / bias
+      GET(bw, "tor_bond_conv.batch_norm.weight", 2 * NS);
+      GET(bb, "tor_bond_conv.batch_norm.bias", NS);
+      GET(bm, "tor_bond_conv.batch_norm.running_mean", NS);
+      GET(bv, "tor_bond_conv.batch_norm.running_var", 2 * NS);
+      for (int k = 0; k < 2 * NS; ++k) sc[k] = powf(bv->data[k] + 1e-5f, -0.5f) * bw->data[k];
+      for (int k = 0; k < NS; ++k) { mn[NS + k] = bm->data[k]; bi[NS + k] = bb->data[k]; }
+    }
+    D.tb_bn_scale = dev_upload(ctx, sc); D.tb_bn_mean = dev_upload(ctx, mn); D.tb_bn_bias = dev_upload(ctx, bi);
+    GET(f0, "tor_final_layer.0.weight", NS, 2 * NS);
+    GET(f3, "tor_final_layer.3.weight", 1, NS);
+    D.tf_w0 = dev_upload(ctx, f0->data); D.tf_w3 = dev_upload(ctx, f3->data);
+  }
+#undef GET
+  for (int l = 0; l < c.num_conv_layers; ++l)
+    if (!ctx->conv[l].has_weights) return fail(ctx, DDK_ERR_INVALID, "score model checkpoint lacks conv_layers." + std::to_string(l));
+  H.ready = true;
+  return DDK_OK;
+}
+
+void model_destroy(ddk_ctx* ctx) {
+  if (ctx->model) { delete (Model*)ctx->model; ctx->model = nullptr; }
+}
+
+static void matvec(const std::vector<float>& W, const float* x, int rows, int colsn, const float* bias, float* out) {
+  for (int r = 0; r < rows; ++r) {
+    float a = bias ? bias[r] : 0.0f;
+    for (int k = 0; k < colsn; ++k) a += W[(size_t)r * colsn + k] * x[k];
+    out[r] = a;
+  }
+}
+
+// host scalars of one forward at diffusion time (t_tr, t_rot, t_tor); fp32 like the reference's tensors
+static int make_step_params(ddk_ctx* ctx, float t_tr, float t_rot, float t_tor, StepParams& sp) {
+  const ddk_config& c = ctx->cfg;
+  const ModelHost& H = ((Model*)ctx->model)->host;
+  // sinusoidal_embedding(embedding_scale * t, 32)  (utils/diffusion_utils.py:58-69)
+  float emb[SIG];
+  const int half = SIG / 2;
+  const double e = log(10000.0) / (double)(half - 1);
+  const float ts = c.embedding_scale * t_tr;
+  for (int k = 0; k < half; ++k) {
+    const float f = expf((float)k * (float)(-e));
+    const float a = ts * f;
+    emb[k] = sinf(a);
+    emb[half + k] = cosf(a);
+  }
+  matvec(H.lig_w_sig, emb, NS, SIG, nullptr, sp.lig_node_sig);
+  matvec(H.rec_w_sig, emb, NS, SIG, nullptr, sp.rec_node_sig);
+  matvec(H.le_w1s, emb, NS, SIG, H.le_b1.data(), sp.lig_edge_sigb);
+  matvec(H.re_w1s, emb, NS, SIG, H.re_b1.data(), sp.rec_edge_sigb);
+  matvec(H.ce_w1s, emb, NS, SIG, H.ce_b1.data(), sp.cross_edge_sigb);
+  matvec(H.cen_w1s, emb, NS, SIG, H.cen_b1.data(), sp.center_edge_sigb);
+  matvec(H.tr_w0s, emb, NS, SIG, H.tr_b0.data(), sp.tr_sigb);
+  matvec(H.rot_w0s, emb, NS, SIG, H.rot_b0.data(), sp.rot_sigb);
+  // t_to_sigma on fp32 tensors (utils/diffusion_utils.py:12-16)
+  sp.tr_sigma = powf(c.tr_sigma_min, 1.0f - t_tr) * powf(c.tr_sigma_max, t_tr);
+  sp.rot_sigma = powf(c.rot_sigma_min, 1.0f - t_rot) * powf(c.rot_sigma_max, t_rot);
+  sp.tor_sigma = powf(c.tor_sigma_min, 1.0f - t_tor) * powf(c.tor_sigma_max, t_tor);
+  sp.cross_cutoff = c.dynamic_max_cross ? sp.tr_sigma * 3.0f + 20.0f : c.cross_max_distance;
+  if (ctx->so3_table.size() != 1000 || ctx->torus_table.size() != 5001)
+    return fail(ctx, DDK_ERR_STATE, "score-norm tables not set (ddk_set_score_norm_tables)");
+  {   // so3.score_norm (utils/so3.py:91-95), float32 index arithmetic like numpy on a float32 array
+    float idx = (log10f(sp.rot_sigma) - (float)log10(0.01)) / (float)(log10(2.0) - log10(0.01)) * 1000.0f;
+    long i = lrintf(idx);
+    i = i < 0 ? 0 : (i > 999 ? 999 : i);
+    sp.so3_norm = (float)ctx->so3_table[i];
+  }
+  {   // torus.score_norm (utils/torus.py:79-83)
+    float s = logf(sp.tor_sigma / (float)M_PI);
+    s = (s - (float)log(3e-3)) / (float)(log(2.0) - log(3e-3)) * 5000.0f;
+    s = s < 0.f ? 0.f : (s > 5000.f ? 5000.f : s);
+    const long i = lrintf(s);
+    sp.torus_norm_sqrt = sqrtf((float)ctx->torus_table[i]);
+  }
+  return DDK_OK;
+}
+
+template <typename T>
+static T* cx_upload(ddk_complex* cx, const T* src, size_t n) {
+  T* p = nullptr;
+  if (hipMalloc((void**)&p, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr;
+  cx->allocs.push_back(p);
+  if (n && src && hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  return p;
+}
+
+static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float* lig_pos, const StepParams& sp,
+                              float* tr_out, float* rot_out, float* tor_out, hipStream_t s) {
+  const ddk_config& c = ctx->cfg;
+  Model* M = (Model*)ctx->model;
+  const int n_lig = cx->n_lig, n_rec = cx->n_rec;
+  const int64_t N = (int64_t)B * (n_lig + n_rec);
+  hipError_t e;
+#define CK(x, what) do { e = (x); if (e != hipSuccess) return hip_fail(ctx, e, what); } while (0)
+  GraphArgs G;
+  G.lig_pos = lig_pos; G.rec_pos = cx->rec_pos; G.bond_src = cx->bond_src; G.bond_dst = cx->bond_dst;
+  G.rr_src = cx->rr_src; G.rr_dst = cx->rr_dst; G.rr_outdeg = cx->rr_outdeg;
+  G.B = B; G.n_lig = n_lig; G.n_rec = n_rec; G.M = cx->M; G.E_rr = cx->E_rr;
+  G.lig_r2 = c.lig_max_radius * c.lig_max_radius; G.cross_cutoff = sp.cross_cutoff;
+  G.counts = cx->counts; G.offs = cx->offs; G.info = cx->info; G.e_src = cx->e_src; G.e_dst = cx->e_dst; G.e_aux = cx->e_aux;
+  G.deg = cx->deg;
+  CK(launch_graph(G, cx->edge_cap, s), "graph build");
+  EdgeFeatArgs F;
+  F.lig_pos = lig_pos; F.rec_pos = cx->rec_pos; F.bond_attr = cx->bond_attr; F.rr_pre1 = cx->rr_pre1; F.rr_sh = cx->rr_sh;
+  F.e_src = cx->e_src; F.e_dst = cx->e_dst; F.e_aux = cx->e_aux; F.info = cx->info; F.e_emb = cx->e_emb; F.e_sh = cx->e_sh;
+  F.lig = M->dev.lig_edge; F.rec = M->dev.rec_edge; F.cross = M->dev.cross_edge; F.sp = sp;
+  F.n_lig_total = B * n_lig; F.n_rec = n_rec;
+  // worst-case edge count of THIS batch size bounds the launch
+  const int64_t cap_b = (int64_t)B * ((int64_t)cx->M + (int64_t)n_lig * (LIG_CAP - 1) + 2LL * n_lig * n_rec + cx->E_rr);
+  CK(launch_edge_features(F, cap_b < cx->edge_cap ? cap_b : cx->edge_cap, s), "edge features");
+  float* xin = cx->xa;
+  float* xout = cx->xb;
+  CK(launch_node_embed(cx->lig_node_static, cx->rec_node_static, sp, B, n_lig, n_rec, xin, s), "node embed");
+  for (int l = 0; l < c.num_conv_layers; ++l) {
+    const ConvLayerDev& L = ctx->conv[l];
+    CK(hipMemsetAsync(cx->sum, 0, (size_t)N * XW * sizeof(float), s), "memset sum");
+    ConvLaunch a;
+    a.x = xin; a.src = cx->e_src; a.dst = cx->e_dst; a.edge_attr = cx->e_emb; a.sh = cx->e_sh; a.sum = cx->sum;
+    a.tile_info = cx->info; a.counter = cx->info + 10 + (l % 8); a.gather = 1;
+    if (l >= 8) CK(hipMemsetAsync(cx->info + 10 + (l % 8), 0, sizeof(int32_t), s), "counter reset");
+    CK(launch_conv_fused(L, a, ctx->n_cu, s), "conv_fused");
+    CK(launch_node_finalize(cx->sum, cx->deg, xin, L.bn_mean, L.bn_scale, L.bn_bias, N, L.dout, XW, xout, s), "node_finalize");
+    float* t = xin; xin = xout; xout = t;
+  }
+  cx->x_last = xin;
+  cx->last_B = B;
+  HeadArgs Hd;
+  Hd.lig_pos = lig_pos; Hd.x = xin; Hd.md = M->dev; Hd.sp = sp; Hd.B = B; Hd.n_lig = n_lig; Hd.R = cx->R;
+  Hd.scale_by_sigma = c.scale_by_sigma; Hd.rot_u = cx->rot_u; Hd.rot_v = cx->rot_v; Hd.lig_r2 = c.lig_max_radius * c.lig_max_radius;
+  Hd.tr_out = tr_out; Hd.rot_out = rot_out; Hd.tor_out = tor_out;
+  CK(launch_heads(Hd, !c.no_torsion && tor_out != nullptr, s), "heads");
+#undef CK
+  return DDK_OK;
+}
+
+}  // namespace ddk
+
 using namespace ddk;
-extern "C" {
-int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc*, int32_t, ddk_complex**) { return fail(ctx, DDK_ERR_STATE, "not implemented"); }
-void ddk_complex_destroy(ddk_ctx*, ddk_complex*) {}
-int ddk_score_forward(ddk_ctx* ctx, ddk_complex*, int32_t, const float*, float, float, float, float*, float*, float*, void*) { return fail(ctx, DDK_ERR_STATE, "not implemented"); }
-int ddk_se3_update(ddk_ctx* ctx, ddk_complex*, int32_t, const float*, const float*, const float*, const float*, float*, void*) { return fail(ctx, DDK_ERR_STATE, "not implemented"); }
-int ddk_sample(ddk_ctx* ctx, ddk_complex*, int32_t, int32_t, const float*, const float*, const float*, const float*, float*, void*) { return fail(ctx, DDK_ERR_STATE, "not implemented"); }
-int ddk_last_graph_stats(ddk_ctx* ctx, ddk_complex*, int64_t*, void*) { return fail(ctx, DDK_ERR_STATE, "not implemented"); }
-int ddk_last_node_features(ddk_ctx* ctx, ddk_complex*, int32_t, float*, float*, void*) { return fail(ctx, DDK_ERR_STATE, "not implemented"); }
+
+static int check_model(ddk_ctx* ctx, ddk_complex* cx, int B) {
+  if (!ctx) return DDK_ERR_INVALID;
+  if (ctx->host_only) return fail(ctx, DDK_ERR_STATE, "host-only context (device < 0) cannot launch kernels");
+  if (!ctx->finalized || !ctx->model || !((Model*)ctx->model)->host.ready)
+    return fail(ctx, DDK_ERR_STATE, "score model weights not loaded / finalised");
+  if (!cx) return fail(ctx, DDK_ERR_INVALID, "null complex");
+  if (B < 1 || B > cx->max_batch) return fail(ctx, DDK_ERR_INVALID, "batch size exceeds the complex's max_batch");
+  return DDK_OK;
 }
+
+extern "C" {
+
+int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batch, ddk_complex** out) {
+  if (!ctx || !d || !out) return DDK_ERR_INVALID;
+  if (ctx->host_only) return fail(ctx, DDK_ERR_STATE, "host-only context (device < 0) cannot hold device data");
+  if (!ctx->finalized || !ctx->model) return fail(ctx, DDK_ERR_STATE, "score model weights not loaded / finalised");
+  const ddk_config& c = ctx->cfg;
+  const ModelHost& H = ((Model*)ctx->model)->host;
+  if (d->n_lig < 1 || d->n_lig > MAX_LIG) return fail(ctx, DDK_ERR_INVALID, "n_lig must be in [1, 256]");
+  if (d->n_rec < 1 || d->n_rec > MAX_REC) return fail(ctx, DDK_ERR_INVALID, "n_rec must be in [1, 8192]");
+  if (d->rec_feat_dim != 1 + c.lm_embedding_dim) return fail(ctx, DDK_ERR_INVALID, "receptor feature width != 1 + lm_embedding_dim");
+  if (max_batch < 1) return fail(ctx, DDK_ERR_INVALID, "max_batch < 1");
+  hipSetDevice(c.device);
+  ddk_complex* cx = new ddk_complex();
+  *out = cx;
+  cx->n_lig = d->n_lig; cx->n_rec = d->n_rec; cx->M = d->n_bond_edges; cx->R = d->n_rot; cx->E_rr = d->n_rec_edges;
+  cx->max_batch = max_batch;
+  const int n_lig = d->n_lig, n_rec = d->n_rec, M = d->n_bond_edges, lm = c.lm_embedding_dim;
+  // ---- topology ------------------------------------------------------------------------------
+  std::vector<int32_t> ru, rv;
+  for (int m = 0; m < M; ++m) {
+    const int a = d->bond_index[m], b = d->bond_index[M + m];
+    if (a < 0 || a >= n_lig || b < 0 || b >= n_lig) return fail(ctx, DDK_ERR_INVALID, "bond index out of range");
+    if (d->edge_mask[m]) { ru.push_back(a); rv.push_back(b); }
+  }
+  if ((int)ru.size() != d->n_rot) return fail(ctx, DDK_ERR_INVALID, "edge_mask.sum() != n_rot");
+  for (int r = 0; r < d->n_rot; ++r)   // orientation asserted by utils/torsion.py:77-78
+    if (d->mask_rotate[(size_t)r * n_lig + ru[r]] || !d->mask_rotate[(size_t)r * n_lig + rv[r]])
+      return fail(ctx, DDK_ERR_INVALID, "mask_rotate orientation: u must be fixed and v rotating for every rotatable bond");
+  cx->bond_src = cx_upload(cx, d->bond_index, (size_t)M);
+  cx->bond_dst = cx_upload(cx, d->bond_index + M, (size_t)M);
+  cx->bond_attr = cx_upload(cx, d->bond_attr, (size_t)M * 4);
+  cx->rot_u = cx_upload(cx, ru.data(), ru.size());
+  cx->rot_v = cx_upload(cx, rv.data(), rv.size());
+  cx->mask_rotate = cx_upload(cx, d->mask_rotate, (size_t)d->n_rot * n_lig);
+  cx->rec_pos = cx_upload(cx, d->rec_pos, (size_t)n_rec * 3);
+  // ---- static node embeddings (AtomEncoder without its sigma columns, models/layers.py:140-149) ----
+  std::vector<float> ls((size_t)n_lig * NS), rs((size_t)n_rec * NS);
+  for (int i = 0; i < n_lig; ++i) {
+    float emb[NS] = {0};
+    for (int f = 0; f < 16; ++f) {
+      const int v = d->lig_x[(size_t)i * 16 + f];
+      if (v < 0 || v >= LIG_DIMS[f]) return fail(ctx, DDK_ERR_INVALID, "ligand categorical feature out of range");
+      const float* row = H.lig_tables.data() + (size_t)(H.lig_table_off[f] + v) * NS;
+      for (int k = 0; k < NS; ++k) emb[k] += row[k];
+    }
+    for (int o = 0; o < NS; ++o) {
+      double a = H.lig_b[o];
+      for (int k = 0; k < NS; ++k) a += (double)H.lig_w_emb[(size_t)o * NS + k] * emb[k];
+      ls[(size_t)i * NS + o] = (float)a;
+    }
+  }
+  for (int j = 0; j < n_rec; ++j) {
+    const float* xr = d->rec_x + (size_t)j * d->rec_feat_dim;
+    const int res = (int)xr[0];
+    if (res < 0 || res >= REC_DIM) return fail(ctx, DDK_ERR_INVALID, "residue id out of range");
+    const float* emb = H.rec_table.data() + (size_t)res * NS;
+    for (int o = 0; o < NS; ++o) {
+      double a = H.rec_b[o];
+      for (int k = 0; k < NS; ++k) a += (double)H.rec_w_emb[(size_t)o * NS + k] * emb[k];
+      const float* w = H.rec_w_esm.data() + (size_t)o * lm;
+      for (int k = 0; k < lm; ++k) a += (double)w[k] * xr[1 + k];
+      rs[(size_t)j * NS + o] = (float)a;
+    }
+  }
+  cx->lig_node_static = cx_upload(cx, ls.data(), ls.size());
+  cx->rec_node_static = cx_upload(cx, rs.data(), rs.size());
+  // ---- static receptor edges: geometry, SH and the distance half of rec_edge_embedding.0 --------
+  const int E = d->n_rec_edges;
+  std::vector<int32_t> outdeg(n_rec, 0);
+  std::vector<float> pre1((size_t)E * NS), sh((size_t)E * 4);
+  for (int k = 0; k < E; ++k) {
+    const int a = d->rec_edge_index[k], b = d->rec_edge_index[E + k];
+    if (a < 0 || a >= n_rec || b < 0 || b >= n_rec) return fail(ctx, DDK_ERR_INVALID, "receptor edge index out of range");
+    if (k > 0 && a < d->rec_edge_index[k - 1]) return fail(ctx, DDK_ERR_INVALID, "receptor edges must be grouped by source (process_mols.py:337-353 order)");
+    outdeg[a]++;
+    const float vx = d->rec_pos[3 * b] - d->rec_pos[3 * a], vy = d->rec_pos[3 * b + 1] - d->rec_pos[3 * a + 1],
+                vz = d->rec_pos[3 * b + 2] - d->rec_pos[3 * a + 2];
+    const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
+    const float inv = 1.7320508075688772f / fmaxf(dist, 1e-12f);
+    sh[4 * (size_t)k] = 1.0f; sh[4 * (size_t)k + 1] = vx * inv; sh[4 * (size_t)k + 2] = vy * inv; sh[4 * (size_t)k + 3] = vz * inv;
+    float gs[DE];
+    for (int q = 0; q < DE; ++q) { const float t = dist - H.rec_offset[q]; gs[q] = expf(H.rec_coeff * (t * t)); }
+    for (int o = 0; o < NS; ++o) {
+      float a2 = 0.0f;
+      for (int q = 0; q < DE; ++q) a2 += H.re_w1d[(size_t)o * DE + q] * gs[q];
+      pre1[(size_t)k * NS + o] = a2;
+    }
+  }
+  cx->rr_src = cx_upload(cx, d->rec_edge_index, (size_t)E);
+  cx->rr_dst = cx_upload(cx, d->rec_edge_index + E, (size_t)E);
+  cx->rr_outdeg = cx_upload(cx, outdeg.data(), outdeg.size());
+  cx->rr_pre1 = cx_upload(cx, pre1.data(), pre1.size());
+  cx->rr_sh = cx_upload(cx, sh.data(), sh.size());
+  // ---- workspaces -------------------------------------------------------------------------------
+  const int64_t Bm = max_batch;
+  cx->edge_cap = Bm * ((int64_t)M + (int64_t)n_lig * (LIG_CAP - 1) + 2LL * n_lig * n_rec + E) + 64;
+  if (cx->edge_cap >= ((int64_t)1 << 31)) return fail(ctx, DDK_ERR_INVALID, "edge capacity exceeds int32 (reduce max_batch)");
+  const int64_t N = Bm * (n_lig + n_rec);
+  cx->e_src = cx_upload<int32_t>(cx, nullptr, cx->edge_cap);
+  cx->e_dst = cx_upload<int32_t>(cx, nullptr, cx->edge_cap);
+  cx->e_aux = cx_upload<int32_t>(cx, nullptr, cx->edge_cap);
+  cx->e_emb = cx_upload<float>(cx, nullptr, cx->edge_cap * NS);
+  cx->e_sh = cx_upload<float>(cx, nullptr, cx->edge_cap * 4);
+  cx->deg = cx_upload<int32_t>(cx, nullptr, N);
+  cx->counts = cx_upload<int32_t>(cx, nullptr, Bm * 2);
+  cx->offs = cx_upload<int32_t>(cx, nullptr, Bm * 2);
+  cx->info = cx_upload<int32_t>(cx, nullptr, 64);
+  cx->xa = cx_upload<float>(cx, nullptr, N * XW);
+  cx->xb = cx_upload<float>(cx, nullptr, N * XW);
+  cx->sum = cx_upload<float>(cx, nullptr, N * XW);
+  cx->pos_tmp = cx_upload<float>(cx, nullptr, Bm * n_lig * 3);
+  cx->scores = cx_upload<float>(cx, nullptr, Bm * (6 + (d->n_rot > 0 ? d->n_rot : 1)));
+  for (void* p : cx->allocs)
+    if (!p) return fail(ctx, DDK_ERR_NOMEM, "device allocation failed in ddk_complex_create");
+  if (!cx->bond_src || !cx->rr_sh || !cx->scores) return fail(ctx, DDK_ERR_NOMEM, "device allocation failed in ddk_complex_create");
+  hipMemset(cx->info, 0, 64 * sizeof(int32_t));
+  return DDK_OK;
+}
+
+void ddk_complex_destroy(ddk_ctx* ctx, ddk_complex* cx) {
+  if (!cx) return;
+  if (ctx) hipSetDevice(ctx->cfg.device);
+  for (void* p : cx->allocs)
+    if (p) hipFree(p);
+  delete cx;
+}
+
+int ddk_score_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* lig_pos, float t_tr, float t_rot, float t_tor,
+                      float* tr_out, float* rot_out, float* tor_out, void* stream) {
+  int rc = check_model(ctx, cx, B);
+  if (rc) return rc;
+  StepParams sp;
+  if ((rc = make_step_params(ctx, t_tr, t_rot, t_tor, sp))) return rc;
+  return score_forward_impl(ctx, cx, B, lig_pos, sp, tr_out, rot_out, tor_out, (hipStream_t)stream);
+}
+
+int ddk_se3_update(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* pos, const float* tr, const float* rot,
+                   const float* tor, float* pos_out, void* stream) {
+  if (!ctx) return DDK_ERR_INVALID;
+  if (ctx->host_only) return fail(ctx, DDK_ERR_STATE, "host-only context (device < 0) cannot launch kernels");
+  if (!cx || B < 1) return fail(ctx, DDK_ERR_INVALID, "bad complex / batch");
+  Se3Args A;
+  A.pos = pos; A.tr = tr; A.rot = rot; A.tor = tor; A.noise = nullptr;
+  for (int k = 0; k < 3; ++k) { A.sc[k] = 1.0f; A.nc[k] = 0.0f; }
+  A.rot_u = cx->rot_u; A.rot_v = cx->rot_v; A.mask_rotate = cx->mask_rotate; A.B = B; A.n_lig = cx->n_lig; A.R = cx->R;
+  A.pos_out = pos_out;
+  hipError_t e = launch_se3(A, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(ctx, e, "se3_update launch");
+  return DDK_OK;
+}
+
+int ddk_sample(ddk_ctx* ctx, ddk_complex* cx, int32_t B, int32_t steps, const float* t, const float* score_coeff,
+               const float* noise_coeff, const float* noise, float* pos, void* stream) {
+  int rc = check_model(ctx, cx, B);
+  if (rc) return rc;
+  if (steps < 1 || !t || !score_coeff || !noise_coeff || !pos) return fail(ctx, DDK_ERR_INVALID, "ddk_sample: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  const int R = cx->R;
+  float* tr = cx->scores;
+  float* rot = tr + (size_t)B * 3;
+  float* tor = rot + (size_t)B * 3;
+  const bool torsion = !ctx->cfg.no_torsion && R > 0;
+  std::vector<StepParams> sps(steps);
+  for (int k = 0; k < steps; ++k)
+    if ((rc = make_step_params(ctx, t[3 * k], t[3 * k + 1], t[3 * k + 2], sps[k]))) return rc;
+  for (int k = 0; k < steps; ++k) {
+    if ((rc = score_forward_impl(ctx, cx, B, pos, sps[k], tr, rot, torsion ? tor : nullptr, s))) return rc;
+    Se3Args A;
+    A.pos = pos; A.tr = tr; A.rot = rot; A.tor = torsion ? tor : nullptr;
+    A.noise = noise ? noise + (size_t)k * B * (6 + R) : nullptr;
+    for (int j = 0; j < 3; ++j) { A.sc[j] = score_coeff[3 * k + j]; A.nc[j] = noise_coeff[3 * k + j]; }
+    A.rot_u = cx->rot_u; A.rot_v = cx->rot_v; A.mask_rotate = cx->mask_rotate; A.B = B; A.n_lig = cx->n_lig; A.R = R;
+    A.pos_out = cx->pos_tmp;
+    hipError_t e = launch_se3(A, s);
+    if (e != hipSuccess) return hip_fail(ctx, e, "se3_update launch");
+    e = hipMemcpyAsync(pos, cx->pos_tmp, (size_t)B * cx->n_lig * 3 * sizeof(float), hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) return hip_fail(ctx, e, "pos copy");
+  }
+  return DDK_OK;
+}
+
+int ddk_last_graph_stats(ddk_ctx* ctx, ddk_complex* cx, int64_t* out, void* stream) {
+  if (!ctx || !cx || !out) return DDK_ERR_INVALID;
+  int32_t info[32];
+  hipError_t e = hipMemcpyAsync(info, cx->info, sizeof(info), hipMemcpyDeviceToHost, (hipStream_t)stream);
+  if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(ctx, e, "graph stats readback");
+  for (int g = 0; g < 4; ++g) out[g] = info[6 + g] - info[5 + g];
+  out[4] = info[4];    // conv tiles
+  out[5] = info[23];   // total edges
+  out[6] = info[24];   // overflow flag
+  out[7] = cx->edge_cap;
+  return DDK_OK;
+}
+
+int ddk_last_node_features(ddk_ctx* ctx, ddk_complex* cx, int32_t B, float* lig_out, float* rec_out, void* stream) {
+  if (!ctx || !cx || !cx->x_last || B != cx->last_B) return fail(ctx, DDK_ERR_STATE, "no forward with this batch size has run");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t nl = (size_t)B * cx->n_lig * XW, nr = (size_t)B * cx->n_rec * XW;
+  hipError_t e = hipSuccess;
+  if (lig_out) e = hipMemcpyAsync(lig_out, cx->x_last, nl * sizeof(float), hipMemcpyDeviceToDevice, s);
+  if (e == hipSuccess && rec_out) e = hipMemcpyAsync(rec_out, cx->x_last + nl, nr * sizeof(float), hipMemcpyDeviceToDevice, s);
+  if (e != hipSuccess) return hip_fail(ctx, e, "node feature copy");
+  return DDK_OK;
+}
+
+// Test hook: copy raw device-side edge arrays of the last forward to host buffers (counts via ddk_last_graph_stats).
+int ddk_debug_read_edges(ddk_ctx* ctx, ddk_complex* cx, int64_t n, int32_t* src, int32_t* dst, float* emb, float* sh, int32_t* deg,
+                         int64_t n_nodes) {
+  if (!ctx || !cx) return DDK_ERR_INVALID;
+  hipDeviceSynchronize();
+  if (src) hipMemcpy(src, cx->e_src, n * 4, hipMemcpyDeviceToHost);
+  if (dst) hipMemcpy(dst, cx->e_dst, n * 4, hipMemcpyDeviceToHost);
+  if (emb) hipMemcpy(emb, cx->e_emb, n * NS * 4, hipMemcpyDeviceToHost);
+  if (sh) hipMemcpy(sh, cx->e_sh, n * 16, hipMemcpyDeviceToHost);
+  if (deg) hipMemcpy(deg, cx->deg, n_nodes * 4, hipMemcpyDeviceToHost);
+  return DDK_OK;
+}
+
+}  // extern "C"

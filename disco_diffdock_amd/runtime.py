@@ -132,3 +132,107 @@ class Context:
         self._check(self.L.ddk_conv_forward(self.h, layer, _ptr(x), N, _ptr(edge_src), _ptr(edge_dst), go, _ptr(edge_attr),
                                             _ptr(sh), _ptr(out), _stream()), 'ddk_conv_forward')
         return out
+
+
+class Complex:
+    """Device-resident static data of one complex (ddk_complex): topology, receptor embedding without its
+    sigma part, receptor-receptor geometry, and the per-forward workspaces for up to max_batch samples."""
+
+    def __init__(self, ctx, c, max_batch):
+        """c: dict with the arrays of SURVEY.md Appendix B.1 (numpy or torch): lig_x [n,16], bond_index [2,M],
+        bond_attr [M,4], edge_mask [M], mask_rotate [R,n], rec_x [n_rec,1+lm], rec_pos [n_rec,3], rec_edge_index [2,E]."""
+        self.ctx = ctx
+        f = lambda a, dt: np.ascontiguousarray(a.detach().cpu().numpy() if torch.is_tensor(a) else a, dtype=dt)
+        self.arr = dict(lig_x=f(c['lig_x'], np.int32), bond_index=f(c['bond_index'], np.int32), bond_attr=f(c['bond_attr'], np.float32),
+                        edge_mask=f(c['edge_mask'], np.uint8), mask_rotate=f(c['mask_rotate'], np.uint8).reshape(-1, len(c['lig_x'])),
+                        rec_x=f(c['rec_x'], np.float32), rec_pos=f(c['rec_pos'], np.float32),
+                        rec_edge_index=f(c['rec_edge_index'], np.int32))
+        a = self.arr
+        self.n_lig, self.n_rec = a['lig_x'].shape[0], a['rec_pos'].shape[0]
+        self.M, self.R, self.E_rr = a['bond_index'].shape[1], a['mask_rotate'].shape[0], a['rec_edge_index'].shape[1]
+        self.max_batch = max_batch
+        d = _lib.ddk_complex_desc(n_lig=self.n_lig, n_rec=self.n_rec, n_bond_edges=self.M, n_rot=self.R, n_rec_edges=self.E_rr,
+                                  rec_feat_dim=a['rec_x'].shape[1],
+                                  **{k: v.ctypes.data_as(C.c_void_p) for k, v in a.items()})
+        self.h = C.c_void_p()
+        rc = ctx.L.ddk_complex_create(ctx.h, C.byref(d), max_batch, C.byref(self.h))
+        if rc != 0:
+            msg = ctx.L.ddk_last_error(ctx.h).decode()
+            if self.h:
+                ctx.L.ddk_complex_destroy(ctx.h, self.h)
+                self.h = None
+            raise RuntimeError(f'ddk_complex_create: {msg}')
+
+    def close(self):
+        if getattr(self, 'h', None) and getattr(self.ctx, 'h', None):
+            self.ctx.L.ddk_complex_destroy(self.ctx.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- model.score_model(batch) ------------------------------------------------------------------
+    def score_forward(self, pos, t_tr, t_rot, t_tor):
+        ctx = self.ctx
+        pos = pos.contiguous().float().reshape(-1, self.n_lig, 3)
+        B = pos.shape[0]
+        dev = pos.device
+        tr = torch.empty((B, 3), dtype=torch.float32, device=dev)
+        rot = torch.empty((B, 3), dtype=torch.float32, device=dev)
+        tor = torch.empty((B * self.R,), dtype=torch.float32, device=dev)
+        ctx._check(ctx.L.ddk_score_forward(ctx.h, self.h, B, _ptr(pos), float(t_tr), float(t_rot), float(t_tor),
+                                           _ptr(tr), _ptr(rot), _ptr(tor), _stream()), 'ddk_score_forward')
+        return tr, rot, tor
+
+    def se3_update(self, pos, tr, rot, tor):
+        ctx = self.ctx
+        pos = pos.contiguous().float().reshape(-1, self.n_lig, 3)
+        B = pos.shape[0]
+        out = torch.empty_like(pos)
+        tr, rot = tr.contiguous().float(), rot.contiguous().float()
+        tor = tor.contiguous().float() if tor is not None else None
+        ctx._check(ctx.L.ddk_se3_update(ctx.h, self.h, B, _ptr(pos), _ptr(tr), _ptr(rot), _ptr(tor), _ptr(out), _stream()),
+                   'ddk_se3_update')
+        return out
+
+    def sample(self, pos, t, score_coeff, noise_coeff, noise=None):
+        """in-place reverse diffusion of pos [B,n_lig,3]; t/score_coeff/noise_coeff: [steps,3] host arrays."""
+        ctx = self.ctx
+        assert pos.is_contiguous() and pos.dtype == torch.float32
+        B = pos.numel() // (self.n_lig * 3)
+        t = np.ascontiguousarray(t, dtype=np.float32)
+        sc = np.ascontiguousarray(score_coeff, dtype=np.float32)
+        nc = np.ascontiguousarray(noise_coeff, dtype=np.float32)
+        steps = t.shape[0]
+        if noise is not None:
+            noise = noise.contiguous().float()
+            assert tuple(noise.shape) == (steps, B, 6 + self.R)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        ctx._check(ctx.L.ddk_sample(ctx.h, self.h, B, steps, p(t), p(sc), p(nc), _ptr(noise), _ptr(pos), _stream()), 'ddk_sample')
+        return pos
+
+    def graph_stats(self):
+        out = (C.c_int64 * 8)()
+        self.ctx._check(self.ctx.L.ddk_last_graph_stats(self.ctx.h, self.h, out, _stream()), 'ddk_last_graph_stats')
+        v = list(out)
+        if v[6]:
+            raise RuntimeError('ddk: edge capacity overflow')
+        return dict(E_ll=v[0], E_lr=v[1], E_rr=v[2], E_rl=v[3], tiles=v[4], E=v[5], cap=v[7])
+
+    def node_features(self, B, device):
+        lig = torch.empty((B * self.n_lig, 84), dtype=torch.float32, device=device)
+        rec = torch.empty((B * self.n_rec, 84), dtype=torch.float32, device=device)
+        self.ctx._check(self.ctx.L.ddk_last_node_features(self.ctx.h, self.h, B, _ptr(lig), _ptr(rec), _stream()), 'ddk_last_node_features')
+        return lig, rec
+
+    def read_edges(self, B):
+        st = self.graph_stats()
+        E, N = st['E'], B * (self.n_lig + self.n_rec)
+        src, dst = np.zeros(E, np.int32), np.zeros(E, np.int32)
+        emb, sh, deg = np.zeros((E, 24), np.float32), np.zeros((E, 4), np.float32), np.zeros(N, np.int32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        self.ctx.L.ddk_debug_read_edges(self.ctx.h, self.h, E, p(src), p(dst), p(emb), p(sh), p(deg), N)
+        return st, src, dst, emb, sh, deg

@@ -1,0 +1,221 @@
+#!/usr/bin/env python
+"""bench.py - headline benchmark of the ddk hot path (BASELINE.json metric):
+
+    complexes/sec, 20-step 40-sample reverse-diffusion inference of the DiffDock-S score model
+
+One "step" = the complete hot path for ONE complex: 40 samples x 20 reverse steps (score-model forward with the
+fused TP-conv kernels + SE(3)/torsion update), inputs already resident in HBM (complex uploaded, start poses on the
+device) when the timed region starts.  N = 1 workload = BASELINE.json configs[1]: 8 synthetic complexes
+(~30 ligand atoms / ~300 C-alpha), samples_per_complex = 40, 20 steps; the K timed steps cycle through them.
+N > 1: one process per GPU (torch.distributed, backend nccl == RCCL), every rank runs K steps on its own shard of
+complexes (weak scaling), no collective on the data path, one final pose gather.
+
+Prints ONE JSON line on rank 0, with two extra objects:
+  roofline      fused TP-conv kernel: algorithmic FLOPs of the launches in the timed region / their HIP-event time
+                vs the fp32 MFMA peak (the kernel is MFMA-bound), plus the algorithmic HBM bytes rate
+  cpu_baseline  the CPU oracle (PyTorch-CPU restatement of the reference, oracle/) timed on this box's host cores
+                on a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SAMPLES, STEPS, N_COMPLEXES, N_RES = 40, 20, 8, 300
+README_S = dict(temp_sampling=[1.886430780895051, 5.659562317960644, 2.8888668488630156],
+                temp_psi=[0.07085125444659945, 2.686505606141324, 4.089493860493927],
+                temp_sigma_data=[0.3617563913086843, 0.7437588205919711, 0.08897393057297842])
+W_LAYER = [720, 936, 1152, 1872, 1872]
+TP_FLOP = [2016, 2736, 3456, 5472, 5472]
+FUSED_BYTES = [408, 480, 552, 648, 648]                        # fused boundary, bytes per edge
+PEAK_F32_MFMA_TFLOPS = 157.3                                   # MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def model_args():
+    from argparse import Namespace
+    return Namespace(tr_sigma_min=0.1, tr_sigma_max=19.0, rot_sigma_min=0.03, rot_sigma_max=1.55, tor_sigma_min=0.03,
+                     tor_sigma_max=3.14, no_torsion=False)
+
+
+def start_poses(c, rng, samples, tr_sigma_max=19.0):
+    """randomize_position (reference utils/sampling.py:12-34): random torsions are skipped (synthetic ligands are
+    already random conformers), random rotation about the centroid + N(0, tr_sigma_max) translation."""
+    from scipy.spatial.transform import Rotation
+    lp = c['lig_pos'].astype(np.float64)
+    ctr = lp.mean(0, keepdims=True)
+    out = []
+    for _ in range(samples):
+        Rm = Rotation.random(random_state=rng).as_matrix()
+        out.append((lp - ctr) @ Rm.T + rng.normal(0, tr_sigma_max, size=(1, 3)))
+    return np.stack(out).astype(np.float32)
+
+
+def cpu_baseline(c, P, coeffs, seconds_budget=30.0):
+    """Time the CPU oracle on a bounded sample: `b` samples x 1 reverse step of one complex, extrapolated."""
+    from oracle import score_model_ref as smr, sampler_ref as spr, graph_lite
+    cfg = smr.ScoreModelConfig(latent_vocab=64)
+    d = os.path.join(ROOT, 'disco_diffdock_amd', 'data')
+    tables = (np.load(os.path.join(d, 'so3_exp_score_norms.npy')), np.load(os.path.join(d, 'torus_score_norm_seed0.npy')))
+    b = 2
+    rng = np.random.default_rng(0)
+    pos = start_poses(c, rng, b)
+
+    def graph():
+        g = graph_lite.make_complex(c['lig_x'], c['lig_pos'], c['bond_index'], c['bond_attr'], c['edge_mask'], c['mask_rotate'],
+                                    c['rec_x'], c['rec_pos'], c['rec_edge_index'])
+        g['ligand'].mask_rotate = [g['ligand'].mask_rotate]
+        return g
+    times = []
+    t_arr, sc, nc = coeffs
+    for rep in range(3):
+        dl = [graph() for _ in range(b)]
+        for g, p in zip(dl, pos):
+            g['ligand'].pos = torch.from_numpy(p)
+        batch = graph_lite.collate(dl)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            spr.set_time(batch, 1.0, 1.0, 1.0, b)
+            tr, rot, tor = smr.score_model_forward(P, cfg, batch, tables[0], tables[1])
+            spr.modify_conformer_batch(batch['ligand'].pos, batch, sc[0, 0] * tr, sc[0, 1] * rot, sc[0, 2] * tor,
+                                       torch.from_numpy(c['mask_rotate']))
+        times.append(time.perf_counter() - t0)
+        if sum(times) > seconds_budget:
+            break
+    t_step = float(np.median(times[1:] if len(times) > 1 else times))
+    per_complex = t_step * STEPS * (SAMPLES / b)
+    return dict(value=1.0 / per_complex, unit='complexes/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'oracle (PyTorch-CPU restatement, materialised [E,W] weights): {b} samples x 1 reverse step at t=1 of one '
+                       f'{N_RES}-residue complex, median of {max(len(times) - 1, 1)} warm runs = {t_step:.2f} s, extrapolated x{STEPS} steps x{SAMPLES // b} '
+                       f'(batch {SAMPLES})')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    a = ap.parse_args()
+    rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    import torch.distributed as dist
+    if world > 1:
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+
+    from functools import partial
+    from disco_diffdock_amd import build, synthetic
+    from disco_diffdock_amd.runtime import Context, Complex
+    from disco_diffdock_amd.sampling import step_coefficients
+    from disco_diffdock_amd.diffusion_utils import t_to_sigma, get_t_schedule
+    from disco_diffdock_amd.distributed import shard_indices, gather_poses
+    build.build(verbose=False)
+
+    # ---- workload: this rank's shard of the (world * 8) synthetic complexes ---------------------------------
+    n_total = N_COMPLEXES * world
+    mine = [rank * N_COMPLEXES + i for i in range(N_COMPLEXES)] if world == 1 else \
+        shard_indices([1.0] * n_total, rank, world)
+    complexes = {i: synthetic.make_complex(i, n_res=N_RES) for i in mine}
+    P = synthetic.random_score_model_state_dict(seed=0)
+    ctx = Context(device=local)
+    ctx.load_state_dict(P)
+    margs = model_args()
+    sched = get_t_schedule(STEPS)
+    coeffs = step_coefficients(STEPS, sched, sched, sched, partial(t_to_sigma, args=margs), margs, False, False, True,
+                               README_S['temp_sampling'], README_S['temp_psi'], README_S['temp_sigma_data'])
+    t_arr, sc, nc = coeffs
+    cxs, poses0, noises = {}, {}, {}
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    for i in mine:
+        c = complexes[i]
+        cxs[i] = Complex(ctx, c, SAMPLES)
+        poses0[i] = torch.from_numpy(start_poses(c, np.random.default_rng(i), SAMPLES)).to(dev)
+        noises[i] = torch.randn((STEPS, SAMPLES, 6 + cxs[i].R), device=dev, generator=gen)
+    order = [mine[k % len(mine)] for k in range(a.warmup + a.steps)]
+
+    def run_one(i):
+        pos = poses0[i].clone()
+        cxs[i].sample(pos, t_arr, sc, nc, noises[i])
+        return pos
+
+    for k in range(a.warmup):
+        run_one(order[k])
+    torch.cuda.synchronize()
+    ctx.profile_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    final = {}
+    for k in range(a.warmup, a.warmup + a.steps):
+        final[order[k]] = run_one(order[k])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        # the one exchange of the path: final poses of every complex to every rank (RCCL over xGMI)
+        nl = torch.zeros(n_total, dtype=torch.int64, device=dev)
+        for i in mine:
+            nl[i] = cxs[i].n_lig
+        dist.all_reduce(nl)
+        if len(final) == len(mine):
+            gathered = gather_poses(final, [int(v) for v in nl.tolist()], SAMPLES, dev)
+            assert len(gathered) == n_total
+    for p in final.values():
+        assert bool(torch.isfinite(p).all()), 'non-finite pose'
+
+    if rank == 0:
+        conv_ms = sum(p['ms'] for p in prof)
+        flops = sum(p['edges'] * (2 * 72 * (72 + W_LAYER[l]) + TP_FLOP[l]) for l, p in enumerate(prof))
+        byts = sum(p['edges'] * FUSED_BYTES[l] for l, p in enumerate(prof))
+        launches = sum(p['launches'] for p in prof)
+        achieved = flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        out = {
+            'metric': 'complexes/sec, 20-step 40-sample inference',
+            'value': world * a.steps / elapsed, 'unit': 'complexes/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'DiffDock-S score model (random-init weights, reference state_dict layout), 8 synthetic complexes per GPU '
+                                   '(20-40 ligand atoms / 300 C-alpha, 24-NN receptor graph), samples_per_complex=40, inference_steps=20, '
+                                   'README low-temperature sampling, no_final_step_noise; 1 step = 1 complex',
+                       'samples_per_complex': SAMPLES, 'inference_steps': STEPS, 'complexes_per_gpu': N_COMPLEXES,
+                       'parallelism': f'complexes sharded over {world} process(es), one per GPU, final RCCL pose gather'},
+            'roofline': {'bound': 'mfma', 'kernel': 'ddk::conv_fused_kernel<true>', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS,
+                         'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                         'launches': launches, 'avg_launch_ms': conv_ms / max(launches, 1),
+                         'flop_per_launch': flops / max(launches, 1),
+                         'algorithmic_hbm_GBps': byts / (conv_ms * 1e-3) / 1e9 if conv_ms > 0 else 0.0,
+                         'algorithmic_hbm_frac_of_peak': (byts / (conv_ms * 1e-3) / 1e9) / PEAK_HBM_GBS if conv_ms > 0 else 0.0,
+                         'conv_share_of_wall': conv_ms * 1e-3 / elapsed,
+                         'per_layer': [{'layer': l, 'ms_per_launch': p['ms'] / max(p['launches'], 1),
+                                        'TFLOPs': p['edges'] * (2 * 72 * (72 + W_LAYER[l]) + TP_FLOP[l]) / max(p['ms'], 1e-9) / 1e9}
+                                       for l, p in enumerate(prof)]},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(complexes[mine[0]], P, coeffs)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -286,6 +286,8 @@ void ddk_destroy(ddk_ctx* ctx) {
   if (!ctx->host_only) {
     hipSetDevice(ctx->cfg.device);
     model_destroy(ctx);
+    for (auto& r : ctx->prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    if (ctx->prof_edges) hipHostFree(ctx->prof_edges);
     for (void* p : ctx->dev_allocs) hipFree(p);
     if (ctx->ws.xpad) hipFree(ctx->ws.xpad);
     if (ctx->ws.sum) hipFree(ctx->ws.sum);

@@ -104,6 +104,12 @@ struct ddk_ctx {
   std::vector<void*> dev_allocs;
   // packed small weights for the non-conv kernels live in model.hip (opaque here)
   void* model = nullptr;
+  // profiling (ddk_profile_enable / ddk_profile_read)
+  bool prof = false;
+  struct ProfRec { hipEvent_t a, b; int layer; int slot; };
+  std::vector<ProfRec> prof_recs;
+  int32_t* prof_edges = nullptr;   // pinned host: total edges of forward #slot
+  int prof_slots = 0, prof_cap = 0;
 };
 
 namespace ddk {

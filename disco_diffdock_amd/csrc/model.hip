@@ -261,12 +261,27 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
     a.x = xin; a.src = cx->e_src; a.dst = cx->e_dst; a.edge_attr = cx->e_emb; a.sh = cx->e_sh; a.sum = cx->sum;
     a.tile_info = cx->info; a.counter = cx->info + 10 + (l % 8); a.gather = 1;
     if (l >= 8) CK(hipMemsetAsync(cx->info + 10 + (l % 8), 0, sizeof(int32_t), s), "counter reset");
+    ddk_ctx::ProfRec pr;
+    const bool prof = ctx->prof && ctx->prof_slots < ctx->prof_cap;
+    if (prof) {
+      CK(hipEventCreate(&pr.a), "event"); CK(hipEventCreate(&pr.b), "event");
+      pr.layer = l; pr.slot = ctx->prof_slots;
+      CK(hipEventRecord(pr.a, s), "event record");
+    }
     CK(launch_conv_fused(L, a, ctx->n_cu, s), "conv_fused");
+    if (prof) {
+      CK(hipEventRecord(pr.b, s), "event record");
+      ctx->prof_recs.push_back(pr);
+    }
     CK(launch_node_finalize(cx->sum, cx->deg, xin, L.bn_mean, L.bn_scale, L.bn_bias, N, L.dout, XW, xout, s), "node_finalize");
     float* t = xin; xin = xout; xout = t;
   }
   cx->x_last = xin;
   cx->last_B = B;
+  if (ctx->prof && ctx->prof_slots < ctx->prof_cap) {
+    CK(hipMemcpyAsync(ctx->prof_edges + ctx->prof_slots, cx->info + 23, sizeof(int32_t), hipMemcpyDeviceToHost, s), "profile edge count");
+    ctx->prof_slots++;
+  }
   HeadArgs Hd;
   Hd.lig_pos = lig_pos; Hd.x = xin; Hd.md = M->dev; Hd.sp = sp; Hd.B = B; Hd.n_lig = n_lig; Hd.R = cx->R;
   Hd.scale_by_sigma = c.scale_by_sigma; Hd.rot_u = cx->rot_u; Hd.rot_v = cx->rot_v; Hd.lig_r2 = c.lig_max_radius * c.lig_max_radius;
@@ -295,12 +310,15 @@ extern "C" {
 int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batch, ddk_complex** out) {
   if (!ctx || !d || !out) return DDK_ERR_INVALID;
   if (ctx->host_only) return fail(ctx, DDK_ERR_STATE, "host-only context (device < 0) cannot hold device data");
-  if (!ctx->finalized || !ctx->model) return fail(ctx, DDK_ERR_STATE, "score model weights not loaded / finalised");
+  if (!ctx->finalized) return fail(ctx, DDK_ERR_STATE, "ddk_finalize_weights has not run");
   const ddk_config& c = ctx->cfg;
-  const ModelHost& H = ((Model*)ctx->model)->host;
+  // without a loaded score model the complex carries topology only (enough for ddk_se3_update)
+  const bool has_model = ctx->model != nullptr;
+  static const ModelHost no_model;
+  const ModelHost& H = has_model ? ((Model*)ctx->model)->host : no_model;
   if (d->n_lig < 1 || d->n_lig > MAX_LIG) return fail(ctx, DDK_ERR_INVALID, "n_lig must be in [1, 256]");
   if (d->n_rec < 1 || d->n_rec > MAX_REC) return fail(ctx, DDK_ERR_INVALID, "n_rec must be in [1, 8192]");
-  if (d->rec_feat_dim != 1 + c.lm_embedding_dim) return fail(ctx, DDK_ERR_INVALID, "receptor feature width != 1 + lm_embedding_dim");
+  if (has_model && d->rec_feat_dim != 1 + c.lm_embedding_dim) return fail(ctx, DDK_ERR_INVALID, "receptor feature width != 1 + lm_embedding_dim");
   if (max_batch < 1) return fail(ctx, DDK_ERR_INVALID, "max_batch < 1");
   hipSetDevice(c.device);
   ddk_complex* cx = new ddk_complex();
@@ -328,7 +346,7 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
   cx->rec_pos = cx_upload(cx, d->rec_pos, (size_t)n_rec * 3);
   // ---- static node embeddings (AtomEncoder without its sigma columns, models/layers.py:140-149) ----
   std::vector<float> ls((size_t)n_lig * NS), rs((size_t)n_rec * NS);
-  for (int i = 0; i < n_lig; ++i) {
+  for (int i = 0; has_model && i < n_lig; ++i) {
     float emb[NS] = {0};
     for (int f = 0; f < 16; ++f) {
       const int v = d->lig_x[(size_t)i * 16 + f];
@@ -342,7 +360,7 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
       ls[(size_t)i * NS + o] = (float)a;
     }
   }
-  for (int j = 0; j < n_rec; ++j) {
+  for (int j = 0; has_model && j < n_rec; ++j) {
     const float* xr = d->rec_x + (size_t)j * d->rec_feat_dim;
     const int res = (int)xr[0];
     if (res < 0 || res >= REC_DIM) return fail(ctx, DDK_ERR_INVALID, "residue id out of range");
@@ -371,6 +389,7 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
     const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
     const float inv = 1.7320508075688772f / fmaxf(dist, 1e-12f);
     sh[4 * (size_t)k] = 1.0f; sh[4 * (size_t)k + 1] = vx * inv; sh[4 * (size_t)k + 2] = vy * inv; sh[4 * (size_t)k + 3] = vz * inv;
+    if (!has_model) continue;
     float gs[DE];
     for (int q = 0; q < DE; ++q) { const float t = dist - H.rec_offset[q]; gs[q] = expf(H.rec_coeff * (t * t)); }
     for (int o = 0; o < NS; ++o) {
@@ -494,6 +513,39 @@ int ddk_last_node_features(ddk_ctx* ctx, ddk_complex* cx, int32_t B, float* lig_
   if (lig_out) e = hipMemcpyAsync(lig_out, cx->x_last, nl * sizeof(float), hipMemcpyDeviceToDevice, s);
   if (e == hipSuccess && rec_out) e = hipMemcpyAsync(rec_out, cx->x_last + nl, nr * sizeof(float), hipMemcpyDeviceToDevice, s);
   if (e != hipSuccess) return hip_fail(ctx, e, "node feature copy");
+  return DDK_OK;
+}
+
+int ddk_profile_enable(ddk_ctx* ctx, int32_t on) {
+  if (!ctx) return DDK_ERR_INVALID;
+  if (ctx->host_only) return fail(ctx, DDK_ERR_STATE, "host-only context");
+  for (auto& r : ctx->prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+  ctx->prof_recs.clear();
+  ctx->prof_slots = 0;
+  if (on && !ctx->prof_edges) {
+    ctx->prof_cap = 16384;
+    if (hipHostMalloc((void**)&ctx->prof_edges, ctx->prof_cap * sizeof(int32_t)) != hipSuccess)
+      return fail(ctx, DDK_ERR_NOMEM, "hipHostMalloc failed");
+  }
+  ctx->prof = on != 0;
+  return DDK_OK;
+}
+
+int ddk_profile_read(ddk_ctx* ctx, double* out, int32_t n) {
+  if (!ctx || !out) return DDK_ERR_INVALID;
+  const int L = ctx->cfg.num_conv_layers;
+  if (n < 3 * L) return fail(ctx, DDK_ERR_INVALID, "profile buffer too small");
+  for (int i = 0; i < 3 * L; ++i) out[i] = 0.0;
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) return hip_fail(ctx, e, "profile sync");
+  for (auto& r : ctx->prof_recs) {
+    float ms = 0.f;
+    e = hipEventElapsedTime(&ms, r.a, r.b);
+    if (e != hipSuccess) return hip_fail(ctx, e, "hipEventElapsedTime");
+    out[3 * r.layer] += ms;
+    out[3 * r.layer + 1] += 1.0;
+    out[3 * r.layer + 2] += (double)ctx->prof_edges[r.slot];
+  }
   return DDK_OK;
 }
 

@@ -1,0 +1,36 @@
+"""Multi-GPU layout of the hot path: complexes are independent units -> shard them across ranks
+(one process per GPU) with NO collective on the data path; one final gather of the poses over RCCL
+(backend 'nccl' on ROCm) / gloo on CPU tests."""
+import torch
+import torch.distributed as dist
+
+
+def shard_indices(costs, rank, world):
+    """Greedy longest-processing-time partition: complexes sorted by descending cost (~ n_rec * n_lig), each
+    assigned to the currently least loaded rank.  Deterministic; every rank computes the same assignment."""
+    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+    loads = [0.0] * world
+    mine = []
+    for i in order:
+        r = min(range(world), key=lambda k: (loads[k], k))
+        loads[r] += costs[i]
+        if r == rank:
+            mine.append(i)
+    return sorted(mine)
+
+
+def gather_poses(poses, n_lig, samples, device):
+    """poses: {complex index: tensor [samples, n_lig_i, 3]} held by this rank -> on every rank the full
+    {index: tensor}.  One padded all_gather ([n_complexes, samples, max n_lig, 3] fp32, a few MB)."""
+    n = len(n_lig)
+    nmax = max(n_lig)
+    buf = torch.zeros((n, samples, nmax, 3), dtype=torch.float32, device=device)
+    own = torch.zeros(n, dtype=torch.float32, device=device)
+    for i, p in poses.items():
+        buf[i, :, :n_lig[i]] = p.to(device)
+        own[i] = 1.0
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)      # every slot is written by exactly one rank
+        dist.all_reduce(own, op=dist.ReduceOp.SUM)
+    assert bool((own == 1).all()), 'every complex must be owned by exactly one rank'
+    return {i: buf[i, :, :n_lig[i]].clone() for i in range(n)}

@@ -1,0 +1,34 @@
+"""Host mirror of utils/model_utils.py:25-101 (get_model): model_parameters.yml Namespace -> score model."""
+from functools import partial
+
+import torch
+
+from .diffusion_utils import get_timestep_embedding, t_to_sigma as t_to_sigma_compl
+from .score_model import TensorProductScoreModel, ModelWrapper
+
+
+def get_model(args, device, t_to_sigma, no_parallel=False, confidence_mode=False):
+    if 'all_atoms' in args and args.all_atoms:
+        raise RuntimeError('ddk: the all-atom (confidence) model is outside the accelerated hot path')
+    if confidence_mode:
+        raise RuntimeError('ddk: confidence_mode is outside the accelerated hot path')
+    g = lambda k, d: getattr(args, k, d)
+    if g('latent_dim', 0) > 0:
+        raise RuntimeError('ddk: latent conditioning (DisCo-DiffDock-S, latent_dim > 0) is not implemented on the device yet')
+    lm = 'esm' if g('esm_embeddings_path', None) is not None else None
+    score_model = TensorProductScoreModel(
+        t_to_sigma=t_to_sigma, device=device, no_torsion=args.no_torsion,
+        timestep_emb_func=get_timestep_embedding(args.embedding_type, args.sigma_embed_dim, args.embedding_scale),
+        num_conv_layers=args.num_conv_layers, lig_max_radius=args.max_radius, scale_by_sigma=args.scale_by_sigma,
+        sigma_embed_dim=args.sigma_embed_dim, ns=args.ns, nv=args.nv, distance_embed_dim=args.distance_embed_dim,
+        cross_distance_embed_dim=args.cross_distance_embed_dim, batch_norm=not args.no_batch_norm, dropout=args.dropout,
+        sh_lmax=g('sh_lmax', 2), use_second_order_repr=args.use_second_order_repr, cross_max_distance=args.cross_max_distance,
+        dynamic_max_cross=args.dynamic_max_cross, lm_embedding_type=lm, confidence_mode=confidence_mode,
+        use_old_atom_encoder=g('use_old_atom_encoder', True), latent_dim=g('latent_dim', 0), latent_vocab=g('latent_vocab', 0),
+        latent_cross_attention=g('latent_cross_attention', False), latent_droprate=g('latent_droprate', 0),
+        embedding_scale=args.embedding_scale,
+        sigma_limits=dict(tr_sigma_min=args.tr_sigma_min, tr_sigma_max=args.tr_sigma_max, rot_sigma_min=args.rot_sigma_min,
+                          rot_sigma_max=args.rot_sigma_max, tor_sigma_min=args.tor_sigma_min, tor_sigma_max=args.tor_sigma_max))
+    if hasattr(args, 'latent_vocab'):
+        return ModelWrapper(encoder=None, score_model=score_model)   # model_utils.py:93-94
+    return score_model

@@ -115,6 +115,17 @@ class Context:
         self.L.ddk_debug_export(self.h, what.encode(), buf.ctypes.data_as(C.c_void_p), n)
         return buf
 
+    # ---- measurement -------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._check(self.L.ddk_profile_enable(self.h, int(on)), 'ddk_profile_enable')
+
+    def profile_read(self):
+        n = 3 * self.cfg.num_conv_layers
+        buf = (C.c_double * n)()
+        self._check(self.L.ddk_profile_read(self.h, buf, n), 'ddk_profile_read')
+        a = np.array(list(buf)).reshape(-1, 3)
+        return [dict(ms=float(r[0]), launches=int(r[1]), edges=int(r[2])) for r in a]
+
     # ---- operators ---------------------------------------------------------------------------
     def tp_forward(self, layer, x_dst, sh, w, dout):
         x_dst, sh, w = x_dst.contiguous().float(), sh.contiguous().float(), w.contiguous().float()

@@ -1,0 +1,149 @@
+"""Host mirror of the reference's utils/sampling.py: same ``sampling(...)`` signature and return value
+(sampling.py:49-54,249) and ``randomize_position`` (:12-46).  The 20-step loop itself - score model forward,
+SDE perturbation, SE(3)/torsion update, Kabsch re-alignment - runs inside libddk.so (``ddk_sample``) without any
+host synchronisation; this file only prepares the per-step host scalars exactly as the reference computes them.
+Options outside the accelerated path (confidence model, AR/latent models, classifier-free guidance, visualisation)
+raise instead of silently doing something else."""
+import copy
+
+import numpy as np
+import torch
+
+from .data import DataLoader
+from .score_model import complex_for_batch
+
+
+def is_iterable(arr):
+    try:
+        iter(arr)
+        return True
+    except TypeError:
+        return False
+
+
+def _modify_conformer_torsion_angles_np(pos, edge_index, mask_rotate, torsion_updates):
+    """utils/torsion.py:48-68 (numpy/scipy variant used for the initial randomisation)."""
+    from scipy.spatial.transform import Rotation as R
+    pos = copy.deepcopy(pos)
+    if type(pos) != np.ndarray:
+        pos = pos.cpu().numpy()
+    for idx_edge, e in enumerate(edge_index.cpu().numpy()):
+        if torsion_updates[idx_edge] == 0:
+            continue
+        u, v = e[0], e[1]
+        assert not mask_rotate[idx_edge, u] and mask_rotate[idx_edge, v]
+        rot_vec = pos[u] - pos[v]
+        rot_vec = rot_vec * torsion_updates[idx_edge] / np.linalg.norm(rot_vec)
+        rot_mat = R.from_rotvec(rot_vec).as_matrix()
+        pos[mask_rotate[idx_edge]] = (pos[mask_rotate[idx_edge]] - pos[v]) @ rot_mat.T + pos[v]
+    return torch.from_numpy(pos.astype(np.float32))
+
+
+def randomize_position(data_list, no_torsion, no_random, tr_sigma_max, unbatched=False, ar_args=None):
+    from scipy.spatial.transform import Rotation as R
+    if ar_args is not None:
+        raise RuntimeError('ddk: the AR latent model is outside the accelerated hot path')
+    if not no_torsion:
+        for g in data_list:
+            upd = np.random.uniform(low=-np.pi, high=np.pi, size=int(g['ligand'].edge_mask.sum()))
+            g['ligand'].pos = _modify_conformer_torsion_angles_np(
+                g['ligand'].pos, g['ligand', 'ligand'].edge_index.T[g['ligand'].edge_mask],
+                g['ligand'].mask_rotate[0] if not unbatched else g['ligand'].mask_rotate, upd)
+    for g in data_list:
+        center = torch.mean(g['ligand'].pos, dim=0, keepdim=True)
+        rot = torch.from_numpy(R.random().as_matrix()).float()
+        g['ligand'].pos = (g['ligand'].pos - center) @ rot.T
+        if not no_random:
+            g['ligand'].pos = g['ligand'].pos + torch.normal(mean=0, std=tr_sigma_max, size=(1, 3))
+
+
+def step_coefficients(inference_steps, tr_schedule, rot_schedule, tor_schedule, t_to_sigma, model_args, ode, no_random,
+                      no_final_step_noise, temp_sampling, temp_psi, temp_sigma_data):
+    """Host scalars of every reverse step, formed with the reference's expressions and dtypes
+    (utils/sampling.py:106-111,137-192): perturb = score_coeff*score + noise_coeff*z per tr/rot/tor."""
+    if not is_iterable(temp_sampling):
+        temp_sampling = [temp_sampling] * 3
+    if not is_iterable(temp_psi):
+        temp_psi = [temp_psi] * 3
+    if not is_iterable(temp_sigma_data):
+        temp_sigma_data = [temp_sigma_data] * 3
+    assert len(temp_sampling) == 3 and len(temp_psi) == 3 and len(temp_sigma_data) == 3
+    scheds = (tr_schedule, rot_schedule, tor_schedule)
+    lims = ((model_args.tr_sigma_min, model_args.tr_sigma_max), (model_args.rot_sigma_min, model_args.rot_sigma_max),
+            (model_args.tor_sigma_min, model_args.tor_sigma_max))
+    t_arr = np.zeros((inference_steps, 3), np.float32)
+    sc = np.zeros((inference_steps, 3), np.float32)
+    nc = np.zeros((inference_steps, 3), np.float32)
+    for t_idx in range(inference_steps):
+        ts = [s[t_idx] for s in scheds]
+        sig = t_to_sigma(*ts)
+        zero = no_random or (no_final_step_noise and t_idx == inference_steps - 1)
+        for k in range(3):
+            s = scheds[k]
+            dt = s[t_idx] - s[t_idx + 1] if t_idx < inference_steps - 1 else s[t_idx]
+            lo, hi = lims[k]
+            g = sig[k] * torch.sqrt(torch.tensor(2 * np.log(hi / lo)))
+            if ode:
+                a, b = 0.5 * g ** 2 * dt, 0.0 * g
+                if temp_sampling[k] != 1.0:
+                    raise RuntimeError('ode=True with temp_sampling != 1 is undefined in the reference (sampling.py:142-144 vs :182)')
+            else:
+                a, b = g ** 2 * dt, g * np.sqrt(dt)
+            if temp_sampling[k] != 1.0:
+                sd = np.exp(temp_sigma_data[k] * np.log(hi) + (1 - temp_sigma_data[k]) * np.log(lo))
+                lam = (sd + sig[k]) / (sd + sig[k] / temp_sampling[k])
+                a = g ** 2 * dt * (lam + temp_sampling[k] * temp_psi[k] / 2)
+                b = g * np.sqrt(dt * (1 + temp_psi[k]))
+            t_arr[t_idx, k] = ts[k]
+            sc[t_idx, k] = float(a)
+            nc[t_idx, k] = 0.0 if zero else float(b)
+    return t_arr, sc, nc
+
+
+def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_schedule, device, t_to_sigma, model_args,
+             no_random=False, ode=False, visualization_list=None, confidence_model=None, confidence_data_list=None,
+             confidence_model_args=None, batch_size=32, no_final_step_noise=False, use_latent=True,
+             gumbel_latent_temperature=0.01, ar_model=None, ar_args=None, temp_sampling=1.0, temp_psi=0.0, temp_sigma_data=0.5,
+             classifier_free_guidance_weight=0.0, softmax_latent_temperature=1.0, cfg_start=1.0, cfg_end=0.0,
+             compute_ar_accuracy=False, noise=None):
+    """``noise`` (extra, optional): list with one tensor [steps, b, 6+R] per batch of N(0,1) draws (tr xyz, rot xyz,
+    torsions) to replace the device generator - used by the parity tests (the reference never seeds its RNGs)."""
+    if confidence_model is not None or ar_model is not None or visualization_list is not None:
+        raise RuntimeError('ddk: confidence / AR models and visualisation are outside the accelerated hot path')
+    if classifier_free_guidance_weight != 0.0:
+        raise RuntimeError('ddk: classifier-free guidance needs the latent-conditioned model (not implemented on the device)')
+    if use_latent and getattr(model_args, 'latent_dim', 0) > 0:
+        raise RuntimeError('ddk: latent conditioning (latent_dim > 0) is not implemented on the device yet')
+    device = torch.device(device)
+    if device.type != 'cuda':
+        raise RuntimeError('ddk sampling runs on the GPU only (no CPU fallback)')
+    N = len(data_list)
+    loader = DataLoader(data_list, batch_size=batch_size)
+    score_model = model.module.score_model if hasattr(model, 'module') else getattr(model, 'score_model', model)
+    t_arr, sc, nc = step_coefficients(inference_steps, tr_schedule, rot_schedule, tor_schedule, t_to_sigma, model_args, ode,
+                                      no_random, no_final_step_noise, temp_sampling, temp_psi, temp_sigma_data)
+    with torch.no_grad():
+        for batch_id, batch in enumerate(loader):
+            b = batch.num_graphs
+            if b != min(batch_size, N):
+                raise RuntimeError('ragged last batch: the reference draws noise of size min(batch_size, N) (sampling.py:146-153)')
+            cx, _ = complex_for_batch(batch, device, ctx=score_model.ctx)
+            pos = batch['ligand'].pos.to(device).float().reshape(b, -1, 3).contiguous()
+            R = cx.R if not model_args.no_torsion else 0
+            if noise is not None:
+                z = noise[batch_id].to(device)
+            elif no_random or ode:
+                z = None
+            else:
+                z = torch.empty((inference_steps, b, 6 + cx.R), device=device)
+                for t_idx in range(inference_steps):   # draw order of the reference: tr, rot, tor per step
+                    z[t_idx, :, 0:3] = torch.normal(mean=0, std=1, size=(b, 3), device=device)
+                    z[t_idx, :, 3:6] = torch.normal(mean=0, std=1, size=(b, 3), device=device)
+                    if R:
+                        z[t_idx, :, 6:] = torch.normal(mean=0, std=1, size=(b * R,), device=device).reshape(b, R)
+            cx.sample(pos, t_arr, sc, nc, z)
+            len_lig = pos.shape[1]
+            flat = pos.reshape(-1, 3)
+            for i in range(b):
+                data_list[batch_id * batch_size + i]['ligand'].pos = flat[i * len_lig:len_lig * (i + 1)]
+    return data_list, None

@@ -1,0 +1,125 @@
+"""Host mirror of the reference's models/score_model.py call surface: ``TensorProductScoreModel`` whose
+``forward(batch) -> (tr_pred [B,3], rot_pred [B,3], tor_pred [sum R])`` (score_model.py:259-308) runs entirely in
+libddk.so.  The checkpoint format is the reference's ``score_model.state_dict()`` (evaluate.py:169-171)."""
+import numpy as np
+import torch
+from torch import nn
+
+from .runtime import Context, Complex, config_from_args, DEFAULTS
+
+_complex_cache = {}
+_default_ctx = {}
+
+
+def _fingerprint(batch, B):
+    lig, rec = batch['ligand'], batch['receptor']
+    n_l, n_r = lig.num_nodes // B, rec.num_nodes // B
+    x0 = lig.x[:n_l]
+    rp = rec.pos[:n_r]
+    return (B, n_l, n_r, int(x0.sum().item()), float(rp.double().sum().item()), float(rec.x[:n_r, 1:9].double().sum().item()),
+            batch['ligand', 'ligand'].num_edges // B, batch['receptor', 'receptor'].num_edges // B)
+
+
+def arrays_from_batch(batch, B, mask_rotate=None):
+    """Slice the first graph out of a batch of B copies of one complex (utils/sampling.py:57, Appendix A.10)."""
+    lig, rec = batch['ligand'], batch['receptor']
+    n_l, n_r = lig.num_nodes // B, rec.num_nodes // B
+    M = batch['ligand', 'ligand'].num_edges // B
+    E = batch['receptor', 'receptor'].num_edges // B
+    if mask_rotate is None:
+        mr = lig.mask_rotate
+        while isinstance(mr, (list, tuple)):
+            mr = mr[0]
+        mask_rotate = mr
+    mask_rotate = mask_rotate.cpu().numpy() if torch.is_tensor(mask_rotate) else np.asarray(mask_rotate)
+    return dict(lig_x=lig.x[:n_l].cpu(), bond_index=batch['ligand', 'ligand'].edge_index[:, :M].cpu(),
+                bond_attr=batch['ligand', 'ligand'].edge_attr[:M].cpu(), edge_mask=lig.edge_mask[:M].cpu(),
+                mask_rotate=mask_rotate.reshape(-1, n_l), rec_x=rec.x[:n_r].cpu(), rec_pos=rec.pos[:n_r].cpu(),
+                rec_edge_index=batch['receptor', 'receptor'].edge_index[:, :E].cpu())
+
+
+def complex_for_batch(batch, device, ctx=None, mask_rotate=None, need_model=True):
+    B = batch.num_graphs
+    if ctx is None:
+        if need_model:
+            raise RuntimeError('ddk: no model context bound to this call')
+        from .tensor_layers import _shape_context
+        ctx = _shape_context(device.index or 0)
+    key = (id(ctx),) + _fingerprint(batch, B)
+    cx = _complex_cache.get(key)
+    if cx is None or cx.max_batch < B:
+        if len(_complex_cache) > 8:
+            _complex_cache.clear()
+        cx = Complex(ctx, arrays_from_batch(batch, B, mask_rotate), max_batch=B)
+        _complex_cache[key] = cx
+    return cx, B
+
+
+class TensorProductScoreModel(nn.Module):
+    """Constructor keywords follow models/score_model.py:15-24; only the coarse-grained sh_lmax=1 score model
+    (DiffDock-S) is implemented on the device - anything else raises instead of silently falling back."""
+
+    def __init__(self, t_to_sigma=None, device=None, timestep_emb_func=None, in_lig_edge_features=4, sigma_embed_dim=32,
+                 sh_lmax=2, ns=16, nv=4, num_conv_layers=2, lig_max_radius=5, rec_max_radius=30, cross_max_distance=250,
+                 center_max_distance=30, distance_embed_dim=32, cross_distance_embed_dim=32, no_torsion=False,
+                 scale_by_sigma=True, use_second_order_repr=False, batch_norm=True, dynamic_max_cross=False, dropout=0.0,
+                 lm_embedding_type=None, confidence_mode=False, use_old_atom_encoder=False, latent_dim=0, latent_vocab=32,
+                 latent_cross_attention=False, latent_droprate=0.0, embedding_scale=1000.0, sigma_limits=None, **unused):
+        super().__init__()
+        if sh_lmax != 1 or use_second_order_repr or confidence_mode or use_old_atom_encoder or latent_cross_attention:
+            raise RuntimeError('ddk implements the sh_lmax=1 first-order score model with the new AtomEncoder only')
+        if in_lig_edge_features != 4:
+            raise RuntimeError('ddk: in_lig_edge_features must be 4')
+        lim = sigma_limits or {k: DEFAULTS[k] for k in ('tr_sigma_min', 'tr_sigma_max', 'rot_sigma_min', 'rot_sigma_max',
+                                                        'tor_sigma_min', 'tor_sigma_max')}
+        dev_index = (device.index or 0) if isinstance(device, torch.device) and device.type == 'cuda' else 0
+        self.device = torch.device('cuda', dev_index)
+        self.cfg = dict(ns=ns, nv=nv, num_conv_layers=num_conv_layers, sigma_embed_dim=sigma_embed_dim,
+                        distance_embed_dim=distance_embed_dim, cross_distance_embed_dim=cross_distance_embed_dim,
+                        lig_max_radius=float(lig_max_radius), rec_max_radius=float(rec_max_radius),
+                        cross_max_distance=float(cross_max_distance), center_max_distance=float(center_max_distance),
+                        dynamic_max_cross=int(bool(dynamic_max_cross)), embedding_scale=float(embedding_scale),
+                        scale_by_sigma=int(bool(scale_by_sigma)), no_torsion=int(bool(no_torsion)), batch_norm=int(bool(batch_norm)),
+                        latent_dim=int(latent_dim), latent_vocab=int(latent_vocab), latent_droprate=float(latent_droprate),
+                        lm_embedding_dim=1280 if lm_embedding_type == 'esm' else 0, **lim)
+        self.ctx = Context(device=dev_index, **self.cfg)
+        self.no_torsion = no_torsion
+        self._loaded = False
+
+    # the parameters live in the ddk context (packed for the kernels), not in nn.Parameters
+    def load_state_dict(self, state_dict, strict=True):
+        self.ctx.load_state_dict(state_dict)
+        self._loaded = True
+        return self
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        return self
+
+    def forward(self, data):
+        if not self._loaded:
+            raise RuntimeError('ddk score model: load_state_dict() first')
+        pos = data['ligand'].pos
+        if not pos.is_cuda:
+            raise RuntimeError('ddk score model runs on the GPU only (no CPU fallback)')
+        cx, B = complex_for_batch(data, pos.device, ctx=self.ctx)
+        t = [float(data.complex_t[k][0]) for k in ('tr', 'rot', 'tor')]
+        tr, rot, tor = cx.score_forward(pos.reshape(B, -1, 3), *t)
+        self.last_complex = cx
+        if self.no_torsion or cx.R == 0:
+            tor = torch.empty(0, device=pos.device)
+        return tr, rot, tor
+
+
+class ModelWrapper(nn.Module):
+    """models/model_classes.py:53-85 as far as inference needs it: ``model.score_model`` and ``model.encoder``."""
+
+    def __init__(self, encoder, score_model):
+        super().__init__()
+        self.encoder = encoder
+        self.score_model = score_model
+
+    def forward(self, data):
+        return self.score_model(data)

@@ -222,3 +222,78 @@ def make_complex(seed, n_res=300, n_lig=None, cutoff=15.0, max_neighbor=24, esm_
     out['original_center'] = np.zeros((1, 3), dtype=np.float32)
     out['name'] = f'synthetic_{seed}'
     return out
+
+
+def score_model_state_dict_spec(ns=24, nv=6, num_conv_layers=5, sigma=32, dist=32, lm=1280):
+    """name -> shape of the DiffDock-S ``score_model.state_dict()`` (171 tensors / 2 107 134 elements)."""
+    spec = {}
+
+    def lin(name, o, i, bias=True):
+        spec[f'{name}.weight'] = (o, i)
+        if bias:
+            spec[f'{name}.bias'] = (o,)
+
+    for i, d in enumerate(LIG_FEATURE_DIMS):
+        spec[f'lig_node_embedding.atom_embedding_list.{i}.weight'] = (d, ns)
+    lin('lig_node_embedding.additional_features_embedder', ns, ns + sigma)
+    lin('lig_edge_embedding.0', ns, 4 + sigma + dist)
+    lin('lig_edge_embedding.3', ns, ns)
+    spec['rec_node_embedding.atom_embedding_list.0.weight'] = (REC_RESIDUE_FEATURE_DIMS[0], ns)
+    lin('rec_node_embedding.additional_features_embedder', ns, ns + sigma + lm)
+    lin('rec_edge_embedding.0', ns, sigma + dist)
+    lin('rec_edge_embedding.3', ns, ns)
+    lin('cross_edge_embedding.0', ns, sigma + dist)
+    lin('cross_edge_embedding.3', ns, ns)
+    for k in ('lig', 'rec', 'cross', 'center'):
+        spec[f'{k}_distance_expansion.offset'] = (dist,)
+    seq = [(ns, 0, 0, 0), (ns, nv, 0, 0), (ns, nv, nv, 0), (ns, nv, nv, ns)]
+    for l in range(num_conv_layers):
+        i, o = seq[min(l, 3)], seq[min(l + 1, 3)]
+        W = (i[0] + i[1]) * o[0] + (i[0] + i[1] + i[2]) * o[1] + (i[1] + i[2] + i[3]) * o[2] + (i[2] + i[3]) * o[3]
+        for g in range(4):
+            lin(f'conv_layers.{l}.fc.{g}.0', 3 * ns, 3 * ns)
+            lin(f'conv_layers.{l}.fc.{g}.4', W, 3 * ns)
+        spec[f'conv_layers.{l}.batch_norm.weight'] = (sum(o),)
+        spec[f'conv_layers.{l}.batch_norm.bias'] = (o[0],)
+        spec[f'conv_layers.{l}.batch_norm.running_mean'] = (o[0],)
+        spec[f'conv_layers.{l}.batch_norm.running_var'] = (sum(o),)
+    lin('center_edge_embedding.0', ns, dist + sigma)
+    lin('center_edge_embedding.3', ns, ns)
+    lin('final_conv.fc.0', 2 * ns, 2 * ns)
+    lin('final_conv.fc.4', 2 * (2 * ns + 4 * nv), 2 * ns)
+    spec.update({'final_conv.batch_norm.weight': (4,), 'final_conv.batch_norm.bias': (0,),
+                 'final_conv.batch_norm.running_mean': (0,), 'final_conv.batch_norm.running_var': (4,)})
+    lin('tr_final_layer.0', ns, 1 + sigma)
+    lin('tr_final_layer.3', 1, ns)
+    lin('rot_final_layer.0', ns, 1 + sigma)
+    lin('rot_final_layer.3', 1, ns)
+    lin('final_edge_embedding.0', ns, dist)
+    lin('final_edge_embedding.3', ns, ns)
+    lin('tor_bond_conv.fc.0', 3 * ns, 3 * ns)
+    lin('tor_bond_conv.fc.4', 2 * nv * ns, 3 * ns)
+    spec.update({'tor_bond_conv.batch_norm.weight': (2 * ns,), 'tor_bond_conv.batch_norm.bias': (ns,),
+                 'tor_bond_conv.batch_norm.running_mean': (ns,), 'tor_bond_conv.batch_norm.running_var': (2 * ns,)})
+    lin('tor_final_layer.0', ns, 2 * ns, bias=False)
+    lin('tor_final_layer.3', 1, ns, bias=False)
+    return spec
+
+
+def random_score_model_state_dict(seed=0):
+    """Random-init DiffDock-S weights (PyTorch-default style, randomised BatchNorm statistics) - no checkpoints exist offline."""
+    import math
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    stops = {'lig': 5.0, 'rec': 30.0, 'cross': 80.0, 'center': 30.0}
+    spec = score_model_state_dict_spec()
+    P = {}
+    for name, shape in spec.items():
+        if name.endswith('distance_expansion.offset'):
+            P[name] = torch.linspace(0.0, stops[name.split('_')[0]], shape[0])
+        elif 'atom_embedding_list' in name:
+            P[name] = (torch.rand(shape, generator=g) * 2 - 1) * math.sqrt(6.0 / (shape[0] + shape[1]))
+        elif '.batch_norm.' in name:
+            P[name] = torch.rand(shape, generator=g) + 0.5 if name.endswith(('running_var', 'weight')) else torch.randn(shape, generator=g) * 0.1
+        else:
+            fan_in = shape[1] if name.endswith('weight') else spec[name[:-4] + 'weight'][1]
+            P[name] = (torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(fan_in)
+    return P

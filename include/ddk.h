@@ -129,6 +129,12 @@ int ddk_last_graph_stats(ddk_ctx* ctx, ddk_complex* cx, int64_t* out, void* stre
 /* Node features after the conv stack of the last forward: lig [B*n_lig, 84], rec [B*n_rec, 84] (device ptrs, may be NULL). */
 int ddk_last_node_features(ddk_ctx* ctx, ddk_complex* cx, int32_t B, float* lig_out, float* rec_out, void* stream);
 
+/* ---- measurement: HIP-event timing of every fused TP-conv launch on the stream it is launched on (bench.py's
+ *      roofline leg).  ddk_profile_read synchronises, then fills per conv layer l: out[3l] = total kernel ms,
+ *      out[3l+1] = launches, out[3l+2] = total edges processed; n = 3 * num_conv_layers doubles (HOST). */
+int ddk_profile_enable(ddk_ctx* ctx, int32_t on);
+int ddk_profile_read(ddk_ctx* ctx, double* out, int32_t n);
+
 #ifdef __cplusplus
 }
 #endif

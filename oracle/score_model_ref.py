@@ -234,7 +234,8 @@ def tp_conv_layer(P, prefix, node_attr, edge_index, edge_attr, edge_sh, in_irrep
 # score-norm table lookups (utils/so3.py:91-95, utils/torus.py:79-83)
 # ---------------------------------------------------------------------------------------------
 def so3_score_norm(eps, exp_score_norms):
-    eps = np.asarray(eps, dtype=np.float64) if not torch.is_tensor(eps) else eps.double().numpy()
+    """utils/so3.py:91-95; eps is the fp32 rot_sigma tensor -> numpy float32 arithmetic like the reference."""
+    eps = eps.float().numpy() if torch.is_tensor(eps) else np.asarray(eps, dtype=np.float32)
     lo, hi, n = 0.01, 2.0, 1000
     idx = (np.log10(eps) - np.log10(lo)) / (np.log10(hi) - np.log10(lo)) * n
     idx = np.clip(np.around(idx).astype(int), a_min=0, a_max=n - 1)
@@ -242,7 +243,8 @@ def so3_score_norm(eps, exp_score_norms):
 
 
 def torus_score_norm(sigma, score_norm_table):
-    sigma = np.asarray(sigma, dtype=np.float64)
+    """utils/torus.py:79-83; sigma arrives as a float32 numpy array (score_model.py:306)."""
+    sigma = np.asarray(sigma)
     lo, hi, n = 3e-3, 2.0, 5000
     s = np.log(sigma / np.pi)
     s = (s - np.log(lo)) / (np.log(hi) - np.log(lo)) * n
@@ -456,7 +458,7 @@ def score_model_forward(P, cfg, data, so3_table, torus_table, dtype=torch.float3
     tor_pred = F.linear(h, P['tor_final_layer.3.weight']).squeeze(1)
     edge_sigma = tor_sigma[lig.batch][data['ligand', 'ligand'].edge_index[0]][lig.edge_mask]
     if cfg.scale_by_sigma:
-        tor_pred = tor_pred * torch.sqrt(torch.tensor(torus_score_norm(edge_sigma.double().numpy(), torus_table)).float()).to(dtype)
+        tor_pred = tor_pred * torch.sqrt(torch.tensor(torus_score_norm(edge_sigma.float().numpy(), torus_table)).float()).to(dtype)
     out = (tr_pred, rot_pred, tor_pred)
     return out + (inter,) if return_intermediates else out
 

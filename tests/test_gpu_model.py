@@ -1,0 +1,260 @@
+"""GPU parity tests of the score-model / sampler hot path through the C ABI (drop-in call surface of the
+reference: get_model -> model.score_model(batch), modify_conformer_batch, sampling()).
+
+* golden vectors produced by the reference (tests/golden/make_golden.py): 1e-4 relative on tr/rot/tor (north star)
+* oracle comparisons on seeded synthetic complexes
+* size-independent properties at the BASELINE.json config-2 size (40 samples, ~300 residues): SE(3) equivariance,
+  batch-permutation consistency, rigid-update isometry."""
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import score_model_ref as smr
+from oracle import sampler_ref as spr
+from helpers import complex_from_npz, batch_of, rel_err
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+ARGS_S = Namespace(ns=24, nv=6, num_conv_layers=5, sigma_embed_dim=32, distance_embed_dim=32, cross_distance_embed_dim=32,
+                   max_radius=5.0, cross_max_distance=80, dynamic_max_cross=True, embedding_scale=1000, embedding_type='sinusoidal',
+                   scale_by_sigma=True, no_torsion=False, no_batch_norm=False, dropout=0.1, sh_lmax=1, use_second_order_repr=False,
+                   use_old_atom_encoder=False, esm_embeddings_path='data/esm2_3billion_embeddings.pt', latent_dim=0, latent_vocab=64,
+                   latent_cross_attention=False, tr_sigma_min=0.1, tr_sigma_max=19.0, rot_sigma_min=0.03, rot_sigma_max=1.55,
+                   tor_sigma_min=0.03, tor_sigma_max=3.14)
+README_S = dict(temp_sampling=[1.886430780895051, 5.659562317960644, 2.8888668488630156],
+                temp_psi=[0.07085125444659945, 2.686505606141324, 4.089493860493927],
+                temp_sigma_data=[0.3617563913086843, 0.7437588205919711, 0.08897393057297842])
+CFG = smr.ScoreModelConfig(latent_vocab=64)
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a MI355X'
+    from disco_diffdock_amd import build
+    build.build(verbose=False)
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def model7(dev):
+    """the reference call surface: get_model(args, device, t_to_sigma) + load_state_dict of the score model"""
+    from functools import partial
+    from disco_diffdock_amd.model_utils import get_model
+    from disco_diffdock_amd.diffusion_utils import t_to_sigma
+    model = get_model(ARGS_S, dev, partial(t_to_sigma, args=ARGS_S), no_parallel=True)
+    model.score_model.load_state_dict(smr.random_state_dict(CFG, seed=7), strict=True)
+    return model
+
+
+def _dev_batch(c, B, pos, dev, t):
+    from disco_diffdock_amd.data import from_arrays, collate
+    from disco_diffdock_amd.diffusion_utils import set_time
+    b = collate([from_arrays(c) for _ in range(B)])
+    b['ligand'].pos = torch.as_tensor(pos).float().reshape(-1, 3)
+    b = b.to(dev)
+    set_time(b, t, t, t, B, False, dev)
+    return b
+
+
+@pytest.mark.parametrize('t', [1.0, 0.55, 0.05])
+def test_score_model_golden(dev, model7, golden, t):
+    tag = 'diffdockS_score_model'
+    z = golden(f'score_{tag}_t{t}')
+    c = complex_from_npz(golden(f'complex_{tag}'))
+    B = int(z['B'])
+    b = _dev_batch(c, B, z['pos'], dev, t)
+    tr, rot, tor = model7.score_model(b)
+    cx = model7.score_model.last_complex
+    lig, rec = cx.node_features(B, dev)
+    assert rel_err(lig.cpu(), z['lig_node_attr']) < 1e-4
+    assert rel_err(rec.cpu(), z['rec_node_attr']) < 1e-4
+    for name, a in (('tr', tr), ('rot', rot), ('tor', tor)):
+        assert rel_err(a.cpu(), z[name]) < 1e-4, name
+
+
+def test_conformer_update_golden(dev, golden):
+    from disco_diffdock_amd.diffusion_utils import modify_conformer_batch
+    z = golden('conformer_update')
+    c = complex_from_npz(golden('toy_complex'))
+    B = int(z['B'])
+    b = _dev_batch(c, B, z['pos'], dev, 0.5)
+    mr = T(z['mask_rotate'])
+    new = modify_conformer_batch(T(z['pos']).to(dev), b, T(z['tr']).to(dev), T(z['rot']).to(dev), T(z['tor']).to(dev), mr)
+    assert rel_err(new.cpu(), z['new_pos']) < 2e-5
+    rigid = modify_conformer_batch(T(z['pos']).to(dev), b, T(z['tr']).to(dev), T(z['rot']).to(dev), None, mr)
+    assert rel_err(rigid.cpu(), z['rigid_only']) < 1e-5
+
+
+@pytest.mark.parametrize('tag,kw', [('plain', {}), ('lowtemp', README_S), ('ode', dict(ode=True))])
+def test_sde_steps_golden(dev, golden, tag, kw):
+    """reference sampling() arithmetic with fixed scores: host step coefficients + GPU conformer update,
+    noise from the reference's torch.manual_seed CPU stream (draw order tr, rot, tor per step)."""
+    from functools import partial
+    from disco_diffdock_amd.sampling import step_coefficients
+    from disco_diffdock_amd.diffusion_utils import t_to_sigma, get_t_schedule, modify_conformer_batch
+    z = golden(f'sde_steps_{tag}')
+    c = complex_from_npz(golden('toy_complex'))
+    B, steps = z['tr'].shape[0], int(z['steps'])
+    sched = get_t_schedule(steps)
+    kw = dict(kw)
+    ode = kw.pop('ode', False)
+    t_arr, sc, nc = step_coefficients(steps, sched, sched, sched, partial(t_to_sigma, args=ARGS_S), ARGS_S, ode, False, True,
+                                      kw.get('temp_sampling', 1.0), kw.get('temp_psi', 0.0), kw.get('temp_sigma_data', 0.5))
+    torch.manual_seed(int(z['seed']))
+    pos = T(z['pos0']).to(dev)
+    b = _dev_batch(c, B, z['pos0'], dev, 1.0)
+    R = int(c['edge_mask'].sum())
+    for k in range(steps):
+        last = k == steps - 1
+        zt = torch.zeros(B, 3) if (last or ode) else torch.normal(mean=0, std=1, size=(B, 3))
+        zr = torch.zeros(B, 3) if (last or ode) else torch.normal(mean=0, std=1, size=(B, 3))
+        zo = torch.zeros(B * R) if (last or ode) else torch.normal(mean=0, std=1, size=(B * R,))
+        tr = sc[k, 0] * T(z['tr']) + nc[k, 0] * zt
+        rot = sc[k, 1] * T(z['rot']) + nc[k, 1] * zr
+        tor = sc[k, 2] * T(z['tor']) + nc[k, 2] * zo
+        pos = modify_conformer_batch(pos, b, tr.to(dev), rot.to(dev), tor.to(dev), T(c['mask_rotate']))
+    assert rel_err(pos.cpu(), z['pos_out']) < 5e-5
+
+
+def _ref_noise(seed, steps, B, R, no_final_step_noise=True):
+    torch.manual_seed(seed)
+    z = torch.zeros(steps, B, 6 + R)
+    for k in range(steps):
+        if no_final_step_noise and k == steps - 1:
+            continue
+        z[k, :, 0:3] = torch.normal(mean=0, std=1, size=(B, 3))
+        z[k, :, 3:6] = torch.normal(mean=0, std=1, size=(B, 3))
+        z[k, :, 6:] = torch.normal(mean=0, std=1, size=(B * R,)).reshape(B, R)
+    return z
+
+
+def test_trajectory_golden(dev, model7, golden):
+    """3-step sampling() trajectory of the reference (its own sampler + score model on the stand-ins)."""
+    from functools import partial
+    from disco_diffdock_amd.sampling import sampling
+    from disco_diffdock_amd.data import from_arrays
+    from disco_diffdock_amd.diffusion_utils import t_to_sigma, get_t_schedule
+    tag = 'diffdockS_score_model'
+    z = golden(f'trajectory_{tag}')
+    c = complex_from_npz(golden(f'complex_{tag}'))
+    B, steps, n = 2, int(z['steps']), len(c['lig_pos'])
+    dl = [from_arrays(c) for _ in range(B)]
+    for i, d in enumerate(dl):
+        d['ligand'].pos = T(z['pos0'][i * n:(i + 1) * n])
+    sched = get_t_schedule(steps)
+    noise = [_ref_noise(int(z['seed']), steps, B, int(c['edge_mask'].sum()))]
+    out, conf = sampling(dl, model7, steps, sched, sched, sched, dev, partial(t_to_sigma, args=ARGS_S), ARGS_S, batch_size=B,
+                         no_final_step_noise=True, use_latent=False, noise=noise, **README_S)
+    assert conf is None
+    pos = torch.cat([d['ligand'].pos for d in out]).cpu()
+    assert rel_err(pos, z['pos_out']) < 1e-4
+
+
+def test_sampling_vs_oracle(dev, tables):
+    """5 reverse steps, 4 samples, README DiffDock-S temperatures, against the CPU oracle with the same noise."""
+    from functools import partial
+    from disco_diffdock_amd import synthetic
+    from disco_diffdock_amd.model_utils import get_model
+    from disco_diffdock_amd.sampling import sampling
+    from disco_diffdock_amd.data import from_arrays
+    from disco_diffdock_amd.diffusion_utils import t_to_sigma, get_t_schedule
+    from helpers import to_graph
+    c = synthetic.make_complex(21, n_res=50, n_lig=24)
+    P = smr.random_state_dict(CFG, seed=11)
+    model = get_model(ARGS_S, dev, partial(t_to_sigma, args=ARGS_S), no_parallel=True)
+    model.score_model.load_state_dict(P)
+    B, steps, R, n = 4, 5, int(c['edge_mask'].sum()), len(c['lig_pos'])
+    rng = np.random.default_rng(1)
+    start = [c['lig_pos'] + rng.normal(0, 6.0, size=(1, 3)).astype(np.float32) for _ in range(B)]
+    z = _ref_noise(77, steps, B, R)
+    sched = get_t_schedule(steps)
+    dl = [from_arrays(c) for _ in range(B)]
+    for d, p in zip(dl, start):
+        d['ligand'].pos = T(p).float()
+    out, _ = sampling(dl, model, steps, sched, sched, sched, dev, partial(t_to_sigma, args=ARGS_S), ARGS_S, batch_size=B,
+                      no_final_step_noise=True, noise=[z], **README_S)
+    ol = [to_graph(c) for _ in range(B)]
+    for d, p in zip(ol, start):
+        d['ligand'].pos = T(p).float()
+    nf = lambda b, t, name, shape: {'tr': z[t, :, 0:3], 'rot': z[t, :, 3:6], 'tor': z[t, :, 6:].reshape(-1)}[name]
+    ref, _ = spr.sampling(ol, P, CFG, tables[0], tables[1], steps, sched, sched, sched, noise_fn=nf, batch_size=B,
+                          no_final_step_noise=True, **README_S)
+    a = torch.cat([d['ligand'].pos for d in out]).cpu()
+    r = torch.cat([d['ligand'].pos for d in ref])
+    assert rel_err(a, r) < 1e-4
+
+
+def test_equivariance_and_batch_consistency_full_size(dev):
+    """BASELINE config-2 shape (40 samples, 300 residues): rotating + translating the whole complex rotates tr/rot and
+    leaves tor unchanged; permuting the samples of the batch permutes the outputs."""
+    from scipy.spatial.transform import Rotation
+    from disco_diffdock_amd import synthetic
+    from disco_diffdock_amd.runtime import Context, Complex
+    c = synthetic.make_complex(2, n_res=300)
+    P = smr.random_state_dict(CFG, seed=3)
+    ctx = Context(device=0)
+    ctx.load_state_dict(P)
+    B = 40
+    rng = np.random.default_rng(0)
+    pos = np.stack([c['lig_pos'] + rng.normal(0, 4.0, size=(1, 3)) + rng.normal(0, 0.3, size=c['lig_pos'].shape) for _ in range(B)]).astype(np.float32)
+    cx = Complex(ctx, c, B)
+    tr0, rot0, tor0 = [x.double().cpu() for x in cx.score_forward(T(pos).to(dev), 0.4, 0.4, 0.4)]
+    st = cx.graph_stats()
+    assert st['E_rr'] == B * c['rec_edge_index'].shape[1] and st['E_lr'] == st['E_rl'] and st['E'] > 500000
+    perm = rng.permutation(B)
+    tr1, rot1, tor1 = [x.double().cpu() for x in cx.score_forward(T(pos[perm]).to(dev), 0.4, 0.4, 0.4)]
+    R = cx.R
+    assert rel_err(tr1, tr0[perm]) < 1e-5 and rel_err(rot1, rot0[perm]) < 1e-5
+    assert rel_err(tor1.reshape(B, R), tor0.reshape(B, R)[perm]) < 1e-5
+    Rm = Rotation.random(random_state=4).as_matrix()
+    shift = np.array([[2.0, -3.0, 1.5]])
+    c2 = dict(c)
+    c2['rec_pos'] = (c['rec_pos'].astype(np.float64) @ Rm.T + shift).astype(np.float32)
+    pos2 = (pos.astype(np.float64) @ Rm.T + shift).astype(np.float32)
+    cx2 = Complex(ctx, c2, B)
+    tr2, rot2, tor2 = [x.double().cpu() for x in cx2.score_forward(T(pos2).to(dev), 0.4, 0.4, 0.4)]
+    Rt = torch.from_numpy(Rm)
+    assert rel_err(tr0 @ Rt.T, tr2) < 2e-4
+    assert rel_err(rot0 @ Rt.T, rot2) < 2e-4
+    assert rel_err(tor0, tor2) < 2e-4
+    # rigid update is an isometry: pairwise distances preserved
+    out = cx.se3_update(T(pos).to(dev), torch.randn(B, 3, device=dev), torch.randn(B, 3, device=dev), None).cpu()
+    d0 = torch.cdist(T(pos), T(pos))
+    d1 = torch.cdist(out, out)
+    assert float((d0 - d1).abs().max()) < 2e-4
+
+
+def test_rigid_ligand_and_single_sample(dev, tables):
+    """ligand without rotatable bonds (tor is empty, reference returns torch.empty(0)) and B = 1"""
+    from disco_diffdock_amd import synthetic
+    from disco_diffdock_amd.runtime import Context, Complex
+    c = synthetic.make_complex(8, n_res=40, n_lig=20)
+    c['edge_mask'] = np.zeros_like(c['edge_mask'])
+    c['mask_rotate'] = np.zeros((0, len(c['lig_pos'])), dtype=bool)
+    P = smr.random_state_dict(CFG, seed=5)
+    ctx = Context(device=0)
+    ctx.load_state_dict(P)
+    cx = Complex(ctx, c, 1)
+    pos = c['lig_pos'][None] + 1.0
+    tr, rot, tor = cx.score_forward(T(pos).to(dev), 0.3, 0.3, 0.3)
+    assert tor.numel() == 0
+    b = batch_of(c, 1, pos)
+    spr.set_time(b, 0.3, 0.3, 0.3, 1)
+    tr_r, rot_r, tor_r = smr.score_model_forward(P, CFG, b, tables[0], tables[1])
+    assert rel_err(tr.cpu(), tr_r) < 1e-4 and rel_err(rot.cpu(), rot_r) < 1e-4 and tor_r.numel() == 0
+    out = cx.se3_update(T(pos).to(dev), tr, rot, None)
+    ref = spr.modify_conformer_batch(T(pos).reshape(-1, 3), b, tr.cpu(), rot.cpu(), None, T(c['mask_rotate']))
+    assert rel_err(out.cpu().reshape(-1, 3), ref) < 1e-5
+
+
+def test_unsupported_options_are_loud(dev, model7):
+    from functools import partial
+    from disco_diffdock_amd.sampling import sampling
+    from disco_diffdock_amd.diffusion_utils import t_to_sigma
+    with pytest.raises(RuntimeError, match='confidence'):
+        sampling([], model7, 2, [1, .5], [1, .5], [1, .5], dev, partial(t_to_sigma, args=ARGS_S), ARGS_S, confidence_model=object())
+    with pytest.raises(RuntimeError, match='GPU only'):
+        sampling([], model7, 2, [1, .5], [1, .5], [1, .5], 'cpu', partial(t_to_sigma, args=ARGS_S), ARGS_S)

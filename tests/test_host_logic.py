@@ -1,0 +1,114 @@
+"""CPU tests of the host-side logic above the C ABI: step coefficients vs the oracle, graph containers,
+config mapping / loud failures, and the multi-process sharding + gather (gloo, world_size 2)."""
+import os
+import sys
+from argparse import Namespace
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import score_model_ref as smr
+from oracle import sampler_ref as spr
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+ARGS = Namespace(tr_sigma_min=0.1, tr_sigma_max=19.0, rot_sigma_min=0.03, rot_sigma_max=1.55, tor_sigma_min=0.03,
+                 tor_sigma_max=3.14, no_torsion=False)
+README_S = dict(temp_sampling=[1.886430780895051, 5.659562317960644, 2.8888668488630156],
+                temp_psi=[0.07085125444659945, 2.686505606141324, 4.089493860493927],
+                temp_sigma_data=[0.3617563913086843, 0.7437588205919711, 0.08897393057297842])
+
+
+@pytest.mark.parametrize('kw', [{}, README_S, dict(ode=True)])
+def test_step_coefficients_match_oracle(kw):
+    from disco_diffdock_amd.sampling import step_coefficients
+    from disco_diffdock_amd.diffusion_utils import t_to_sigma, get_t_schedule
+    steps = 20
+    sched = get_t_schedule(steps)
+    assert np.array_equal(sched, spr.get_t_schedule(steps))
+    kw = dict(kw)
+    ode = kw.pop('ode', False)
+    t_arr, sc, nc = step_coefficients(steps, sched, sched, sched, partial(t_to_sigma, args=ARGS), ARGS, ode, False, True,
+                                      kw.get('temp_sampling', 1.0), kw.get('temp_psi', 0.0), kw.get('temp_sigma_data', 0.5))
+    cfg = smr.ScoreModelConfig()
+    for k in range(steps):
+        ref = spr.sde_step_coefficients(k, steps, (sched, sched, sched), cfg, ode, kw.get('temp_sampling', 1.0),
+                                        kw.get('temp_psi', 0.0), kw.get('temp_sigma_data', 0.5))
+        for j in range(3):
+            assert abs(sc[k, j] - float(ref[j][1])) <= 1e-6 * abs(float(ref[j][1]))
+            if k < steps - 1:
+                assert abs(nc[k, j] - float(ref[j][2])) <= 1e-6 * abs(float(ref[j][2])) + 1e-12
+            else:
+                assert nc[k, j] == 0.0     # no_final_step_noise
+
+
+def test_collate_matches_oracle_container():
+    from disco_diffdock_amd import synthetic
+    from disco_diffdock_amd.data import from_arrays, collate
+    from helpers import batch_of
+    c = synthetic.make_complex(1, n_res=12, n_lig=20, esm_dim=8)
+    a = collate([from_arrays(c) for _ in range(3)])
+    b = batch_of(c, 3)
+    assert a.num_graphs == 3
+    for nt in ('ligand', 'receptor'):
+        assert torch.equal(a[nt].batch, b[nt].batch) and torch.equal(a[nt].pos, b[nt].pos)
+    for et in (('ligand', 'ligand'), ('receptor', 'receptor')):
+        assert torch.equal(a[et].edge_index, b[et].edge_index)
+
+
+def test_get_model_refuses_unsupported_configs():
+    from disco_diffdock_amd.model_utils import get_model
+    base = dict(ns=24, nv=6, num_conv_layers=5, sigma_embed_dim=32, distance_embed_dim=32, cross_distance_embed_dim=32,
+                max_radius=5.0, cross_max_distance=80, dynamic_max_cross=True, embedding_scale=1000, embedding_type='sinusoidal',
+                scale_by_sigma=True, no_torsion=False, no_batch_norm=False, dropout=0.1, sh_lmax=1, use_second_order_repr=False,
+                use_old_atom_encoder=False, esm_embeddings_path='x',
+                **{k: v for k, v in vars(ARGS).items() if k != 'no_torsion'})
+    with pytest.raises(RuntimeError, match='latent'):
+        get_model(Namespace(**dict(base, latent_dim=2, latent_vocab=1)), torch.device('cpu'), None)
+    with pytest.raises(RuntimeError, match='sh_lmax=1'):
+        get_model(Namespace(**dict(base, sh_lmax=2)), torch.device('cpu'), None)
+    with pytest.raises(RuntimeError, match='all-atom'):
+        get_model(Namespace(**dict(base, all_atoms=True)), torch.device('cpu'), None)
+
+
+def test_shard_assignment_is_a_balanced_partition():
+    from disco_diffdock_amd.distributed import shard_indices
+    costs = [300 * 30, 2000 * 40, 100 * 20, 500 * 25, 800 * 33, 120 * 22, 640 * 28, 50 * 20, 900 * 31, 310 * 30, 15 * 20]
+    for world in (1, 2, 4, 8):
+        parts = [shard_indices(costs, r, world) for r in range(world)]
+        assert sorted(i for p in parts for i in p) == list(range(len(costs)))
+        loads = [sum(costs[i] for i in p) for p in parts]
+        if world <= 4:
+            assert max(loads) <= 1.6 * (sum(costs) / world) + max(costs)
+
+
+def _worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from disco_diffdock_amd.distributed import shard_indices, gather_poses
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    n_lig = [20, 33, 25, 40, 22]
+    S = 3
+    mine = shard_indices([n * 100 for n in n_lig], rank, world)
+    poses = {i: torch.full((S, n_lig[i], 3), float(i)) + torch.arange(S).reshape(S, 1, 1) for i in mine}
+    full = gather_poses(poses, n_lig, S, device=torch.device('cpu'))
+    if rank == 0:
+        ok = all(torch.equal(full[i], torch.full((S, n_lig[i], 3), float(i)) + torch.arange(S).reshape(S, 1, 1)) for i in range(len(n_lig)))
+        open(os.path.join(tmp, 'ok'), 'w').write(str(ok))
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_shard_and_gather(tmp_path):
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert open(tmp_path / 'ok').read() == 'True'
+
+
+def test_product_state_dict_spec_equals_reference_layout():
+    from disco_diffdock_amd import synthetic
+    a = {k: tuple(v) for k, v in synthetic.score_model_state_dict_spec().items()}
+    b = {k: tuple(v) for k, v in smr.state_dict_spec(smr.ScoreModelConfig(latent_vocab=64)).items()}
+    assert a == b and len(a) == 171 and sum(int(np.prod(v)) for v in a.values()) == 2107134

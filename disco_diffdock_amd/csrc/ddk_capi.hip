@@ -105,7 +105,10 @@ static int build_conv_layer(ddk_ctx* ctx, int l, ConvLayerDev& L) {
   struct URow { int blk, kpair, row0, nvalid; };
   std::vector<Unit> units;
   std::vector<URow> urows;
-  for (int b = 0; b < 4; ++b) {
+  // unit stream order: scalar-output blocks first (0e, 0o) - their k-pairs are whole tiles - then the vector blocks
+  const int border[4] = {0, 3, 1, 2};
+  for (int bi = 0; bi < 4; ++bi) {
+    const int b = border[bi];
     if (L.n_in[b] == 0 || L.n_out[b] == 0) continue;
     if (L.n_out[b] % 2) return fail(ctx, DDK_ERR_INVALID, "odd output multiplicity unsupported");
     const bool vec = (b == 1 || b == 2);
@@ -124,7 +127,7 @@ static int build_conv_layer(ddk_ctx* ctx, int l, ConvLayerDev& L) {
     }
   }
   while (units.size() % 4) {
-    units.push_back(make_unit(U_PAD, 0, 1, 0, 0, 0.f));
+    units.push_back(make_unit(U_PAD, 0, 1, XW, 0, 0.f));   // dummy channel XW (scratch column of the LDS message row)
     urows.push_back({-1, 0, 0, 0});
   }
   L.n_tiles = (int)units.size() / 4;

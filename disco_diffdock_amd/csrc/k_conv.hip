@@ -15,7 +15,10 @@
 //     the 4-row groups of D.  The hidden vector h = relu(W1 e + b1) therefore comes out of GEMM1 already in
 //     the register layout GEMM2 needs for its B operand (the K order of GEMM2 is permuted at weight-packing
 //     time to make this true) - h never leaves the VGPRs.
-//   * the [32 rows x 72] W2 tiles are streamed from L2 in MFMA fragment order (9 x 16 B per lane per tile);
+//   * the [32 rows x 72] W2 tiles are streamed from L2 in MFMA fragment order (9 x 16 B per lane per tile) into ONE
+//     register set: each 16-B fragment is reloaded with the next tile's data right after the 4 MFMAs that consumed it,
+//     so the stream for tile t+1 lands under the rest of tile t's 36-MFMA burst; the F operands of the tile's 4 units
+//     are requested from LDS before the burst and the epilogue arithmetic is branch-free (unit kinds select multipliers);
 //     the per-edge weights w[row] appear in D and are consumed immediately: each group of 4 D registers is a
 //     "unit" = 4 consecutive TP rows i for the output-channel pair (2k, 2k+1) (k = 2*kpair + lane-half);
 //     the row operands u_i = f(x[dst], sh) are read from a per-edge LDS table (F row, 140 floats, stride chosen
@@ -25,6 +28,8 @@
 //   * bias vectors ride in the MFMA C operand (accumulator init), so no separate bias pass exists.
 //
 // Roofline: MFMA-bound (2*72*(72+W) flop per edge vs ~650 B per edge of HBM traffic), see DESIGN.md.
+#include <stdlib.h>
+
 #include "ddk_internal.h"
 
 namespace ddk {
@@ -72,8 +77,9 @@ __device__ __forceinline__ UnitQuad load_unit_quad(const Unit* p) {
 
 template <bool GATHER>
 __global__ __launch_bounds__(64) void conv_fused_kernel(ConvKArgs A) {
-  __shared__ __attribute__((aligned(16))) float F[32 * F_STRIDE];
+  __shared__ __attribute__((aligned(16))) float F[32 * F_STRIDE + 16];
   const int lane = threadIdx.x;
+  if (lane < 16) F[32 * F_STRIDE + lane] = 0.0f;   // pad: the v5 epilogue always reads 12 floats per unit
   const int el = lane & 31;
   const int hh = lane >> 5;
   const int ts1 = A.tile_info[1], ts2 = A.tile_info[2], ts3 = A.tile_info[3], ts4 = A.tile_info[4];
@@ -203,62 +209,58 @@ __global__ __launch_bounds__(64) void conv_fused_kernel(ConvKArgs A) {
     const float* w2 = A.w2p + (size_t)g * A.n_tiles * (9 * 64 * 4) + (size_t)lane * 4;
     const float* b2 = A.b2p + (size_t)g * A.n_tiles * 32 + hh * 16;
     float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f;
-    // software prefetch one W2 tile ahead: A fragments (9 x 16 B), accumulator-init bias (4 x 16 B) and the
-    // 4 unit descriptors (scalar loads) of tile t+1 are requested before the 36 MFMAs of tile t are issued
-    float4 an[9], bn[4];
+    // v5 loop: ONE set of A-fragment registers, reloaded in place right after the 4 MFMAs that consumed them
+    // (the next tile's fragments stream in under the rest of the burst); the F operands of the tile's 4 units
+    // are requested BEFORE the burst; the epilogue arithmetic is branch-free (kinds select multipliers).
+    float4 a[9], bn[4];
     UnitQuad un = load_unit_quad(A.units);
 #pragma unroll
-    for (int s4 = 0; s4 < 9; ++s4) an[s4] = ld4(w2 + s4 * 256);
+    for (int s4 = 0; s4 < 9; ++s4) a[s4] = ld4(w2 + s4 * 256);
 #pragma unroll
     for (int j = 0; j < 4; ++j) bn[j] = ld4(b2 + 4 * j);
     for (int t = 0; t < A.n_tiles; ++t) {
-      float4 ac[9];
+      const UnitQuad uc = un;
+      float4 f[4][3];
 #pragma unroll
-      for (int s4 = 0; s4 < 9; ++s4) ac[s4] = an[s4];
+      for (int rq = 0; rq < 4; ++rq) {
+        const float* Fp = Fr + (uc.u[rq].w0 >> 16);
+        f[rq][0] = ld4(Fp); f[rq][1] = ld4(Fp + 4); f[rq][2] = ld4(Fp + 8);
+      }
       f32x16 D;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         D[4 * j + 0] = bn[j].x; D[4 * j + 1] = bn[j].y; D[4 * j + 2] = bn[j].z; D[4 * j + 3] = bn[j].w;
       }
-      const UnitQuad uc = un;
-      if (t + 1 < A.n_tiles) {
-        const float* wn = w2 + (size_t)(t + 1) * (9 * 64 * 4);
-        const float* bp = b2 + (size_t)(t + 1) * 32;
-#pragma unroll
-        for (int s4 = 0; s4 < 9; ++s4) an[s4] = ld4(wn + s4 * 256);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bn[j] = ld4(bp + 4 * j);
-        un = load_unit_quad(A.units + 4 * (t + 1));
-      }
+      const int tn = min(t + 1, A.n_tiles - 1);
+      const float* wn = w2 + (size_t)tn * (9 * 64 * 4);
+      const float* bp = b2 + (size_t)tn * 32;
 #pragma unroll
       for (int s4 = 0; s4 < 9; ++s4) {
-        D = MFMA(ac[s4].x, h[4 * s4 + 0], D);
-        D = MFMA(ac[s4].y, h[4 * s4 + 1], D);
-        D = MFMA(ac[s4].z, h[4 * s4 + 2], D);
-        D = MFMA(ac[s4].w, h[4 * s4 + 3], D);
+        D = MFMA(a[s4].x, h[4 * s4 + 0], D);
+        D = MFMA(a[s4].y, h[4 * s4 + 1], D);
+        D = MFMA(a[s4].z, h[4 * s4 + 2], D);
+        D = MFMA(a[s4].w, h[4 * s4 + 3], D);
+        a[s4] = ld4(wn + s4 * 256);
       }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bn[j] = ld4(bp + 4 * j);
+      un = load_unit_quad(A.units + 4 * tn);
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
         const int w0 = uc.u[rq].w0, w1 = uc.u[rq].w1;
         const int kind = w0 & 15, flags = (w0 >> 4) & 15;
         const float d0 = D[4 * rq + 0], d1 = D[4 * rq + 1], d2 = D[4 * rq + 2], d3 = D[4 * rq + 3];
-        const float* Fp = Fr + (w0 >> 16);
-        if (kind == U_T_V) {
-          const float4 f0 = ld4(Fp), f1 = ld4(Fp + 4), f2 = ld4(Fp + 8);   // [row][xyz]
-          acc0 += f0.x * d0 + f0.w * d1 + f1.z * d2 + f2.y * d3;
-          acc1 += f0.y * d0 + f1.x * d1 + f1.w * d2 + f2.z * d3;
-          acc2 += f0.z * d0 + f1.y * d1 + f2.x * d2 + f2.w * d3;
-        } else if (kind != U_PAD) {
-          const float4 f = ld4(Fp);
-          const float part = f.x * d0 + f.y * d1 + f.z * d2 + f.w * d3;
-          if (kind == U_R1_S0) {
-            acc0 += s0 * part;
-          } else if (kind == U_T_S) {
-            acc0 += part;
-          } else {
-            acc0 += vx * part; acc1 += vy * part; acc2 += vz * part;
-          }
-        }
+        const float4 f0 = f[rq][0], f1 = f[rq][1], f2 = f[rq][2];
+        const float ps = f0.x * d0 + f0.y * d1 + f0.z * d2 + f0.w * d3;
+        const float pv0 = f0.x * d0 + f0.w * d1 + f1.z * d2 + f2.y * d3;
+        const float pv1 = f0.y * d0 + f1.x * d1 + f1.w * d2 + f2.z * d3;
+        const float pv2 = f0.z * d0 + f1.y * d1 + f2.x * d2 + f2.w * d3;
+        const bool kS0 = kind == U_R1_S0, kV = kind == U_R1_V, kTS = kind == U_T_S, kTV = kind == U_T_V;
+        const float ms0 = kS0 ? s0 : (kV ? vx : (kTS ? 1.0f : 0.0f));
+        const float ms1 = kV ? vy : 0.0f, ms2 = kV ? vz : 0.0f, mv = kTV ? 1.0f : 0.0f;
+        acc0 = fmaf(ms0, ps, fmaf(mv, pv0, acc0));
+        acc1 = fmaf(ms1, ps, fmaf(mv, pv1, acc1));
+        acc2 = fmaf(ms2, ps, fmaf(mv, pv2, acc2));
         if (flags & 2) {
           const float scale = uc.u[rq].scale;
           const int ncomp = (w0 >> 8) & 15;

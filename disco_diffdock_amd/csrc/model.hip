@@ -43,8 +43,8 @@ static bool smearing(ddk_ctx* ctx, const char* name, float stop, EdgeMlpDev& m, 
 
 int model_finalize(ddk_ctx* ctx) {
   if (ctx->model) { delete (Model*)ctx->model; ctx->model = nullptr; }
-  if (ctx->weights.find("lig_node_embedding.additional_features_embedder.weight") == ctx->weights.end())
-    return DDK_OK;   // operator-only context (no score model loaded)
+  if (ctx->host_only || ctx->weights.find("lig_node_embedding.additional_features_embedder.weight") == ctx->weights.end())
+    return DDK_OK;   // packing-only / operator-only context (no score model on the device)
   const ddk_config& c = ctx->cfg;
   if (c.latent_dim != 0)
     return fail(ctx, DDK_ERR_INVALID, "latent_dim > 0 (DisCo latent conditioning) is not implemented on the device yet");

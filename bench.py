@@ -39,6 +39,14 @@ PEAK_F32_MFMA_TFLOPS = 157.3                                   # MI355X_MICROARC
 PEAK_HBM_GBS = 8000.0
 
 
+def pmc_traffic():
+    """HBM bytes per fused-conv launch from the committed PMC passes of this same command (None if absent)."""
+    try:
+        return json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))['traffic_bytes_per_launch']
+    except Exception:
+        return None
+
+
 def model_args():
     from argparse import Namespace
     return Namespace(tr_sigma_min=0.1, tr_sigma_max=19.0, rot_sigma_min=0.03, rot_sigma_max=1.55, tor_sigma_min=0.03,
@@ -198,7 +206,10 @@ def main():
                        'samples_per_complex': SAMPLES, 'inference_steps': STEPS, 'complexes_per_gpu': N_COMPLEXES,
                        'parallelism': f'complexes sharded over {world} process(es), one per GPU, final RCCL pose gather'},
             'roofline': {'bound': 'mfma', 'kernel': 'ddk::conv_fused_kernel<true>', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                         'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': pmc_traffic(),
+                         'traffic_source': 'profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over this '
+                                           'command, bytes per conv_fused launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 FETCH correction)',
+                         'algorithmic_bytes_per_launch': byts / max(launches, 1),
                          'launches': launches, 'avg_launch_ms': conv_ms / max(launches, 1),
                          'flop_per_launch': flops / max(launches, 1),
                          'algorithmic_hbm_GBps': byts / (conv_ms * 1e-3) / 1e9 if conv_ms > 0 else 0.0,

@@ -237,9 +237,22 @@ __global__ __launch_bounds__(256) void edge_features_kernel(EdgeFeatArgs A) {
         h[o] += M.w1b[o * 4] * ba.x + M.w1b[o * 4 + 1] * ba.y + M.w1b[o * 4 + 2] * ba.z + M.w1b[o * 4 + 3] * ba.w;
     }
   }
+  // DisCo latent conditioning (score_model.py:329-337,358-366): [latent[src] | latent[dst]] columns of the first layer for
+  // lig-lig and rec-rec edges; the cross edges' latent columns multiply zeros (score_model.py:401)
+  if (A.latent_dim > 0 && (g == 0 || g == 2)) {
+    const float* lat = g == 0 ? A.lig_latent : A.rec_latent;
+    const int off = g == 0 ? 0 : A.n_lig_total;
+    const int ld = A.latent_dim;
+    for (int j = 0; j < ld; ++j) {
+      const float ls = lat[(size_t)(sn - off) * ld + j], ldv = lat[(size_t)(dn - off) * ld + j];
+#pragma unroll
+      for (int o = 0; o < NS; ++o) h[o] += M.w1l[o * 2 * ld + j] * ls + M.w1l[o * 2 * ld + ld + j] * ldv;
+    }
+  }
 #pragma unroll
   for (int o = 0; o < NS; ++o) h[o] = fmaxf(h[o], 0.0f);
   float* out = A.e_emb + (size_t)e * NS;
+  const float uncw = (A.latent_dim > 0 && M.unc != nullptr) ? A.unconditional : 0.0f;
 #pragma unroll
   for (int o4 = 0; o4 < NS / 4; ++o4) {
     float r[4];
@@ -249,6 +262,7 @@ __global__ __launch_bounds__(256) void edge_features_kernel(EdgeFeatArgs A) {
       float a = M.b2[o];
 #pragma unroll
       for (int k = 0; k < NS; ++k) a += M.w2[o * NS + k] * h[k];
+      if (uncw != 0.0f) a += uncw * M.unc[o];     // + unconditional[src] * *_edge_unconditional_embedding (score_model.py:213-215)
       r[q] = a;
     }
     *reinterpret_cast<float4*>(out + 4 * o4) = make_float4(r[0], r[1], r[2], r[3]);
@@ -258,19 +272,26 @@ __global__ __launch_bounds__(256) void edge_features_kernel(EdgeFeatArgs A) {
 
 // node embeddings: static part (categorical embeddings, ESM projection, bias) + the per-step sigma part
 // (AtomEncoder, models/layers.py:140-149), written zero-padded to XW floats per node
-__global__ void node_embed_kernel(const float* lig_static, const float* rec_static, StepParams sp, int B, int n_lig,
-                                  int n_rec, float* x) {
+__global__ void node_embed_kernel(NodeEmbedArgs A) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t n_l = (int64_t)B * n_lig, n = n_l + (int64_t)B * n_rec;
+  const int64_t n_l = (int64_t)A.B * A.n_lig, n = n_l + (int64_t)A.B * A.n_rec;
   if (i >= n * XW) return;
   const int64_t node = i / XW;
   const int c = (int)(i % XW);
   float v = 0.0f;
   if (c < NS) {
-    if (node < n_l) v = lig_static[(node % n_lig) * NS + c] + sp.lig_node_sig[c];
-    else v = rec_static[((node - n_l) % n_rec) * NS + c] + sp.rec_node_sig[c];
+    const bool lig = node < n_l;
+    if (lig) v = A.lig_static[(node % A.n_lig) * NS + c] + A.sp.lig_node_sig[c];
+    else v = A.rec_static[((node - n_l) % A.n_rec) * NS + c] + A.sp.rec_node_sig[c];
+    if (A.latent_dim > 0) {   // latent columns of the AtomEncoder Linear + unconditional embedding (score_model.py:211-212)
+      const float* lat = lig ? A.lig_latent + node * A.latent_dim : A.rec_latent + (node - n_l) * A.latent_dim;
+      const float* w = (lig ? A.lig_w_lat : A.rec_w_lat) + c * A.latent_dim;
+      for (int j = 0; j < A.latent_dim; ++j) v += w[j] * lat[j];
+      const float* u = lig ? A.lig_unc : A.rec_unc;
+      if (u != nullptr) v += A.unconditional * u[c];
+    }
   }
-  x[i] = v;
+  A.x[i] = v;
 }
 
 hipError_t launch_graph(const GraphArgs& G, int64_t edge_cap, hipStream_t s) {
@@ -287,11 +308,9 @@ hipError_t launch_edge_features(const EdgeFeatArgs& A, int64_t edge_cap, hipStre
   return hipGetLastError();
 }
 
-hipError_t launch_node_embed(const float* lig_static, const float* rec_static, const StepParams& sp, int B, int n_lig,
-                             int n_rec, float* x, hipStream_t s) {
-  const int64_t tot = (int64_t)B * (n_lig + n_rec) * XW;
-  hipLaunchKernelGGL(node_embed_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, lig_static, rec_static, sp, B,
-                     n_lig, n_rec, x);
+hipError_t launch_node_embed(const NodeEmbedArgs& a, hipStream_t s) {
+  const int64_t tot = (int64_t)a.B * (a.n_lig + a.n_rec) * XW;
+  hipLaunchKernelGGL(node_embed_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 

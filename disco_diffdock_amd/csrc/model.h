@@ -29,6 +29,8 @@ struct EdgeMlpDev {
   const float* w1b;   // [NS][4]   bond one-hot columns (ligand edges) or null
   const float* w2;    // [NS][NS]
   const float* b2;    // [NS]
+  const float* w1l;   // [NS][2*latent_dim] latent columns (DisCo latent conditioning) or null
+  const float* unc;   // [NS] *_edge_unconditional_embedding (latent_droprate > 0) or null
   float coeff;        // GaussianSmearing coeff
   float step;         // offset spacing (offset_k = k*step)
   const float* offset;  // [DE]
@@ -37,6 +39,10 @@ struct EdgeMlpDev {
 struct ModelDev {
   EdgeMlpDev lig_edge, rec_edge, cross_edge, center_edge, final_edge;
   const float* final_edge_b1;   // [NS] (final_edge_embedding has no sigma part)
+  // latent conditioning (latent_dim > 0, latent_vocab == 1): node-level weights
+  const float *lig_w_lat, *rec_w_lat;       // [NS][latent_dim]
+  const float *lig_node_unc, *rec_node_unc; // [NS] *_node_unconditional_embedding
+  int latent_dim;
   // final_conv (tr/rot head)
   const float *fc_w0, *fc_b0, *fc_w4, *fc_b4;   // [2ns][2ns],[2ns],[144][2ns],[144]
   float fc_bn_scale[4];
@@ -104,6 +110,10 @@ struct EdgeFeatArgs {
   StepParams sp;
   int n_lig_total;         // B*n_lig
   int n_rec;
+  const float* lig_latent; // [B*n_lig, latent_dim] or null
+  const float* rec_latent; // [B*n_rec, latent_dim] or null
+  float unconditional;     // data[...].unconditional (same value on every node of a forward, sampling.py:114-115,121-122)
+  int latent_dim;
 };
 
 struct HeadArgs {
@@ -137,8 +147,11 @@ struct Se3Args {
 
 hipError_t launch_graph(const GraphArgs& G, int64_t edge_cap, hipStream_t s);
 hipError_t launch_edge_features(const EdgeFeatArgs& A, int64_t edge_cap, hipStream_t s);
-hipError_t launch_node_embed(const float* lig_static, const float* rec_static, const StepParams& sp, int B, int n_lig,
-                             int n_rec, float* x, hipStream_t s);
+struct NodeEmbedArgs {
+  const float* lig_static; const float* rec_static; StepParams sp; int B, n_lig, n_rec; float* x;
+  const float *lig_latent, *rec_latent, *lig_w_lat, *rec_w_lat, *lig_unc, *rec_unc; float unconditional; int latent_dim;
+};
+hipError_t launch_node_embed(const NodeEmbedArgs& a, hipStream_t s);
 hipError_t launch_heads(const HeadArgs& A, bool torsion, hipStream_t s);
 hipError_t launch_se3(const Se3Args& A, hipStream_t s);
 
@@ -158,6 +171,8 @@ struct ddk_complex {
   int32_t *e_src = nullptr, *e_dst = nullptr, *e_aux = nullptr, *deg = nullptr, *counts = nullptr, *offs = nullptr, *info = nullptr;
   float *e_emb = nullptr, *e_sh = nullptr, *xa = nullptr, *xb = nullptr, *sum = nullptr;
   float *pos_tmp = nullptr, *scores = nullptr;
+  const float *lig_latent = nullptr, *rec_latent = nullptr;   // caller-owned device arrays set by ddk_set_latents
+  float unconditional = 0.0f;
   float* x_last = nullptr;    // node features after the conv stack of the last forward
   int last_B = 0;
   std::vector<void*> allocs;

@@ -46,8 +46,10 @@ int model_finalize(ddk_ctx* ctx) {
   if (ctx->host_only || ctx->weights.find("lig_node_embedding.additional_features_embedder.weight") == ctx->weights.end())
     return DDK_OK;   // packing-only / operator-only context (no score model on the device)
   const ddk_config& c = ctx->cfg;
-  if (c.latent_dim != 0)
-    return fail(ctx, DDK_ERR_INVALID, "latent_dim > 0 (DisCo latent conditioning) is not implemented on the device yet");
+  if (c.latent_dim != 0 && c.latent_vocab != 1)
+    return fail(ctx, DDK_ERR_INVALID, "latent conditioning is implemented for the equivariant-latent models only (latent_vocab == 1)");
+  if (c.latent_dim < 0 || c.latent_dim > 8) return fail(ctx, DDK_ERR_INVALID, "latent_dim out of range");
+  const int LD = c.latent_dim, LE = 2 * c.latent_dim;   // node / edge latent columns (latent_dim * max(latent_vocab, 2))
   Model* M = new Model();
   ctx->model = M;
   ModelHost& H = M->host;
@@ -62,18 +64,30 @@ int model_finalize(ddk_ctx* ctx) {
     H.lig_tables.insert(H.lig_tables.end(), t->data.begin(), t->data.end());
     off += LIG_DIMS[i];
   }
-  GET(lw, "lig_node_embedding.additional_features_embedder.weight", NS, NS + SIG);
+  GET(lw, "lig_node_embedding.additional_features_embedder.weight", NS, NS + SIG + LD);
   GET(lb, "lig_node_embedding.additional_features_embedder.bias", NS);
   H.lig_w_emb = cols(lw, 0, NS); H.lig_w_sig = cols(lw, NS, NS + SIG); H.lig_b = lb->data;
   GET(rt, "rec_node_embedding.atom_embedding_list.0.weight", REC_DIM, NS);
-  GET(rw, "rec_node_embedding.additional_features_embedder.weight", NS, NS + lm + SIG);
+  GET(rw, "rec_node_embedding.additional_features_embedder.weight", NS, NS + lm + SIG + LD);
   GET(rb, "rec_node_embedding.additional_features_embedder.bias", NS);
   H.rec_table = rt->data; H.rec_w_emb = cols(rw, 0, NS); H.rec_w_esm = cols(rw, NS, NS + lm);
   H.rec_w_sig = cols(rw, NS + lm, NS + lm + SIG); H.rec_b = rb->data;
+  D.latent_dim = LD;
+  D.lig_w_lat = D.rec_w_lat = D.lig_node_unc = D.rec_node_unc = nullptr;
+  if (LD > 0) {
+    D.lig_w_lat = dev_upload(ctx, cols(lw, NS + SIG, NS + SIG + LD));
+    D.rec_w_lat = dev_upload(ctx, cols(rw, NS + lm + SIG, NS + lm + SIG + LD));
+    if (c.latent_droprate > 0) {
+      GET(lu, "lig_node_unconditional_embedding", 1, NS);
+      GET(ru, "rec_node_unconditional_embedding", 1, NS);
+      D.lig_node_unc = dev_upload(ctx, lu->data);
+      D.rec_node_unc = dev_upload(ctx, ru->data);
+    }
+  }
   // ---- edge embedding MLPs -------------------------------------------------------------------
   auto edge_mlp = [&](const char* name, int n_bond, bool sigma_first, EdgeMlpDev& m, std::vector<float>* w1s,
-                      std::vector<float>* b1, std::vector<float>* w1d_host) -> bool {
-    const int in = n_bond + (w1s ? SIG : 0) + DE;
+                      std::vector<float>* b1, std::vector<float>* w1d_host, int lat_cols = 0, const char* unc_name = nullptr) -> bool {
+    const int in = n_bond + (w1s ? SIG : 0) + DE + lat_cols;
     const HostTensor* w0 = getw(ctx, std::string(name) + ".0.weight", {NS, in});
     const HostTensor* b0 = getw(ctx, std::string(name) + ".0.bias", {NS});
     const HostTensor* w3 = getw(ctx, std::string(name) + ".3.weight", {NS, NS});
@@ -89,14 +103,21 @@ int model_finalize(ddk_ctx* ctx) {
     m.w1b = n_bond ? dev_upload(ctx, cols(w0, 0, n_bond)) : nullptr;
     m.w2 = dev_upload(ctx, w3->data);
     m.b2 = dev_upload(ctx, b3->data);
+    m.w1l = lat_cols ? dev_upload(ctx, cols(w0, in - lat_cols, in)) : nullptr;   // latent columns are the last ones
+    m.unc = nullptr;
+    if (unc_name && c.latent_droprate > 0 && LD > 0) {
+      const HostTensor* u = getw(ctx, unc_name, {1, NS});
+      if (!u) return false;
+      m.unc = dev_upload(ctx, u->data);
+    }
     if (w1s) *w1s = cols(w0, c_sig, c_sig + SIG);
     *b1 = b0->data;
     return m.w1d && m.w2 && m.b2;
   };
   std::vector<float> fe_b1;
-  if (!edge_mlp("lig_edge_embedding", 4, true, D.lig_edge, &H.le_w1s, &H.le_b1, nullptr)) return DDK_ERR_INVALID;
-  if (!edge_mlp("rec_edge_embedding", 0, true, D.rec_edge, &H.re_w1s, &H.re_b1, &H.re_w1d)) return DDK_ERR_INVALID;
-  if (!edge_mlp("cross_edge_embedding", 0, true, D.cross_edge, &H.ce_w1s, &H.ce_b1, nullptr)) return DDK_ERR_INVALID;
+  if (!edge_mlp("lig_edge_embedding", 4, true, D.lig_edge, &H.le_w1s, &H.le_b1, nullptr, LE, "lig_edge_unconditional_embedding")) return DDK_ERR_INVALID;
+  if (!edge_mlp("rec_edge_embedding", 0, true, D.rec_edge, &H.re_w1s, &H.re_b1, &H.re_w1d, LE, "rec_edge_unconditional_embedding")) return DDK_ERR_INVALID;
+  if (!edge_mlp("cross_edge_embedding", 0, true, D.cross_edge, &H.ce_w1s, &H.ce_b1, nullptr, LE, "cross_edge_unconditional_embedding")) return DDK_ERR_INVALID;
   if (!edge_mlp("center_edge_embedding", 0, false, D.center_edge, &H.cen_w1s, &H.cen_b1, nullptr)) return DDK_ERR_INVALID;
   if (!smearing(ctx, "lig", c.lig_max_radius, D.lig_edge, nullptr, nullptr)) return fail(ctx, DDK_ERR_NOMEM, "alloc");
   if (!smearing(ctx, "rec", c.rec_max_radius, D.rec_edge, &H.rec_offset, &H.rec_coeff)) return fail(ctx, DDK_ERR_NOMEM, "alloc");
@@ -248,12 +269,19 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
   F.e_src = cx->e_src; F.e_dst = cx->e_dst; F.e_aux = cx->e_aux; F.info = cx->info; F.e_emb = cx->e_emb; F.e_sh = cx->e_sh;
   F.lig = M->dev.lig_edge; F.rec = M->dev.rec_edge; F.cross = M->dev.cross_edge; F.sp = sp;
   F.n_lig_total = B * n_lig; F.n_rec = n_rec;
+  F.latent_dim = c.latent_dim; F.lig_latent = cx->lig_latent; F.rec_latent = cx->rec_latent; F.unconditional = cx->unconditional;
+  if (c.latent_dim > 0 && (!cx->lig_latent || !cx->rec_latent))
+    return fail(ctx, DDK_ERR_STATE, "latent-conditioned model: call ddk_set_latents before the forward");
   // worst-case edge count of THIS batch size bounds the launch
   const int64_t cap_b = (int64_t)B * ((int64_t)cx->M + (int64_t)n_lig * (LIG_CAP - 1) + 2LL * n_lig * n_rec + cx->E_rr);
   CK(launch_edge_features(F, cap_b < cx->edge_cap ? cap_b : cx->edge_cap, s), "edge features");
   float* xin = cx->xa;
   float* xout = cx->xb;
-  CK(launch_node_embed(cx->lig_node_static, cx->rec_node_static, sp, B, n_lig, n_rec, xin, s), "node embed");
+  NodeEmbedArgs NE_;
+  NE_.lig_static = cx->lig_node_static; NE_.rec_static = cx->rec_node_static; NE_.sp = sp; NE_.B = B; NE_.n_lig = n_lig; NE_.n_rec = n_rec;
+  NE_.x = xin; NE_.lig_latent = cx->lig_latent; NE_.rec_latent = cx->rec_latent; NE_.lig_w_lat = M->dev.lig_w_lat; NE_.rec_w_lat = M->dev.rec_w_lat;
+  NE_.lig_unc = M->dev.lig_node_unc; NE_.rec_unc = M->dev.rec_node_unc; NE_.unconditional = cx->unconditional; NE_.latent_dim = c.latent_dim;
+  CK(launch_node_embed(NE_, s), "node embed");
   for (int l = 0; l < c.num_conv_layers; ++l) {
     const ConvLayerDev& L = ctx->conv[l];
     CK(hipMemsetAsync(cx->sum, 0, (size_t)N * XW * sizeof(float), s), "memset sum");
@@ -513,6 +541,13 @@ int ddk_last_node_features(ddk_ctx* ctx, ddk_complex* cx, int32_t B, float* lig_
   if (lig_out) e = hipMemcpyAsync(lig_out, cx->x_last, nl * sizeof(float), hipMemcpyDeviceToDevice, s);
   if (e == hipSuccess && rec_out) e = hipMemcpyAsync(rec_out, cx->x_last + nl, nr * sizeof(float), hipMemcpyDeviceToDevice, s);
   if (e != hipSuccess) return hip_fail(ctx, e, "node feature copy");
+  return DDK_OK;
+}
+
+int ddk_set_latents(ddk_ctx* ctx, ddk_complex* cx, const float* lig_latent, const float* rec_latent, float unconditional) {
+  if (!ctx || !cx) return DDK_ERR_INVALID;
+  if ((lig_latent == nullptr) != (rec_latent == nullptr)) return fail(ctx, DDK_ERR_INVALID, "ddk_set_latents: pass both latent arrays or neither");
+  cx->lig_latent = lig_latent; cx->rec_latent = rec_latent; cx->unconditional = unconditional;
   return DDK_OK;
 }
 

@@ -185,6 +185,14 @@ class Complex:
         except Exception:
             pass
 
+    def set_latents(self, lig_latent=None, rec_latent=None, unconditional=0.0):
+        """data['ligand'|'receptor'].latent_h of the batch ([B*n, latent_dim], device) for the following forwards."""
+        if lig_latent is not None:
+            lig_latent, rec_latent = lig_latent.contiguous().float(), rec_latent.contiguous().float()
+        self._latents = (lig_latent, rec_latent)      # keep the device arrays alive
+        self.ctx._check(self.ctx.L.ddk_set_latents(self.ctx.h, self.h, _ptr(lig_latent), _ptr(rec_latent), float(unconditional)),
+                        'ddk_set_latents')
+
     # ---- model.score_model(batch) ------------------------------------------------------------------
     def score_forward(self, pos, t_tr, t_rot, t_tor):
         ctx = self.ctx

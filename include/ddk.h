@@ -102,6 +102,12 @@ typedef struct ddk_complex_desc {
 int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* desc, int32_t max_batch, ddk_complex** out);
 void ddk_complex_destroy(ddk_ctx* ctx, ddk_complex* cx);
 
+/* ---- DisCo latent conditioning (models/score_model.py:170-184, 209-215, 329-337, 358-366, 392-402; latent_vocab == 1):
+ *      lig_latent [B*n_lig, latent_dim], rec_latent [B*n_rec, latent_dim] (data['ligand'|'receptor'].latent_h, DEVICE,
+ *      caller-owned, must stay valid for the following forwards) and the value of data[...].unconditional.
+ *      Applies to the subsequent ddk_score_forward / ddk_sample calls on this complex; NULL, NULL clears. */
+int ddk_set_latents(ddk_ctx* ctx, ddk_complex* cx, const float* lig_latent, const float* rec_latent, float unconditional);
+
 /* ---- a5-a17: model.score_model(batch) -> (tr[B,3], rot[B,3], tor[B*R])  models/score_model.py:259-308
  *      for B copies of one complex at a common time (utils/sampling.py:113-117).
  *      lig_pos [B, n_lig, 3]; outputs tr [B,3], rot [B,3], tor [B*n_rot]. */

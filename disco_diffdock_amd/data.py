@@ -70,6 +70,16 @@ class HeteroData:
     def clone(self):
         return copy.deepcopy(self)
 
+    def __copy__(self):
+        """shallow copy with its own storages (tensors are shared): rebinding attributes on the copy leaves the original intact"""
+        new = HeteroData()
+        for k, st in self._stores.items():
+            new._stores[k] = Storage(**st.__dict__)
+        for k, v in self.__dict__.items():
+            if not k.startswith('_'):
+                new.__dict__[k] = v
+        return new
+
 
 def from_arrays(c, loader_style=True):
     """Build one complex graph from the array dict of :mod:`disco_diffdock_amd.synthetic` (layout of SURVEY.md B.1).

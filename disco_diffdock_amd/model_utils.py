@@ -13,8 +13,8 @@ def get_model(args, device, t_to_sigma, no_parallel=False, confidence_mode=False
     if confidence_mode:
         raise RuntimeError('ddk: confidence_mode is outside the accelerated hot path')
     g = lambda k, d: getattr(args, k, d)
-    if g('latent_dim', 0) > 0:
-        raise RuntimeError('ddk: latent conditioning (DisCo-DiffDock-S, latent_dim > 0) is not implemented on the device yet')
+    if g('latent_dim', 0) > 0 and g('latent_vocab', 0) != 1:
+        raise RuntimeError('ddk: latent conditioning is implemented for the equivariant-latent models (latent_vocab == 1) only')
     lm = 'esm' if g('esm_embeddings_path', None) is not None else None
     score_model = TensorProductScoreModel(
         t_to_sigma=t_to_sigma, device=device, no_torsion=args.no_torsion,
@@ -32,3 +32,22 @@ def get_model(args, device, t_to_sigma, no_parallel=False, confidence_mode=False
     if hasattr(args, 'latent_vocab'):
         return ModelWrapper(encoder=None, score_model=score_model)   # model_utils.py:93-94
     return score_model
+
+
+def get_ar_model(args, score_model_args, device, training=True):
+    """utils/model_utils.py:104-152 for `use_pretrained_score: true` AR models (the shipped disco_diffdockS_ar_model).
+    The checkpoint of the ORIGINAL score model (args.original_model_dir/args.ckpt) is not needed at inference: the AR
+    checkpoint overwrites it (evaluate.py:179-180), so it is only loaded when present."""
+    if training:
+        raise RuntimeError('ddk: AR model training is outside the accelerated hot path (training=False only)')
+    if not ('use_pretrained_score' in args and args.use_pretrained_score):
+        raise RuntimeError('ddk: only AR models built on the pretrained score model (use_pretrained_score) are implemented')
+    from .pretrained_score_encoder import PretrainedScoreEncoder
+    t_to_sigma = partial(t_to_sigma_compl, args=score_model_args)
+    model = get_model(score_model_args, device, t_to_sigma)
+    score_model = getattr(model, 'score_model', model)
+    ar = PretrainedScoreEncoder(pretrained_score_model=score_model, ns=args.ns, latent_dim=1,
+                                latent_vocab=score_model_args.latent_vocab, latent_no_batchnorm=args.latent_no_batchnorm,
+                                latent_dropout=args.latent_dropout, latent_hidden_dim=args.latent_hidden_dim,
+                                input_latent_dim=score_model_args.latent_dim, apply_gumbel_softmax=True)
+    return ar.to(device)

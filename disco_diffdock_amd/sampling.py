@@ -41,8 +41,6 @@ def _modify_conformer_torsion_angles_np(pos, edge_index, mask_rotate, torsion_up
 
 def randomize_position(data_list, no_torsion, no_random, tr_sigma_max, unbatched=False, ar_args=None):
     from scipy.spatial.transform import Rotation as R
-    if ar_args is not None:
-        raise RuntimeError('ddk: the AR latent model is outside the accelerated hot path')
     if not no_torsion:
         for g in data_list:
             upd = np.random.uniform(low=-np.pi, high=np.pi, size=int(g['ligand'].edge_mask.sum()))
@@ -55,6 +53,15 @@ def randomize_position(data_list, no_torsion, no_random, tr_sigma_max, unbatched
         g['ligand'].pos = (g['ligand'].pos - center) @ rot.T
         if not no_random:
             g['ligand'].pos = g['ligand'].pos + torch.normal(mean=0, std=tr_sigma_max, size=(1, 3))
+    if ar_args is not None:   # utils/sampling.py:36-46: the pose the AR model sees
+        for g in data_list:
+            if ar_args.no_randomness:
+                g['ligand'].ar_pos = torch.from_numpy(g['ligand'].orig_rdkit_pos[0]).float()
+                center = torch.mean(g['ligand'].ar_pos, dim=0, keepdim=True)
+                rot = torch.from_numpy(R.random().as_matrix()).float()
+                g['ligand'].ar_pos = (g['ligand'].ar_pos - center) @ rot.T
+            else:
+                g['ligand'].ar_pos = copy.deepcopy(g['ligand'].pos)
 
 
 def step_coefficients(inference_steps, tr_schedule, rot_schedule, tor_schedule, t_to_sigma, model_args, ode, no_random,
@@ -108,12 +115,14 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
              compute_ar_accuracy=False, noise=None):
     """``noise`` (extra, optional): list with one tensor [steps, b, 6+R] per batch of N(0,1) draws (tr xyz, rot xyz,
     torsions) to replace the device generator - used by the parity tests (the reference never seeds its RNGs)."""
-    if confidence_model is not None or ar_model is not None or visualization_list is not None:
-        raise RuntimeError('ddk: confidence / AR models and visualisation are outside the accelerated hot path')
+    if confidence_model is not None or visualization_list is not None:
+        raise RuntimeError('ddk: the confidence model and visualisation are outside the accelerated hot path')
     if classifier_free_guidance_weight != 0.0:
-        raise RuntimeError('ddk: classifier-free guidance needs the latent-conditioned model (not implemented on the device)')
-    if use_latent and getattr(model_args, 'latent_dim', 0) > 0:
-        raise RuntimeError('ddk: latent conditioning (latent_dim > 0) is not implemented on the device yet')
+        raise RuntimeError('ddk: classifier-free guidance (two forwards per step) is not implemented in ddk_sample')
+    latent_model = use_latent and getattr(model_args, 'latent_dim', 0) > 0
+    if latent_model and (ar_model is None or compute_ar_accuracy):
+        raise RuntimeError('ddk: latent-conditioned sampling needs ar_model (the oracle encoder needs the ground-truth pose and is '
+                           'outside the hot path)')
     device = torch.device(device)
     if device.type != 'cuda':
         raise RuntimeError('ddk sampling runs on the GPU only (no CPU fallback)')
@@ -128,6 +137,18 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
             if b != min(batch_size, N):
                 raise RuntimeError('ragged last batch: the reference draws noise of size min(batch_size, N) (sampling.py:146-153)')
             cx, _ = complex_for_batch(batch, device, ctx=score_model.ctx)
+            latent_h = None
+            if latent_model:   # utils/sampling.py:69-103: AR decoding on the ar_pos pose, then the latents condition every step
+                batch = batch.to(device)
+                temp_lig_pos = batch['ligand'].pos
+                if 'ar_pos' in batch['ligand']:
+                    batch['ligand'].pos = batch['ligand'].ar_pos
+                latent_h = ar_model.encode_ar(batch, softmax_latent_temperature)
+                batch['ligand'].pos = temp_lig_pos
+                batch['ligand'].latent_h, batch['receptor'].latent_h = latent_h
+                cx.set_latents(latent_h[0], latent_h[1], 0.0)
+            elif score_model.cfg['latent_dim'] > 0:
+                raise RuntimeError('ddk: a latent-conditioned score model was given but use_latent / model_args.latent_dim disable the latents')
             pos = batch['ligand'].pos.to(device).float().reshape(b, -1, 3).contiguous()
             R = cx.R if not model_args.no_torsion else 0
             if noise is not None:
@@ -144,6 +165,23 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
             cx.sample(pos, t_arr, sc, nc, z)
             len_lig = pos.shape[1]
             flat = pos.reshape(-1, 3)
+            len_rec = len(batch['receptor'].pos) // b
             for i in range(b):
-                data_list[batch_id * batch_size + i]['ligand'].pos = flat[i * len_lig:len_lig * (i + 1)]
+                d_i = data_list[batch_id * batch_size + i]
+                d_i['ligand'].pos = flat[i * len_lig:len_lig * (i + 1)]
+                if latent_model:   # latent bookkeeping of utils/sampling.py:205-221
+                    lig_lat, rec_lat = latent_h[0][i * len_lig:len_lig * (i + 1)], latent_h[1][i * len_rec:len_rec * (i + 1)]
+                    lat_str, lat_pos = "", []
+                    for j in range(model_args.latent_dim):
+                        assert torch.sum(lig_lat[:, j]) + torch.sum(rec_lat[:, j]) == 1
+                        if torch.sum(lig_lat[:, j]) == 1:
+                            idx = int(torch.argmax(lig_lat[:, j]))
+                            lat_str += 'L' + str(idx)
+                            lat_pos.append(d_i['ligand'].pos[idx:idx + 1].detach().cpu() + d_i.original_center.detach().cpu())
+                        else:
+                            idx = int(torch.argmax(rec_lat[:, j]))
+                            lat_str += 'R' + str(idx)
+                            lat_pos.append(d_i['receptor'].pos[idx:idx + 1].detach().cpu() + d_i.original_center.detach().cpu())
+                    d_i.latent_str = lat_str
+                    d_i.latent_pos = torch.cat(lat_pos, dim=0)
     return data_list, None

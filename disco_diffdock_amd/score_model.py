@@ -98,6 +98,16 @@ class TensorProductScoreModel(nn.Module):
     def to(self, device):
         return self
 
+    def _bind_latents(self, cx, data):
+        """latent_h / unconditional inputs of the DisCo models (score_model.py:170-184,209-215)."""
+        if self.cfg['latent_dim'] <= 0:
+            return
+        lig, rec = data['ligand'], data['receptor']
+        if 'latent_h' not in lig or 'latent_h' not in rec:
+            raise RuntimeError('ddk: latent-conditioned score model needs data[...].latent_h (sampling.py:87-88)')
+        unc = float(lig.unconditional.reshape(-1)[0]) if 'unconditional' in lig else 0.0
+        cx.set_latents(lig.latent_h.to(self.device), rec.latent_h.to(self.device), unc)
+
     def forward(self, data):
         if not self._loaded:
             raise RuntimeError('ddk score model: load_state_dict() first')
@@ -105,12 +115,23 @@ class TensorProductScoreModel(nn.Module):
         if not pos.is_cuda:
             raise RuntimeError('ddk score model runs on the GPU only (no CPU fallback)')
         cx, B = complex_for_batch(data, pos.device, ctx=self.ctx)
+        self._bind_latents(cx, data)
         t = [float(data.complex_t[k][0]) for k in ('tr', 'rot', 'tor')]
         tr, rot, tor = cx.score_forward(pos.reshape(B, -1, 3), *t)
         self.last_complex = cx
         if self.no_torsion or cx.R == 0:
             tor = torch.empty(0, device=pos.device)
         return tr, rot, tor
+
+    def embed(self, data):
+        """models/score_model.py:169-257: (lig_node_attr, rec_node_attr, tr_sigma, rot_sigma, tor_sigma) after the conv stack."""
+        from .diffusion_utils import t_to_sigma
+        from types import SimpleNamespace
+        self.forward(data)
+        B = data.num_graphs
+        lig, rec = self.last_complex.node_features(B, data['ligand'].pos.device)
+        sig = t_to_sigma(*[data.complex_t[k] for k in ('tr', 'rot', 'tor')], SimpleNamespace(**self.cfg))
+        return (lig, rec) + tuple(sig)
 
 
 class ModelWrapper(nn.Module):

@@ -157,7 +157,7 @@ def sde_step_coefficients(t_idx, inference_steps, schedules, cfg, ode=False, tem
 def sampling(data_list, P, cfg, so3_table, torus_table, inference_steps, tr_schedule, rot_schedule, tor_schedule,
              noise_fn=None, no_random=False, ode=False, batch_size=32, no_final_step_noise=False,
              temp_sampling=1.0, temp_psi=0.0, temp_sigma_data=0.5, dtype=torch.float32, trace=None):
-    """utils/sampling.py:49-249 for latent_dim == 0, no CFG, no confidence model.
+    """utils/sampling.py:49-249 without CFG / confidence model; latent-conditioned models read latent_h / unconditional from the graphs (set by the caller after AR decoding, sampling.py:69-103).
 
     ``noise_fn(batch_id, t_idx, name, shape)`` supplies z ~ N(0,1) (name in 'tr','rot','tor');
     default: torch.normal under the global generator, like the reference."""

@@ -231,6 +231,34 @@ def main():
         save(f'weights_probe_{tag}', seed=7, n_tensors=len(P), n_elements=n_params,
              checksum=np.float64(sum(float(v.double().sum()) for v in P.values())))
         save(f'complex_{tag}', **{k: v for k, v in c.items() if k != 'name'})
+        if cfgm.latent_dim > 0:
+            # ---- Tier B: AR latent model (PretrainedScoreEncoder + GenericEncoder.encode_ar), reference code on the stand-ins
+            from oracle import ar_ref
+            from models.pretrained_score_encoder import PretrainedScoreEncoder
+            import copy as _copy
+            P_ar = ar_ref.random_ar_state_dict(cfgm, ar_ns=16, hidden=128, seed=21)
+            ar_score = get_model(args, torch.device('cpu'), t_to_sigma, no_parallel=True).score_model
+            ar = PretrainedScoreEncoder(pretrained_score_model=ar_score, ns=16, latent_dim=1, latent_vocab=1, latent_no_batchnorm=False,
+                                        latent_dropout=0.0, latent_hidden_dim=128, input_latent_dim=cfgm.latent_dim, apply_gumbel_softmax=True)
+            ar.load_state_dict(P_ar, strict=True)      # pins the AR checkpoint key layout
+            ar.eval()
+            dl = [to_graph(c) for _ in range(Bs)]
+            rng = np.random.default_rng(15)
+            for d_ in dl:
+                d_['ligand'].pos = d_['ligand'].pos + torch.from_numpy(rng.normal(0, 1.0, size=(1, 3))).float()
+            b = graph_lite.collate(dl)
+            pos_in = b['ligand'].pos.clone()
+            with torch.no_grad():
+                bb = _copy.deepcopy(b)
+                bb['ligand'].input_latent = torch.zeros(bb['ligand'].num_nodes, cfgm.latent_dim)
+                bb['receptor'].input_latent = torch.zeros(bb['receptor'].num_nodes, cfgm.latent_dim)
+                bb.decoding_idx = torch.zeros(Bs).long()
+                ar.apply_gumbel_softmax = False
+                logits0 = torch.cat(ar(bb), dim=0)
+                ar.apply_gumbel_softmax = True
+                lat_l, lat_r = ar.encode_ar(_copy.deepcopy(b), 100.0)       # temperature >= 100 -> argmax (deterministic)
+            save(f'ar_{tag}', pos=pos_in, logits0=logits0, latent_l=lat_l, latent_r=lat_r, seed=21, B=Bs,
+                 n_tensors=len(ar.state_dict()))
         if cfgm.latent_dim == 0:
             steps = 3
             sched = diffusion_utils.get_t_schedule(steps)

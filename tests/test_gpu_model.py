@@ -257,3 +257,126 @@ def test_unsupported_options_are_loud(dev, model7):
         sampling([], model7, 2, [1, .5], [1, .5], [1, .5], dev, partial(t_to_sigma, args=ARGS_S), ARGS_S, confidence_model=object())
     with pytest.raises(RuntimeError, match='GPU only'):
         sampling([], model7, 2, [1, .5], [1, .5], [1, .5], 'cpu', partial(t_to_sigma, args=ARGS_S), ARGS_S)
+
+
+def test_disco_latent_score_model_golden(dev, golden):
+    """DisCo-DiffDock-S score model (latent_dim=2, latent_vocab=1, latent_droprate=0.1) with one-hot node latents."""
+    from functools import partial
+    from disco_diffdock_amd.model_utils import get_model
+    from disco_diffdock_amd.diffusion_utils import t_to_sigma
+    tag = 'disco_diffdockS_score_model'
+    args = Namespace(**dict(vars(ARGS_S), latent_dim=2, latent_vocab=1, latent_droprate=0.1))
+    cfg = smr.ScoreModelConfig(latent_dim=2, latent_vocab=1, latent_droprate=0.1)
+    model = get_model(args, dev, partial(t_to_sigma, args=args), no_parallel=True)
+    model.score_model.load_state_dict(smr.random_state_dict(cfg, seed=7), strict=True)
+    c = complex_from_npz(golden(f'complex_{tag}'))
+    for t in (1.0, 0.55, 0.05):
+        z = golden(f'score_{tag}_t{t}')
+        B = int(z['B'])
+        b = _dev_batch(c, B, z['pos'], dev, t)
+        b['ligand'].latent_h, b['receptor'].latent_h = T(z['latent_l']).to(dev), T(z['latent_r']).to(dev)
+        b['ligand'].unconditional = torch.zeros(b['ligand'].num_nodes, 1, device=dev)
+        b['receptor'].unconditional = torch.zeros(b['receptor'].num_nodes, 1, device=dev)
+        tr, rot, tor = model.score_model(b)
+        lig, rec = model.score_model.last_complex.node_features(B, dev)
+        assert rel_err(lig.cpu(), z['lig_node_attr']) < 1e-4 and rel_err(rec.cpu(), z['rec_node_attr']) < 1e-4
+        for name, a in (('tr', tr), ('rot', rot), ('tor', tor)):
+            assert rel_err(a.cpu(), z[name]) < 1e-4, name
+    # unconditional = 1 and zeroed latents (the classifier-free-guidance / AR-encoder input) against the oracle
+    from oracle import sampler_ref
+    from helpers import batch_of
+    B = 2
+    pos = golden(f'score_{tag}_t0.55')['pos']
+    b = _dev_batch(c, B, pos, dev, 1.0)
+    b['ligand'].latent_h = torch.zeros(b['ligand'].num_nodes, 2, device=dev)
+    b['receptor'].latent_h = torch.zeros(b['receptor'].num_nodes, 2, device=dev)
+    b['ligand'].unconditional = torch.ones(b['ligand'].num_nodes, 1, device=dev)
+    b['receptor'].unconditional = torch.ones(b['receptor'].num_nodes, 1, device=dev)
+    tr, rot, tor = model.score_model(b)
+    ob = batch_of(c, B, pos)
+    sampler_ref.set_time(ob, 1.0, 1.0, 1.0, B)
+    ob['ligand'].latent_h, ob['receptor'].latent_h = torch.zeros(ob['ligand'].num_nodes, 2), torch.zeros(ob['receptor'].num_nodes, 2)
+    ob['ligand'].unconditional, ob['receptor'].unconditional = torch.ones(ob['ligand'].num_nodes, 1), torch.ones(ob['receptor'].num_nodes, 1)
+    import numpy as _np, os as _os
+    d = _os.path.join(_os.path.dirname(__file__), '..', 'disco_diffdock_amd', 'data')
+    tab = (_np.load(_os.path.join(d, 'so3_exp_score_norms.npy')), _np.load(_os.path.join(d, 'torus_score_norm_seed0.npy')))
+    tr_r, rot_r, tor_r = smr.score_model_forward(smr.random_state_dict(cfg, seed=7), cfg, ob, tab[0], tab[1])
+    assert rel_err(tr.cpu(), tr_r) < 1e-4 and rel_err(rot.cpu(), rot_r) < 1e-4 and rel_err(tor.cpu(), tor_r) < 1e-4
+
+
+def test_ar_latent_model_golden(dev, golden):
+    """AR latent model (a22): logits of PretrainedScoreEncoder and the argmax-decoded latents of encode_ar vs the reference."""
+    from disco_diffdock_amd.model_utils import get_ar_model
+    from oracle import ar_ref
+    tag = 'disco_diffdockS_score_model'
+    z = golden(f'ar_{tag}')
+    score_args = Namespace(**dict(vars(ARGS_S), latent_dim=2, latent_vocab=1, latent_droprate=0.1))
+    ar_args = Namespace(use_pretrained_score=True, ns=16, latent_no_batchnorm=False, latent_dropout=0.0, latent_hidden_dim=128,
+                        esm_embeddings_path='x', original_model_dir='unused', ckpt='unused')
+    cfg = smr.ScoreModelConfig(latent_dim=2, latent_vocab=1, latent_droprate=0.1)
+    ar = get_ar_model(ar_args, score_args, dev, training=False)
+    ar.load_state_dict(ar_ref.random_ar_state_dict(cfg, ar_ns=16, hidden=128, seed=int(z['seed'])), strict=True)
+    ar.eval()
+    c = complex_from_npz(golden(f'complex_{tag}'))
+    B = int(z['B'])
+    b = _dev_batch(c, B, z['pos'], dev, 1.0)
+    b['ligand'].input_latent = torch.zeros(b['ligand'].num_nodes, 2, device=dev)
+    b['receptor'].input_latent = torch.zeros(b['receptor'].num_nodes, 2, device=dev)
+    with torch.no_grad():
+        logits = ar.logits(b)
+        assert rel_err(logits.cpu(), z['logits0']) < 1e-4
+        assert 'latent_h' not in b['ligand']          # the input batch is left untouched
+        lat_l, lat_r = ar.encode_ar(b, 100.0)
+    assert torch.equal(lat_l.cpu(), T(z['latent_l'])) and torch.equal(lat_r.cpu(), T(z['latent_r']))
+
+
+def test_disco_sampling_with_ar_model_vs_oracle(dev, tables):
+    """config-3 path end to end on a small complex: AR decoding (injected choices) -> latent-conditioned 3-step sampling."""
+    from functools import partial
+    from disco_diffdock_amd import synthetic
+    from disco_diffdock_amd.model_utils import get_model, get_ar_model
+    from disco_diffdock_amd.sampling import sampling
+    from disco_diffdock_amd.data import from_arrays
+    from disco_diffdock_amd.diffusion_utils import t_to_sigma, get_t_schedule
+    from oracle import ar_ref
+    from helpers import to_graph
+    score_args = Namespace(**dict(vars(ARGS_S), latent_dim=2, latent_vocab=1, latent_droprate=0.1))
+    ar_args = Namespace(use_pretrained_score=True, ns=16, latent_no_batchnorm=False, latent_dropout=0.0, latent_hidden_dim=128,
+                        esm_embeddings_path='x', no_randomness=False)
+    cfg = smr.ScoreModelConfig(latent_dim=2, latent_vocab=1, latent_droprate=0.1)
+    P, P_ar = smr.random_state_dict(cfg, seed=13), ar_ref.random_ar_state_dict(cfg, seed=14)
+    model = get_model(score_args, dev, partial(t_to_sigma, args=score_args), no_parallel=True)
+    model.score_model.load_state_dict(P)
+    ar = get_ar_model(ar_args, score_args, dev, training=False)
+    ar.load_state_dict(P_ar)
+    ar.eval()
+    c = synthetic.make_complex(31, n_res=40, n_lig=22)
+    B, steps, R = 3, 3, int(c['edge_mask'].sum())
+    rng = np.random.default_rng(2)
+    start = [c['lig_pos'] + rng.normal(0, 4.0, size=(1, 3)).astype(np.float32) for _ in range(B)]
+    z = _ref_noise(5, steps, B, R)
+    sched = get_t_schedule(steps)
+    dl = [from_arrays(c) for _ in range(B)]
+    for d, p in zip(dl, start):
+        d['ligand'].pos = T(p).float()
+        d['ligand'].ar_pos = T(p).float()
+    out, _ = sampling(dl, model, steps, sched, sched, sched, dev, partial(t_to_sigma, args=score_args), score_args, batch_size=B,
+                      no_final_step_noise=True, ar_model=ar, ar_args=ar_args, softmax_latent_temperature=100.0, noise=[z], **README_S)
+    # oracle: same AR decoding (argmax) and latent-conditioned sampling
+    ol = [to_graph(c) for _ in range(B)]
+    for d, p in zip(ol, start):
+        d['ligand'].pos = T(p).float()
+    from oracle import graph_lite
+    ob = graph_lite.collate(ol)
+    lat_l, lat_r = ar_ref.encode_ar(P_ar, cfg, 16, ob, sampling_temperature=100.0)
+    n_l, n_r = len(c['lig_pos']), len(c['rec_pos'])
+    for i, d in enumerate(ol):
+        d['ligand'].latent_h, d['receptor'].latent_h = lat_l[i * n_l:(i + 1) * n_l], lat_r[i * n_r:(i + 1) * n_r]
+        d['ligand'].unconditional, d['receptor'].unconditional = torch.zeros(n_l, 1), torch.zeros(n_r, 1)
+    nf = lambda b, t, name, shape: {'tr': z[t, :, 0:3], 'rot': z[t, :, 3:6], 'tor': z[t, :, 6:].reshape(-1)}[name]
+    ref, _ = spr.sampling(ol, P, cfg, tables[0], tables[1], steps, sched, sched, sched, noise_fn=nf, batch_size=B,
+                          no_final_step_noise=True, **README_S)
+    a = torch.cat([d['ligand'].pos for d in out]).cpu()
+    r = torch.cat([d['ligand'].pos for d in ref])
+    assert rel_err(a, r) < 1e-4
+    assert all(hasattr(d, 'latent_str') and len(d.latent_pos) == 2 for d in out)

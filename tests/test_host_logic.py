@@ -65,7 +65,7 @@ def test_get_model_refuses_unsupported_configs():
                 use_old_atom_encoder=False, esm_embeddings_path='x',
                 **{k: v for k, v in vars(ARGS).items() if k != 'no_torsion'})
     with pytest.raises(RuntimeError, match='latent'):
-        get_model(Namespace(**dict(base, latent_dim=2, latent_vocab=1)), torch.device('cpu'), None)
+        get_model(Namespace(**dict(base, latent_dim=2, latent_vocab=64)), torch.device('cpu'), None)
     with pytest.raises(RuntimeError, match='sh_lmax=1'):
         get_model(Namespace(**dict(base, sh_lmax=2)), torch.device('cpu'), None)
     with pytest.raises(RuntimeError, match='all-atom'):

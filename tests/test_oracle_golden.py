@@ -213,3 +213,24 @@ def test_equivariance(tables):
     assert rel_err(tr0 @ Rm.T, tr1) < 1e-9
     assert rel_err(rot0 @ Rm.T, rot1) < 1e-9
     assert rel_err(tor0, tor1) < 1e-9
+
+
+def test_ar_latent_model(golden):
+    """Tier B: AR latent model logits and the argmax-decoded latents vs the reference's PretrainedScoreEncoder / encode_ar."""
+    from oracle import ar_ref
+    tag = 'disco_diffdockS_score_model'
+    z = golden(f'ar_{tag}')
+    cfg = _cfg_for(tag)
+    P = ar_ref.random_ar_state_dict(cfg, ar_ns=16, hidden=128, seed=int(z['seed']))
+    assert len(P) == int(z['n_tensors'])
+    c = complex_from_npz(golden(f'complex_{tag}'))
+    B = int(z['B'])
+    b = batch_of(c, B, z['pos'])
+    b['ligand'].input_latent = torch.zeros(b['ligand'].num_nodes, cfg.latent_dim)
+    b['receptor'].input_latent = torch.zeros(b['receptor'].num_nodes, cfg.latent_dim)
+    logits = ar_ref.ar_logits(P, cfg, 16, b)
+    assert rel_err(logits, z['logits0']) < 1e-4
+    b = batch_of(c, B, z['pos'])
+    lat_l, lat_r = ar_ref.encode_ar(P, cfg, 16, b, sampling_temperature=100.0)
+    assert torch.equal(lat_l, T(z['latent_l'])) and torch.equal(lat_r, T(z['latent_r']))
+    assert float(lat_l.sum() + lat_r.sum()) == B * cfg.latent_dim

@@ -147,6 +147,18 @@ __global__ __launch_bounds__(256) void se3_update_kernel(Se3Args A) {
   }
 }
 
+// classifier-free guidance: score <- score + w * (score - score_unconditional)   (utils/sampling.py:131-133)
+__global__ void cfg_combine_kernel(float* score, const float* uncond, float w, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) score[i] = score[i] + w * (score[i] - uncond[i]);
+}
+
+hipError_t launch_cfg_combine(float* score, const float* uncond, float weight, int64_t n, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(cfg_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, score, uncond, weight, n);
+  return hipGetLastError();
+}
+
 hipError_t launch_se3(const Se3Args& A, hipStream_t s) {
   hipLaunchKernelGGL(se3_update_kernel, dim3(A.B), dim3(256), 0, s, A);
   return hipGetLastError();

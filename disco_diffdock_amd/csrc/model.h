@@ -154,6 +154,7 @@ struct NodeEmbedArgs {
 hipError_t launch_node_embed(const NodeEmbedArgs& a, hipStream_t s);
 hipError_t launch_heads(const HeadArgs& A, bool torsion, hipStream_t s);
 hipError_t launch_se3(const Se3Args& A, hipStream_t s);
+hipError_t launch_cfg_combine(float* score, const float* uncond, float weight, int64_t n, hipStream_t s);
 
 }  // namespace ddk
 
@@ -173,6 +174,8 @@ struct ddk_complex {
   float *pos_tmp = nullptr, *scores = nullptr;
   const float *lig_latent = nullptr, *rec_latent = nullptr;   // caller-owned device arrays set by ddk_set_latents
   float unconditional = 0.0f;
+  float cfg_weight = 0.0f, cfg_start = 1.0f, cfg_end = 0.0f;   // ddk_set_guidance
+  float *zero_lat = nullptr, *scores2 = nullptr;
   float* x_last = nullptr;    // node features after the conv stack of the last forward
   int last_B = 0;
   std::vector<void*> allocs;

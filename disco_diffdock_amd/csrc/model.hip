@@ -450,6 +450,11 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
   cx->sum = cx_upload<float>(cx, nullptr, N * XW);
   cx->pos_tmp = cx_upload<float>(cx, nullptr, Bm * n_lig * 3);
   cx->scores = cx_upload<float>(cx, nullptr, Bm * (6 + (d->n_rot > 0 ? d->n_rot : 1)));
+  cx->scores2 = cx_upload<float>(cx, nullptr, Bm * (6 + (d->n_rot > 0 ? d->n_rot : 1)));
+  if (c.latent_dim > 0) {
+    cx->zero_lat = cx_upload<float>(cx, nullptr, N * c.latent_dim);
+    if (cx->zero_lat) hipMemset(cx->zero_lat, 0, (size_t)N * c.latent_dim * sizeof(float));
+  }
   for (void* p : cx->allocs)
     if (!p) return fail(ctx, DDK_ERR_NOMEM, "device allocation failed in ddk_complex_create");
   if (!cx->bond_src || !cx->rr_sh || !cx->scores) return fail(ctx, DDK_ERR_NOMEM, "device allocation failed in ddk_complex_create");
@@ -503,8 +508,22 @@ int ddk_sample(ddk_ctx* ctx, ddk_complex* cx, int32_t B, int32_t steps, const fl
   std::vector<StepParams> sps(steps);
   for (int k = 0; k < steps; ++k)
     if ((rc = make_step_params(ctx, t[3 * k], t[3 * k + 1], t[3 * k + 2], sps[k]))) return rc;
+  const size_t n_sc = (size_t)B * (6 + (torsion ? R : 0));
   for (int k = 0; k < steps; ++k) {
     if ((rc = score_forward_impl(ctx, cx, B, pos, sps[k], tr, rot, torsion ? tor : nullptr, s))) return rc;
+    if (cx->cfg_weight != 0.0f && ctx->cfg.latent_dim > 0 && t[3 * k] <= cx->cfg_start && t[3 * k] >= cx->cfg_end) {
+      // second, unconditional forward: unconditional = 1, latents zeroed (sampling.py:119-129)
+      const float* ll = cx->lig_latent; const float* rl = cx->rec_latent; const float un = cx->unconditional;
+      cx->lig_latent = cx->zero_lat; cx->rec_latent = cx->zero_lat + (size_t)B * cx->n_lig * ctx->cfg.latent_dim; cx->unconditional = 1.0f;
+      float* tr2 = cx->scores2;
+      float* rot2 = tr2 + (size_t)B * 3;
+      float* tor2 = rot2 + (size_t)B * 3;
+      rc = score_forward_impl(ctx, cx, B, pos, sps[k], tr2, rot2, torsion ? tor2 : nullptr, s);
+      cx->lig_latent = ll; cx->rec_latent = rl; cx->unconditional = un;
+      if (rc) return rc;
+      hipError_t e2 = launch_cfg_combine(cx->scores, cx->scores2, cx->cfg_weight, (int64_t)n_sc, s);
+      if (e2 != hipSuccess) return hip_fail(ctx, e2, "cfg_combine launch");
+    }
     Se3Args A;
     A.pos = pos; A.tr = tr; A.rot = rot; A.tor = torsion ? tor : nullptr;
     A.noise = noise ? noise + (size_t)k * B * (6 + R) : nullptr;
@@ -548,6 +567,13 @@ int ddk_set_latents(ddk_ctx* ctx, ddk_complex* cx, const float* lig_latent, cons
   if (!ctx || !cx) return DDK_ERR_INVALID;
   if ((lig_latent == nullptr) != (rec_latent == nullptr)) return fail(ctx, DDK_ERR_INVALID, "ddk_set_latents: pass both latent arrays or neither");
   cx->lig_latent = lig_latent; cx->rec_latent = rec_latent; cx->unconditional = unconditional;
+  return DDK_OK;
+}
+
+int ddk_set_guidance(ddk_ctx* ctx, ddk_complex* cx, float weight, float cfg_start, float cfg_end) {
+  if (!ctx || !cx) return DDK_ERR_INVALID;
+  if (weight != 0.0f && ctx->cfg.latent_dim <= 0) return fail(ctx, DDK_ERR_INVALID, "classifier-free guidance needs a latent-conditioned model");
+  cx->cfg_weight = weight; cx->cfg_start = cfg_start; cx->cfg_end = cfg_end;
   return DDK_OK;
 }
 

@@ -193,6 +193,9 @@ class Complex:
         self.ctx._check(self.ctx.L.ddk_set_latents(self.ctx.h, self.h, _ptr(lig_latent), _ptr(rec_latent), float(unconditional)),
                         'ddk_set_latents')
 
+    def set_guidance(self, weight=0.0, cfg_start=1.0, cfg_end=0.0):
+        self.ctx._check(self.ctx.L.ddk_set_guidance(self.ctx.h, self.h, float(weight), float(cfg_start), float(cfg_end)), 'ddk_set_guidance')
+
     # ---- model.score_model(batch) ------------------------------------------------------------------
     def score_forward(self, pos, t_tr, t_rot, t_tor):
         ctx = self.ctx

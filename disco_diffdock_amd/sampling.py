@@ -117,9 +117,9 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
     torsions) to replace the device generator - used by the parity tests (the reference never seeds its RNGs)."""
     if confidence_model is not None or visualization_list is not None:
         raise RuntimeError('ddk: the confidence model and visualisation are outside the accelerated hot path')
-    if classifier_free_guidance_weight != 0.0:
-        raise RuntimeError('ddk: classifier-free guidance (two forwards per step) is not implemented in ddk_sample')
     latent_model = use_latent and getattr(model_args, 'latent_dim', 0) > 0
+    if classifier_free_guidance_weight != 0.0 and not latent_model:
+        raise RuntimeError('ddk: classifier-free guidance needs the latent-conditioned model (sampling.py:119-135)')
     if latent_model and (ar_model is None or compute_ar_accuracy):
         raise RuntimeError('ddk: latent-conditioned sampling needs ar_model (the oracle encoder needs the ground-truth pose and is '
                            'outside the hot path)')
@@ -147,6 +147,7 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
                 batch['ligand'].pos = temp_lig_pos
                 batch['ligand'].latent_h, batch['receptor'].latent_h = latent_h
                 cx.set_latents(latent_h[0], latent_h[1], 0.0)
+                cx.set_guidance(classifier_free_guidance_weight, cfg_start, cfg_end)
             elif score_model.cfg['latent_dim'] > 0:
                 raise RuntimeError('ddk: a latent-conditioned score model was given but use_latent / model_args.latent_dim disable the latents')
             pos = batch['ligand'].pos.to(device).float().reshape(b, -1, 3).contiguous()

@@ -108,6 +108,11 @@ void ddk_complex_destroy(ddk_ctx* ctx, ddk_complex* cx);
  *      Applies to the subsequent ddk_score_forward / ddk_sample calls on this complex; NULL, NULL clears. */
 int ddk_set_latents(ddk_ctx* ctx, ddk_complex* cx, const float* lig_latent, const float* rec_latent, float unconditional);
 
+/* ---- classifier-free guidance of the sampler (utils/sampling.py:119-135): while cfg_end <= t_tr <= cfg_start every step of
+ *      ddk_sample runs a second forward with unconditional = 1 and zeroed latents and uses
+ *      score + weight * (score - score_unconditional).  weight = 0 (default) disables it. */
+int ddk_set_guidance(ddk_ctx* ctx, ddk_complex* cx, float weight, float cfg_start, float cfg_end);
+
 /* ---- a5-a17: model.score_model(batch) -> (tr[B,3], rot[B,3], tor[B*R])  models/score_model.py:259-308
  *      for B copies of one complex at a common time (utils/sampling.py:113-117).
  *      lig_pos [B, n_lig, 3]; outputs tr [B,3], rot [B,3], tor [B*n_rot]. */

@@ -156,7 +156,8 @@ def sde_step_coefficients(t_idx, inference_steps, schedules, cfg, ode=False, tem
 
 def sampling(data_list, P, cfg, so3_table, torus_table, inference_steps, tr_schedule, rot_schedule, tor_schedule,
              noise_fn=None, no_random=False, ode=False, batch_size=32, no_final_step_noise=False,
-             temp_sampling=1.0, temp_psi=0.0, temp_sigma_data=0.5, dtype=torch.float32, trace=None):
+             temp_sampling=1.0, temp_psi=0.0, temp_sigma_data=0.5, dtype=torch.float32, trace=None,
+             classifier_free_guidance_weight=0.0, cfg_start=1.0, cfg_end=0.0):
     """utils/sampling.py:49-249 without CFG / confidence model; latent-conditioned models read latent_h / unconditional from the graphs (set by the caller after AR decoding, sampling.py:69-103).
 
     ``noise_fn(batch_id, t_idx, name, shape)`` supplies z ~ N(0,1) (name in 'tr','rot','tor');
@@ -174,6 +175,14 @@ def sampling(data_list, P, cfg, so3_table, torus_table, inference_steps, tr_sche
                 t_tr, t_rot, t_tor = tr_schedule[t_idx], rot_schedule[t_idx], tor_schedule[t_idx]
                 set_time(batch, t_tr, t_rot, t_tor, b)
                 tr_score, rot_score, tor_score = smr.score_model_forward(P, cfg, batch, so3_table, torus_table, dtype)
+                if classifier_free_guidance_weight != 0.0 and t_tr <= cfg_start and t_tr >= cfg_end:   # sampling.py:119-135
+                    w = classifier_free_guidance_weight
+                    keep = (batch['ligand'].latent_h, batch['receptor'].latent_h, batch['ligand'].unconditional, batch['receptor'].unconditional)
+                    batch['ligand'].unconditional, batch['receptor'].unconditional = torch.ones_like(keep[2]), torch.ones_like(keep[3])
+                    batch['ligand'].latent_h, batch['receptor'].latent_h = 0 * keep[0], 0 * keep[1]
+                    u_tr, u_rot, u_tor = smr.score_model_forward(P, cfg, batch, so3_table, torus_table, dtype)
+                    tr_score, rot_score, tor_score = tr_score + w * (tr_score - u_tr), rot_score + w * (rot_score - u_rot), tor_score + w * (tor_score - u_tor)
+                    batch['ligand'].latent_h, batch['receptor'].latent_h, batch['ligand'].unconditional, batch['receptor'].unconditional = keep
                 coef = sde_step_coefficients(t_idx, inference_steps, schedules, cfg, ode, temp_sampling, temp_psi, temp_sigma_data)
                 zero = no_random or (no_final_step_noise and t_idx == inference_steps - 1)
                 nb = min(batch_size, N)

@@ -259,6 +259,26 @@ def main():
                 lat_l, lat_r = ar.encode_ar(_copy.deepcopy(b), 100.0)       # temperature >= 100 -> argmax (deterministic)
             save(f'ar_{tag}', pos=pos_in, logits0=logits0, latent_l=lat_l, latent_r=lat_r, seed=21, B=Bs,
                  n_tensors=len(ar.state_dict()))
+            # full reference sampling() of the DisCo path: AR decoding (argmax) -> latent-conditioned reverse diffusion with
+            # classifier-free guidance active on the middle step, README DisCo temperatures
+            README_D = dict(temp_sampling=[1.546842681537956, 4.005218254154881, 3.6499018519649384],
+                            temp_psi=[1.2685697872473618, 1.2760150490206228, 2.0625243924678136],
+                            temp_sigma_data=[0.8456140350087653, 0.453446580767075, 0.3292199987743284])
+            steps = 3
+            sched = diffusion_utils.get_t_schedule(steps)
+            dl = [to_graph(c) for _ in range(Bs)]
+            rng = np.random.default_rng(19)
+            for d_ in dl:
+                d_['ligand'].pos = d_['ligand'].pos + torch.from_numpy(rng.normal(0, 4.0, size=(1, 3))).float()
+                d_['ligand'].ar_pos = d_['ligand'].pos.clone()
+            pos0 = torch.cat([d_['ligand'].pos for d_ in dl])
+            torch.manual_seed(99)
+            out_list, _ = ref_sampling.sampling(dl, model, steps, sched, sched, sched, torch.device('cpu'), t_to_sigma, args,
+                                                batch_size=Bs, no_final_step_noise=True, use_latent=True, ar_model=ar,
+                                                ar_args=Namespace(no_randomness=False), softmax_latent_temperature=100.0,
+                                                classifier_free_guidance_weight=0.7, cfg_start=0.9, cfg_end=0.2, **README_D)
+            save(f'trajectory_{tag}', pos0=pos0, pos_out=torch.cat([d_['ligand'].pos for d_ in out_list]), steps=steps, seed=99,
+                 ar_seed=21, latent_str=np.array([d_.latent_str for d_ in out_list]))
         if cfgm.latent_dim == 0:
             steps = 3
             sched = diffusion_utils.get_t_schedule(steps)

@@ -360,8 +360,9 @@ def test_disco_sampling_with_ar_model_vs_oracle(dev, tables):
     for d, p in zip(dl, start):
         d['ligand'].pos = T(p).float()
         d['ligand'].ar_pos = T(p).float()
+    CFG = dict(classifier_free_guidance_weight=0.7, cfg_start=0.9, cfg_end=0.2)     # active on the middle step only (t = 1, 2/3, 1/3)
     out, _ = sampling(dl, model, steps, sched, sched, sched, dev, partial(t_to_sigma, args=score_args), score_args, batch_size=B,
-                      no_final_step_noise=True, ar_model=ar, ar_args=ar_args, softmax_latent_temperature=100.0, noise=[z], **README_S)
+                      no_final_step_noise=True, ar_model=ar, ar_args=ar_args, softmax_latent_temperature=100.0, noise=[z], **README_S, **CFG)
     # oracle: same AR decoding (argmax) and latent-conditioned sampling
     ol = [to_graph(c) for _ in range(B)]
     for d, p in zip(ol, start):
@@ -375,8 +376,45 @@ def test_disco_sampling_with_ar_model_vs_oracle(dev, tables):
         d['ligand'].unconditional, d['receptor'].unconditional = torch.zeros(n_l, 1), torch.zeros(n_r, 1)
     nf = lambda b, t, name, shape: {'tr': z[t, :, 0:3], 'rot': z[t, :, 3:6], 'tor': z[t, :, 6:].reshape(-1)}[name]
     ref, _ = spr.sampling(ol, P, cfg, tables[0], tables[1], steps, sched, sched, sched, noise_fn=nf, batch_size=B,
-                          no_final_step_noise=True, **README_S)
+                          no_final_step_noise=True, **README_S, **CFG)
     a = torch.cat([d['ligand'].pos for d in out]).cpu()
     r = torch.cat([d['ligand'].pos for d in ref])
     assert rel_err(a, r) < 1e-4
     assert all(hasattr(d, 'latent_str') and len(d.latent_pos) == 2 for d in out)
+
+
+def test_disco_trajectory_golden(dev, golden):
+    """the reference's sampling() on the DisCo path (AR argmax decoding, latents, CFG, README DisCo temperatures) through ddk."""
+    from functools import partial
+    from disco_diffdock_amd.model_utils import get_model, get_ar_model
+    from disco_diffdock_amd.sampling import sampling
+    from disco_diffdock_amd.data import from_arrays
+    from disco_diffdock_amd.diffusion_utils import t_to_sigma, get_t_schedule
+    from oracle import ar_ref
+    tag = 'disco_diffdockS_score_model'
+    z = golden(f'trajectory_{tag}')
+    score_args = Namespace(**dict(vars(ARGS_S), latent_dim=2, latent_vocab=1, latent_droprate=0.1))
+    ar_args = Namespace(use_pretrained_score=True, ns=16, latent_no_batchnorm=False, latent_dropout=0.0, latent_hidden_dim=128,
+                        esm_embeddings_path='x', no_randomness=False)
+    cfg = smr.ScoreModelConfig(latent_dim=2, latent_vocab=1, latent_droprate=0.1)
+    model = get_model(score_args, dev, partial(t_to_sigma, args=score_args), no_parallel=True)
+    model.score_model.load_state_dict(smr.random_state_dict(cfg, seed=7))
+    ar = get_ar_model(ar_args, score_args, dev, training=False)
+    ar.load_state_dict(ar_ref.random_ar_state_dict(cfg, ar_ns=16, hidden=128, seed=int(z['ar_seed'])))
+    ar.eval()
+    c = complex_from_npz(golden(f'complex_{tag}'))
+    B, steps, n = 2, int(z['steps']), len(c['lig_pos'])
+    dl = [from_arrays(c) for _ in range(B)]
+    for i, d in enumerate(dl):
+        d['ligand'].pos = T(z['pos0'][i * n:(i + 1) * n])
+        d['ligand'].ar_pos = d['ligand'].pos.clone()
+    sched = get_t_schedule(steps)
+    README_D = dict(temp_sampling=[1.546842681537956, 4.005218254154881, 3.6499018519649384],
+                    temp_psi=[1.2685697872473618, 1.2760150490206228, 2.0625243924678136],
+                    temp_sigma_data=[0.8456140350087653, 0.453446580767075, 0.3292199987743284])
+    noise = [_ref_noise(int(z['seed']), steps, B, int(c['edge_mask'].sum()))]
+    out, _ = sampling(dl, model, steps, sched, sched, sched, dev, partial(t_to_sigma, args=score_args), score_args, batch_size=B,
+                      no_final_step_noise=True, use_latent=True, ar_model=ar, ar_args=ar_args, softmax_latent_temperature=100.0,
+                      classifier_free_guidance_weight=0.7, cfg_start=0.9, cfg_end=0.2, noise=noise, **README_D)
+    assert [d.latent_str for d in out] == [str(x) for x in z['latent_str']]
+    assert rel_err(torch.cat([d['ligand'].pos for d in out]).cpu(), z['pos_out']) < 1e-4

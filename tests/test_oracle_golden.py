@@ -234,3 +234,40 @@ def test_ar_latent_model(golden):
     lat_l, lat_r = ar_ref.encode_ar(P, cfg, 16, b, sampling_temperature=100.0)
     assert torch.equal(lat_l, T(z['latent_l'])) and torch.equal(lat_r, T(z['latent_r']))
     assert float(lat_l.sum() + lat_r.sum()) == B * cfg.latent_dim
+
+
+README_D = dict(temp_sampling=[1.546842681537956, 4.005218254154881, 3.6499018519649384],
+                temp_psi=[1.2685697872473618, 1.2760150490206228, 2.0625243924678136],
+                temp_sigma_data=[0.8456140350087653, 0.453446580767075, 0.3292199987743284])
+
+
+def test_disco_trajectory_with_ar_and_cfg(golden, tables):
+    """Tier B: the reference's own sampling() on the DisCo path (AR decoding -> latents -> CFG on the middle step)."""
+    from oracle import ar_ref, graph_lite
+    tag = 'disco_diffdockS_score_model'
+    z = golden(f'trajectory_{tag}')
+    cfg = _cfg_for(tag)
+    P = smr.random_state_dict(cfg, seed=7)
+    P_ar = ar_ref.random_ar_state_dict(cfg, ar_ns=16, hidden=128, seed=int(z['ar_seed']))
+    c = complex_from_npz(golden(f'complex_{tag}'))
+    B, n_l, n_r = 2, len(c['lig_pos']), len(c['rec_pos'])
+    dl = [to_graph(c) for _ in range(B)]
+    for i, d in enumerate(dl):
+        d['ligand'].pos = T(z['pos0'][i * n_l:(i + 1) * n_l])
+    lat_l, lat_r = ar_ref.encode_ar(P_ar, cfg, 16, graph_lite.collate(dl), sampling_temperature=100.0)
+    strs = []
+    for i, d in enumerate(dl):
+        d['ligand'].latent_h, d['receptor'].latent_h = lat_l[i * n_l:(i + 1) * n_l], lat_r[i * n_r:(i + 1) * n_r]
+        d['ligand'].unconditional, d['receptor'].unconditional = torch.zeros(n_l, 1), torch.zeros(n_r, 1)
+        s = ''
+        for j in range(cfg.latent_dim):
+            s += ('L' + str(int(d['ligand'].latent_h[:, j].argmax()))) if d['ligand'].latent_h[:, j].sum() == 1 else \
+                 ('R' + str(int(d['receptor'].latent_h[:, j].argmax())))
+        strs.append(s)
+    assert strs == [str(x) for x in z['latent_str']]
+    steps = int(z['steps'])
+    sched = spr.get_t_schedule(steps)
+    torch.manual_seed(int(z['seed']))
+    out, _ = spr.sampling(dl, P, cfg, tables[0], tables[1], steps, sched, sched, sched, batch_size=B, no_final_step_noise=True,
+                          classifier_free_guidance_weight=0.7, cfg_start=0.9, cfg_end=0.2, **README_D)
+    assert rel_err(torch.cat([d['ligand'].pos for d in out]), z['pos_out']) < 1e-4

@@ -127,7 +127,10 @@ def main():
     from disco_diffdock_amd.sampling import step_coefficients
     from disco_diffdock_amd.diffusion_utils import t_to_sigma, get_t_schedule
     from disco_diffdock_amd.distributed import shard_indices, gather_poses
-    build.build(verbose=False)
+    if rank == 0:
+        build.build(verbose=False)       # no-op when the shipped libddk.so is current; never build concurrently
+    if world > 1:
+        dist.barrier()
 
     # ---- workload: this rank's shard of the (world * 8) synthetic complexes ---------------------------------
     n_total = N_COMPLEXES * world

@@ -418,3 +418,65 @@ def test_disco_trajectory_golden(dev, golden):
                       classifier_free_guidance_weight=0.7, cfg_start=0.9, cfg_end=0.2, noise=noise, **README_D)
     assert [d.latent_str for d in out] == [str(x) for x in z['latent_str']]
     assert rel_err(torch.cat([d['ligand'].pos for d in out]).cpu(), z['pos_out']) < 1e-4
+
+
+def test_neighbour_caps_bind_dense_ligand(dev, tables):
+    """Edge case of the radius graphs: a compact 70-atom ligand where radius_graph's max_num_neighbors=32 (score_model.py:315)
+    and the bond-centre radius cap of 32 (score_model.py:430) both bind; ligand far from the pocket at small t (empty cross
+    graph).  Edge sets and scores must agree with the oracle's restatement of the cap semantics (first-k by index)."""
+    from disco_diffdock_amd import synthetic
+    from disco_diffdock_amd.runtime import Context, Complex
+    rng = np.random.default_rng(3)
+    c = synthetic.make_complex(12, n_res=40, n_lig=40)
+    n = 70
+    # compact blob: points on a jittered grid of 1.6 A spacing -> ~45 atoms within 5 A of an interior atom
+    g = np.stack(np.meshgrid(np.arange(5), np.arange(4), np.arange(4), indexing='ij'), -1).reshape(-1, 3)[:n] * 1.6
+    pos = (g + rng.normal(0, 0.1, size=g.shape)).astype(np.float32)
+    bonds = [(i, i + 1) for i in range(n - 1)]
+    edge_mask, mask_rotate = synthetic.transformation_mask(n, bonds)
+    ei = np.zeros((2, 2 * len(bonds)), np.int64)
+    for bi, (a, b) in enumerate(bonds):
+        ei[:, 2 * bi], ei[:, 2 * bi + 1] = (a, b), (b, a)
+    ea = np.zeros((2 * len(bonds), 4), np.float32)
+    ea[:, 0] = 1
+    c.update(lig_x=np.stack([rng.integers(0, d, size=n) for d in synthetic.LIG_FEATURE_DIMS], 1), lig_pos=pos, bond_index=ei,
+             bond_attr=ea, edge_mask=edge_mask, mask_rotate=mask_rotate)
+    P = smr.random_state_dict(CFG, seed=2)
+    ctx = Context(device=0)
+    ctx.load_state_dict(P)
+    cx = Complex(ctx, c, 2)
+    for shift, t in ((np.zeros(3), 0.7), (np.array([200.0, 0, 0]), 0.05)):
+        p2 = np.stack([pos + shift, pos + shift + 0.3]).astype(np.float32)
+        tr, rot, tor = cx.score_forward(T(p2).to(dev), t, t, t)
+        st = cx.graph_stats()
+        b = batch_of(c, 2, p2)
+        spr.set_time(b, t, t, t, 2)
+        tr_r, rot_r, tor_r, inter = smr.score_model_forward(P, CFG, b, tables[0], tables[1], return_intermediates=True)
+        s1, s2, s3 = inter['graph']['splits']
+        assert (st['E_ll'], st['E_lr'], st['E_rr']) == (s1, s2 - s1, s3 - s2)
+        assert st['E_ll'] < 2 * (2 * len(bonds) + n * 32) + 1 and st['E_ll'] > 2 * (2 * len(bonds) + n * 20)   # the cap binds
+        if shift[0] > 0:
+            assert st['E_lr'] == 0
+        for name, a, r in (('tr', tr, tr_r), ('rot', rot, rot_r), ('tor', tor, tor_r)):
+            assert rel_err(a.cpu(), r) < 1e-4, name
+
+
+def test_size_limits_are_loud(dev):
+    from disco_diffdock_amd import synthetic
+    from disco_diffdock_amd.runtime import Context, Complex
+    ctx = Context(device=0)
+    ctx.load_state_dict(smr.random_state_dict(CFG, seed=2))
+    c = synthetic.make_complex(1, n_res=20, n_lig=20)
+    big = dict(c)
+    n = 257
+    big.update(lig_x=np.zeros((n, 16), np.int64), lig_pos=np.zeros((n, 3), np.float32), mask_rotate=np.zeros((0, n), bool),
+               edge_mask=np.zeros(c['bond_index'].shape[1], bool))
+    with pytest.raises(RuntimeError, match='n_lig'):
+        Complex(ctx, big, 1)
+    cx = Complex(ctx, c, 2)
+    with pytest.raises(RuntimeError, match='max_batch'):
+        cx.score_forward(torch.zeros(3, 20, 3, device=dev), 0.5, 0.5, 0.5)
+    bad = dict(c)
+    bad['rec_x'] = c['rec_x'][:, :100]
+    with pytest.raises(RuntimeError, match='feature width'):
+        Complex(ctx, bad, 1)

@@ -106,7 +106,7 @@ struct ddk_ctx {
   void* model = nullptr;
   // profiling (ddk_profile_enable / ddk_profile_read)
   bool prof = false;
-  struct ProfRec { hipEvent_t a, b; int layer; int slot; };
+  struct ProfRec { hipEvent_t a, b; int layer; int slot; int64_t skipped = 0; };   // skipped: edges not evaluated (layer-0 rec-rec dedup)
   std::vector<ProfRec> prof_recs;
   int32_t* prof_edges = nullptr;   // pinned host: total edges of forward #slot
   int prof_slots = 0, prof_cap = 0;
@@ -130,6 +130,12 @@ struct ConvLaunch {
   const int32_t* tile_info;  // device: tile_start[5], group_off[5]
   int32_t* counter;          // device tile counter (zeroed by the caller)
   int gather;                // 1: edge_attr is edge_emb[E,24] and x[src][:24], x[dst][:24] are gathered
+  // layer-0 receptor-receptor de-duplication (all samples of a batch share the receptor and, before the first conv,
+  // its node/edge features): only the first g2_limit edges of group 2 (sample 0) are evaluated, their messages go to
+  // sum_g2[(src - g2_node_off)] and node_finalize adds that row to every sample's copy.  g2_limit < 0: off.
+  int g2_limit = -1;
+  float* sum_g2 = nullptr;
+  int g2_node_off = 0;
 };
 hipError_t launch_conv_fused(const ConvLayerDev& L, const ConvLaunch& a, int n_cu, hipStream_t s);
 hipError_t launch_conv_setup(int32_t* tile_info, const int64_t* group_offsets_host, hipStream_t s);
@@ -137,7 +143,8 @@ hipError_t launch_pad_rows(const float* x, int64_t n, int din, float* xpad, hipS
 hipError_t launch_count_deg(const int32_t* src, int64_t E, int32_t* deg, hipStream_t s);
 hipError_t launch_node_finalize(const float* sum, const int32_t* deg, const float* x_in /*[N,XW] or null*/,
                                 const float* bn_mean, const float* bn_scale, const float* bn_bias, int64_t n, int dout,
-                                int out_stride, float* out, hipStream_t s);
+                                int out_stride, float* out, hipStream_t s, const float* sum_rr0 = nullptr,
+                                int64_t n_lig_total = 0, int n_rec = 1);
 // k_tp.hip
 hipError_t launch_tp_forward(const ConvLayerDev& L, const float* x_dst, const float* sh, const float* w, int64_t E,
                              float* out, hipStream_t s);

@@ -51,6 +51,9 @@ struct ConvKArgs {
   const float* b2p;   // [4][n_tiles][2][16]
   const Unit* units;  // [n_tiles*4]
   int n_tiles;
+  int g2_limit;       // >= 0: evaluate only the first g2_limit edges of group 2 (see ConvLaunch)
+  float* sum_g2;
+  int g2_node_off;
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -82,8 +85,17 @@ __global__ __launch_bounds__(64) void conv_fused_kernel(ConvKArgs A) {
   if (lane < 16) F[32 * F_STRIDE + lane] = 0.0f;   // pad: the v5 epilogue always reads 12 floats per unit
   const int el = lane & 31;
   const int hh = lane >> 5;
-  const int ts1 = A.tile_info[1], ts2 = A.tile_info[2], ts3 = A.tile_info[3], ts4 = A.tile_info[4];
+  const int ts1 = A.tile_info[1], ts2 = A.tile_info[2];
+  int ts3 = A.tile_info[3], ts4 = A.tile_info[4];
   const int go0 = A.tile_info[5], go1 = A.tile_info[6], go2 = A.tile_info[7], go3 = A.tile_info[8], go4 = A.tile_info[9];
+  int g2_end = go3;
+  const bool g2_shared = A.g2_limit >= 0;
+  if (A.g2_limit >= 0) {   // shortened group 2: shift the tile ranges of groups 2 and 3
+    const int len = min(A.g2_limit, go3 - go2);
+    const int delta = (ts3 - ts2) - (len + 31) / 32;
+    ts3 -= delta; ts4 -= delta;
+    g2_end = go2 + len;
+  }
   float* Fr = F + el * F_STRIDE;
   const float inv_s3 = 0.57735026918962576451f, inv_s2 = 0.70710678118654752440f;
 
@@ -95,7 +107,7 @@ __global__ __launch_bounds__(64) void conv_fused_kernel(ConvKArgs A) {
     const int g = (tile >= ts1) + (tile >= ts2) + (tile >= ts3);
     const int tstart = g == 0 ? 0 : (g == 1 ? ts1 : (g == 2 ? ts2 : ts3));
     const int gbeg = g == 0 ? go0 : (g == 1 ? go1 : (g == 2 ? go2 : go3));
-    const int gend = g == 0 ? go1 : (g == 1 ? go2 : (g == 2 ? go3 : go4));
+    const int gend = g == 0 ? go1 : (g == 1 ? go2 : (g == 2 ? g2_end : go4));
     const int e0 = gbeg + 32 * (tile - tstart);
     const int nvalid = min(32, gend - e0);
     const bool valid = el < nvalid;
@@ -264,7 +276,8 @@ __global__ __launch_bounds__(64) void conv_fused_kernel(ConvKArgs A) {
         if (flags & 2) {
           const float scale = uc.u[rq].scale;
           const int ncomp = (w0 >> 8) & 15;
-          float* dstp = A.sum + (size_t)sn * XW + (w1 & 0xffff) + hh * (w1 >> 16);
+          float* dstp = (g2_shared && g == 2 ? A.sum_g2 + (size_t)(sn - A.g2_node_off) * XW : A.sum + (size_t)sn * XW) +
+                        (w1 & 0xffff) + hh * (w1 >> 16);
           float vals[3] = {acc0 * scale, acc1 * scale, acc2 * scale};
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
@@ -319,7 +332,7 @@ __global__ void count_deg_kernel(const int32_t* src, int64_t E, int32_t* deg) {
 //   out = ((sum/max(deg,1) - mean) * scale + bias) + pad(x_in)
 __global__ void node_finalize_kernel(const float* sum, const int32_t* deg, const float* x_in, const float* bn_mean,
                                      const float* bn_scale, const float* bn_bias, int64_t n, int dout, int out_stride,
-                                     float* out) {
+                                     float* out, const float* sum_rr0, int64_t n_lig_total, int n_rec) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * out_stride) return;
   const int64_t r = i / out_stride;
@@ -327,7 +340,9 @@ __global__ void node_finalize_kernel(const float* sum, const int32_t* deg, const
   float v = 0.0f;
   if (c < dout) {
     const int d = deg[r];
-    v = sum[r * XW + c] / (float)(d > 1 ? d : 1);
+    float sv = sum[r * XW + c];
+    if (sum_rr0 != nullptr && r >= n_lig_total) sv += sum_rr0[((r - n_lig_total) % n_rec) * XW + c];   // shared layer-0 rec-rec messages
+    v = sv / (float)(d > 1 ? d : 1);
     v = (v - bn_mean[c]) * bn_scale[c] + bn_bias[c];
   }
   if (x_in != nullptr && c < XW) v += x_in[r * XW + c];
@@ -339,6 +354,7 @@ hipError_t launch_conv_fused(const ConvLayerDev& L, const ConvLaunch& a, int n_c
   k.x = a.x; k.src = a.src; k.dst = a.dst; k.edge_attr = a.edge_attr; k.sh = a.sh; k.sum = a.sum;
   k.tile_info = a.tile_info; k.counter = a.counter;
   k.w1p = L.w1p[0]; k.b1p = L.b1p[0]; k.w2p = L.w2p[0]; k.b2p = L.b2p[0]; k.units = L.units; k.n_tiles = L.n_tiles;
+  k.g2_limit = a.g2_limit; k.sum_g2 = a.sum_g2; k.g2_node_off = a.g2_node_off;
   const int grid = n_cu * 8;   // 8 single-wave workgroups per CU (2 per SIMD), persistent, dynamic tile queue
   if (a.gather)
     hipLaunchKernelGGL(conv_fused_kernel<true>, dim3(grid), dim3(64), 0, s, k);
@@ -368,11 +384,11 @@ hipError_t launch_count_deg(const int32_t* src, int64_t E, int32_t* deg, hipStre
 
 hipError_t launch_node_finalize(const float* sum, const int32_t* deg, const float* x_in, const float* bn_mean,
                                 const float* bn_scale, const float* bn_bias, int64_t n, int dout, int out_stride,
-                                float* out, hipStream_t s) {
+                                float* out, hipStream_t s, const float* sum_rr0, int64_t n_lig_total, int n_rec) {
   const int64_t tot = n * out_stride;
   if (tot == 0) return hipSuccess;
   hipLaunchKernelGGL(node_finalize_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, sum, deg, x_in, bn_mean,
-                     bn_scale, bn_bias, n, dout, out_stride, out);
+                     bn_scale, bn_bias, n, dout, out_stride, out, sum_rr0, n_lig_total, n_rec);
   return hipGetLastError();
 }
 

@@ -176,6 +176,7 @@ struct ddk_complex {
   float unconditional = 0.0f;
   float cfg_weight = 0.0f, cfg_start = 1.0f, cfg_end = 0.0f;   // ddk_set_guidance
   float *zero_lat = nullptr, *scores2 = nullptr;
+  float* sum_rr0 = nullptr;   // [n_rec, XW] layer-0 rec-rec messages shared by all samples
   float* x_last = nullptr;    // node features after the conv stack of the last forward
   int last_B = 0;
   std::vector<void*> allocs;

@@ -288,12 +288,19 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
     ConvLaunch a;
     a.x = xin; a.src = cx->e_src; a.dst = cx->e_dst; a.edge_attr = cx->e_emb; a.sh = cx->e_sh; a.sum = cx->sum;
     a.tile_info = cx->info; a.counter = cx->info + 10 + (l % 8); a.gather = 1;
+    // layer 0: the receptor's node features and rec-rec edge features are the same for every sample of the batch
+    // (no latents) -> evaluate the rec-rec messages once, exact in real arithmetic
+    const bool dedup = (l == 0 && c.latent_dim == 0 && B > 1 && cx->E_rr > 0);
+    if (dedup) {
+      CK(hipMemsetAsync(cx->sum_rr0, 0, (size_t)n_rec * XW * sizeof(float), s), "memset sum_rr0");
+      a.g2_limit = cx->E_rr; a.sum_g2 = cx->sum_rr0; a.g2_node_off = B * n_lig;
+    }
     if (l >= 8) CK(hipMemsetAsync(cx->info + 10 + (l % 8), 0, sizeof(int32_t), s), "counter reset");
     ddk_ctx::ProfRec pr;
     const bool prof = ctx->prof && ctx->prof_slots < ctx->prof_cap;
     if (prof) {
       CK(hipEventCreate(&pr.a), "event"); CK(hipEventCreate(&pr.b), "event");
-      pr.layer = l; pr.slot = ctx->prof_slots;
+      pr.layer = l; pr.slot = ctx->prof_slots; pr.skipped = dedup ? (int64_t)(B - 1) * cx->E_rr : 0;
       CK(hipEventRecord(pr.a, s), "event record");
     }
     CK(launch_conv_fused(L, a, ctx->n_cu, s), "conv_fused");
@@ -301,7 +308,8 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
       CK(hipEventRecord(pr.b, s), "event record");
       ctx->prof_recs.push_back(pr);
     }
-    CK(launch_node_finalize(cx->sum, cx->deg, xin, L.bn_mean, L.bn_scale, L.bn_bias, N, L.dout, XW, xout, s), "node_finalize");
+    CK(launch_node_finalize(cx->sum, cx->deg, xin, L.bn_mean, L.bn_scale, L.bn_bias, N, L.dout, XW, xout, s,
+                            dedup ? cx->sum_rr0 : nullptr, (int64_t)B * n_lig, n_rec), "node_finalize");
     float* t = xin; xin = xout; xout = t;
   }
   cx->x_last = xin;
@@ -448,6 +456,7 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
   cx->xa = cx_upload<float>(cx, nullptr, N * XW);
   cx->xb = cx_upload<float>(cx, nullptr, N * XW);
   cx->sum = cx_upload<float>(cx, nullptr, N * XW);
+  cx->sum_rr0 = cx_upload<float>(cx, nullptr, (int64_t)n_rec * XW);
   cx->pos_tmp = cx_upload<float>(cx, nullptr, Bm * n_lig * 3);
   cx->scores = cx_upload<float>(cx, nullptr, Bm * (6 + (d->n_rot > 0 ? d->n_rot : 1)));
   cx->scores2 = cx_upload<float>(cx, nullptr, Bm * (6 + (d->n_rot > 0 ? d->n_rot : 1)));
@@ -605,7 +614,7 @@ int ddk_profile_read(ddk_ctx* ctx, double* out, int32_t n) {
     if (e != hipSuccess) return hip_fail(ctx, e, "hipEventElapsedTime");
     out[3 * r.layer] += ms;
     out[3 * r.layer + 1] += 1.0;
-    out[3 * r.layer + 2] += (double)ctx->prof_edges[r.slot];
+    out[3 * r.layer + 2] += (double)ctx->prof_edges[r.slot] - (double)r.skipped;
   }
   return DDK_OK;
 }

@@ -33,7 +33,8 @@ _lib = None
 SYMBOLS = ['ddk_create', 'ddk_destroy', 'ddk_last_error', 'ddk_version', 'ddk_load_weights', 'ddk_finalize_weights',
            'ddk_set_score_norm_tables', 'ddk_tp_forward', 'ddk_conv_forward', 'ddk_complex_create', 'ddk_complex_destroy',
            'ddk_score_forward', 'ddk_se3_update', 'ddk_sample', 'ddk_last_graph_stats', 'ddk_last_node_features',
-           'ddk_profile_enable', 'ddk_profile_read', 'ddk_set_latents', 'ddk_set_guidance']
+           'ddk_profile_enable', 'ddk_profile_read', 'ddk_set_latents', 'ddk_set_guidance',
+           'ddk_set_keep_receptor_features']
 
 
 def lib():
@@ -66,6 +67,7 @@ def lib():
     L.ddk_last_node_features.argtypes = [vp, vp, i32, vp, vp, vp]
     L.ddk_set_latents.argtypes = [vp, vp, vp, vp, f32]
     L.ddk_set_guidance.argtypes = [vp, vp, f32, f32, f32]
+    L.ddk_set_keep_receptor_features.argtypes = [vp, vp, i32]
     L.ddk_profile_enable.argtypes = [vp, i32]
     L.ddk_profile_read.argtypes = [vp, vp, i32]
     L.ddk_debug_export.argtypes = [vp, C.c_char_p, vp, i64]

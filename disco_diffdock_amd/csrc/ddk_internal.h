@@ -106,7 +106,7 @@ struct ddk_ctx {
   void* model = nullptr;
   // profiling (ddk_profile_enable / ddk_profile_read)
   bool prof = false;
-  struct ProfRec { hipEvent_t a, b; int layer; int slot; int64_t skipped = 0; };   // skipped: edges not evaluated (layer-0 rec-rec dedup)
+  struct ProfRec { hipEvent_t a, b; int layer; int slot; int64_t skipped = 0; bool lig_only = false; };   // skipped: edges not evaluated (layer-0 rec-rec dedup)
   std::vector<ProfRec> prof_recs;
   int32_t* prof_edges = nullptr;   // pinned host: total edges of forward #slot
   int prof_slots = 0, prof_cap = 0;
@@ -134,6 +134,7 @@ struct ConvLaunch {
   // its node/edge features): only the first g2_limit edges of group 2 (sample 0) are evaluated, their messages go to
   // sum_g2[(src - g2_node_off)] and node_finalize adds that row to every sample's copy.  g2_limit < 0: off.
   int g2_limit = -1;
+  int lig_side_only = 0;     // 1: evaluate only groups 0 and 1 (messages into ligand nodes); the last layer's receptor rows are dead
   float* sum_g2 = nullptr;
   int g2_node_off = 0;
 };

@@ -51,6 +51,7 @@ struct ConvKArgs {
   const float* b2p;   // [4][n_tiles][2][16]
   const Unit* units;  // [n_tiles*4]
   int n_tiles;
+  int lig_side_only;  // evaluate groups 0,1 only
   int g2_limit;       // >= 0: evaluate only the first g2_limit edges of group 2 (see ConvLaunch)
   float* sum_g2;
   int g2_node_off;
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(64) void conv_fused_kernel(ConvKArgs A) {
     ts3 -= delta; ts4 -= delta;
     g2_end = go2 + len;
   }
+  if (A.lig_side_only) ts4 = ts2;
   float* Fr = F + el * F_STRIDE;
   const float inv_s3 = 0.57735026918962576451f, inv_s2 = 0.70710678118654752440f;
 
@@ -354,7 +356,7 @@ hipError_t launch_conv_fused(const ConvLayerDev& L, const ConvLaunch& a, int n_c
   k.x = a.x; k.src = a.src; k.dst = a.dst; k.edge_attr = a.edge_attr; k.sh = a.sh; k.sum = a.sum;
   k.tile_info = a.tile_info; k.counter = a.counter;
   k.w1p = L.w1p[0]; k.b1p = L.b1p[0]; k.w2p = L.w2p[0]; k.b2p = L.b2p[0]; k.units = L.units; k.n_tiles = L.n_tiles;
-  k.g2_limit = a.g2_limit; k.sum_g2 = a.sum_g2; k.g2_node_off = a.g2_node_off;
+  k.lig_side_only = a.lig_side_only; k.g2_limit = a.g2_limit; k.sum_g2 = a.sum_g2; k.g2_node_off = a.g2_node_off;
   const int grid = n_cu * 8;   // 8 single-wave workgroups per CU (2 per SIMD), persistent, dynamic tile queue
   if (a.gather)
     hipLaunchKernelGGL(conv_fused_kernel<true>, dim3(grid), dim3(64), 0, s, k);

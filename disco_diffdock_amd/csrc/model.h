@@ -179,5 +179,6 @@ struct ddk_complex {
   float* sum_rr0 = nullptr;   // [n_rec, XW] layer-0 rec-rec messages shared by all samples
   float* x_last = nullptr;    // node features after the conv stack of the last forward
   int last_B = 0;
+  bool keep_rec = false, last_full = false;   // last conv layer: all groups (true) or ligand-side groups only
   std::vector<void*> allocs;
 };

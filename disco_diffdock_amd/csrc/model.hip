@@ -295,12 +295,15 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
       CK(hipMemsetAsync(cx->sum_rr0, 0, (size_t)n_rec * XW * sizeof(float), s), "memset sum_rr0");
       a.g2_limit = cx->E_rr; a.sum_g2 = cx->sum_rr0; a.g2_node_off = B * n_lig;
     }
+    // last layer: only ligand rows are read downstream (heads) unless the caller asked for the receptor rows
+    const bool lig_only = (l == c.num_conv_layers - 1 && !cx->keep_rec);
+    a.lig_side_only = lig_only ? 1 : 0;
     if (l >= 8) CK(hipMemsetAsync(cx->info + 10 + (l % 8), 0, sizeof(int32_t), s), "counter reset");
     ddk_ctx::ProfRec pr;
-    const bool prof = ctx->prof && ctx->prof_slots < ctx->prof_cap;
+    const bool prof = ctx->prof && ctx->prof_slots + 1 < ctx->prof_cap;
     if (prof) {
       CK(hipEventCreate(&pr.a), "event"); CK(hipEventCreate(&pr.b), "event");
-      pr.layer = l; pr.slot = ctx->prof_slots; pr.skipped = dedup ? (int64_t)(B - 1) * cx->E_rr : 0;
+      pr.layer = l; pr.slot = ctx->prof_slots; pr.skipped = dedup ? (int64_t)(B - 1) * cx->E_rr : 0; pr.lig_only = lig_only;
       CK(hipEventRecord(pr.a, s), "event record");
     }
     CK(launch_conv_fused(L, a, ctx->n_cu, s), "conv_fused");
@@ -308,15 +311,17 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
       CK(hipEventRecord(pr.b, s), "event record");
       ctx->prof_recs.push_back(pr);
     }
-    CK(launch_node_finalize(cx->sum, cx->deg, xin, L.bn_mean, L.bn_scale, L.bn_bias, N, L.dout, XW, xout, s,
+    CK(launch_node_finalize(cx->sum, cx->deg, xin, L.bn_mean, L.bn_scale, L.bn_bias, lig_only ? (int64_t)B * n_lig : N, L.dout, XW, xout, s,
                             dedup ? cx->sum_rr0 : nullptr, (int64_t)B * n_lig, n_rec), "node_finalize");
     float* t = xin; xin = xout; xout = t;
   }
   cx->x_last = xin;
   cx->last_B = B;
-  if (ctx->prof && ctx->prof_slots < ctx->prof_cap) {
+  cx->last_full = cx->keep_rec;
+  if (ctx->prof && ctx->prof_slots + 1 < ctx->prof_cap) {
+    CK(hipMemcpyAsync(ctx->prof_edges + ctx->prof_slots + 1, cx->info + 7, sizeof(int32_t), hipMemcpyDeviceToHost, s), "profile edge count");   // group_off[2] = edges of groups 0+1
     CK(hipMemcpyAsync(ctx->prof_edges + ctx->prof_slots, cx->info + 23, sizeof(int32_t), hipMemcpyDeviceToHost, s), "profile edge count");
-    ctx->prof_slots++;
+    ctx->prof_slots += 2;
   }
   HeadArgs Hd;
   Hd.lig_pos = lig_pos; Hd.x = xin; Hd.md = M->dev; Hd.sp = sp; Hd.B = B; Hd.n_lig = n_lig; Hd.R = cx->R;
@@ -563,6 +568,8 @@ int ddk_last_graph_stats(ddk_ctx* ctx, ddk_complex* cx, int64_t* out, void* stre
 
 int ddk_last_node_features(ddk_ctx* ctx, ddk_complex* cx, int32_t B, float* lig_out, float* rec_out, void* stream) {
   if (!ctx || !cx || !cx->x_last || B != cx->last_B) return fail(ctx, DDK_ERR_STATE, "no forward with this batch size has run");
+  if (rec_out && !cx->last_full)
+    return fail(ctx, DDK_ERR_STATE, "receptor rows of the last conv layer were not evaluated: call ddk_set_keep_receptor_features(on) before the forward");
   hipStream_t s = (hipStream_t)stream;
   const size_t nl = (size_t)B * cx->n_lig * XW, nr = (size_t)B * cx->n_rec * XW;
   hipError_t e = hipSuccess;
@@ -576,6 +583,12 @@ int ddk_set_latents(ddk_ctx* ctx, ddk_complex* cx, const float* lig_latent, cons
   if (!ctx || !cx) return DDK_ERR_INVALID;
   if ((lig_latent == nullptr) != (rec_latent == nullptr)) return fail(ctx, DDK_ERR_INVALID, "ddk_set_latents: pass both latent arrays or neither");
   cx->lig_latent = lig_latent; cx->rec_latent = rec_latent; cx->unconditional = unconditional;
+  return DDK_OK;
+}
+
+int ddk_set_keep_receptor_features(ddk_ctx* ctx, ddk_complex* cx, int32_t on) {
+  if (!ctx || !cx) return DDK_ERR_INVALID;
+  cx->keep_rec = on != 0;
   return DDK_OK;
 }
 
@@ -614,7 +627,7 @@ int ddk_profile_read(ddk_ctx* ctx, double* out, int32_t n) {
     if (e != hipSuccess) return hip_fail(ctx, e, "hipEventElapsedTime");
     out[3 * r.layer] += ms;
     out[3 * r.layer + 1] += 1.0;
-    out[3 * r.layer + 2] += (double)ctx->prof_edges[r.slot] - (double)r.skipped;
+    out[3 * r.layer + 2] += r.lig_only ? (double)ctx->prof_edges[r.slot + 1] : (double)ctx->prof_edges[r.slot] - (double)r.skipped;
   }
   return DDK_OK;
 }

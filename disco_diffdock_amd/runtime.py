@@ -229,6 +229,7 @@ class Complex:
         sc = np.ascontiguousarray(score_coeff, dtype=np.float32)
         nc = np.ascontiguousarray(noise_coeff, dtype=np.float32)
         steps = t.shape[0]
+        self.keep_receptor_features(False)   # the sampler reads ligand rows only
         if noise is not None:
             noise = noise.contiguous().float()
             assert tuple(noise.shape) == (steps, B, 6 + self.R)
@@ -243,6 +244,10 @@ class Complex:
         if v[6]:
             raise RuntimeError('ddk: edge capacity overflow')
         return dict(E_ll=v[0], E_lr=v[1], E_rr=v[2], E_rl=v[3], tiles=v[4], E=v[5], cap=v[7])
+
+    def keep_receptor_features(self, on=True):
+        """Evaluate the receptor rows of the last conv layer too (needed before ``node_features``' receptor output)."""
+        self.ctx._check(self.ctx.L.ddk_set_keep_receptor_features(self.ctx.h, self.h, int(bool(on))), 'ddk_set_keep_receptor_features')
 
     def node_features(self, B, device):
         lig = torch.empty((B * self.n_lig, 84), dtype=torch.float32, device=device)

@@ -108,7 +108,7 @@ class TensorProductScoreModel(nn.Module):
         unc = float(lig.unconditional.reshape(-1)[0]) if 'unconditional' in lig else 0.0
         cx.set_latents(lig.latent_h.to(self.device), rec.latent_h.to(self.device), unc)
 
-    def forward(self, data):
+    def forward(self, data, keep_receptor_features=False):
         if not self._loaded:
             raise RuntimeError('ddk score model: load_state_dict() first')
         pos = data['ligand'].pos
@@ -116,6 +116,7 @@ class TensorProductScoreModel(nn.Module):
             raise RuntimeError('ddk score model runs on the GPU only (no CPU fallback)')
         cx, B = complex_for_batch(data, pos.device, ctx=self.ctx)
         self._bind_latents(cx, data)
+        cx.keep_receptor_features(keep_receptor_features)
         t = [float(data.complex_t[k][0]) for k in ('tr', 'rot', 'tor')]
         tr, rot, tor = cx.score_forward(pos.reshape(B, -1, 3), *t)
         self.last_complex = cx
@@ -127,7 +128,7 @@ class TensorProductScoreModel(nn.Module):
         """models/score_model.py:169-257: (lig_node_attr, rec_node_attr, tr_sigma, rot_sigma, tor_sigma) after the conv stack."""
         from .diffusion_utils import t_to_sigma
         from types import SimpleNamespace
-        self.forward(data)
+        self.forward(data, keep_receptor_features=True)
         B = data.num_graphs
         lig, rec = self.last_complex.node_features(B, data['ligand'].pos.device)
         sig = t_to_sigma(*[data.complex_t[k] for k in ('tr', 'rot', 'tor')], SimpleNamespace(**self.cfg))

@@ -113,6 +113,13 @@ int ddk_set_latents(ddk_ctx* ctx, ddk_complex* cx, const float* lig_latent, cons
  *      score + weight * (score - score_unconditional).  weight = 0 (default) disables it. */
 int ddk_set_guidance(ddk_ctx* ctx, ddk_complex* cx, float weight, float cfg_start, float cfg_end);
 
+/* ---- The heads read ligand rows only (models/score_model.py:286-308), so by default the LAST conv layer evaluates only
+ *      the messages into ligand nodes (edge groups lig-lig and lig->rec) and the receptor rows after it are not produced.
+ *      Turn this on before a forward whose receptor rows will be read with ddk_last_node_features (the embed() path of
+ *      the AR latent model, models/pretrained_score_encoder.py:66-75): the last layer then evaluates all four groups as
+ *      the reference does.  tr/rot/tor are identical either way. */
+int ddk_set_keep_receptor_features(ddk_ctx* ctx, ddk_complex* cx, int32_t on);
+
 /* ---- a5-a17: model.score_model(batch) -> (tr[B,3], rot[B,3], tor[B*R])  models/score_model.py:259-308
  *      for B copies of one complex at a common time (utils/sampling.py:113-117).
  *      lig_pos [B, n_lig, 3]; outputs tr [B,3], rot [B,3], tor [B*n_rot]. */
@@ -137,7 +144,8 @@ int ddk_sample(ddk_ctx* ctx, ddk_complex* cx, int32_t B, int32_t steps, const fl
 /* ---- introspection for tests / benches ------------------------------------------------------ */
 /* Copies the last forward's per-stage edge counts into out[8] (HOST): E_ll, E_lr, E_rr, E_rl, tiles, ... */
 int ddk_last_graph_stats(ddk_ctx* ctx, ddk_complex* cx, int64_t* out, void* stream);
-/* Node features after the conv stack of the last forward: lig [B*n_lig, 84], rec [B*n_rec, 84] (device ptrs, may be NULL). */
+/* Node features after the conv stack of the last forward: lig [B*n_lig, 84], rec [B*n_rec, 84] (device ptrs, may be NULL).
+ * rec_out != NULL requires ddk_set_keep_receptor_features(on) before that forward (DDK_ERR_STATE otherwise). */
 int ddk_last_node_features(ddk_ctx* ctx, ddk_complex* cx, int32_t B, float* lig_out, float* rec_out, void* stream);
 
 /* ---- measurement: HIP-event timing of every fused TP-conv launch on the stream it is launched on (bench.py's

@@ -66,7 +66,7 @@ def test_score_model_golden(dev, model7, golden, t):
     c = complex_from_npz(golden(f'complex_{tag}'))
     B = int(z['B'])
     b = _dev_batch(c, B, z['pos'], dev, t)
-    tr, rot, tor = model7.score_model(b)
+    tr, rot, tor = model7.score_model(b, keep_receptor_features=True)
     cx = model7.score_model.last_complex
     lig, rec = cx.node_features(B, dev)
     assert rel_err(lig.cpu(), z['lig_node_attr']) < 1e-4
@@ -277,7 +277,7 @@ def test_disco_latent_score_model_golden(dev, golden):
         b['ligand'].latent_h, b['receptor'].latent_h = T(z['latent_l']).to(dev), T(z['latent_r']).to(dev)
         b['ligand'].unconditional = torch.zeros(b['ligand'].num_nodes, 1, device=dev)
         b['receptor'].unconditional = torch.zeros(b['receptor'].num_nodes, 1, device=dev)
-        tr, rot, tor = model.score_model(b)
+        tr, rot, tor = model.score_model(b, keep_receptor_features=True)
         lig, rec = model.score_model.last_complex.node_features(B, dev)
         assert rel_err(lig.cpu(), z['lig_node_attr']) < 1e-4 and rel_err(rec.cpu(), z['rec_node_attr']) < 1e-4
         for name, a in (('tr', tr), ('rot', rot), ('tor', tor)):
@@ -480,3 +480,23 @@ def test_size_limits_are_loud(dev):
     bad['rec_x'] = c['rec_x'][:, :100]
     with pytest.raises(RuntimeError, match='feature width'):
         Complex(ctx, bad, 1)
+
+
+def test_last_layer_receptor_rows_on_request(dev, model7, golden):
+    """The last conv layer skips the messages into receptor nodes unless asked (ddk_set_keep_receptor_features);
+    scores are the same either way and reading the missing rows fails loudly."""
+    tag = 'diffdockS_score_model'
+    z = golden(f'score_{tag}_t0.55')
+    c = complex_from_npz(golden(f'complex_{tag}'))
+    B = int(z['B'])
+    b = _dev_batch(c, B, z['pos'], dev, 0.55)
+    out_lean = [a.clone() for a in model7.score_model(b)]
+    cx = model7.score_model.last_complex
+    with pytest.raises(RuntimeError, match='receptor rows'):
+        cx.node_features(B, dev)
+    out_full = model7.score_model(b, keep_receptor_features=True)
+    lig, rec = cx.node_features(B, dev)
+    assert rel_err(rec.cpu(), z['rec_node_attr']) < 1e-4
+    for a, f_, name in zip(out_lean, out_full, ('tr', 'rot', 'tor')):
+        assert rel_err(a.cpu(), f_.cpu().numpy()) < 2e-6, name
+        assert rel_err(a.cpu(), z[name]) < 1e-4, name

@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libddk.so')
+LIB_PATH = os.environ.get('DDK_LIB') or os.path.join(_HERE, 'libddk.so')   # DDK_LIB: kernel-experiment builds (tools/build_variant.py)
 
 
 class ddk_config(C.Structure):

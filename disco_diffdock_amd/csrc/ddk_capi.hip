@@ -71,7 +71,7 @@ static inline int hid_of(int s, int hh) { return s < 32 ? 32 * (s / 16) + d_row(
 // input index consumed by GEMM1 step s in lane-half hh
 static inline int kin_of(int s, int hh) { return 24 * (s / 12) + 12 * hh + (s % 12); }
 
-struct Part { int kind, f_off, row_start, rows; };
+struct Quad { int kind, f_off, row0, jlo, n; };   // tile rows j in [jlo, jlo+n) <-> block rows row0 .. row0+n-1
 
 static int build_conv_layer(ddk_ctx* ctx, int l, ConvLayerDev& L) {
   const ddk_config& c = ctx->cfg;
@@ -91,59 +91,57 @@ static int build_conv_layer(ddk_ctx* ctx, int l, ConvLayerDev& L) {
   L.dout = out[0] + 3 * out[1] + 3 * out[2] + out[3];
   if (in[2] > 0 && in[1] == 0) return fail(ctx, DDK_ERR_INVALID, "unsupported irreps sequence");
 
-  std::vector<Part> parts[4];
-  parts[0].push_back({U_R1_S0, F_A, 0, in[0]});
-  if (in[1]) parts[0].push_back({U_T_S, F_PV, in[0], in[1]});
-  parts[1].push_back({U_R1_V, F_A, 0, in[0]});
-  if (in[1] + in[2]) parts[1].push_back({U_T_V, F_T1O, in[0], in[1] + in[2]});
-  if (in[1] + in[2]) parts[2].push_back({U_T_V, F_T1E, 0, in[1] + in[2]});
-  if (in[3]) parts[2].push_back({U_R1_V, F_C, in[1] + in[2], in[3]});
-  if (in[2]) parts[3].push_back({U_T_S, F_QV, 0, in[2]});
-  if (in[3]) parts[3].push_back({U_R1_S0, F_C, in[2], in[3]});
+  // row quads of each block in the reference's row order (tensor_layers.py:72-83)
+  std::vector<Quad> quads[4];
+  auto add_rows = [&](int b, int kind, int f_off, int row_start, int rows) {
+    for (int q = 0; 4 * q < rows; ++q)
+      quads[b].push_back({kind, f_off + (kind == T_TV ? 12 * q : 4 * q), row_start + 4 * q, 0, rows - 4 * q < 4 ? rows - 4 * q : 4});
+  };
+  auto add_dot_rows = [&](int b, int which /*0: p.v, 1: q.v*/, int row_start, int rows) {   // F_PQ = [pv0..3 | qv0..3 | pv4 pv5 qv4 qv5]
+    quads[b].push_back({T_RT, F_PQ + 4 * which, row_start, 0, rows < 4 ? rows : 4});
+    if (rows > 4) quads[b].push_back({T_RT, F_PQ + 8, row_start + 4, 2 * which, rows - 4});
+  };
+  add_rows(0, T_RA, F_A, 0, in[0]);                                        // a * s0
+  if (in[1]) add_dot_rows(0, 0, in[0], in[1]);                             // (p.v)/sqrt3
+  add_rows(1, T_RA, F_A, 0, in[0]);                                        // a (x) v
+  if (in[1] + in[2]) add_rows(1, T_TV, F_T1O, in[0], in[1] + in[2]);       // p*s0 ; (q x v)/sqrt2
+  if (in[1] + in[2]) add_rows(2, T_TV, F_T1E, 0, in[1] + in[2]);           // (p x v)/sqrt2 ; q*s0
+  if (in[3]) add_rows(2, T_RA, F_C, in[1] + in[2], in[3]);                 // c (x) v
+  if (in[2]) add_dot_rows(3, 1, 0, in[2]);                                 // (q.v)/sqrt3
+  if (in[3]) add_rows(3, T_RA, F_C, in[2], in[3]);                         // c * s0
 
   const int oc[4] = {0, out[0], out[0] + 3 * out[1], out[0] + 3 * out[1] + 3 * out[2]};
-  struct URow { int blk, kpair, row0, nvalid; };
-  std::vector<Unit> units;
-  std::vector<URow> urows;
-  // unit stream order: scalar-output blocks first (0e, 0o) - their k-pairs are whole tiles - then the vector blocks
-  const int border[4] = {0, 3, 1, 2};
-  for (int bi = 0; bi < 4; ++bi) {
-    const int b = border[bi];
+  struct TRow { int blk, col, row0, jlo, n; };
+  std::vector<TileDesc> tiles;
+  std::vector<TRow> trows;
+  for (int b = 0; b < 4; ++b) {
     if (L.n_in[b] == 0 || L.n_out[b] == 0) continue;
     if (L.n_out[b] % 2) return fail(ctx, DDK_ERR_INVALID, "odd output multiplicity unsupported");
     const bool vec = (b == 1 || b == 2);
-    for (int kp = 0; kp < L.n_out[b] / 2; ++kp) {
-      const size_t first = units.size();
-      for (const Part& p : parts[b]) {
-        for (int q = 0; 4 * q < p.rows; ++q) {
-          Unit u = make_unit(p.kind, p.f_off + (p.kind == U_T_V ? 12 * q : 4 * q), vec ? 3 : 1,
-                             oc[b] + (vec ? 3 : 1) * (2 * kp), vec ? 3 : 1, 1.0f / sqrtf((float)L.n_in[b]));
-          units.push_back(u);
-          urows.push_back({b, kp, p.row_start + 4 * q, p.rows - 4 * q < 4 ? p.rows - 4 * q : 4});
-        }
+    for (int col = 0; 8 * col < L.n_out[b]; ++col) {
+      const int nch = L.n_out[b] - 8 * col < 8 ? L.n_out[b] - 8 * col : 8;
+      for (const Quad& q : quads[b]) {
+        tiles.push_back(make_tile(q.kind, q.f_off, FL_NONE, nch / 2, oc[b] + (vec ? 3 : 1) * 8 * col));
+        trows.push_back({b, col, q.row0, q.jlo, q.n});
       }
-      units[first].w0 |= 1 << 4;
-      units.back().w0 |= 2 << 4;
+      tiles.back().w0 |= (vec ? FL_V : FL_S) << 2;
     }
   }
-  while (units.size() % 4) {
-    units.push_back(make_unit(U_PAD, 0, 1, XW, 0, 0.f));   // dummy channel XW (scratch column of the LDS message row)
-    urows.push_back({-1, 0, 0, 0});
-  }
-  L.n_tiles = (int)units.size() / 4;
-  L.h_units = units;
+  L.n_tiles = (int)tiles.size();
+  L.h_tiles = tiles;
 
-  // row map: tile row rho = 8*rq + 4*hh + r4  ->  row of the reference weight vector (or -1 = zero row)
+  // row map: tile row rho = 8*rq + 4*hh + j  ->  row of the reference weight vector (or -1 = zero row)
   std::vector<int> rowmap((size_t)L.n_tiles * 32, -1);
-  for (size_t u = 0; u < units.size(); ++u) {
-    const URow& ur = urows[u];
-    if (ur.blk < 0) continue;
-    const int t = (int)u / 4, rq = (int)u % 4;
-    for (int hh = 0; hh < 2; ++hh)
-      for (int r4 = 0; r4 < 4; ++r4)
-        if (r4 < ur.nvalid) {
-          const int i = ur.row0 + r4, k = 2 * ur.kpair + hh;
-          rowmap[(size_t)t * 32 + 8 * rq + 4 * hh + r4] = L.blk_off[ur.blk] + i * L.n_out[ur.blk] + k;
+  std::vector<float> rowscale((size_t)L.n_tiles * 32, 0.f);
+  for (int t = 0; t < L.n_tiles; ++t) {
+    const TRow& tr = trows[t];
+    for (int rq = 0; rq < 4; ++rq)
+      for (int hh = 0; hh < 2; ++hh)
+        for (int j = tr.jlo; j < tr.jlo + tr.n; ++j) {
+          const int i = tr.row0 + j - tr.jlo, k = 8 * tr.col + 2 * rq + hh;
+          if (k >= L.n_out[tr.blk]) continue;
+          rowmap[(size_t)t * 32 + 8 * rq + 4 * hh + j] = L.blk_off[tr.blk] + i * L.n_out[tr.blk] + k;
+          rowscale[(size_t)t * 32 + 8 * rq + 4 * hh + j] = 1.0f / sqrtf((float)L.n_in[tr.blk]);   // tensor_layers.py:89-92, folded
         }
   }
   // every weight row must be used exactly once
@@ -189,12 +187,13 @@ static int build_conv_layer(ddk_ctx* ctx, int l, ConvLayerDev& L) {
       for (int s = 0; s < 36; ++s)
         for (int lane = 0; lane < 64; ++lane) {
           const int row = rowmap[(size_t)t * 32 + (lane & 31)], hh = lane >> 5;
-          w2[(((size_t)t * 9 + s / 4) * 64 + lane) * 4 + (s & 3)] = row >= 0 ? W2->data[(size_t)row * ne + hid_of(s, hh)] : 0.f;
+          w2[(((size_t)t * 9 + s / 4) * 64 + lane) * 4 + (s & 3)] =
+              row >= 0 ? W2->data[(size_t)row * ne + hid_of(s, hh)] * rowscale[(size_t)t * 32 + (lane & 31)] : 0.f;
         }
       for (int hh = 0; hh < 2; ++hh)
         for (int r = 0; r < 16; ++r) {
           const int row = rowmap[(size_t)t * 32 + d_row(r, hh)];
-          b2[((size_t)t * 2 + hh) * 16 + r] = row >= 0 ? B2->data[row] : 0.f;
+          b2[((size_t)t * 2 + hh) * 16 + r] = row >= 0 ? B2->data[row] * rowscale[(size_t)t * 32 + d_row(r, hh)] : 0.f;
         }
     }
   }
@@ -229,21 +228,27 @@ static int build_conv_layer(ddk_ctx* ctx, int l, ConvLayerDev& L) {
   if (!ctx->host_only) {
     float* d1 = dev_upload(ctx, w1all);
     float* db1 = dev_upload(ctx, b1all);
-    float* d2 = dev_upload(ctx, w2all);
-    float* db2 = dev_upload(ctx, b2all);
-    L.units = (Unit*)dev_alloc(ctx, units.size() * sizeof(Unit));
+    std::vector<float> w2rec((size_t)4 * L.n_tiles * W2_TILE_FLOATS);
+    for (int g = 0; g < 4; ++g)
+      for (int t = 0; t < L.n_tiles; ++t) {
+        float* rec = w2rec.data() + ((size_t)g * L.n_tiles + t) * W2_TILE_FLOATS;
+        memcpy(rec, w2all.data() + g * w2sz + (size_t)t * 2304, 2304 * sizeof(float));
+        memcpy(rec + 2304, b2all.data() + g * b2sz + (size_t)t * 32, 32 * sizeof(float));
+        memcpy(rec + 2336, &tiles[t], 2 * sizeof(int32_t));   // descriptor rides with the record (bit pattern)
+      }
+    float* d2 = dev_upload(ctx, w2rec);
+    L.tiles = (TileDesc*)dev_alloc(ctx, tiles.size() * sizeof(TileDesc));
     L.bn_mean = dev_upload(ctx, L.h_bn_mean);
     L.bn_scale = dev_upload(ctx, L.h_bn_scale);
     L.bn_bias = dev_upload(ctx, L.h_bn_bias);
-    if (!d1 || !db1 || !d2 || !db2 || !L.units || !L.bn_mean || !L.bn_scale || !L.bn_bias)
+    if (!d1 || !db1 || !d2 || !L.tiles || !L.bn_mean || !L.bn_scale || !L.bn_bias)
       return fail(ctx, DDK_ERR_NOMEM, "device allocation failed while packing conv weights");
-    if (hipMemcpy(L.units, units.data(), units.size() * sizeof(Unit), hipMemcpyHostToDevice) != hipSuccess)
-      return fail(ctx, DDK_ERR_HIP, "unit table upload failed");
+    if (hipMemcpy(L.tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice) != hipSuccess)
+      return fail(ctx, DDK_ERR_HIP, "tile table upload failed");
     for (int g = 0; g < 4; ++g) {
       L.w1p[g] = d1 + g * w1sz;
       L.b1p[g] = db1 + g * b1sz;
-      L.w2p[g] = d2 + g * w2sz;
-      L.b2p[g] = db2 + g * b2sz;
+      L.w2r[g] = d2 + (size_t)g * L.n_tiles * W2_TILE_FLOATS;
     }
   }
   return DDK_OK;
@@ -411,7 +416,7 @@ int64_t ddk_debug_export(ddk_ctx* ctx, const char* what, void* buf, int64_t cap_
     else if (it == "b1p") { src = L.h_b1p[g].data(); n = L.h_b1p[g].size(); }
     else if (it == "w2p") { src = L.h_w2p[g].data(); n = L.h_w2p[g].size(); }
     else if (it == "b2p") { src = L.h_b2p[g].data(); n = L.h_b2p[g].size(); }
-    else if (it == "units") { src = L.h_units.data(); n = L.h_units.size() * (sizeof(Unit) / 4); }
+    else if (it == "tiles") { src = L.h_tiles.data(); n = L.h_tiles.size() * (sizeof(TileDesc) / 4); }
     else if (it == "bn_mean") { src = L.h_bn_mean.data(); n = XW; }
     else if (it == "bn_scale") { src = L.h_bn_scale.data(); n = XW; }
     else if (it == "bn_bias") { src = L.h_bn_bias.data(); n = XW; }

@@ -25,34 +25,44 @@ constexpr int OFF_C = NS + 6 * NV;   // 0o block
 
 // LDS "F row" of one edge in the fused conv kernel (floats); see k_conv.hip
 constexpr int F_A = 0;                 // a[ns]
-constexpr int F_PV = NS;               // (p.v)/sqrt3 [nv] (+pad to 8)
-constexpr int F_T1O = NS + 8;          // [p*s0 (nv x3) ; (q x v)/sqrt2 (nv x3)]
-constexpr int F_T1E = F_T1O + 6 * NV;  // [(p x v)/sqrt2 (nv x3) ; q*s0 (nv x3)]
-constexpr int F_QV = F_T1E + 6 * NV;   // (q.v)/sqrt3 [nv] (+pad to 8)
-constexpr int F_C = F_QV + 8;          // c[ns]
-constexpr int F_SH = F_C + NS;         // s0, vx, vy, vz
-constexpr int F_STRIDE = F_SH + 4;     // 140 floats: 16-B aligned rows, bank-conflict free for ds_read_b128
-static_assert(F_STRIDE == 140, "F row layout");
+constexpr int F_C = NS;                // c[ns]
+constexpr int F_T1O = 2 * NS;          // 12 rows x xyz: [p*s0 (nv) ; (q x v)/sqrt2 (nv)], component-major inside each quad of rows
+constexpr int F_T1E = F_T1O + 6 * NV;  // 12 rows x xyz: [(p x v)/sqrt2 (nv) ; q*s0 (nv)]
+constexpr int F_PQ = F_T1E + 6 * NV;   // [pv0..3 | qv0..3 | pv4 pv5 qv4 qv5]   pv = (p.v)/sqrt3, qv = (q.v)/sqrt3
+constexpr int F_STRIDE = F_PQ + 12;    // 132 floats: 16-B aligned rows, 16-B slot = row mod 16 -> conflict free for ds_read_b128
+static_assert(F_STRIDE == 132 && NV == 6, "F row layout");
 
-enum UnitKind : int { U_R1_S0 = 0, U_R1_V = 1, U_T_S = 2, U_T_V = 3, U_PAD = 4 };
+// Workgroup shape of the fused conv kernel: 8 waves (2 per SIMD) x 32 edges, one workgroup per CU; the W2 tile records
+// are fetched once per workgroup into a 2-stage LDS ring.
+constexpr int CONV_WAVES = 8;
+constexpr int CONV_BLOCK_EDGES = 32 * CONV_WAVES;
+constexpr int W2_TILE_FLOATS = 9 * 64 * 4 + 32 + 4;   // MFMA fragments [9][64][4] + bias [2][16] + tile descriptor (w0, chan0, 0, 0)
+constexpr int CONV_LDS_FLOATS = CONV_WAVES * 32 * F_STRIDE + 2 * W2_TILE_FLOATS + 16;
+constexpr size_t CONV_LDS_BYTES = (size_t)CONV_LDS_FLOATS * 4;   // 153,952 B of the 160 KiB
+static_assert(CONV_LDS_BYTES <= 160 * 1024, "LDS budget");
 
-// One "unit" = 4 consecutive rows (i) of one weight block for the output-channel pair (2k, 2k+1):
-// lanes 0-31 of the wave hold channel 2k, lanes 32-63 channel 2k+1 (MFMA 32x32 D layout).
-struct Unit {
-  int32_t w0;         // kind | flags<<4 | ncomp<<8 | f_off<<16
-                      //   kind: UnitKind; flags bit0: first unit of its (block, kpair), bit1: last;
-                      //   ncomp: 1 (scalar output) or 3 (vector output); f_off: float offset into the F row
-  int32_t w1;         // chan0 | chan_step<<16  (output channel of lane-half 0 / delta for lane-half 1)
-  float scale;        // 1/sqrt(n_in of the block)
-  int32_t pad;
+// One W2 "tile" = 32 weight rows x 72 hidden units = one burst of 36 v_mfma_f32_32x32x2_f32 per 32 edges.
+// Tile row rho = 8*rq + 4*hh + j (rq = accumulator quad 0..3, hh = lane half, j = 0..3) holds the weight that multiplies
+// input row (row0 + j) of one FasterTensorProduct block for output channel k = 8*col + 2*rq + hh: every lane owns four
+// output channels (rq) of its edge and the whole tile consumes the SAME four feature rows -> one F read per tile and a
+// kind-specialised epilogue (VALU work steals issue cycles from the fp32 MFMA pipe).
+enum TileKind : int {
+  T_RA = 0,   // scalar features F[f_off..+4); accumulate into accA (multiplied by s0 or v when the column is flushed)
+  T_RT = 1,   // scalar features F[f_off..+4); accumulate into accV[0] (already complete: (p.v)/sqrt3, (q.v)/sqrt3)
+  T_TV = 2    // vector features F[f_off..+12) (4 rows x xyz); accumulate into accV[0..2]
 };
-static inline Unit make_unit(int kind, int f_off, int ncomp, int chan0, int chan_step, float scale) {
-  Unit u;
-  u.w0 = kind | (ncomp << 8) | (f_off << 16);
-  u.w1 = chan0 | (chan_step << 16);
-  u.scale = scale;
-  u.pad = 0;
-  return u;
+enum FlushMode : int { FL_NONE = 0, FL_S = 1 /* out = accA*s0 + accV0 */, FL_V = 2 /* out_c = accA*v_c + accV_c */ };
+
+struct TileDesc {
+  int32_t w0;     // kind | flush_mode<<2 | nrq<<4 (valid accumulator quads of the column, 1..4) | f_off<<16
+  int32_t chan0;  // flush: output column of (rq=0, hh=0); slot (rq,hh) writes chan0 + cstep*(2*rq+hh) (+c), cstep = 1 (FL_S) / 3 (FL_V)
+  int32_t pad0, pad1;
+};
+static inline TileDesc make_tile(int kind, int f_off, int flush, int nrq, int chan0) {
+  TileDesc t;
+  t.w0 = kind | (flush << 2) | (nrq << 4) | (f_off << 16);
+  t.chan0 = chan0; t.pad0 = 0; t.pad1 = 0;
+  return t;
 }
 
 struct ConvLayerDev {          // device copies for one TensorProductConvLayer with FasterTensorProduct
@@ -62,15 +72,14 @@ struct ConvLayerDev {          // device copies for one TensorProductConvLayer w
   int din = 0, dout = 0;
   float* w1p[4] = {};          // [3][9][64][4]
   float* b1p[4] = {};          // [3][2][16]
-  float* w2p[4] = {};          // [n_tiles][9][64][4]
-  float* b2p[4] = {};          // [n_tiles][2][16]
-  Unit* units = nullptr;       // [n_tiles*4]
+  float* w2r[4] = {};          // [n_tiles][W2_TILE_FLOATS]: per tile the fragments [9][64][4], the bias [2][16], the TileDesc words
+  TileDesc* tiles = nullptr;   // [n_tiles]
   float* bn_mean = nullptr;    // [XW]  running_mean on 0e channels, 0 elsewhere
   float* bn_scale = nullptr;   // [XW]  weight/sqrt(var+eps)   (1 when batch_norm is off)
   float* bn_bias = nullptr;    // [XW]  bias on 0e channels, 0 elsewhere
   // host copies kept for tests (ddk_debug_export)
   std::vector<float> h_w1p[4], h_b1p[4], h_w2p[4], h_b2p[4], h_bn_mean, h_bn_scale, h_bn_bias;
-  std::vector<Unit> h_units;
+  std::vector<TileDesc> h_tiles;
   // block shapes of the FasterTensorProduct (tensor_layers.py:58-63), order 0e,1o,1e,0o
   int n_in[4] = {}, n_out[4] = {}, blk_off[4] = {};
   int in_mul[4] = {}, out_mul[4] = {};   // 0e,1o,1e,0o multiplicities of the layer's in/out irreps

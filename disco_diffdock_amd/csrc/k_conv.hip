@@ -15,17 +15,20 @@
 //     the 4-row groups of D.  The hidden vector h = relu(W1 e + b1) therefore comes out of GEMM1 already in
 //     the register layout GEMM2 needs for its B operand (the K order of GEMM2 is permuted at weight-packing
 //     time to make this true) - h never leaves the VGPRs.
-//   * the [32 rows x 72] W2 tiles are streamed from L2 in MFMA fragment order (9 x 16 B per lane per tile) into ONE
-//     register set: each 16-B fragment is reloaded with the next tile's data right after the 4 MFMAs that consumed it,
-//     so the stream for tile t+1 lands under the rest of tile t's 36-MFMA burst; the F operands of the tile's 4 units
-//     are requested from LDS before the burst and the epilogue arithmetic is branch-free (unit kinds select multipliers);
-//     the per-edge weights w[row] appear in D and are consumed immediately: each group of 4 D registers is a
-//     "unit" = 4 consecutive TP rows i for the output-channel pair (2k, 2k+1) (k = 2*kpair + lane-half);
-//     the row operands u_i = f(x[dst], sh) are read from a per-edge LDS table (F row, 140 floats, stride chosen
-//     bank-conflict free for ds_read_b128).
-//   * when a (block, kpair) finishes, the value is reduced over runs of equal edge_src inside the wave with a
-//     5-step segmented scan (ds_bpermute) and only the run tails issue global fp32 atomics.
-//   * bias vectors ride in the MFMA C operand (accumulator init), so no separate bias pass exists.
+//   * on CDNA4 the fp32 MFMA and the VALU share issue time (tools/probes/mfma_probe3.hip: every VALU instruction costs the
+//     matrix pipe 1.7-3.7 cycles even when it comes from the other wave of the SIMD), and any instruction placed between two
+//     dependent MFMAs breaks the accumulator forwarding.  So a [32 rows x 72] W2 tile is ONE uninterrupted burst of 36
+//     v_mfma_f32_32x32x2_f32, everything else happens at the tile boundary, and the epilogue is as few VALU instructions as
+//     the algebra allows:
+//       - tile row 8*rq + 4*hh + j = weight of TP input row (row0 + j) for output channel 8*col + 2*rq + hh: all four
+//         accumulator quads of a tile consume the SAME four feature rows (one 16-B / 48-B LDS read of the per-edge "F row")
+//         and the tile kind (scalar rows -> 4 fma per quad, vector rows -> 12) is wave-uniform: one scalar branch per tile;
+//       - the a*s0 / a(x)v / c*s0 / c(x)v rows accumulate the plain dot product; s0 or v is applied once per channel when
+//         the column is flushed; the 1/sqrt(n_in) of tensor_layers.py:89-92 and the bias are folded into the packed W2 / C operand;
+//       - the next tile's fragments (9 x 16 B of W2 + 4 x 16 B of bias per lane, L2 resident) are requested in one batch
+//         BEFORE the burst into a second register set.
+//   * when a column (8 output channels) finishes, each value is reduced over runs of equal edge_src inside the wave with a
+//     5-step segmented scan and only the run tails issue global fp32 atomics.
 //
 // Roofline: MFMA-bound (2*72*(72+W) flop per edge vs ~650 B per edge of HBM traffic), see DESIGN.md.
 #include <stdlib.h>
@@ -47,9 +50,8 @@ struct ConvKArgs {
   int32_t* counter;
   const float* w1p;   // [4][3][9][64][4]
   const float* b1p;   // [4][3][2][16]
-  const float* w2p;   // [4][n_tiles][9][64][4]
-  const float* b2p;   // [4][n_tiles][2][16]
-  const Unit* units;  // [n_tiles*4]
+  const float* w2r;   // [4][n_tiles][W2_TILE_FLOATS]
+  const TileDesc* tiles;  // [n_tiles]
   int n_tiles;
   int lig_side_only;  // evaluate groups 0,1 only
   int g2_limit;       // >= 0: evaluate only the first g2_limit edges of group 2 (see ConvLaunch)
@@ -62,73 +64,165 @@ __device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-struct UnitQuad { Unit u[4]; };
-// unit descriptors are wave-uniform: read them through the constant address space so that they take the scalar
-// (s_load_dwordx16) path and end up in SGPRs
+// tile descriptors are wave-uniform: read them through the constant address space (s_load -> SGPRs)
 typedef const int32_t __attribute__((address_space(4))) cint32;
-__device__ __forceinline__ UnitQuad load_unit_quad(const Unit* p) {
+struct TileQ { int w0, chan0; };
+__device__ __forceinline__ TileQ load_tile(const TileDesc* p) {
   cint32* q = (cint32*)(uintptr_t)p;
-  UnitQuad r;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    r.u[i].w0 = q[4 * i + 0];
-    r.u[i].w1 = q[4 * i + 1];
-    r.u[i].scale = __int_as_float(q[4 * i + 2]);
-    r.u[i].pad = 0;
-  }
+  TileQ r;
+  r.w0 = q[0]; r.chan0 = q[1];
   return r;
 }
 
+__device__ __forceinline__ void load_frags(float4 (&a)[9], f32x16& B, const float* w, const float* b) {
+#pragma unroll
+  for (int s4 = 0; s4 < 9; ++s4) a[s4] = ld4(w + s4 * 256);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float4 v = ld4(b + 4 * j);
+    B[4 * j + 0] = v.x; B[4 * j + 1] = v.y; B[4 * j + 2] = v.z; B[4 * j + 3] = v.w;
+  }
+}
+
+__device__ __forceinline__ f32x16 burst(const float4 (&a)[9], const float (&h)[36], const f32x16& C) {
+  f32x16 D = MFMA(a[0].x, h[0], C);
+  D = MFMA(a[0].y, h[1], D);
+  D = MFMA(a[0].z, h[2], D);
+  D = MFMA(a[0].w, h[3], D);
+#pragma unroll
+  for (int s4 = 1; s4 < 9; ++s4) {
+    D = MFMA(a[s4].x, h[4 * s4 + 0], D);
+    D = MFMA(a[s4].y, h[4 * s4 + 1], D);
+    D = MFMA(a[s4].z, h[4 * s4 + 2], D);
+    D = MFMA(a[s4].w, h[4 * s4 + 3], D);
+  }
+  return D;
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 ldv4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+#define D_LO(D, rq) (f32x2{(D)[4 * (rq)], (D)[4 * (rq) + 1]})
+#define D_HI(D, rq) (f32x2{(D)[4 * (rq) + 2], (D)[4 * (rq) + 3]})
+#define V_LO(f) __builtin_shufflevector(f, f, 0, 1)
+#define V_HI(f) __builtin_shufflevector(f, f, 2, 3)
+
+// kind-specialised tensor-product epilogue of one W2 tile (wave-uniform branch).  Every accumulator is a register PAIR
+// {sum over even rows j, sum over odd rows j} so that the whole epilogue is v_pk_fma_f32 on adjacent registers
+// (D[4rq+j], D[4rq+j+1]) x (f[j], f[j+1]) without any shuffling moves; the pair is added up when the column is flushed.
+__device__ __forceinline__ void tile_epilogue(int kind, const f32x16& D, f32x4 f0, f32x4 f1, f32x4 f2, f32x2 (&accA)[4],
+                                              f32x2 (&accV)[4][3]) {
+  if (kind == T_TV) {   // f0/f1/f2 = x/y/z components of the 4 feature rows
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const f32x2 dl = D_LO(D, rq), dh = D_HI(D, rq);
+      accV[rq][0] = __builtin_elementwise_fma(dh, V_HI(f0), __builtin_elementwise_fma(dl, V_LO(f0), accV[rq][0]));
+      accV[rq][1] = __builtin_elementwise_fma(dh, V_HI(f1), __builtin_elementwise_fma(dl, V_LO(f1), accV[rq][1]));
+      accV[rq][2] = __builtin_elementwise_fma(dh, V_HI(f2), __builtin_elementwise_fma(dl, V_LO(f2), accV[rq][2]));
+    }
+  } else if (kind == T_RA) {
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) accA[rq] = __builtin_elementwise_fma(D_LO(D, rq), V_LO(f0), accA[rq]);
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) accA[rq] = __builtin_elementwise_fma(D_HI(D, rq), V_HI(f0), accA[rq]);
+  } else {
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) accV[rq][0] = __builtin_elementwise_fma(D_LO(D, rq), V_LO(f0), accV[rq][0]);
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) accV[rq][0] = __builtin_elementwise_fma(D_HI(D, rq), V_HI(f0), accV[rq][0]);
+  }
+}
+
+// control words of the 5-step segmented scan over runs of equal edge_src (identical for every channel of an edge tile)
+struct SegCtl { bool m1, m2, m4, m8, m16, tail, valid; };
+__device__ __forceinline__ void seg_add(float* dst, float xv, const SegCtl& c) {
+  xv = c.valid ? xv : 0.0f;
+  float up;
+  up = __shfl_up(xv, 1, 32);  if (c.m1) xv += up;
+  up = __shfl_up(xv, 2, 32);  if (c.m2) xv += up;
+  up = __shfl_up(xv, 4, 32);  if (c.m4) xv += up;
+  up = __shfl_up(xv, 8, 32);  if (c.m8) xv += up;
+  up = __shfl_up(xv, 16, 32); if (c.m16) xv += up;
+  if (c.tail) unsafeAtomicAdd(dst, xv);
+}
+
+// LDS fragments of one staged W2 tile -> registers (lane-contiguous 16-B reads: conflict free)
+__device__ __forceinline__ void lds_frags(float4 (&a)[9], f32x16& B, const float* stage, int lane, int hh) {
+#pragma unroll
+  for (int s4 = 0; s4 < 9; ++s4) a[s4] = ld4(stage + s4 * 256 + lane * 4);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float4 v = ld4(stage + 2304 + hh * 16 + 4 * j);
+    B[4 * j + 0] = v.x; B[4 * j + 1] = v.y; B[4 * j + 2] = v.z; B[4 * j + 3] = v.w;
+  }
+}
+
 template <bool GATHER>
-__global__ __launch_bounds__(64) void conv_fused_kernel(ConvKArgs A) {
-  __shared__ __attribute__((aligned(16))) float F[32 * F_STRIDE + 16];
-  const int lane = threadIdx.x;
-  if (lane < 16) F[32 * F_STRIDE + lane] = 0.0f;   // pad: the v5 epilogue always reads 12 floats per unit
+__global__ __launch_bounds__(64 * CONV_WAVES) void conv_fused_kernel(ConvKArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* F = lds + wave * (32 * F_STRIDE);                    // this wave's 32 F rows
+  float* ring = lds + CONV_WAVES * (32 * F_STRIDE);           // [2][W2_TILE_FLOATS]
+  int* blk_slot = reinterpret_cast<int*>(ring + 2 * W2_TILE_FLOATS);
   const int el = lane & 31;
   const int hh = lane >> 5;
-  const int ts1 = A.tile_info[1], ts2 = A.tile_info[2];
-  int ts3 = A.tile_info[3], ts4 = A.tile_info[4];
   const int go0 = A.tile_info[5], go1 = A.tile_info[6], go2 = A.tile_info[7], go3 = A.tile_info[8], go4 = A.tile_info[9];
-  int g2_end = go3;
   const bool g2_shared = A.g2_limit >= 0;
-  if (A.g2_limit >= 0) {   // shortened group 2: shift the tile ranges of groups 2 and 3
-    const int len = min(A.g2_limit, go3 - go2);
-    const int delta = (ts3 - ts2) - (len + 31) / 32;
-    ts3 -= delta; ts4 -= delta;
-    g2_end = go2 + len;
-  }
-  if (A.lig_side_only) ts4 = ts2;
+  const int g2_end = g2_shared ? go2 + min(A.g2_limit, go3 - go2) : go3;   // shortened group 2 (layer-0 rec-rec de-duplication)
+  // work unit: a block of CONV_BLOCK_EDGES consecutive edges of ONE edge group (its radial-MLP weights are shared by the workgroup)
+  const int bs1 = (go1 - go0 + CONV_BLOCK_EDGES - 1) / CONV_BLOCK_EDGES;
+  const int bs2 = bs1 + (go2 - go1 + CONV_BLOCK_EDGES - 1) / CONV_BLOCK_EDGES;
+  const int bs3 = bs2 + (g2_end - go2 + CONV_BLOCK_EDGES - 1) / CONV_BLOCK_EDGES;
+  const int bs4 = A.lig_side_only ? bs2 : bs3 + (go4 - go3 + CONV_BLOCK_EDGES - 1) / CONV_BLOCK_EDGES;
   float* Fr = F + el * F_STRIDE;
   const float inv_s3 = 0.57735026918962576451f, inv_s2 = 0.70710678118654752440f;
+  const int n_tiles = A.n_tiles;
+  constexpr int REC4 = W2_TILE_FLOATS / 4;                    // 584 float4 per tile record
+  const bool second = tid < REC4 - 64 * CONV_WAVES;           // threads that move a second float4 of the record
 
   for (;;) {
-    int tile = 0;
-    if (lane == 0) tile = atomicAdd(A.counter, 1);
-    tile = __builtin_amdgcn_readfirstlane(tile);
-    if (tile >= ts4) break;
-    const int g = (tile >= ts1) + (tile >= ts2) + (tile >= ts3);
-    const int tstart = g == 0 ? 0 : (g == 1 ? ts1 : (g == 2 ? ts2 : ts3));
+    if (tid == 0) *blk_slot = atomicAdd(A.counter, 1);
+    __syncthreads();
+    const int blk = __builtin_amdgcn_readfirstlane(*blk_slot);
+    if (blk >= bs4) break;
+    const int g = (blk >= bs1) + (blk >= bs2) + (blk >= bs3);
+    const int bstart = g == 0 ? 0 : (g == 1 ? bs1 : (g == 2 ? bs2 : bs3));
     const int gbeg = g == 0 ? go0 : (g == 1 ? go1 : (g == 2 ? go2 : go3));
     const int gend = g == 0 ? go1 : (g == 1 ? go2 : (g == 2 ? g2_end : go4));
-    const int e0 = gbeg + 32 * (tile - tstart);
-    const int nvalid = min(32, gend - e0);
+    const int e0 = gbeg + CONV_BLOCK_EDGES * (blk - bstart) + 32 * wave;
+    const int nvalid = min(32, gend - e0);                    // <= 0: this wave's slice lies past the end of the group
     const bool valid = el < nvalid;
-    const int e = e0 + min(el, nvalid - 1);
+    const int e = nvalid > 0 ? e0 + min(el, nvalid - 1) : gend - 1;
     const int sn = A.src[e], dn = A.dst[e];
 
-    // ---- segmented-scan control words (identical for every output channel of this edge tile) ----
-    bool m1, m2, m4, m8, m16, tail;
+    // ---- stage W2 tiles 0 and 1 of this group (the ring is idle: the previous block ended with a barrier) ----
+    const float* wrec = A.w2r + (size_t)g * n_tiles * W2_TILE_FLOATS;
+    {
+      const float4 r0 = ld4(wrec + 4 * tid), r1 = ld4(wrec + W2_TILE_FLOATS + 4 * tid);
+      *reinterpret_cast<float4*>(ring + 4 * tid) = r0;
+      *reinterpret_cast<float4*>(ring + W2_TILE_FLOATS + 4 * tid) = r1;
+      if (second) {
+        const int q = 4 * (tid + 64 * CONV_WAVES);
+        const float4 r2 = ld4(wrec + q), r3 = ld4(wrec + W2_TILE_FLOATS + q);
+        *reinterpret_cast<float4*>(ring + q) = r2;
+        *reinterpret_cast<float4*>(ring + W2_TILE_FLOATS + q) = r3;
+      }
+    }
+
+    // ---- segmented-scan control words (identical for every output channel of this wave's 32 edges) ----
+    SegCtl seg;
     {
       const int prev = __shfl_up(sn, 1, 32);
       const int next = __shfl_down(sn, 1, 32);
       int f = (el == 0) || (prev != sn);
-      tail = (el == 31) || (next != sn);
+      seg.tail = valid && ((el == nvalid - 1) || (next != sn));   // lanes past nvalid are clamped duplicates of the last edge
+      seg.valid = valid;
       int fu;
-      fu = __shfl_up(f, 1, 32);  m1 = (el >= 1) && !f;   if (m1) f |= fu;
-      fu = __shfl_up(f, 2, 32);  m2 = (el >= 2) && !f;   if (m2) f |= fu;
-      fu = __shfl_up(f, 4, 32);  m4 = (el >= 4) && !f;   if (m4) f |= fu;
-      fu = __shfl_up(f, 8, 32);  m8 = (el >= 8) && !f;   if (m8) f |= fu;
-      fu = __shfl_up(f, 16, 32); m16 = (el >= 16) && !f; (void)fu;
+      fu = __shfl_up(f, 1, 32);  seg.m1 = (el >= 1) && !f;   if (seg.m1) f |= fu;
+      fu = __shfl_up(f, 2, 32);  seg.m2 = (el >= 2) && !f;   if (seg.m2) f |= fu;
+      fu = __shfl_up(f, 4, 32);  seg.m4 = (el >= 4) && !f;   if (seg.m4) f |= fu;
+      fu = __shfl_up(f, 8, 32);  seg.m8 = (el >= 8) && !f;   if (seg.m8) f |= fu;
+      fu = __shfl_up(f, 16, 32); seg.m16 = (el >= 16) && !f; (void)fu;
     }
 
     // ---- GEMM1: h = relu(W1 [edge_emb | x_src[:ns] | x_dst[:ns]] + b1), K order kappa(s,hh) = 24*(s/12)+12*hh+s%12 ----
@@ -189,11 +283,11 @@ __global__ __launch_bounds__(64) void conv_fused_kernel(ConvKArgs A) {
     const float s0 = shv.x, vx = shv.y, vy = shv.z, vz = shv.w;
     {
       const float* xr = A.x + (size_t)dn * XW;
-      // half 0: a -> F_A, p: dot -> F_PV, p*s0 -> T1O[0..], (p x v)/sqrt2 -> T1E[0..]
-      // half 1: c -> F_C, q: dot -> F_QV, (q x v)/sqrt2 -> T1O[3nv..], q*s0 -> T1E[3nv..]
+      // half 0: a -> F_A, p: (p.v) -> F_PQ, p*s0 -> rows 0..nv-1 of T1O, (p x v)/sqrt2 -> rows 0..nv-1 of T1E
+      // half 1: c -> F_C, q: (q.v) -> F_PQ, q*s0 -> rows nv.. of T1E, (q x v)/sqrt2 -> rows nv.. of T1O
       const int o_main_src = hh ? OFF_C : 0, o_main_dst = hh ? F_C : F_A;
-      const int o_vec_src = hh ? OFF_Q : OFF_P, o_dot = hh ? F_QV : F_PV;
-      const int o_s0 = hh ? (F_T1E + 3 * NV) : F_T1O, o_cross = hh ? (F_T1O + 3 * NV) : F_T1E;
+      const int o_vec_src = hh ? OFF_Q : OFF_P;
+      const int o_vs = hh ? F_T1E : F_T1O, o_vc = hh ? F_T1O : F_T1E, r0 = hh ? NV : 0;
 #pragma unroll
       for (int j = 0; j < NS / 4; ++j) *reinterpret_cast<float4*>(Fr + o_main_dst + 4 * j) = ld4(xr + o_main_src + 4 * j);
       float pv[3 * NV];
@@ -205,100 +299,84 @@ __global__ __launch_bounds__(64) void conv_fused_kernel(ConvKArgs A) {
 #pragma unroll
       for (int m = 0; m < NV; ++m) {
         const float px = pv[3 * m], py = pv[3 * m + 1], pz = pv[3 * m + 2];
-        Fr[o_dot + m] = (px * vx + py * vy + pz * vz) * inv_s3;
-        Fr[o_s0 + 3 * m + 0] = px * s0;
-        Fr[o_s0 + 3 * m + 1] = py * s0;
-        Fr[o_s0 + 3 * m + 2] = pz * s0;
-        Fr[o_cross + 3 * m + 0] = (py * vz - pz * vy) * inv_s2;
-        Fr[o_cross + 3 * m + 1] = (pz * vx - px * vz) * inv_s2;
-        Fr[o_cross + 3 * m + 2] = (px * vy - py * vx) * inv_s2;
+        // F_PQ = [pv0..3 | qv0..3 | pv4 pv5 qv4 qv5]
+        Fr[F_PQ + (m < 4 ? 4 * hh + m : 8 + 2 * hh + (m - 4))] = (px * vx + py * vy + pz * vz) * inv_s3;
+        // vector parts: row r of the 12-row part lives at 12*(r/4) + 4*c + r%4 (component-major inside a quad of rows)
+        const int r = r0 + m;
+        float* Ps = Fr + o_vs + 12 * (r >> 2) + (r & 3);
+        float* Pc = Fr + o_vc + 12 * (r >> 2) + (r & 3);
+        Ps[0] = px * s0;
+        Ps[4] = py * s0;
+        Ps[8] = pz * s0;
+        Pc[0] = (py * vz - pz * vy) * inv_s2;
+        Pc[4] = (pz * vx - px * vz) * inv_s2;
+        Pc[8] = (px * vy - py * vx) * inv_s2;
       }
-      Fr[o_dot + NV] = 0.0f;
-      Fr[o_dot + NV + 1] = 0.0f;
-      if (hh) *reinterpret_cast<float4*>(Fr + F_SH) = shv;
     }
-    __syncthreads();
+    __syncthreads();   // ring stages 0/1 and the F rows are visible
 
     // ---- GEMM2 over the W2 tiles + fused tensor-product epilogue ----
-    const float* w2 = A.w2p + (size_t)g * A.n_tiles * (9 * 64 * 4) + (size_t)lane * 4;
-    const float* b2 = A.b2p + (size_t)g * A.n_tiles * 32 + hh * 16;
-    float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f;
-    // v5 loop: ONE set of A-fragment registers, reloaded in place right after the 4 MFMAs that consumed them
-    // (the next tile's fragments stream in under the rest of the burst); the F operands of the tile's 4 units
-    // are requested BEFORE the burst; the epilogue arithmetic is branch-free (kinds select multipliers).
-    float4 a[9], bn[4];
-    UnitQuad un = load_unit_quad(A.units);
+    float* const node_row = (g2_shared && g == 2) ? A.sum_g2 + (size_t)(sn - A.g2_node_off) * XW : A.sum + (size_t)sn * XW;
+    f32x2 accA[4], accV[4][3];
 #pragma unroll
-    for (int s4 = 0; s4 < 9; ++s4) a[s4] = ld4(w2 + s4 * 256);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bn[j] = ld4(b2 + 4 * j);
-    for (int t = 0; t < A.n_tiles; ++t) {
-      const UnitQuad uc = un;
-      float4 f[4][3];
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const float* Fp = Fr + (uc.u[rq].w0 >> 16);
-        f[rq][0] = ld4(Fp); f[rq][1] = ld4(Fp + 4); f[rq][2] = ld4(Fp + 8);
-      }
-      f32x16 D;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        D[4 * j + 0] = bn[j].x; D[4 * j + 1] = bn[j].y; D[4 * j + 2] = bn[j].z; D[4 * j + 3] = bn[j].w;
-      }
-      const int tn = min(t + 1, A.n_tiles - 1);
-      const float* wn = w2 + (size_t)tn * (9 * 64 * 4);
-      const float* bp = b2 + (size_t)tn * 32;
-#pragma unroll
-      for (int s4 = 0; s4 < 9; ++s4) {
-        D = MFMA(a[s4].x, h[4 * s4 + 0], D);
-        D = MFMA(a[s4].y, h[4 * s4 + 1], D);
-        D = MFMA(a[s4].z, h[4 * s4 + 2], D);
-        D = MFMA(a[s4].w, h[4 * s4 + 3], D);
-        a[s4] = ld4(wn + s4 * 256);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bn[j] = ld4(bp + 4 * j);
-      un = load_unit_quad(A.units + 4 * tn);
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const int w0 = uc.u[rq].w0, w1 = uc.u[rq].w1;
-        const int kind = w0 & 15, flags = (w0 >> 4) & 15;
-        const float d0 = D[4 * rq + 0], d1 = D[4 * rq + 1], d2 = D[4 * rq + 2], d3 = D[4 * rq + 3];
-        const float4 f0 = f[rq][0], f1 = f[rq][1], f2 = f[rq][2];
-        const float ps = f0.x * d0 + f0.y * d1 + f0.z * d2 + f0.w * d3;
-        const float pv0 = f0.x * d0 + f0.w * d1 + f1.z * d2 + f2.y * d3;
-        const float pv1 = f0.y * d0 + f1.x * d1 + f1.w * d2 + f2.z * d3;
-        const float pv2 = f0.z * d0 + f1.y * d1 + f2.x * d2 + f2.w * d3;
-        const bool kS0 = kind == U_R1_S0, kV = kind == U_R1_V, kTS = kind == U_T_S, kTV = kind == U_T_V;
-        const float ms0 = kS0 ? s0 : (kV ? vx : (kTS ? 1.0f : 0.0f));
-        const float ms1 = kV ? vy : 0.0f, ms2 = kV ? vz : 0.0f, mv = kTV ? 1.0f : 0.0f;
-        acc0 = fmaf(ms0, ps, fmaf(mv, pv0, acc0));
-        acc1 = fmaf(ms1, ps, fmaf(mv, pv1, acc1));
-        acc2 = fmaf(ms2, ps, fmaf(mv, pv2, acc2));
-        if (flags & 2) {
-          const float scale = uc.u[rq].scale;
-          const int ncomp = (w0 >> 8) & 15;
-          float* dstp = (g2_shared && g == 2 ? A.sum_g2 + (size_t)(sn - A.g2_node_off) * XW : A.sum + (size_t)sn * XW) +
-                        (w1 & 0xffff) + hh * (w1 >> 16);
-          float vals[3] = {acc0 * scale, acc1 * scale, acc2 * scale};
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            if (c < ncomp) {
-              float xv = valid ? vals[c] : 0.0f;
-              float up;
-              up = __shfl_up(xv, 1, 32);  if (m1) xv += up;
-              up = __shfl_up(xv, 2, 32);  if (m2) xv += up;
-              up = __shfl_up(xv, 4, 32);  if (m4) xv += up;
-              up = __shfl_up(xv, 8, 32);  if (m8) xv += up;
-              up = __shfl_up(xv, 16, 32); if (m16) xv += up;
-              if (tail) unsafeAtomicAdd(dstp + c, xv);
-            }
-          }
-          acc0 = acc1 = acc2 = 0.0f;
-        }
-      }
+    for (int rq = 0; rq < 4; ++rq) { accA[rq] = 0.0f; accV[rq][0] = 0.0f; accV[rq][1] = 0.0f; accV[rq][2] = 0.0f; }
+    float4 a0[9], a1[9];
+    f32x16 B0, B1;
+    lds_frags(a0, B0, ring, lane, hh);
+    int2 tqv = *reinterpret_cast<const int2*>(ring + 2336);
+    TileQ tq;
+    tq.w0 = __builtin_amdgcn_readfirstlane(tqv.x); tq.chan0 = __builtin_amdgcn_readfirstlane(tqv.y);
+#define PSUM(p) ((p).x + (p).y)
+// one W2 tile: (1) request this thread's share of tile t+2 from L2 and the descriptor of tile t+1, (2) read tile t+1's
+// fragments from the ring into the other register set, (3) the uninterrupted 36-MFMA burst of tile t, (4) epilogue and,
+// at the end of a column, the flush, (5) publish tile t+2 into the ring stage tile t came from, (6) barrier.
+#define DDK_TILE(T, AC, BC, AN, BN)                                                                            \
+    {                                                                                                          \
+      const int w0 = tq.w0, chan0 = tq.chan0;                                                                  \
+      const int t2 = min((T) + 2, n_tiles - 1);                                                                \
+      const float* rec2 = wrec + (size_t)t2 * W2_TILE_FLOATS;                                                  \
+      const float4 st0 = ld4(rec2 + 4 * tid);                                                                  \
+      float4 st1 = st0;                                                                                        \
+      if (second) st1 = ld4(rec2 + 4 * (tid + 64 * CONV_WAVES));                                               \
+      const float* Fp = Fr + (w0 >> 16);                                                                       \
+      const f32x4 f0 = ldv4(Fp), f1 = ldv4(Fp + 4), f2 = ldv4(Fp + 8);                                        \
+      lds_frags(AN, BN, ring + (((T) + 1) & 1) * W2_TILE_FLOATS, lane, hh);                                    \
+      tqv = *reinterpret_cast<const int2*>(ring + (((T) + 1) & 1) * W2_TILE_FLOATS + 2336);                    \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+      const f32x16 D = burst(AC, h, BC);                                                                       \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+      tile_epilogue(w0 & 3, D, f0, f1, f2, accA, accV);                                                        \
+      const int fl = (w0 >> 2) & 3;                                                                            \
+      if (fl) {                                                                                                \
+        const int nrq = (w0 >> 4) & 7;                                                                         \
+        _Pragma("unroll") for (int rq = 0; rq < 4; ++rq) {                                                     \
+          if (rq < nrq) {                                                                                      \
+            if (fl == FL_S) {                                                                                  \
+              seg_add(node_row + chan0 + 2 * rq + hh, fmaf(PSUM(accA[rq]), s0, PSUM(accV[rq][0])), seg);       \
+            } else {                                                                                           \
+              float* d = node_row + chan0 + 3 * (2 * rq + hh);                                                 \
+              const float sa = PSUM(accA[rq]);                                                                 \
+              seg_add(d + 0, fmaf(sa, vx, PSUM(accV[rq][0])), seg);                                            \
+              seg_add(d + 1, fmaf(sa, vy, PSUM(accV[rq][1])), seg);                                            \
+              seg_add(d + 2, fmaf(sa, vz, PSUM(accV[rq][2])), seg);                                            \
+            }                                                                                                  \
+          }                                                                                                    \
+          accA[rq] = 0.0f; accV[rq][0] = 0.0f; accV[rq][1] = 0.0f; accV[rq][2] = 0.0f;                         \
+        }                                                                                                      \
+      }                                                                                                        \
+      float* stg = ring + ((T) & 1) * W2_TILE_FLOATS;                                                          \
+      *reinterpret_cast<float4*>(stg + 4 * tid) = st0;                                                         \
+      if (second) *reinterpret_cast<float4*>(stg + 4 * (tid + 64 * CONV_WAVES)) = st1;                         \
+      tq.w0 = __builtin_amdgcn_readfirstlane(tqv.x); tq.chan0 = __builtin_amdgcn_readfirstlane(tqv.y);       \
+      __syncthreads();                                                                                         \
     }
-    __syncthreads();   // F is rewritten by the next edge tile
+    for (int t = 0; t < n_tiles; t += 2) {
+      DDK_TILE(t, a0, B0, a1, B1)
+      if (t + 1 >= n_tiles) break;
+      DDK_TILE(t + 1, a1, B1, a0, B0)
+    }
+#undef DDK_TILE
+#undef PSUM
   }
 }
 
@@ -355,13 +433,19 @@ hipError_t launch_conv_fused(const ConvLayerDev& L, const ConvLaunch& a, int n_c
   ConvKArgs k;
   k.x = a.x; k.src = a.src; k.dst = a.dst; k.edge_attr = a.edge_attr; k.sh = a.sh; k.sum = a.sum;
   k.tile_info = a.tile_info; k.counter = a.counter;
-  k.w1p = L.w1p[0]; k.b1p = L.b1p[0]; k.w2p = L.w2p[0]; k.b2p = L.b2p[0]; k.units = L.units; k.n_tiles = L.n_tiles;
+  k.w1p = L.w1p[0]; k.b1p = L.b1p[0]; k.w2r = L.w2r[0]; k.tiles = L.tiles; k.n_tiles = L.n_tiles;
   k.lig_side_only = a.lig_side_only; k.g2_limit = a.g2_limit; k.sum_g2 = a.sum_g2; k.g2_node_off = a.g2_node_off;
-  const int grid = n_cu * 8;   // 8 single-wave workgroups per CU (2 per SIMD), persistent, dynamic tile queue
+  // one persistent 8-wave workgroup per CU (its F rows + the W2 ring fill the LDS), dynamic block queue
+  static const hipError_t attr = [] {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONV_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONV_LDS_BYTES);
+  }();
+  if (attr != hipSuccess) return attr;
   if (a.gather)
-    hipLaunchKernelGGL(conv_fused_kernel<true>, dim3(grid), dim3(64), 0, s, k);
+    hipLaunchKernelGGL(conv_fused_kernel<true>, dim3(n_cu), dim3(64 * CONV_WAVES), CONV_LDS_BYTES, s, k);
   else
-    hipLaunchKernelGGL(conv_fused_kernel<false>, dim3(grid), dim3(64), 0, s, k);
+    hipLaunchKernelGGL(conv_fused_kernel<false>, dim3(n_cu), dim3(64 * CONV_WAVES), CONV_LDS_BYTES, s, k);
   return hipGetLastError();
 }
 

@@ -6,9 +6,10 @@ v_mfma_f32_32x32x2_f32: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31], D[(r&3)+8(r>>2)+4(
 import numpy as np
 
 NS, NV, XW, NE = 24, 6, 84, 72
-F_A, F_PV, F_T1O, F_T1E, F_QV, F_C, F_SH, F_STRIDE = 0, 24, 32, 68, 104, 112, 136, 140
+F_A, F_C, F_T1O, F_T1E, F_PQ, F_STRIDE = 0, 24, 48, 84, 120, 132
 OFF_P, OFF_Q, OFF_C = 24, 42, 60
-U_R1_S0, U_R1_V, U_T_S, U_T_V, U_PAD = range(5)
+T_RA, T_RT, T_TV = range(3)
+FL_NONE, FL_S, FL_V = range(3)
 LANES = np.arange(64)
 EL, HH = LANES & 31, LANES >> 5
 
@@ -34,8 +35,8 @@ def emulate(ctx, layer, x_pad, src, dst, group_offsets, edge_attr, sh):
     """returns sum[N, XW] (pre-mean) in float64."""
     N = x_pad.shape[0]
     out = np.zeros((N, XW), np.float64)
-    units = ctx.export(f'conv.{layer}.units', np.int32).reshape(-1, 4)
-    n_tiles = len(units) // 4
+    tiles = ctx.export(f'conv.{layer}.tiles', np.int32).reshape(-1, 4)
+    n_tiles = len(tiles)
     inv_s3, inv_s2 = 1 / np.sqrt(3.0), 1 / np.sqrt(2.0)
     for g in range(4):
         w1p = ctx.export(f'conv.{layer}.w1p.{g}').reshape(3, 9, 64, 4).astype(np.float64)
@@ -70,41 +71,46 @@ def emulate(ctx, layer, x_pad, src, dst, group_offsets, edge_attr, sh):
                 F[i, F_C:F_C + NS] = xr[OFF_C:OFF_C + NS]
                 p = xr[OFF_P:OFF_P + 3 * NV].reshape(NV, 3)
                 q = xr[OFF_Q:OFF_Q + 3 * NV].reshape(NV, 3)
-                F[i, F_PV:F_PV + NV] = (p @ v) * inv_s3
-                F[i, F_QV:F_QV + NV] = (q @ v) * inv_s3
-                F[i, F_T1O:F_T1O + 3 * NV] = (p * s0).ravel()
-                F[i, F_T1O + 3 * NV:F_T1O + 6 * NV] = (np.cross(q, v[None]) * inv_s2).ravel()
-                F[i, F_T1E:F_T1E + 3 * NV] = (np.cross(p, v[None]) * inv_s2).ravel()
-                F[i, F_T1E + 3 * NV:F_T1E + 6 * NV] = (q * s0).ravel()
-                F[i, F_SH:F_SH + 4] = sh[ee]
+                pv, qv = (p @ v) * inv_s3, (q @ v) * inv_s3            # F_PQ = [pv0..3 | qv0..3 | pv4 pv5 qv4 qv5]
+                F[i, F_PQ:F_PQ + 12] = np.concatenate([pv[:4], qv[:4], pv[4:], qv[4:]])
+                # vector parts: row r of a 12-row part, component c -> 12*(r//4) + 4*c + r%4
+                t1o = np.concatenate([p * s0, np.cross(q, v[None]) * inv_s2])      # [2nv, 3]
+                t1e = np.concatenate([np.cross(p, v[None]) * inv_s2, q * s0])
+                for r in range(2 * NV):
+                    for c in range(3):
+                        F[i, F_T1O + 12 * (r // 4) + 4 * c + r % 4] = t1o[r, c]
+                        F[i, F_T1E + 12 * (r // 4) + 4 * c + r % 4] = t1e[r, c]
             s0l, vl = sh[e, 0], sh[e, 1:4]
-            acc = np.zeros((64, 3))
+            accA = np.zeros((64, 4))
+            accV = np.zeros((64, 4, 3))
+            Fl = np.concatenate([F, np.zeros((32, 16))], 1)[EL]      # per lane its edge's F row (+ the kernel's 16-float pad)
             for t in range(n_tiles):
                 D = b2p[t][HH]
                 for s in range(36):
                     D = mfma(w2p[t, s // 4, :, s % 4], h[:, s], D)
-                for rq in range(4):
-                    w0, w1, scale_bits, _ = units[4 * t + rq]
-                    kind, flags, ncomp, f_off = w0 & 15, (w0 >> 4) & 15, (w0 >> 8) & 15, w0 >> 16
-                    d = D[:, 4 * rq:4 * rq + 4]
-                    Fl = F[EL]                                   # per lane its edge's F row
-                    if kind == U_T_V:
-                        f = Fl[:, f_off:f_off + 12].reshape(64, 4, 3)
-                        acc += np.einsum('lrc,lr->lc', f, d)
-                    elif kind != U_PAD:
-                        part = (Fl[:, f_off:f_off + 4] * d).sum(1)
-                        if kind == U_R1_S0:
-                            acc[:, 0] += s0l * part
-                        elif kind == U_T_S:
-                            acc[:, 0] += part
+                w0, chan0 = tiles[t, 0], tiles[t, 1]
+                kind, fl, nrq, f_off = w0 & 3, (w0 >> 2) & 3, (w0 >> 4) & 7, w0 >> 16
+                d = D.reshape(64, 4, 4)                              # [lane, rq, j]
+                if kind == T_TV:
+                    f = Fl[:, f_off:f_off + 12].reshape(64, 3, 4)    # [lane, c, j]
+                    accV += np.einsum('lcj,lqj->lqc', f, d)
+                else:
+                    part = np.einsum('lj,lqj->lq', Fl[:, f_off:f_off + 4], d)
+                    if kind == T_RA:
+                        accA += part
+                    else:
+                        accV[:, :, 0] += part
+                if fl:
+                    for rq in range(nrq):
+                        if fl == FL_S:
+                            chan = chan0 + 2 * rq + HH
+                            np.add.at(out, (sn[valid], chan[valid]), (accA[:, rq] * s0l + accV[:, rq, 0])[valid])
                         else:
-                            acc += vl * part[:, None]
-                    if flags & 2:
-                        scale = np.array([scale_bits], np.int32).view(np.float32)[0]
-                        chan = (w1 & 0xffff) + HH * (w1 >> 16)
-                        for c in range(ncomp):
-                            np.add.at(out, (sn[valid], chan[valid] + c), acc[valid, c] * scale)
-                        acc[:] = 0
+                            chan = chan0 + 3 * (2 * rq + HH)
+                            for c in range(3):
+                                np.add.at(out, (sn[valid], chan[valid] + c), (accA[:, rq] * vl[:, c] + accV[:, rq, c])[valid])
+                    accA[:] = 0
+                    accV[:] = 0
     return out
 
 

@@ -72,8 +72,8 @@ def test_packing_by_lane_emulation(built, golden, l):
     P = smr.random_conv_layer_params(CFG, l, int(z['param_seed']), True)
     ctx = Context(device=-1)
     ctx.load_state_dict({f'conv_layers.{l}.{k}': v for k, v in P.items()})
-    tiles = len(ctx.export(f'conv.{l}.units', np.int32)) // 16
-    assert tiles == [23, 32, 39, 62, 62][l]
+    tiles = len(ctx.export(f'conv.{l}.tiles', np.int32)) // 4
+    assert tiles == [24, 34, 42, 66, 66][l]
     node = z['node'].astype(np.float64)
     N, din = node.shape
     x_pad = np.zeros((N, 84))

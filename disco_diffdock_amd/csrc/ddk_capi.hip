@@ -119,6 +119,8 @@ static int build_conv_layer(ddk_ctx* ctx, int l, ConvLayerDev& L) {
     if (L.n_out[b] % 2) return fail(ctx, DDK_ERR_INVALID, "odd output multiplicity unsupported");
     const bool vec = (b == 1 || b == 2);
     for (int col = 0; 8 * col < L.n_out[b]; ++col) {
+      if (L.n_cols >= 16) return fail(ctx, DDK_ERR_INVALID, "too many output columns");
+      L.col_start[L.n_cols++] = (int)tiles.size();
       const int nch = L.n_out[b] - 8 * col < 8 ? L.n_out[b] - 8 * col : 8;
       for (const Quad& q : quads[b]) {
         tiles.push_back(make_tile(q.kind, q.f_off, FL_NONE, nch / 2, oc[b] + (vec ? 3 : 1) * 8 * col));
@@ -128,6 +130,7 @@ static int build_conv_layer(ddk_ctx* ctx, int l, ConvLayerDev& L) {
     }
   }
   L.n_tiles = (int)tiles.size();
+  L.col_start[L.n_cols] = L.n_tiles;
   L.h_tiles = tiles;
 
   // row map: tile row rho = 8*rq + 4*hh + j  ->  row of the reference weight vector (or -1 = zero row)

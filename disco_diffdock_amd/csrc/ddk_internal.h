@@ -74,6 +74,8 @@ struct ConvLayerDev {          // device copies for one TensorProductConvLayer w
   float* b1p[4] = {};          // [3][2][16]
   float* w2r[4] = {};          // [n_tiles][W2_TILE_FLOATS]: per tile the fragments [9][64][4], the bias [2][16], the TileDesc words
   TileDesc* tiles = nullptr;   // [n_tiles]
+  int n_cols = 0;              // flush columns (8 output channels each); col_start[c] = first tile of column c, col_start[n_cols] = n_tiles
+  int col_start[17] = {};
   float* bn_mean = nullptr;    // [XW]  running_mean on 0e channels, 0 elsewhere
   float* bn_scale = nullptr;   // [XW]  weight/sqrt(var+eps)   (1 when batch_norm is off)
   float* bn_bias = nullptr;    // [XW]  bias on 0e channels, 0 elsewhere

@@ -53,6 +53,8 @@ struct ConvKArgs {
   const float* w2r;   // [4][n_tiles][W2_TILE_FLOATS]
   const TileDesc* tiles;  // [n_tiles]
   int n_tiles;
+  int n_cols;         // flush columns; col_start[c] .. col_start[c+1] = tiles of column c
+  int col_start[17];
   int lig_side_only;  // evaluate groups 0,1 only
   int g2_limit;       // >= 0: evaluate only the first g2_limit edges of group 2 (see ConvLaunch)
   float* sum_g2;
@@ -180,11 +182,26 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_fused_kernel(ConvKArgs A
   constexpr int REC4 = W2_TILE_FLOATS / 4;                    // 584 float4 per tile record
   const bool second = tid < REC4 - 64 * CONV_WAVES;           // threads that move a second float4 of the record
 
+  // work units: whole blocks, except that the last (bs4 mod #workgroups) blocks are split into column chunks so that the
+  // final round of the persistent workgroups is a fraction of a block long (tail of the dynamic queue)
+  const int nwg = gridDim.x;
+  const int full = bs4 >= nwg ? (bs4 / nwg) * nwg : 0;
+  const int rest = bs4 - full;
+  const int split = rest > 0 ? max(1, min(A.n_cols, nwg / rest)) : 1;
+  const int n_units = full + rest * split;
+
   for (;;) {
     if (tid == 0) *blk_slot = atomicAdd(A.counter, 1);
     __syncthreads();
-    const int blk = __builtin_amdgcn_readfirstlane(*blk_slot);
-    if (blk >= bs4) break;
+    const int unit = __builtin_amdgcn_readfirstlane(*blk_slot);
+    if (unit >= n_units) break;
+    int blk = unit, t_begin = 0, t_end = n_tiles;
+    if (unit >= full) {
+      const int r = unit - full, c = r % split;
+      blk = full + r / split;
+      t_begin = A.col_start[(c * A.n_cols) / split];
+      t_end = A.col_start[((c + 1) * A.n_cols) / split];
+    }
     const int g = (blk >= bs1) + (blk >= bs2) + (blk >= bs3);
     const int bstart = g == 0 ? 0 : (g == 1 ? bs1 : (g == 2 ? bs2 : bs3));
     const int gbeg = g == 0 ? go0 : (g == 1 ? go1 : (g == 2 ? go2 : go3));
@@ -195,15 +212,17 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_fused_kernel(ConvKArgs A
     const int e = nvalid > 0 ? e0 + min(el, nvalid - 1) : gend - 1;
     const int sn = A.src[e], dn = A.dst[e];
 
-    // ---- stage W2 tiles 0 and 1 of this group (the ring is idle: the previous block ended with a barrier) ----
+    // ---- stage the first two W2 tiles of this unit (the ring is idle: the previous block ended with a barrier) ----
     const float* wrec = A.w2r + (size_t)g * n_tiles * W2_TILE_FLOATS;
     {
-      const float4 r0 = ld4(wrec + 4 * tid), r1 = ld4(wrec + W2_TILE_FLOATS + 4 * tid);
+      const float* wr0 = wrec + (size_t)t_begin * W2_TILE_FLOATS;
+      const float* wr1 = wrec + (size_t)min(t_begin + 1, t_end - 1) * W2_TILE_FLOATS;
+      const float4 r0 = ld4(wr0 + 4 * tid), r1 = ld4(wr1 + 4 * tid);
       *reinterpret_cast<float4*>(ring + 4 * tid) = r0;
       *reinterpret_cast<float4*>(ring + W2_TILE_FLOATS + 4 * tid) = r1;
       if (second) {
         const int q = 4 * (tid + 64 * CONV_WAVES);
-        const float4 r2 = ld4(wrec + q), r3 = ld4(wrec + W2_TILE_FLOATS + q);
+        const float4 r2 = ld4(wr0 + q), r3 = ld4(wr1 + q);
         *reinterpret_cast<float4*>(ring + q) = r2;
         *reinterpret_cast<float4*>(ring + W2_TILE_FLOATS + q) = r3;
       }
@@ -333,15 +352,15 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_fused_kernel(ConvKArgs A
 #define DDK_TILE(T, AC, BC, AN, BN)                                                                            \
     {                                                                                                          \
       const int w0 = tq.w0, chan0 = tq.chan0;                                                                  \
-      const int t2 = min((T) + 2, n_tiles - 1);                                                                \
+      const int t2 = min((T) + 2, t_end - 1);                                                                  \
       const float* rec2 = wrec + (size_t)t2 * W2_TILE_FLOATS;                                                  \
       const float4 st0 = ld4(rec2 + 4 * tid);                                                                  \
       float4 st1 = st0;                                                                                        \
       if (second) st1 = ld4(rec2 + 4 * (tid + 64 * CONV_WAVES));                                               \
       const float* Fp = Fr + (w0 >> 16);                                                                       \
       const f32x4 f0 = ldv4(Fp), f1 = ldv4(Fp + 4), f2 = ldv4(Fp + 8);                                        \
-      lds_frags(AN, BN, ring + (((T) + 1) & 1) * W2_TILE_FLOATS, lane, hh);                                    \
-      tqv = *reinterpret_cast<const int2*>(ring + (((T) + 1) & 1) * W2_TILE_FLOATS + 2336);                    \
+      lds_frags(AN, BN, ring + (((T) + 1 - t_begin) & 1) * W2_TILE_FLOATS, lane, hh);                                    \
+      tqv = *reinterpret_cast<const int2*>(ring + (((T) + 1 - t_begin) & 1) * W2_TILE_FLOATS + 2336);          \
       __builtin_amdgcn_sched_barrier(0);                                                                       \
       const f32x16 D = burst(AC, h, BC);                                                                       \
       __builtin_amdgcn_sched_barrier(0);                                                                       \
@@ -364,15 +383,15 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_fused_kernel(ConvKArgs A
           accA[rq] = 0.0f; accV[rq][0] = 0.0f; accV[rq][1] = 0.0f; accV[rq][2] = 0.0f;                         \
         }                                                                                                      \
       }                                                                                                        \
-      float* stg = ring + ((T) & 1) * W2_TILE_FLOATS;                                                          \
+      float* stg = ring + (((T) - t_begin) & 1) * W2_TILE_FLOATS;                                              \
       *reinterpret_cast<float4*>(stg + 4 * tid) = st0;                                                         \
       if (second) *reinterpret_cast<float4*>(stg + 4 * (tid + 64 * CONV_WAVES)) = st1;                         \
       tq.w0 = __builtin_amdgcn_readfirstlane(tqv.x); tq.chan0 = __builtin_amdgcn_readfirstlane(tqv.y);       \
       __syncthreads();                                                                                         \
     }
-    for (int t = 0; t < n_tiles; t += 2) {
+    for (int t = t_begin; t < t_end; t += 2) {
       DDK_TILE(t, a0, B0, a1, B1)
-      if (t + 1 >= n_tiles) break;
+      if (t + 1 >= t_end) break;
       DDK_TILE(t + 1, a1, B1, a0, B0)
     }
 #undef DDK_TILE
@@ -434,6 +453,8 @@ hipError_t launch_conv_fused(const ConvLayerDev& L, const ConvLaunch& a, int n_c
   k.x = a.x; k.src = a.src; k.dst = a.dst; k.edge_attr = a.edge_attr; k.sh = a.sh; k.sum = a.sum;
   k.tile_info = a.tile_info; k.counter = a.counter;
   k.w1p = L.w1p[0]; k.b1p = L.b1p[0]; k.w2r = L.w2r[0]; k.tiles = L.tiles; k.n_tiles = L.n_tiles;
+  k.n_cols = L.n_cols;
+  for (int c = 0; c <= L.n_cols; ++c) k.col_start[c] = L.col_start[c];
   k.lig_side_only = a.lig_side_only; k.g2_limit = a.g2_limit; k.sum_g2 = a.sum_g2; k.g2_node_off = a.g2_node_off;
   // one persistent 8-wave workgroup per CU (its F rows + the W2 ring fill the LDS), dynamic block queue
   static const hipError_t attr = [] {

@@ -346,6 +346,22 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_fused_kernel(ConvKArgs A
     TileQ tq;
     tq.w0 = __builtin_amdgcn_readfirstlane(tqv.x); tq.chan0 = __builtin_amdgcn_readfirstlane(tqv.y);
 #define PSUM(p) ((p).x + (p).y)
+// timing ablations (tools/build_variant.py -DDDK_EXP_...): wrong results, never built into libddk.so
+#ifdef DDK_EXP_NOEPI
+#define DDK_EPILOGUE accA[0] += f32x2{D[0] + D[5] + D[10] + D[15], f0.x + f1.x + f2.x};
+#else
+#define DDK_EPILOGUE tile_epilogue(w0 & 3, D, f0, f1, f2, accA, accV);
+#endif
+#ifdef DDK_EXP_NOFLUSH
+#define DDK_FLUSH_COND (((w0 >> 2) & 3) && t2 + 1 > t_end)
+#else
+#define DDK_FLUSH_COND ((w0 >> 2) & 3)
+#endif
+#ifdef DDK_EXP_NOBARRIER
+#define DDK_TILE_BARRIER
+#else
+#define DDK_TILE_BARRIER __syncthreads();
+#endif
 // one W2 tile: (1) request this thread's share of tile t+2 from L2 and the descriptor of tile t+1, (2) read tile t+1's
 // fragments from the ring into the other register set, (3) the uninterrupted 36-MFMA burst of tile t, (4) epilogue and,
 // at the end of a column, the flush, (5) publish tile t+2 into the ring stage tile t came from, (6) barrier.
@@ -355,7 +371,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_fused_kernel(ConvKArgs A
       const int t2 = min((T) + 2, t_end - 1);                                                                  \
       const float* rec2 = wrec + (size_t)t2 * W2_TILE_FLOATS;                                                  \
       const float4 st0 = ld4(rec2 + 4 * tid);                                                                  \
-      float4 st1 = st0;                                                                                        \
+      float4 st1 = make_float4(0.f, 0.f, 0.f, 0.f);   /* (a copy of st0 here would wait for the load) */     \
       if (second) st1 = ld4(rec2 + 4 * (tid + 64 * CONV_WAVES));                                               \
       const float* Fp = Fr + (w0 >> 16);                                                                       \
       const f32x4 f0 = ldv4(Fp), f1 = ldv4(Fp + 4), f2 = ldv4(Fp + 8);                                        \
@@ -364,8 +380,8 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_fused_kernel(ConvKArgs A
       __builtin_amdgcn_sched_barrier(0);                                                                       \
       const f32x16 D = burst(AC, h, BC);                                                                       \
       __builtin_amdgcn_sched_barrier(0);                                                                       \
-      tile_epilogue(w0 & 3, D, f0, f1, f2, accA, accV);                                                        \
-      const int fl = (w0 >> 2) & 3;                                                                            \
+      DDK_EPILOGUE                                                                                             \
+      const int fl = DDK_FLUSH_COND;                                                                           \
       if (fl) {                                                                                                \
         const int nrq = (w0 >> 4) & 7;                                                                         \
         _Pragma("unroll") for (int rq = 0; rq < 4; ++rq) {                                                     \
@@ -387,8 +403,11 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_fused_kernel(ConvKArgs A
       *reinterpret_cast<float4*>(stg + 4 * tid) = st0;                                                         \
       if (second) *reinterpret_cast<float4*>(stg + 4 * (tid + 64 * CONV_WAVES)) = st1;                         \
       tq.w0 = __builtin_amdgcn_readfirstlane(tqv.x); tq.chan0 = __builtin_amdgcn_readfirstlane(tqv.y);       \
-      __syncthreads();                                                                                         \
+      DDK_TILE_BARRIER                                                                                         \
     }
+#ifdef DDK_EXP_REPEAT2
+    for (int rep = 0; rep < 2; ++rep)
+#endif
     for (int t = t_begin; t < t_end; t += 2) {
       DDK_TILE(t, a0, B0, a1, B1)
       if (t + 1 >= t_end) break;
@@ -396,6 +415,9 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_fused_kernel(ConvKArgs A
     }
 #undef DDK_TILE
 #undef PSUM
+#undef DDK_EPILOGUE
+#undef DDK_FLUSH_COND
+#undef DDK_TILE_BARRIER
   }
 }
 

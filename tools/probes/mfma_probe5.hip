@@ -59,7 +59,8 @@ __global__ __launch_bounds__(64) void probe_private(const float* in, const float
 }
 
 template <int NV, int NW>
-__global__ __launch_bounds__(64 * NW) void probe_shared(const float* in, const float* wts, float* out, int passes, int nt) {
+__global__ __launch_bounds__(64 * NW) void probe_shared(const float* in, const float* wts, float* out, int passes, int nt, long long* clk = nullptr) {
+  const long long c0 = clock64(), w0c = wall_clock64();
   __shared__ __attribute__((aligned(16))) float ring[2][TILE_F];
   float h[36];
   const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(64 * NW) void probe_shared(const float* in, const f
   float s = 0.f;
   for (int k = 0; k < 8; ++k) s += acc[k];
   out[blockIdx.x * 64 * NW + tid] = s;
+  if (clk && blockIdx.x == 7 && tid == 0) { clk[0] = clock64() - c0; clk[1] = wall_clock64() - w0c; }
 }
 
 int main() {
@@ -130,6 +132,12 @@ int main() {
   RUN("shared 4-wave WG NV=96", 4, hipLaunchKernelGGL((probe_shared<96, 4>), dim3(256), dim3(256), 0, 0, in, wts, out, 2, nt), hipLaunchKernelGGL((probe_shared<96, 4>), dim3(256), dim3(256), 0, 0, in, wts, out, passes, nt))
   RUN("shared 8-wave WG NV=32", 8, hipLaunchKernelGGL((probe_shared<32, 8>), dim3(256), dim3(512), 0, 0, in, wts, out, 2, nt), hipLaunchKernelGGL((probe_shared<32, 8>), dim3(256), dim3(512), 0, 0, in, wts, out, passes, nt))
   RUN("shared 8-wave WG NV=96", 8, hipLaunchKernelGGL((probe_shared<96, 8>), dim3(256), dim3(512), 0, 0, in, wts, out, 2, nt), hipLaunchKernelGGL((probe_shared<96, 8>), dim3(256), dim3(512), 0, 0, in, wts, out, passes, nt))
+  {
+    long long* clk; (void)hipMalloc(&clk, 16); long long hc[2];
+    hipLaunchKernelGGL((probe_shared<96, 8>), dim3(256), dim3(512), 0, 0, in, wts, out, passes, nt, clk);
+    (void)hipDeviceSynchronize(); (void)hipMemcpy(hc, clk, 16, hipMemcpyDeviceToHost);
+    printf("shared 8-wave NV=96: clock64 ticks %lld, wall_clock64 ticks %lld (100 MHz) -> %.3f GHz shader clock\n", hc[0], hc[1], (double)hc[0] / ((double)hc[1] / 100e6) / 1e9);
+  }
   RUN("2x shared 4-wave WG / CU NV=32", 8, hipLaunchKernelGGL((probe_shared<32, 4>), dim3(512), dim3(256), 0, 0, in, wts, out, 2, nt), hipLaunchKernelGGL((probe_shared<32, 4>), dim3(512), dim3(256), 0, 0, in, wts, out, passes, nt))
   return 0;
 }

@@ -34,7 +34,7 @@ SYMBOLS = ['ddk_create', 'ddk_destroy', 'ddk_last_error', 'ddk_version', 'ddk_lo
            'ddk_set_score_norm_tables', 'ddk_tp_forward', 'ddk_conv_forward', 'ddk_complex_create', 'ddk_complex_destroy',
            'ddk_score_forward', 'ddk_se3_update', 'ddk_sample', 'ddk_last_graph_stats', 'ddk_last_node_features',
            'ddk_profile_enable', 'ddk_profile_read', 'ddk_set_latents', 'ddk_set_guidance',
-           'ddk_set_keep_receptor_features']
+           'ddk_set_keep_receptor_features', 'ddk_randomize_position']
 
 
 def lib():
@@ -62,6 +62,7 @@ def lib():
     L.ddk_complex_destroy.restype = None
     L.ddk_score_forward.argtypes = [vp, vp, i32, vp, f32, f32, f32, vp, vp, vp, vp]
     L.ddk_se3_update.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp]
+    L.ddk_randomize_position.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp]
     L.ddk_sample.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]
     L.ddk_last_graph_stats.argtypes = [vp, vp, vp, vp]
     L.ddk_last_node_features.argtypes = [vp, vp, i32, vp, vp, vp]

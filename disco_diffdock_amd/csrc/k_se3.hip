@@ -147,6 +147,58 @@ __global__ __launch_bounds__(256) void se3_update_kernel(Se3Args A) {
   }
 }
 
+// randomize_position (utils/sampling.py:12-34) for B copies of one conformer, one workgroup per sample:
+// sequential torsion updates in bond order (utils/torsion.py:48-68: axis pos_u - pos_v, pivot pos_v, zero updates skipped),
+// then (pos - centroid) R^T + tr with the caller's rotation matrix and translation draw.
+__global__ __launch_bounds__(256) void randomize_kernel(RandPosArgs A) {
+  __shared__ float p[MAX_LIG * 3];
+  __shared__ float Rt[9], piv[3], ctr[3];
+  __shared__ int skip;
+  const int b = blockIdx.x, tid = threadIdx.x, n = A.n_lig, R = A.R;
+  for (int i = tid; i < n * 3; i += 256) p[i] = A.pos0[i];
+  __syncthreads();
+  if (A.tor != nullptr) {
+    for (int r = 0; r < R; ++r) {
+      if (tid == 0) {
+        const float th = A.tor[(size_t)b * R + r];
+        skip = th == 0.0f;
+        const int u = A.rot_u[r], v = A.rot_v[r];
+        const float ax = p[3 * u] - p[3 * v], ay = p[3 * u + 1] - p[3 * v + 1], az = p[3 * u + 2] - p[3 * v + 2];
+        const float nn = sqrtf(ax * ax + ay * ay + az * az);
+        axis_angle_to_matrix_dev(ax / nn * th, ay / nn * th, az / nn * th, Rt);
+        piv[0] = p[3 * v]; piv[1] = p[3 * v + 1]; piv[2] = p[3 * v + 2];
+      }
+      __syncthreads();
+      if (!skip && tid < n && A.mask_rotate[(size_t)r * n + tid]) {
+        const float x = p[3 * tid] - piv[0], y = p[3 * tid + 1] - piv[1], z = p[3 * tid + 2] - piv[2];
+        p[3 * tid] = Rt[0] * x + Rt[1] * y + Rt[2] * z + piv[0];
+        p[3 * tid + 1] = Rt[3] * x + Rt[4] * y + Rt[5] * z + piv[1];
+        p[3 * tid + 2] = Rt[6] * x + Rt[7] * y + Rt[8] * z + piv[2];
+      }
+      __syncthreads();
+    }
+  }
+  if (tid < 3) {
+    float s = 0.0f;
+    for (int i = 0; i < n; ++i) s += p[3 * i + tid];
+    ctr[tid] = s / (float)n;
+  }
+  __syncthreads();
+  if (tid < n) {
+    const float* M = A.rot + (size_t)b * 9;
+    const float x = p[3 * tid] - ctr[0], y = p[3 * tid + 1] - ctr[1], z = p[3 * tid + 2] - ctr[2];
+    float ox = M[0] * x + M[1] * y + M[2] * z, oy = M[3] * x + M[4] * y + M[5] * z, oz = M[6] * x + M[7] * y + M[8] * z;
+    if (A.tr != nullptr) { ox += A.tr[3 * b]; oy += A.tr[3 * b + 1]; oz += A.tr[3 * b + 2]; }
+    float* o = A.pos_out + ((size_t)b * n + tid) * 3;
+    o[0] = ox; o[1] = oy; o[2] = oz;
+  }
+}
+
+hipError_t launch_randomize(const RandPosArgs& A, hipStream_t s) {
+  hipLaunchKernelGGL(randomize_kernel, dim3(A.B), dim3(256), 0, s, A);
+  return hipGetLastError();
+}
+
 // classifier-free guidance: score <- score + w * (score - score_unconditional)   (utils/sampling.py:131-133)
 __global__ void cfg_combine_kernel(float* score, const float* uncond, float w, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -145,6 +145,19 @@ struct Se3Args {
   float* pos_out;
 };
 
+struct RandPosArgs {
+  const float* pos0;     // [n_lig, 3]
+  const float* tor;      // [B, R] or null
+  const float* rot;      // [B, 3, 3]
+  const float* tr;       // [B, 3] or null
+  const int32_t* rot_u;
+  const int32_t* rot_v;
+  const uint8_t* mask_rotate;   // [R, n_lig]
+  int B, n_lig, R;
+  float* pos_out;
+};
+hipError_t launch_randomize(const RandPosArgs& A, hipStream_t s);
+
 hipError_t launch_graph(const GraphArgs& G, int64_t edge_cap, hipStream_t s);
 hipError_t launch_edge_features(const EdgeFeatArgs& A, int64_t edge_cap, hipStream_t s);
 struct NodeEmbedArgs {

@@ -508,6 +508,20 @@ int ddk_se3_update(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* pos, c
   return DDK_OK;
 }
 
+int ddk_randomize_position(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* pos0, const float* tor, const float* rot,
+                           const float* tr, float* pos_out, void* stream) {
+  if (!ctx) return DDK_ERR_INVALID;
+  if (ctx->host_only) return fail(ctx, DDK_ERR_STATE, "host-only context (device < 0) cannot launch kernels");
+  if (!cx || B < 1 || !pos0 || !rot || !pos_out) return fail(ctx, DDK_ERR_INVALID, "ddk_randomize_position: bad complex / batch / null argument");
+  RandPosArgs A;
+  A.pos0 = pos0; A.tor = tor; A.rot = rot; A.tr = tr;
+  A.rot_u = cx->rot_u; A.rot_v = cx->rot_v; A.mask_rotate = cx->mask_rotate; A.B = B; A.n_lig = cx->n_lig; A.R = cx->R;
+  A.pos_out = pos_out;
+  hipError_t e = launch_randomize(A, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(ctx, e, "randomize_position launch");
+  return DDK_OK;
+}
+
 int ddk_sample(ddk_ctx* ctx, ddk_complex* cx, int32_t B, int32_t steps, const float* t, const float* score_coeff,
                const float* noise_coeff, const float* noise, float* pos, void* stream) {
   int rc = check_model(ctx, cx, B);

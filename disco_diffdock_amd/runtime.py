@@ -220,6 +220,19 @@ class Complex:
                    'ddk_se3_update')
         return out
 
+    def randomize_position(self, pos0, rot, tor=None, tr=None):
+        """utils/sampling.py:12-34 for B = rot.shape[0] copies of the conformer pos0 [n_lig,3]; returns [B,n_lig,3]."""
+        ctx = self.ctx
+        pos0 = pos0.contiguous().float().reshape(self.n_lig, 3)
+        rot = rot.contiguous().float().reshape(-1, 3, 3)
+        B = rot.shape[0]
+        tor = tor.contiguous().float().reshape(B, self.R) if tor is not None and self.R > 0 else None
+        tr = tr.contiguous().float().reshape(B, 3) if tr is not None else None
+        out = torch.empty((B, self.n_lig, 3), dtype=torch.float32, device=pos0.device)
+        ctx._check(ctx.L.ddk_randomize_position(ctx.h, self.h, B, _ptr(pos0), _ptr(tor), _ptr(rot), _ptr(tr), _ptr(out), _stream()),
+                   'ddk_randomize_position')
+        return out
+
     def sample(self, pos, t, score_coeff, noise_coeff, noise=None):
         """in-place reverse diffusion of pos [B,n_lig,3]; t/score_coeff/noise_coeff: [steps,3] host arrays."""
         ctx = self.ctx

@@ -64,6 +64,41 @@ def randomize_position(data_list, no_torsion, no_random, tr_sigma_max, unbatched
                 g['ligand'].ar_pos = copy.deepcopy(g['ligand'].pos)
 
 
+def randomize_position_device(data_list, no_torsion, no_random, tr_sigma_max, device):
+    """``randomize_position`` (utils/sampling.py:12-34) for the usual case that ``data_list`` holds N copies of ONE complex
+    (evaluate.py:232): the random draws are taken on the host from the reference's own RNG streams in the reference's
+    order (np.random.uniform per graph, then scipy ``Rotation.random()`` and ``torch.normal`` per graph), the geometry of
+    all N copies runs in one ``ddk_randomize_position`` launch, and every ``g['ligand'].pos`` becomes a view of the
+    resulting device tensor.  (The host function above remains the general fallback-free path for mixed lists.)"""
+    from scipy.spatial.transform import Rotation as R
+    from .data import collate
+    from .score_model import complex_for_batch
+    if device is None or torch.device(device).type != 'cuda':
+        raise RuntimeError('ddk: randomize_position_device needs a cuda device (no CPU fallback)')
+    device = torch.device(device)
+    g0, N = data_list[0], len(data_list)
+    n_lig = g0['ligand'].pos.shape[0]
+    if any(g['ligand'].pos.shape[0] != n_lig or getattr(g, 'name', None) != getattr(g0, 'name', None) for g in data_list):
+        raise RuntimeError('ddk: randomize_position_device expects copies of one complex')
+    n_rot = int(g0['ligand'].edge_mask.sum())
+    tor = None
+    if not no_torsion:
+        tor = np.stack([np.random.uniform(low=-np.pi, high=np.pi, size=n_rot) for _ in data_list]).astype(np.float32)
+    rot = np.empty((N, 3, 3), np.float32)
+    tr = None if no_random else torch.empty((N, 3))
+    for b in range(N):
+        rot[b] = R.random().as_matrix()
+        if not no_random:
+            tr[b] = torch.normal(mean=0, std=tr_sigma_max, size=(1, 3))[0]
+    cx, _ = complex_for_batch(collate([g0]), device, need_model=False)
+    pos = cx.randomize_position(torch.as_tensor(np.asarray(g0['ligand'].pos.cpu(), np.float32)).to(device), torch.from_numpy(rot).to(device),
+                                None if tor is None or n_rot == 0 else torch.from_numpy(tor).to(device),
+                                None if tr is None else tr.to(device))
+    for b, g in enumerate(data_list):
+        g['ligand'].pos = pos[b]
+    return pos
+
+
 def step_coefficients(inference_steps, tr_schedule, rot_schedule, tor_schedule, t_to_sigma, model_args, ode, no_random,
                       no_final_step_noise, temp_sampling, temp_psi, temp_sigma_data):
     """Host scalars of every reverse step, formed with the reference's expressions and dtypes

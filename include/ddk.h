@@ -132,6 +132,15 @@ int ddk_score_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* lig
 int ddk_se3_update(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* pos, const float* tr, const float* rot,
                    const float* tor, float* pos_out, void* stream);
 
+/* ---- randomize_position(data_list, no_torsion, no_random, tr_sigma_max)  utils/sampling.py:12-34 for B copies of one
+ *      complex in one launch: per sample  pos = torsions(pos0, tor[b])  (bond order, utils/torsion.py:48-68,
+ *      zero updates skipped);  pos = (pos - mean(pos)) @ rot[b]^T + tr[b].
+ *      pos0 [n_lig,3] the conformer (DEVICE); tor [B, n_rot] = np.random.uniform(-pi, pi) draws or NULL (no_torsion);
+ *      rot [B,3,3] row-major rotation matrices (scipy Rotation.random().as_matrix()); tr [B,3] = N(0, tr_sigma_max) draws or
+ *      NULL (no_random); pos_out [B,n_lig,3].  The draws stay with the caller: the reference's host RNG streams or device RNG. */
+int ddk_randomize_position(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* pos0, const float* tor, const float* rot,
+                           const float* tr, float* pos_out, void* stream);
+
 /* ---- a1-a2: the reverse-diffusion loop of sampling()  utils/sampling.py:105-198 for one batch:
  *      per step  perturb = score_coeff*score + noise_coeff*z  (coefficients are the host scalars of
  *      sampling.py:137-192, including the low-temperature variant), then ddk_se3_update.

@@ -13,7 +13,7 @@ import torch
 
 from oracle import score_model_ref as smr
 from oracle import sampler_ref as spr
-from helpers import complex_from_npz, batch_of, rel_err
+from helpers import complex_from_npz, batch_of, rel_err, to_graph
 
 pytestmark = pytest.mark.gpu
 T = torch.from_numpy
@@ -500,3 +500,46 @@ def test_last_layer_receptor_rows_on_request(dev, model7, golden):
     for a, f_, name in zip(out_lean, out_full, ('tr', 'rot', 'tor')):
         assert rel_err(a.cpu(), f_.cpu().numpy()) < 2e-6, name
         assert rel_err(a.cpu(), z[name]) < 1e-4, name
+
+
+@pytest.mark.parametrize('no_torsion,no_random', [(False, False), (True, False), (False, True)])
+def test_randomize_position_device(dev, golden, no_torsion, no_random):
+    """SURVEY.md §8(f) #3: ddk_randomize_position == the oracle's randomize_position (utils/sampling.py:12-34) on the same draws."""
+    from scipy.spatial.transform import Rotation as R
+    from disco_diffdock_amd.runtime import Context, Complex
+    c = complex_from_npz(golden('complex_diffdockS_score_model'))
+    B, sig = 6, 19.0
+    gl = [to_graph(c) for _ in range(B)]
+    spr.randomize_position(gl, no_torsion, no_random, sig, rng=np.random.default_rng(5))
+    want = np.stack([g['ligand'].pos.numpy() for g in gl])
+    rng = np.random.default_rng(5)                       # replay the oracle's draw order
+    n_rot = int(np.asarray(c['edge_mask']).sum())
+    tor = None if no_torsion else np.stack([rng.uniform(low=-np.pi, high=np.pi, size=n_rot) for _ in range(B)]).astype(np.float32)
+    rot, tr = np.empty((B, 3, 3), np.float32), np.empty((B, 3), np.float32)
+    for b in range(B):
+        rot[b] = R.random(random_state=rng).as_matrix()
+        if not no_random:
+            tr[b] = rng.normal(0, sig, size=(1, 3))[0]
+    from disco_diffdock_amd.tensor_layers import _shape_context
+    cx = Complex(_shape_context(0), c, max_batch=B)
+    got = cx.randomize_position(T(np.asarray(c['lig_pos'], np.float32)).to(dev), T(rot).to(dev),
+                                None if tor is None else T(tor).to(dev), None if no_random else T(tr).to(dev))
+    assert rel_err(got.cpu(), want) < 2e-6
+
+
+def test_randomize_position_device_wrapper(dev, golden):
+    """The list-level wrapper draws from the reference's host RNG streams and writes device views back into the graphs."""
+    from disco_diffdock_amd.sampling import randomize_position_device
+    from disco_diffdock_amd.data import from_arrays
+    c = complex_from_npz(golden('complex_diffdockS_score_model'))
+    gl = [from_arrays(c) for _ in range(4)]
+    np.random.seed(0); torch.manual_seed(0)
+    pos = randomize_position_device(gl, False, False, 19.0, dev)
+    assert pos.shape == (4, c['lig_pos'].shape[0], 3) and all(g['ligand'].pos.is_cuda for g in gl)
+    d0 = torch.cdist(T(np.asarray(c['lig_pos'], np.float32)), T(np.asarray(c['lig_pos'], np.float32)))
+    bonds = np.asarray(c['bond_index'])
+    for g in gl:                                          # torsions + rigid motion keep every bond length
+        p = g['ligand'].pos.cpu()
+        assert torch.allclose(torch.linalg.norm(p[bonds[0]] - p[bonds[1]], dim=1), d0[bonds[0], bonds[1]], atol=1e-4)
+    with pytest.raises(RuntimeError, match='cuda'):
+        randomize_position_device(gl, False, False, 19.0, torch.device('cpu'))

@@ -112,3 +112,28 @@ def test_product_state_dict_spec_equals_reference_layout():
     a = {k: tuple(v) for k, v in synthetic.score_model_state_dict_spec().items()}
     b = {k: tuple(v) for k, v in smr.state_dict_spec(smr.ScoreModelConfig(latent_vocab=64)).items()}
     assert a == b and len(a) == 171 and sum(int(np.prod(v)) for v in a.values()) == 2107134
+
+
+def test_graph_cache_roundtrip(tmp_path):
+    """Flat graph cache (SURVEY.md §8(f) #4): ragged complexes survive save -> mmap load bit-exactly; corrupt files are refused."""
+    from disco_diffdock_amd import graph_cache, synthetic
+    from disco_diffdock_amd.data import from_arrays
+    cs = [synthetic.make_complex(s, n_res=n, esm_dim=8) for s, n in ((0, 40), (1, 17), (2, 64))]
+    path = tmp_path / 'graphs.ddkg'
+    assert graph_cache.save_complexes(path, cs) == 3
+    back = graph_cache.load_complexes(path)
+    assert [c['name'] for c in back] == [c['name'] for c in cs]
+    for a, b in zip(cs, back):
+        for k in ('lig_x', 'lig_pos', 'bond_index', 'bond_attr', 'edge_mask', 'mask_rotate', 'rec_x', 'rec_pos', 'rec_edge_index', 'original_center'):
+            assert np.array_equal(np.asarray(a[k]).reshape(np.asarray(b[k]).shape), b[k]), k
+        g = from_arrays(b)
+        assert g['ligand'].pos.shape == (a['lig_pos'].shape[0], 3) and g['receptor'].x.shape == a['rec_x'].shape
+    raw = path.read_bytes()
+    (tmp_path / 'bad_magic').write_bytes(b'XXXX' + raw[4:])
+    (tmp_path / 'short').write_bytes(raw[:len(raw) // 2])
+    for name in ('bad_magic', 'short'):
+        with pytest.raises(ValueError):
+            graph_cache.load_complexes(tmp_path / name)
+    bad = dict(cs[0]); bad['rec_pos'] = bad['rec_pos'][:-1]
+    with pytest.raises(ValueError, match='rec_pos'):
+        graph_cache.save_complexes(tmp_path / 'x', [bad])

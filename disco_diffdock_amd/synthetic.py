@@ -208,6 +208,48 @@ def make_ligand(rng, n_atoms=None):
                 edge_mask=edge_mask, mask_rotate=mask_rotate)
 
 
+REC_ATOM_FEATURE_DIMS = (38, 119, 23, 38)     # process_mols.py:81-86 (residue type, atomic number, atom type 2, atom type 3)
+
+
+def add_receptor_atoms(c, rng, atom_radius=5.0, atom_max_neighbors=8, atoms_per_residue=(4, 12)):
+    """All-atom receptor level of the confidence model's graphs (datasets_utils/process_mols.py:383-477 layout):
+    ``atom_x`` [n_atom,4] categorical ids, ``atom_pos`` [n_atom,3] (heavy atoms within ~3.5 A of their C-alpha, 1.2 A apart),
+    ``atom_edge_index`` [2,E_aa] = radius_graph(atom_pos, atom_radius, max_num_neighbors) (directed j->i pairs, per target
+    the first ``max`` neighbours in index order) and ``atom_rec_index`` [2,n_atom] = (atom, its residue)."""
+    rec_pos, res_id = c['rec_pos'], c['rec_x'][:, 0].astype(np.int64)
+    pos, owner = [], []
+    for r in range(rec_pos.shape[0]):
+        k = int(rng.integers(atoms_per_residue[0], atoms_per_residue[1] + 1))
+        mine = [rec_pos[r].astype(np.float64)]              # the C-alpha itself is the first atom
+        tries = 0
+        while len(mine) < k and tries < 200:
+            tries += 1
+            p = rec_pos[r] + _rand_unit(rng) * rng.uniform(1.3, 3.5)
+            if all(np.linalg.norm(p - q) > 1.2 for q in mine):
+                mine.append(p)
+        pos += mine
+        owner += [r] * len(mine)
+    pos, owner = np.asarray(pos, np.float32), np.asarray(owner, np.int64)
+    n = pos.shape[0]
+    x = np.stack([res_id[owner], rng.integers(0, REC_ATOM_FEATURE_DIMS[1], n), rng.integers(0, REC_ATOM_FEATURE_DIMS[2], n),
+                  rng.integers(0, REC_ATOM_FEATURE_DIMS[3], n)], axis=1).astype(np.int64)
+    # radius_graph: for every target i its neighbours j (ascending index, first max_num_neighbors), edge (j -> i) stored as [j; i]
+    src, dst = [], []
+    order = np.argsort(pos[:, 0], kind='stable')
+    xs = pos[order, 0]
+    for i in range(n):
+        lo, hi = np.searchsorted(xs, pos[i, 0] - atom_radius), np.searchsorted(xs, pos[i, 0] + atom_radius)
+        cand = np.sort(order[lo:hi])
+        d = np.linalg.norm(pos[cand] - pos[i], axis=1)
+        nb = cand[(d < atom_radius) & (cand != i)][:atom_max_neighbors]
+        src += [int(j) for j in nb]
+        dst += [i] * len(nb)
+    c['atom_x'], c['atom_pos'] = x, pos
+    c['atom_edge_index'] = np.asarray([src, dst], dtype=np.int64)
+    c['atom_rec_index'] = np.asarray([np.arange(n), owner], dtype=np.int64)
+    return c
+
+
 def make_complex(seed, n_res=300, n_lig=None, cutoff=15.0, max_neighbor=24, esm_dim=ESM_DIM):
     """One synthetic complex as a dict of numpy arrays; ligand centred on a random pocket point
     inside the receptor ball (coordinates are receptor-centred like pdbbind.py:341-347)."""

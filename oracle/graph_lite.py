@@ -149,3 +149,12 @@ def make_complex(lig_x, lig_pos, bond_index, bond_attr, edge_mask, mask_rotate, 
     d.original_center = torch.zeros(1, 3) if original_center is None else torch.as_tensor(original_center).float()
     d.name = name
     return d
+
+
+def add_atoms(d, atom_x, atom_pos, atom_edge_index, atom_rec_index):
+    """All-atom level of a complex (datasets_utils/process_mols.py:474-477)."""
+    d['atom'].x = torch.as_tensor(atom_x).long()
+    d['atom'].pos = torch.as_tensor(atom_pos).float()
+    d['atom', 'atom_contact', 'atom'].edge_index = torch.as_tensor(atom_edge_index).long()
+    d['atom', 'atom_rec_contact', 'receptor'].edge_index = torch.as_tensor(atom_rec_index).long()
+    return d

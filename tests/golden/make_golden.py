@@ -293,5 +293,59 @@ def main():
             save(f'trajectory_{tag}', pos0=pos0, pos_out=torch.cat([d_['ligand'].pos for d_ in out_list]), steps=steps, seed=321)
 
 
+def confidence_golden():
+    """Tier B: the all-atom confidence model (models/all_atom_score_model.py in confidence_mode, built by the reference's
+    get_model from workdir/paper_confidence_model/model_parameters.yml) running on the *_lite stand-ins; also the trajectory +
+    confidence output of the reference sampling() with confidence_model / confidence_data_list."""
+    np.random.seed(0)
+    torch.manual_seed(0)
+    install_standins()
+    from functools import partial
+    from utils import diffusion_utils, sampling as ref_sampling
+    from utils.model_utils import get_model
+    from oracle import confidence_ref as cr
+    with open(os.path.join(REF, 'workdir', 'paper_confidence_model', 'model_parameters.yml')) as f:
+        cargs = Namespace(**yaml.full_load(f))
+    t_to_sigma = partial(diffusion_utils.t_to_sigma, args=cargs)
+    cm = get_model(cargs, torch.device('cpu'), t_to_sigma, no_parallel=True, confidence_mode=True)
+    cfg = cr.ConfidenceModelConfig()
+    P = cr.random_state_dict(cfg, seed=31)
+    sd = cm.state_dict()
+    extra = [k for k in sd if k not in P and not k.endswith('num_batches_tracked')]
+    assert not extra, extra
+    cm.load_state_dict({**P, **{k: v for k, v in sd.items() if k.endswith('num_batches_tracked')}}, strict=True)   # pins the key layout
+    cm.eval()
+    n_el = sum(v.numel() for k, v in P.items())
+    print('confidence model state_dict tensors', len(P), 'elements', n_el)
+    c = tiny_complex(13, 36, 12)
+    synthetic.add_receptor_atoms(c, np.random.default_rng(13))
+
+    def graph():
+        g = to_graph(c)
+        return graph_lite.add_atoms(g, c['atom_x'], c['atom_pos'], c['atom_edge_index'], c['atom_rec_index'])
+
+    Bs = 3
+    dl = [graph() for _ in range(Bs)]
+    rng = np.random.default_rng(23)
+    pocket = torch.as_tensor(c['atom_pos'][rng.integers(0, len(c['atom_pos']))]).float()
+    for d_ in dl:      # poses in contact with the receptor atoms so that the ligand-atom graph is not empty
+        p = d_['ligand'].pos
+        d_['ligand'].pos = p - p.mean(0, keepdim=True) + pocket + torch.from_numpy(rng.normal(0, 1.5, size=(1, 3))).float()
+    b = graph_lite.collate(dl)
+    diffusion_utils.set_time(b, 0, 0, 0, Bs, True, torch.device('cpu'))
+    pos_in = b['ligand'].pos.clone()
+    with torch.no_grad():
+        conf = cm(b)
+    conf_o, inter = cr.confidence_forward(P, cfg, b, return_intermediates=True)
+    print('reference vs oracle restatement:', float((conf - conf_o).abs().max()), inter['counts'])
+    save('confidence_paper_model', pos=pos_in, confidence=conf, lig_node_attr=inter['lig_node_attr'], B=Bs, seed=31,
+         n_tensors=len(P), n_elements=n_el, counts=np.asarray([inter['counts'][k] for k in ('ll', 'lr', 'la', 'aa', 'ar', 'rr')]))
+    save('complex_confidence', **{k: v for k, v in c.items() if k != 'name'})
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'confidence':
+        confidence_golden()
+    else:
+        main()
+        confidence_golden()

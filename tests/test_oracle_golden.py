@@ -271,3 +271,27 @@ def test_disco_trajectory_with_ar_and_cfg(golden, tables):
     out, _ = spr.sampling(dl, P, cfg, tables[0], tables[1], steps, sched, sched, sched, batch_size=B, no_final_step_noise=True,
                           classifier_free_guidance_weight=0.7, cfg_start=0.9, cfg_end=0.2, **README_D)
     assert rel_err(torch.cat([d['ligand'].pos for d in out]), z['pos_out']) < 1e-4
+
+
+def test_confidence_model_golden(golden):
+    """the oracle restatement of the all-atom confidence model reproduces the output of the reference's own
+    models/all_atom_score_model.py (confidence_mode, paper_confidence_model yml through get_model) on the same stand-ins."""
+    from oracle import confidence_ref as cr, graph_lite
+    z, c = golden('confidence_paper_model'), complex_from_npz(golden('complex_confidence'))
+    cfg = cr.ConfidenceModelConfig()
+    P = cr.random_state_dict(cfg, seed=int(z['seed']))
+    assert len(P) == int(z['n_tensors']) and sum(v.numel() for v in P.values()) == int(z['n_elements'])
+    B = int(z['B'])
+
+    def graph():
+        return graph_lite.add_atoms(to_graph(c), c['atom_x'], c['atom_pos'], c['atom_edge_index'], c['atom_rec_index'])
+
+    b = graph_lite.collate([graph() for _ in range(B)])
+    b['ligand'].pos = torch.as_tensor(z['pos']).float()
+    for nt in ('ligand', 'receptor', 'atom'):
+        b[nt].node_t = {k: torch.zeros(b[nt].num_nodes) for k in ('tr', 'rot', 'tor')}
+    b.complex_t = {k: torch.zeros(B) for k in ('tr', 'rot', 'tor')}
+    conf, inter = cr.confidence_forward(P, cfg, b, return_intermediates=True)
+    assert [inter['counts'][k] for k in ('ll', 'lr', 'la', 'aa', 'ar', 'rr')] == list(z['counts'])
+    assert rel_err(inter['lig_node_attr'], z['lig_node_attr']) < 1e-5
+    assert rel_err(conf, z['confidence']) < 1e-5

@@ -71,60 +71,128 @@ static inline int hid_of(int s, int hh) { return s < 32 ? 32 * (s / 16) + d_row(
 // input index consumed by GEMM1 step s in lane-half hh
 static inline int kin_of(int s, int hh) { return 24 * (s / 12) + 12 * hh + (s % 12); }
 
-struct Quad { int kind, f_off, row0, jlo, n; };   // tile rows j in [jlo, jlo+n) <-> block rows row0 .. row0+n-1
+struct RowSrc { int wbase; float scale; };           // weight of (row, channel k) = W2[wbase + k] * scale
+struct Part { int kind, f_off, dot_which; std::vector<RowSrc> rows; };   // dot_which >= 0: rows live in the F_PQ layout
 
-static int build_conv_layer(ddk_ctx* ctx, int l, ConvLayerDev& L) {
+// Tile table + weight-row map of one conv layer.  mode 0: FasterTensorProduct (tensor_layers.py:58-63,72-92: blocks 0e,1o,1e,0o,
+// weights [in_,out] row-major, 1/sqrt(in_)); mode 1: e3nn FullyConnectedTensorProduct(in, 0e+1o+2e, out, shared_weights=False)
+// as all_atom_score_model.py:25 builds it: instructions in (in1, sh, out) loop order with 'uvw' weights [mul_in, 1, mul_out],
+// path coefficient sqrt(dim_out / sum of mul_in over the paths into that output irrep), real wigner-3j with Frobenius norm 1
+// (w3j(0,1,1)=w3j(1,0,1)=w3j(1,1,0)=delta/sqrt3, w3j(1,1,1)=eps/sqrt6, w3j(1,2,1).Y2 = sqrt(3/2) (v^ v^T - I/3)).
+static int build_layout(ddk_ctx* ctx, int mode, int l, ConvLayerDev& L, std::vector<int>& rowmap, std::vector<float>& rowscale,
+                        std::vector<TileDesc>& tiles) {
   const ddk_config& c = ctx->cfg;
   const int ns = c.ns, nv = c.nv;
   const int seq[4][4] = {{ns, 0, 0, 0}, {ns, nv, 0, 0}, {ns, nv, nv, 0}, {ns, nv, nv, ns}};
   const int* in = seq[l < 3 ? l : 3];
   const int* out = seq[l + 1 < 3 ? l + 1 : 3];
   for (int b = 0; b < 4; ++b) { L.in_mul[b] = in[b]; L.out_mul[b] = out[b]; }
-  L.n_in[0] = in[0] + in[1];          L.n_out[0] = out[0];
-  L.n_in[1] = in[0] + in[1] + in[2];  L.n_out[1] = out[1];
-  L.n_in[2] = in[1] + in[2] + in[3];  L.n_out[2] = out[2];
-  L.n_in[3] = in[2] + in[3];          L.n_out[3] = out[3];
-  int off = 0;
-  for (int b = 0; b < 4; ++b) { L.blk_off[b] = off; off += L.n_in[b] * L.n_out[b]; }
-  L.W = off;
+  L.n_out[0] = out[0]; L.n_out[1] = out[1]; L.n_out[2] = out[2]; L.n_out[3] = out[3];
   L.din = in[0] + 3 * in[1] + 3 * in[2] + in[3];
   L.dout = out[0] + 3 * out[1] + 3 * out[2] + out[3];
   if (in[2] > 0 && in[1] == 0) return fail(ctx, DDK_ERR_INVALID, "unsupported irreps sequence");
 
-  // row quads of each block in the reference's row order (tensor_layers.py:72-83)
-  std::vector<Quad> quads[4];
-  auto add_rows = [&](int b, int kind, int f_off, int row_start, int rows) {
-    for (int q = 0; 4 * q < rows; ++q)
-      quads[b].push_back({kind, f_off + (kind == T_TV ? 12 * q : 4 * q), row_start + 4 * q, 0, rows - 4 * q < 4 ? rows - 4 * q : 4});
+  std::vector<Part> parts[4];
+  auto rows_of = [](int wbase0, int stride, int n, float scale) {
+    std::vector<RowSrc> r;
+    for (int i = 0; i < n; ++i) r.push_back({wbase0 + i * stride, scale});
+    return r;
   };
-  auto add_dot_rows = [&](int b, int which /*0: p.v, 1: q.v*/, int row_start, int rows) {   // F_PQ = [pv0..3 | qv0..3 | pv4 pv5 qv4 qv5]
-    quads[b].push_back({T_RT, F_PQ + 4 * which, row_start, 0, rows < 4 ? rows : 4});
-    if (rows > 4) quads[b].push_back({T_RT, F_PQ + 8, row_start + 4, 2 * which, rows - 4});
-  };
-  add_rows(0, T_RA, F_A, 0, in[0]);                                        // a * s0
-  if (in[1]) add_dot_rows(0, 0, in[0], in[1]);                             // (p.v)/sqrt3
-  add_rows(1, T_RA, F_A, 0, in[0]);                                        // a (x) v
-  if (in[1] + in[2]) add_rows(1, T_TV, F_T1O, in[0], in[1] + in[2]);       // p*s0 ; (q x v)/sqrt2
-  if (in[1] + in[2]) add_rows(2, T_TV, F_T1E, 0, in[1] + in[2]);           // (p x v)/sqrt2 ; q*s0
-  if (in[3]) add_rows(2, T_RA, F_C, in[1] + in[2], in[3]);                 // c (x) v
-  if (in[2]) add_dot_rows(3, 1, 0, in[2]);                                 // (q.v)/sqrt3
-  if (in[3]) add_rows(3, T_RA, F_C, in[2], in[3]);                         // c * s0
+  auto cat = [](std::vector<RowSrc> a, const std::vector<RowSrc>& b) { a.insert(a.end(), b.begin(), b.end()); return a; };
+  if (mode == 0) {
+    L.n_in[0] = in[0] + in[1];
+    L.n_in[1] = in[0] + in[1] + in[2];
+    L.n_in[2] = in[1] + in[2] + in[3];
+    L.n_in[3] = in[2] + in[3];
+    int off = 0;
+    for (int b = 0; b < 4; ++b) { L.blk_off[b] = off; off += L.n_in[b] * L.n_out[b]; }
+    L.W = off;
+    auto blk = [&](int b, int row0, int n) { return rows_of(L.blk_off[b] + row0 * L.n_out[b], L.n_out[b], n, 1.0f / sqrtf((float)L.n_in[b])); };
+    parts[0].push_back({T_RA, F_A, -1, blk(0, 0, in[0])});                                        // a * s0
+    if (in[1]) parts[0].push_back({T_RT, 0, 0, blk(0, in[0], in[1])});                            // (p.v)/sqrt3
+    parts[1].push_back({T_RA, F_A, -1, blk(1, 0, in[0])});                                        // a (x) v
+    if (in[1] + in[2]) parts[1].push_back({T_TV, F_T1O, -1, blk(1, in[0], in[1] + in[2])});       // p*s0 ; (q x v)/sqrt2
+    if (in[1] + in[2]) parts[2].push_back({T_TV, F_T1E, -1, blk(2, 0, in[1] + in[2])});           // (p x v)/sqrt2 ; q*s0
+    if (in[3]) parts[2].push_back({T_RA, F_C, -1, blk(2, in[1] + in[2], in[3])});                 // c (x) v
+    if (in[2]) parts[3].push_back({T_RT, 0, 1, blk(3, 0, in[2])});                                // (q.v)/sqrt3
+    if (in[3]) parts[3].push_back({T_RA, F_C, -1, blk(3, in[2], in[3])});                         // c * s0
+  } else {
+    // irreps as (l, parity): node 0e,1o,1e,0o ; sh 0e,1o,2e
+    const int nl[4] = {0, 1, 1, 0}, np_[4] = {+1, -1, +1, -1}, sl[3] = {0, 1, 2}, sp[3] = {+1, -1, +1};
+    int inst_off[4][3][4];
+    int fan[4] = {0, 0, 0, 0}, off = 0;
+    for (int i1 = 0; i1 < 4; ++i1)
+      for (int i2 = 0; i2 < 3; ++i2)
+        for (int io = 0; io < 4; ++io) {
+          inst_off[i1][i2][io] = -1;
+          if (!in[i1] || !out[io]) continue;
+          const bool tri = nl[io] >= abs(nl[i1] - sl[i2]) && nl[io] <= nl[i1] + sl[i2];
+          if (!tri || np_[i1] * sp[i2] != np_[io]) continue;
+          inst_off[i1][i2][io] = off;
+          off += in[i1] * out[io];
+          fan[io] += in[i1];
+        }
+    L.W = off;
+    for (int b = 0; b < 4; ++b) { L.n_in[b] = fan[b]; L.blk_off[b] = 0; }
+    const float is3 = 0.57735026918962576451f, kappa = 1.22474487139158904910f;
+    auto coeff = [&](int io) { return sqrtf((float)(2 * nl[io] + 1) / (float)fan[io]); };
+    auto inst = [&](int i1, int i2, int io, float k) { return rows_of(inst_off[i1][i2][io], out[io], in[i1], coeff(io) * k); };
+    if (out[0]) {
+      parts[0].push_back({T_RA, F_A, -1, inst(0, 0, 0, 1.0f)});                                   // 0e x Y0 -> 0e : a*s0
+      if (in[1]) parts[0].push_back({T_RT, 0, 0, inst(1, 1, 0, 1.0f)});                           // 1o x Y1 -> 0e : (p.v)/sqrt3
+    }
+    if (out[1]) {
+      parts[1].push_back({T_RA, F_A, -1, inst(0, 1, 1, is3)});                                    // 0e x Y1 -> 1o : a v / sqrt3
+      if (in[1]) {
+        std::vector<RowSrc> r = inst(1, 0, 1, is3);                                               // 1o x Y0 -> 1o : p*s0 / sqrt3
+        if (in[2]) r = cat(r, inst(2, 1, 1, is3));                                                // 1e x Y1 -> 1o : (q x v)/sqrt6
+        parts[1].push_back({T_TV, F_T1O, -1, r});
+        parts[1].push_back({T_TV, F_T2O, -1, inst(1, 2, 1, kappa)});                              // 1o x Y2 -> 1o
+      }
+    }
+    if (out[2]) {
+      if (in[1]) {
+        std::vector<RowSrc> r = inst(1, 1, 2, is3);                                               // 1o x Y1 -> 1e : (p x v)/sqrt6
+        if (in[2]) r = cat(r, inst(2, 0, 2, is3));                                                // 1e x Y0 -> 1e : q*s0 / sqrt3
+        parts[2].push_back({T_TV, F_T1E, -1, r});
+      }
+      if (in[3]) parts[2].push_back({T_RA, F_C, -1, inst(3, 1, 2, is3)});                         // 0o x Y1 -> 1e : c v / sqrt3
+      if (in[2]) parts[2].push_back({T_TV, F_T2E, -1, inst(2, 2, 2, kappa)});                     // 1e x Y2 -> 1e
+    }
+    if (out[3]) {
+      if (in[2]) parts[3].push_back({T_RT, 0, 1, inst(2, 1, 3, 1.0f)});                           // 1e x Y1 -> 0o : (q.v)/sqrt3
+      if (in[3]) parts[3].push_back({T_RA, F_C, -1, inst(3, 0, 3, 1.0f)});                        // 0o x Y0 -> 0o : c*s0
+    }
+  }
 
   const int oc[4] = {0, out[0], out[0] + 3 * out[1], out[0] + 3 * out[1] + 3 * out[2]};
-  struct TRow { int blk, col, row0, jlo, n; };
-  std::vector<TileDesc> tiles;
+  struct TRow { int blk, col; RowSrc r[4]; bool ok[4]; };
   std::vector<TRow> trows;
+  tiles.clear();
+  L.n_cols = 0;
   for (int b = 0; b < 4; ++b) {
-    if (L.n_in[b] == 0 || L.n_out[b] == 0) continue;
+    if (parts[b].empty() || L.n_out[b] == 0) continue;
     if (L.n_out[b] % 2) return fail(ctx, DDK_ERR_INVALID, "odd output multiplicity unsupported");
     const bool vec = (b == 1 || b == 2);
     for (int col = 0; 8 * col < L.n_out[b]; ++col) {
       if (L.n_cols >= 16) return fail(ctx, DDK_ERR_INVALID, "too many output columns");
       L.col_start[L.n_cols++] = (int)tiles.size();
       const int nch = L.n_out[b] - 8 * col < 8 ? L.n_out[b] - 8 * col : 8;
-      for (const Quad& q : quads[b]) {
-        tiles.push_back(make_tile(q.kind, q.f_off, FL_NONE, nch / 2, oc[b] + (vec ? 3 : 1) * 8 * col));
-        trows.push_back({b, col, q.row0, q.jlo, q.n});
+      for (const Part& p : parts[b]) {
+        const int n = (int)p.rows.size();
+        auto emit = [&](int f_off, int row0, int jlo, int cnt) {
+          tiles.push_back(make_tile(p.kind, f_off, FL_NONE, nch / 2, oc[b] + (vec ? 3 : 1) * 8 * col));
+          TRow t; t.blk = b; t.col = col;
+          for (int j = 0; j < 4; ++j) { t.ok[j] = j >= jlo && j < jlo + cnt; if (t.ok[j]) t.r[j] = p.rows[row0 + j - jlo]; }
+          trows.push_back(t);
+        };
+        if (p.dot_which >= 0) {     // F_PQ = [pv0..3 | qv0..3 | pv4 pv5 qv4 qv5]
+          if (n > 6) return fail(ctx, DDK_ERR_INVALID, "dot-product parts hold at most 6 rows");
+          emit(F_PQ + 4 * p.dot_which, 0, 0, n < 4 ? n : 4);
+          if (n > 4) emit(F_PQ + 8, 4, 2 * p.dot_which, n - 4);
+        } else {
+          for (int q = 0; 4 * q < n; ++q) emit(p.f_off + (p.kind == T_TV ? 12 * q : 4 * q), 4 * q, 0, n - 4 * q < 4 ? n - 4 * q : 4);
+        }
       }
       tiles.back().w0 |= (vec ? FL_V : FL_S) << 2;
     }
@@ -133,42 +201,77 @@ static int build_conv_layer(ddk_ctx* ctx, int l, ConvLayerDev& L) {
   L.col_start[L.n_cols] = L.n_tiles;
   L.h_tiles = tiles;
 
-  // row map: tile row rho = 8*rq + 4*hh + j  ->  row of the reference weight vector (or -1 = zero row)
-  std::vector<int> rowmap((size_t)L.n_tiles * 32, -1);
-  std::vector<float> rowscale((size_t)L.n_tiles * 32, 0.f);
+  // row map: tile row rho = 8*rq + 4*hh + j  ->  index into the reference weight vector (or -1 = zero row) and its scale
+  rowmap.assign((size_t)L.n_tiles * 32, -1);
+  rowscale.assign((size_t)L.n_tiles * 32, 0.f);
   for (int t = 0; t < L.n_tiles; ++t) {
     const TRow& tr = trows[t];
     for (int rq = 0; rq < 4; ++rq)
       for (int hh = 0; hh < 2; ++hh)
-        for (int j = tr.jlo; j < tr.jlo + tr.n; ++j) {
-          const int i = tr.row0 + j - tr.jlo, k = 8 * tr.col + 2 * rq + hh;
-          if (k >= L.n_out[tr.blk]) continue;
-          rowmap[(size_t)t * 32 + 8 * rq + 4 * hh + j] = L.blk_off[tr.blk] + i * L.n_out[tr.blk] + k;
-          rowscale[(size_t)t * 32 + 8 * rq + 4 * hh + j] = 1.0f / sqrtf((float)L.n_in[tr.blk]);   // tensor_layers.py:89-92, folded
+        for (int j = 0; j < 4; ++j) {
+          const int k = 8 * tr.col + 2 * rq + hh;
+          if (!tr.ok[j] || k >= L.n_out[tr.blk]) continue;
+          rowmap[(size_t)t * 32 + 8 * rq + 4 * hh + j] = tr.r[j].wbase + k;
+          rowscale[(size_t)t * 32 + 8 * rq + 4 * hh + j] = tr.r[j].scale;
         }
   }
   // every weight row must be used exactly once
-  {
-    std::vector<int> cnt(L.W, 0);
-    for (int r : rowmap) if (r >= 0) cnt[r]++;
-    for (int r = 0; r < L.W; ++r) if (cnt[r] != 1) return fail(ctx, DDK_ERR_INVALID, "internal: weight row map is not a bijection");
-  }
+  std::vector<int> cnt(L.W, 0);
+  for (int r : rowmap) if (r >= 0) cnt[r]++;
+  for (int r = 0; r < L.W; ++r) if (cnt[r] != 1) return fail(ctx, DDK_ERR_INVALID, "internal: weight row map is not a bijection");
+  return DDK_OK;
+}
 
+// e3nn BatchNorm (eval) folded to per-channel mean / scale / bias over the padded XW columns
+static int fold_batch_norm(ddk_ctx* ctx, const std::string& pre, const int* out, float* mean, float* scale, float* bias) {
+  for (int i = 0; i < XW; ++i) { mean[i] = 0.f; scale[i] = 1.f; bias[i] = 0.f; }
+  const int nf = out[0] + out[1] + out[2] + out[3];
+  const HostTensor* bw = find_w(ctx, pre + ".weight", {nf});
+  const HostTensor* bb = find_w(ctx, pre + ".bias", {out[0]});
+  const HostTensor* bm = find_w(ctx, pre + ".running_mean", {out[0]});
+  const HostTensor* bv = find_w(ctx, pre + ".running_var", {nf});
+  if (!bw || !bb || !bm || !bv) return DDK_ERR_INVALID;
+  int ch = 0, f = 0;
+  const int dims[4] = {1, 3, 3, 1};
+  for (int b = 0; b < 4; ++b)
+    for (int m = 0; m < out[b]; ++m, ++f) {
+      const float sc = powf(bv->data[f] + 1e-5f, -0.5f) * bw->data[f];
+      for (int d = 0; d < dims[b]; ++d, ++ch) {
+        scale[ch] = sc;
+        if (b == 0) { mean[ch] = bm->data[m]; bias[ch] = bb->data[m]; }
+      }
+    }
+  return DDK_OK;
+}
+
+// mode 0: score-model layer l = conv_layers.{l} with 4 edge groups (fc.{g}.{0,4}) and one BatchNorm;
+// mode 1: confidence-model layer l = the 9 convs conv_layers.{9l+g} (fc.{0,3}), each with its own BatchNorm.
+static int build_conv_layer(ddk_ctx* ctx, int mode, int l, ConvLayerDev& L) {
+  const ddk_config& c = ctx->cfg;
+  const int ns = c.ns;
+  std::vector<int> rowmap;
+  std::vector<float> rowscale;
+  std::vector<TileDesc> tiles;
+  int rc = build_layout(ctx, mode, l, L, rowmap, rowscale, tiles);
+  if (rc) return rc;
+  const int NG = mode == 0 ? 4 : 9;
+  L.n_groups = NG;
   const int ne = 3 * ns;
-  const std::string pre = "conv_layers." + std::to_string(l);
-  if (ctx->weights.find(pre + ".fc.0.0.weight") == ctx->weights.end()) {
+  auto fc_name = [&](int g) { return mode == 0 ? "conv_layers." + std::to_string(l) + ".fc." + std::to_string(g) : "conv_layers." + std::to_string(9 * l + g) + ".fc"; };
+  const std::string lin2 = mode == 0 ? ".4" : ".3";
+  if (ctx->weights.find(fc_name(0) + ".0.weight") == ctx->weights.end()) {
     L.has_weights = false;     // shape-only layer: ddk_tp_forward works, ddk_conv_forward refuses
     return DDK_OK;
   }
   L.has_weights = true;
   const size_t w1sz = 3 * 9 * 64 * 4, b1sz = 3 * 2 * 16, w2sz = (size_t)L.n_tiles * 9 * 64 * 4, b2sz = (size_t)L.n_tiles * 32;
-  std::vector<float> w1all(4 * w1sz, 0.f), b1all(4 * b1sz, 0.f), w2all(4 * w2sz, 0.f), b2all(4 * b2sz, 0.f);
-  for (int g = 0; g < 4; ++g) {
-    const std::string f = pre + ".fc." + std::to_string(g);
+  std::vector<float> w1all(NG * w1sz, 0.f), b1all(NG * b1sz, 0.f), w2all(NG * w2sz, 0.f), b2all(NG * b2sz, 0.f);
+  for (int g = 0; g < NG; ++g) {
+    const std::string f = fc_name(g);
     const HostTensor* W1 = find_w(ctx, f + ".0.weight", {ne, ne});
     const HostTensor* B1 = find_w(ctx, f + ".0.bias", {ne});
-    const HostTensor* W2 = find_w(ctx, f + ".4.weight", {L.W, ne});
-    const HostTensor* B2 = find_w(ctx, f + ".4.bias", {L.W});
+    const HostTensor* W2 = find_w(ctx, f + lin2 + ".weight", {L.W, ne});
+    const HostTensor* B2 = find_w(ctx, f + lin2 + ".bias", {L.W});
     if (!W1 || !B1 || !W2 || !B2) return DDK_ERR_INVALID;
     float* w1 = w1all.data() + g * w1sz;
     float* b1 = b1all.data() + g * b1sz;
@@ -200,45 +303,36 @@ static int build_conv_layer(ddk_ctx* ctx, int l, ConvLayerDev& L) {
         }
     }
   }
-  // BatchNorm (e3nn, eval): per multiplicity channel
-  L.h_bn_mean.assign(XW, 0.f);
-  L.h_bn_scale.assign(XW, 1.f);
-  L.h_bn_bias.assign(XW, 0.f);
-  if (c.batch_norm) {
-    const int nf = out[0] + out[1] + out[2] + out[3];
-    const HostTensor* bw = find_w(ctx, pre + ".batch_norm.weight", {nf});
-    const HostTensor* bb = find_w(ctx, pre + ".batch_norm.bias", {out[0]});
-    const HostTensor* bm = find_w(ctx, pre + ".batch_norm.running_mean", {out[0]});
-    const HostTensor* bv = find_w(ctx, pre + ".batch_norm.running_var", {nf});
-    if (!bw || !bb || !bm || !bv) return DDK_ERR_INVALID;
-    int ch = 0, f = 0;
-    const int dims[4] = {1, 3, 3, 1};
-    for (int b = 0; b < 4; ++b)
-      for (int m = 0; m < out[b]; ++m, ++f) {
-        const float sc = powf(bv->data[f] + 1e-5f, -0.5f) * bw->data[f];
-        for (int d = 0; d < dims[b]; ++d, ++ch) {
-          L.h_bn_scale[ch] = sc;
-          if (b == 0) { L.h_bn_mean[ch] = bm->data[m]; L.h_bn_bias[ch] = bb->data[m]; }
-        }
-      }
-  }
-  for (int g = 0; g < 4; ++g) {
+  // BatchNorm (e3nn, eval): per multiplicity channel; one per layer (mode 0) or one per conv (mode 1)
+  const int n_bn = mode == 0 ? 1 : NG;
+  L.h_bn_mean.assign((size_t)n_bn * XW, 0.f);
+  L.h_bn_scale.assign((size_t)n_bn * XW, 1.f);
+  L.h_bn_bias.assign((size_t)n_bn * XW, 0.f);
+  if (c.batch_norm)
+    for (int g = 0; g < n_bn; ++g) {
+      const std::string pre = "conv_layers." + std::to_string(mode == 0 ? l : 9 * l + g) + ".batch_norm";
+      if ((rc = fold_batch_norm(ctx, pre, L.out_mul, L.h_bn_mean.data() + (size_t)g * XW, L.h_bn_scale.data() + (size_t)g * XW,
+                                L.h_bn_bias.data() + (size_t)g * XW)))
+        return rc;
+    }
+  L.h_w1p.resize(NG); L.h_b1p.resize(NG); L.h_w2p.resize(NG); L.h_b2p.resize(NG);
+  for (int g = 0; g < NG; ++g) {
     L.h_w1p[g].assign(w1all.begin() + g * w1sz, w1all.begin() + (g + 1) * w1sz);
     L.h_b1p[g].assign(b1all.begin() + g * b1sz, b1all.begin() + (g + 1) * b1sz);
     L.h_w2p[g].assign(w2all.begin() + g * w2sz, w2all.begin() + (g + 1) * w2sz);
     L.h_b2p[g].assign(b2all.begin() + g * b2sz, b2all.begin() + (g + 1) * b2sz);
   }
   if (!ctx->host_only) {
-    float* d1 = dev_upload(ctx, w1all);
-    float* db1 = dev_upload(ctx, b1all);
-    std::vector<float> w2rec((size_t)4 * L.n_tiles * W2_TILE_FLOATS);
-    for (int g = 0; g < 4; ++g)
+    std::vector<float> w2rec((size_t)NG * L.n_tiles * W2_TILE_FLOATS);
+    for (int g = 0; g < NG; ++g)
       for (int t = 0; t < L.n_tiles; ++t) {
         float* rec = w2rec.data() + ((size_t)g * L.n_tiles + t) * W2_TILE_FLOATS;
         memcpy(rec, w2all.data() + g * w2sz + (size_t)t * 2304, 2304 * sizeof(float));
         memcpy(rec + 2304, b2all.data() + g * b2sz + (size_t)t * 32, 32 * sizeof(float));
         memcpy(rec + 2336, &tiles[t], 2 * sizeof(int32_t));   // descriptor rides with the record (bit pattern)
       }
+    float* d1 = dev_upload(ctx, w1all);
+    float* db1 = dev_upload(ctx, b1all);
     float* d2 = dev_upload(ctx, w2rec);
     L.tiles = (TileDesc*)dev_alloc(ctx, tiles.size() * sizeof(TileDesc));
     L.bn_mean = dev_upload(ctx, L.h_bn_mean);
@@ -248,7 +342,8 @@ static int build_conv_layer(ddk_ctx* ctx, int l, ConvLayerDev& L) {
       return fail(ctx, DDK_ERR_NOMEM, "device allocation failed while packing conv weights");
     if (hipMemcpy(L.tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice) != hipSuccess)
       return fail(ctx, DDK_ERR_HIP, "tile table upload failed");
-    for (int g = 0; g < 4; ++g) {
+    L.w1p[0] = d1; L.b1p[0] = db1; L.w2r[0] = d2;    // group-major contiguous: group g at + g * stride
+    for (int g = 1; g < 4; ++g) {
       L.w1p[g] = d1 + g * w1sz;
       L.b1p[g] = db1 + g * b1sz;
       L.w2r[g] = d2 + (size_t)g * L.n_tiles * W2_TILE_FLOATS;
@@ -331,7 +426,7 @@ int ddk_finalize_weights(ddk_ctx* ctx) {
   ctx->conv.clear();
   ctx->conv.resize(ctx->cfg.num_conv_layers);
   for (int l = 0; l < ctx->cfg.num_conv_layers; ++l) {
-    int rc = build_conv_layer(ctx, l, ctx->conv[l]);
+    int rc = build_conv_layer(ctx, ctx->cfg.all_atoms ? 1 : 0, l, ctx->conv[l]);
     if (rc != DDK_OK) return rc;
   }
   int rc = model_finalize(ctx);
@@ -412,7 +507,7 @@ int64_t ddk_debug_export(ddk_ctx* ctx, const char* what, void* buf, int64_t cap_
   const void* src = nullptr;
   int64_t n = 0;
   if (sscanf(what, "conv.%d.%31[a-z0-9_].%d", &l, item, &g) >= 2) {
-    if (l < 0 || l >= (int)ctx->conv.size() || g < 0 || g > 3) return fail(ctx, DDK_ERR_INVALID, "bad export index");
+    if (l < 0 || l >= (int)ctx->conv.size() || g < 0 || g >= ctx->conv[l].n_groups) return fail(ctx, DDK_ERR_INVALID, "bad export index");
     ConvLayerDev& L = ctx->conv[l];
     const std::string it(item);
     if (it == "w1p") { src = L.h_w1p[g].data(); n = L.h_w1p[g].size(); }
@@ -420,9 +515,9 @@ int64_t ddk_debug_export(ddk_ctx* ctx, const char* what, void* buf, int64_t cap_
     else if (it == "w2p") { src = L.h_w2p[g].data(); n = L.h_w2p[g].size(); }
     else if (it == "b2p") { src = L.h_b2p[g].data(); n = L.h_b2p[g].size(); }
     else if (it == "tiles") { src = L.h_tiles.data(); n = L.h_tiles.size() * (sizeof(TileDesc) / 4); }
-    else if (it == "bn_mean") { src = L.h_bn_mean.data(); n = XW; }
-    else if (it == "bn_scale") { src = L.h_bn_scale.data(); n = XW; }
-    else if (it == "bn_bias") { src = L.h_bn_bias.data(); n = XW; }
+    else if (it == "bn_mean") { src = L.h_bn_mean.data(); n = L.h_bn_mean.size(); }
+    else if (it == "bn_scale") { src = L.h_bn_scale.data(); n = L.h_bn_scale.size(); }
+    else if (it == "bn_bias") { src = L.h_bn_bias.data(); n = L.h_bn_bias.size(); }
     else return fail(ctx, DDK_ERR_INVALID, "unknown export item");
   } else {
     return fail(ctx, DDK_ERR_INVALID, "unknown export name");

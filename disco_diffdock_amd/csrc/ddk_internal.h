@@ -32,14 +32,28 @@ constexpr int F_PQ = F_T1E + 6 * NV;   // [pv0..3 | qv0..3 | pv4 pv5 qv4 qv5]   
 constexpr int F_STRIDE = F_PQ + 12;    // 132 floats: 16-B aligned rows, 16-B slot = row mod 16 -> conflict free for ds_read_b128
 static_assert(F_STRIDE == 132 && NV == 6, "F row layout");
 
-// Workgroup shape of the fused conv kernel: 8 waves (2 per SIMD) x 32 edges, one workgroup per CU; the W2 tile records
-// are fetched once per workgroup into a 2-stage LDS ring.
+// F-row extension of the confidence model's l<=2 tensor product (e3nn FullyConnectedTensorProduct with sh 0e+1o+2e on the
+// same 0e/1o/1e/0o node irreps): the 1o(x)2e->1o and 1e(x)2e->1e paths contract p / q with the symmetric traceless
+// v^ v^T - I/3, i.e. 6 more vector rows per block (two quads, component-major like T1O/T1E).
+constexpr int F_T2O = F_STRIDE;            // 6 rows x xyz (+2 pad rows): v^ (v^.p) - p/3
+constexpr int F_T2E = F_T2O + 24;          // same with q
+constexpr int F_STRIDE2 = F_T2E + 24;      // 180 floats: 16-B slot = 13*row mod 16 -> conflict free
+static_assert(F_STRIDE2 == 180, "F row layout (l<=2)");
+
+// Workgroup shape of the fused conv kernel: 8 waves (2 per SIMD) x 32 edges, one workgroup per CU (6 waves with the wider
+// F rows of the confidence model); the W2 tile records are fetched once per workgroup into a 2-stage LDS ring.
 constexpr int CONV_WAVES = 8;
 constexpr int CONV_BLOCK_EDGES = 32 * CONV_WAVES;
 constexpr int W2_TILE_FLOATS = 9 * 64 * 4 + 32 + 4;   // MFMA fragments [9][64][4] + bias [2][16] + tile descriptor (w0, chan0, 0, 0)
 constexpr int CONV_LDS_FLOATS = CONV_WAVES * 32 * F_STRIDE + 2 * W2_TILE_FLOATS + 16;
 constexpr size_t CONV_LDS_BYTES = (size_t)CONV_LDS_FLOATS * 4;   // 153,952 B of the 160 KiB
 static_assert(CONV_LDS_BYTES <= 160 * 1024, "LDS budget");
+template <int MODE> struct ConvTraits;      // MODE 0: FasterTensorProduct (score model), MODE 1: l<=2 FCTP (confidence model)
+template <> struct ConvTraits<0> { static constexpr int WAVES = CONV_WAVES, FS = F_STRIDE; };
+template <> struct ConvTraits<1> { static constexpr int WAVES = 6, FS = F_STRIDE2; };
+template <int MODE> constexpr size_t conv_lds_bytes() { return (size_t)(ConvTraits<MODE>::WAVES * 32 * ConvTraits<MODE>::FS + 2 * W2_TILE_FLOATS + 16) * 4; }
+static_assert(conv_lds_bytes<1>() <= 160 * 1024, "LDS budget (l<=2)");
+constexpr int CONV_MAX_GROUPS = 9;
 
 // One W2 "tile" = 32 weight rows x 72 hidden units = one burst of 36 v_mfma_f32_32x32x2_f32 per 32 edges.
 // Tile row rho = 8*rq + 4*hh + j (rq = accumulator quad 0..3, hh = lane half, j = 0..3) holds the weight that multiplies
@@ -80,7 +94,9 @@ struct ConvLayerDev {          // device copies for one TensorProductConvLayer w
   float* bn_scale = nullptr;   // [XW]  weight/sqrt(var+eps)   (1 when batch_norm is off)
   float* bn_bias = nullptr;    // [XW]  bias on 0e channels, 0 elsewhere
   // host copies kept for tests (ddk_debug_export)
-  std::vector<float> h_w1p[4], h_b1p[4], h_w2p[4], h_b2p[4], h_bn_mean, h_bn_scale, h_bn_bias;
+  std::vector<std::vector<float>> h_w1p, h_b1p, h_w2p, h_b2p;   // [n_groups]
+  std::vector<float> h_bn_mean, h_bn_scale, h_bn_bias;          // [n_bn][XW]: one BatchNorm per layer (score) or per conv (confidence)
+  int n_groups = 4;
   std::vector<TileDesc> h_tiles;
   // block shapes of the FasterTensorProduct (tensor_layers.py:58-63), order 0e,1o,1e,0o
   int n_in[4] = {}, n_out[4] = {}, blk_off[4] = {};
@@ -148,6 +164,13 @@ struct ConvLaunch {
   int lig_side_only = 0;     // 1: evaluate only groups 0 and 1 (messages into ligand nodes); the last layer's receptor rows are dead
   float* sum_g2 = nullptr;
   int g2_node_off = 0;
+  // general form (confidence model): n_groups edge groups, group g occupies edges [gbeg[g], gend[g]) (device arrays), uses the
+  // g-th radial MLP of the layer and accumulates into sum[(node * n_slots + slot(g)) * XW]; only the first n_active groups run
+  int mode = 0;              // ConvTraits MODE
+  int n_groups = 4, n_active = 4, n_slots = 1;
+  uint32_t slots = 0;        // 2 bits per group
+  const int32_t* gbeg = nullptr;
+  const int32_t* gend = nullptr;
 };
 hipError_t launch_conv_fused(const ConvLayerDev& L, const ConvLaunch& a, int n_cu, hipStream_t s);
 hipError_t launch_conv_setup(int32_t* tile_info, const int64_t* group_offsets_host, hipStream_t s);

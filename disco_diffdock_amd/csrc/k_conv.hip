@@ -55,10 +55,13 @@ struct ConvKArgs {
   int n_tiles;
   int n_cols;         // flush columns; col_start[c] .. col_start[c+1] = tiles of column c
   int col_start[17];
-  int lig_side_only;  // evaluate groups 0,1 only
   int g2_limit;       // >= 0: evaluate only the first g2_limit edges of group 2 (see ConvLaunch)
   float* sum_g2;
   int g2_node_off;
+  int n_groups, n_active, n_slots;   // edge groups [gbeg[g], gend[g]); the first n_active run; sum row = (node*n_slots + slot(g))
+  uint32_t slots;
+  const int32_t* gbeg;
+  const int32_t* gend;
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -159,28 +162,40 @@ __device__ __forceinline__ void lds_frags(float4 (&a)[9], f32x16& B, const float
   }
 }
 
-template <bool GATHER>
-__global__ __launch_bounds__(64 * CONV_WAVES) void conv_fused_kernel(ConvKArgs A) {
+template <bool GATHER, int MODE>
+__global__ __launch_bounds__(64 * ConvTraits<MODE>::WAVES) void conv_fused_kernel(ConvKArgs A) {
+  constexpr int WAVES = ConvTraits<MODE>::WAVES, FS = ConvTraits<MODE>::FS, BLOCK_EDGES = 32 * WAVES;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float* F = lds + wave * (32 * F_STRIDE);                    // this wave's 32 F rows
-  float* ring = lds + CONV_WAVES * (32 * F_STRIDE);           // [2][W2_TILE_FLOATS]
+  float* F = lds + wave * (32 * FS);                          // this wave's 32 F rows
+  float* ring = lds + WAVES * (32 * FS);                      // [2][W2_TILE_FLOATS]
   int* blk_slot = reinterpret_cast<int*>(ring + 2 * W2_TILE_FLOATS);
   const int el = lane & 31;
   const int hh = lane >> 5;
-  const int go0 = A.tile_info[5], go1 = A.tile_info[6], go2 = A.tile_info[7], go3 = A.tile_info[8], go4 = A.tile_info[9];
-  const bool g2_shared = A.g2_limit >= 0;
-  const int g2_end = g2_shared ? go2 + min(A.g2_limit, go3 - go2) : go3;   // shortened group 2 (layer-0 rec-rec de-duplication)
-  // work unit: a block of CONV_BLOCK_EDGES consecutive edges of ONE edge group (its radial-MLP weights are shared by the workgroup)
-  const int bs1 = (go1 - go0 + CONV_BLOCK_EDGES - 1) / CONV_BLOCK_EDGES;
-  const int bs2 = bs1 + (go2 - go1 + CONV_BLOCK_EDGES - 1) / CONV_BLOCK_EDGES;
-  const int bs3 = bs2 + (g2_end - go2 + CONV_BLOCK_EDGES - 1) / CONV_BLOCK_EDGES;
-  const int bs4 = A.lig_side_only ? bs2 : bs3 + (go4 - go3 + CONV_BLOCK_EDGES - 1) / CONV_BLOCK_EDGES;
-  float* Fr = F + el * F_STRIDE;
+  const bool g2_shared = A.g2_limit >= 0;                     // shortened group 2 (layer-0 rec-rec de-duplication)
+  // work unit: a block of BLOCK_EDGES consecutive edges of ONE edge group (its radial-MLP weights are shared by the workgroup)
+  // lane g < n_active keeps group g's edge range and its block range [pbeg, pend) of the work queue; a block index is mapped to
+  // its group with one ballot (no dependent scalar loads per block)
+  int gb_v = 0, ge_v = 0;
+  if (lane < A.n_active) {
+    gb_v = A.gbeg[lane];
+    ge_v = A.gend[lane];
+    if (g2_shared && lane == 2) ge_v = min(ge_v, gb_v + A.g2_limit);
+  }
+  const int nb_v = (ge_v - gb_v + BLOCK_EDGES - 1) / BLOCK_EDGES;
+  int pend_v = nb_v;
+#pragma unroll
+  for (int d = 1; d < 16; d *= 2) {
+    const int t = __shfl_up(pend_v, d, 64);
+    if (lane >= d) pend_v += t;
+  }
+  const int pbeg_v = pend_v - nb_v;
+  const int bs4 = __builtin_amdgcn_readlane(pend_v, 15);
+  float* Fr = F + el * FS;
   const float inv_s3 = 0.57735026918962576451f, inv_s2 = 0.70710678118654752440f;
   const int n_tiles = A.n_tiles;
   constexpr int REC4 = W2_TILE_FLOATS / 4;                    // 584 float4 per tile record
-  const bool second = tid < REC4 - 64 * CONV_WAVES;           // threads that move a second float4 of the record
+  const bool second = tid < REC4 - 64 * WAVES;                 // threads that move a second float4 of the record
 
   // work units: whole blocks, except that the last (bs4 mod #workgroups) blocks are split into column chunks so that the
   // final round of the persistent workgroups is a fraction of a block long (tail of the dynamic queue)
@@ -202,11 +217,10 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_fused_kernel(ConvKArgs A
       t_begin = A.col_start[(c * A.n_cols) / split];
       t_end = A.col_start[((c + 1) * A.n_cols) / split];
     }
-    const int g = (blk >= bs1) + (blk >= bs2) + (blk >= bs3);
-    const int bstart = g == 0 ? 0 : (g == 1 ? bs1 : (g == 2 ? bs2 : bs3));
-    const int gbeg = g == 0 ? go0 : (g == 1 ? go1 : (g == 2 ? go2 : go3));
-    const int gend = g == 0 ? go1 : (g == 1 ? go2 : (g == 2 ? g2_end : go4));
-    const int e0 = gbeg + CONV_BLOCK_EDGES * (blk - bstart) + 32 * wave;
+    const int g = __popcll(__ballot(lane < 16 && blk >= pend_v));
+    const int gbeg = __builtin_amdgcn_readlane(gb_v, g), gend = __builtin_amdgcn_readlane(ge_v, g);
+    const int bstart = __builtin_amdgcn_readlane(pbeg_v, g);
+    const int e0 = gbeg + BLOCK_EDGES * (blk - bstart) + 32 * wave;
     const int nvalid = min(32, gend - e0);                    // <= 0: this wave's slice lies past the end of the group
     const bool valid = el < nvalid;
     const int e = nvalid > 0 ? e0 + min(el, nvalid - 1) : gend - 1;
@@ -221,7 +235,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_fused_kernel(ConvKArgs A
       *reinterpret_cast<float4*>(ring + 4 * tid) = r0;
       *reinterpret_cast<float4*>(ring + W2_TILE_FLOATS + 4 * tid) = r1;
       if (second) {
-        const int q = 4 * (tid + 64 * CONV_WAVES);
+        const int q = 4 * (tid + 64 * WAVES);
         const float4 r2 = ld4(wr0 + q), r3 = ld4(wr1 + q);
         *reinterpret_cast<float4*>(ring + q) = r2;
         *reinterpret_cast<float4*>(ring + W2_TILE_FLOATS + q) = r3;
@@ -330,12 +344,24 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_fused_kernel(ConvKArgs A
         Pc[0] = (py * vz - pz * vy) * inv_s2;
         Pc[4] = (pz * vx - px * vz) * inv_s2;
         Pc[8] = (px * vy - py * vx) * inv_s2;
+        if (MODE == 1) {   // 1o(x)2e->1o / 1e(x)2e->1e: (v^ v^T - I/3) p with v^ = sh[1:4]/sqrt3  (constants folded into the packed weights)
+          const float dv = (px * vx + py * vy + pz * vz) * (1.0f / 3.0f);     // (v^.p) |v| / sqrt3 ... v = sqrt3 v^
+          float* P2 = Fr + (hh ? F_T2E : F_T2O) + 12 * (m >> 2) + (m & 3);
+          P2[0] = dv * vx - px * (1.0f / 3.0f);
+          P2[4] = dv * vy - py * (1.0f / 3.0f);
+          P2[8] = dv * vz - pz * (1.0f / 3.0f);
+        }
+      }
+      if (MODE == 1) {     // pad rows 6,7 of the second quad (their weights are zero; keep them finite)
+        float* P2 = Fr + (hh ? F_T2E : F_T2O) + 12;
+        P2[2] = 0.0f; P2[3] = 0.0f; P2[6] = 0.0f; P2[7] = 0.0f; P2[10] = 0.0f; P2[11] = 0.0f;
       }
     }
     __syncthreads();   // ring stages 0/1 and the F rows are visible
 
     // ---- GEMM2 over the W2 tiles + fused tensor-product epilogue ----
-    float* const node_row = (g2_shared && g == 2) ? A.sum_g2 + (size_t)(sn - A.g2_node_off) * XW : A.sum + (size_t)sn * XW;
+    float* const node_row = (g2_shared && g == 2) ? A.sum_g2 + (size_t)(sn - A.g2_node_off) * XW
+                                                  : A.sum + ((size_t)sn * A.n_slots + ((A.slots >> (2 * g)) & 3)) * XW;
     f32x2 accA[4], accV[4][3];
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) { accA[rq] = 0.0f; accV[rq][0] = 0.0f; accV[rq][1] = 0.0f; accV[rq][2] = 0.0f; }
@@ -372,7 +398,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_fused_kernel(ConvKArgs A
       const float* rec2 = wrec + (size_t)t2 * W2_TILE_FLOATS;                                                  \
       const float4 st0 = ld4(rec2 + 4 * tid);                                                                  \
       float4 st1 = make_float4(0.f, 0.f, 0.f, 0.f);   /* (a copy of st0 here would wait for the load) */     \
-      if (second) st1 = ld4(rec2 + 4 * (tid + 64 * CONV_WAVES));                                               \
+      if (second) st1 = ld4(rec2 + 4 * (tid + 64 * WAVES));                                                    \
       const float* Fp = Fr + (w0 >> 16);                                                                       \
       const f32x4 f0 = ldv4(Fp), f1 = ldv4(Fp + 4), f2 = ldv4(Fp + 8);                                        \
       lds_frags(AN, BN, ring + (((T) + 1 - t_begin) & 1) * W2_TILE_FLOATS, lane, hh);                                    \
@@ -401,7 +427,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_fused_kernel(ConvKArgs A
       }                                                                                                        \
       float* stg = ring + (((T) - t_begin) & 1) * W2_TILE_FLOATS;                                              \
       *reinterpret_cast<float4*>(stg + 4 * tid) = st0;                                                         \
-      if (second) *reinterpret_cast<float4*>(stg + 4 * (tid + 64 * CONV_WAVES)) = st1;                         \
+      if (second) *reinterpret_cast<float4*>(stg + 4 * (tid + 64 * WAVES)) = st1;                              \
       tq.w0 = __builtin_amdgcn_readfirstlane(tqv.x); tq.chan0 = __builtin_amdgcn_readfirstlane(tqv.y);       \
       DDK_TILE_BARRIER                                                                                         \
     }
@@ -470,6 +496,16 @@ __global__ void node_finalize_kernel(const float* sum, const int32_t* deg, const
   out[i] = v;
 }
 
+template <bool GATHER, int MODE>
+static hipError_t launch_conv_t(const ConvKArgs& k, int n_cu, hipStream_t s) {
+  // one persistent workgroup per CU (its F rows + the W2 ring fill the LDS), dynamic block queue
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fused_kernel<GATHER, MODE>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_lds_bytes<MODE>());
+  if (attr != hipSuccess) return attr;
+  hipLaunchKernelGGL((conv_fused_kernel<GATHER, MODE>), dim3(n_cu), dim3(64 * ConvTraits<MODE>::WAVES), conv_lds_bytes<MODE>(), s, k);
+  return hipGetLastError();
+}
+
 hipError_t launch_conv_fused(const ConvLayerDev& L, const ConvLaunch& a, int n_cu, hipStream_t s) {
   ConvKArgs k;
   k.x = a.x; k.src = a.src; k.dst = a.dst; k.edge_attr = a.edge_attr; k.sh = a.sh; k.sum = a.sum;
@@ -477,19 +513,14 @@ hipError_t launch_conv_fused(const ConvLayerDev& L, const ConvLaunch& a, int n_c
   k.w1p = L.w1p[0]; k.b1p = L.b1p[0]; k.w2r = L.w2r[0]; k.tiles = L.tiles; k.n_tiles = L.n_tiles;
   k.n_cols = L.n_cols;
   for (int c = 0; c <= L.n_cols; ++c) k.col_start[c] = L.col_start[c];
-  k.lig_side_only = a.lig_side_only; k.g2_limit = a.g2_limit; k.sum_g2 = a.sum_g2; k.g2_node_off = a.g2_node_off;
-  // one persistent 8-wave workgroup per CU (its F rows + the W2 ring fill the LDS), dynamic block queue
-  static const hipError_t attr = [] {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONV_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONV_LDS_BYTES);
-  }();
-  if (attr != hipSuccess) return attr;
-  if (a.gather)
-    hipLaunchKernelGGL(conv_fused_kernel<true>, dim3(n_cu), dim3(64 * CONV_WAVES), CONV_LDS_BYTES, s, k);
-  else
-    hipLaunchKernelGGL(conv_fused_kernel<false>, dim3(n_cu), dim3(64 * CONV_WAVES), CONV_LDS_BYTES, s, k);
-  return hipGetLastError();
+  k.g2_limit = a.g2_limit; k.sum_g2 = a.sum_g2; k.g2_node_off = a.g2_node_off;
+  if (a.gbeg) {
+    k.n_groups = a.n_groups; k.n_active = a.n_active; k.n_slots = a.n_slots; k.slots = a.slots; k.gbeg = a.gbeg; k.gend = a.gend;
+  } else {   // score model: 4 contiguous groups from the info table (go[g] .. go[g+1]), one accumulator slot
+    k.n_groups = 4; k.n_active = a.lig_side_only ? 2 : 4; k.n_slots = 1; k.slots = 0; k.gbeg = a.tile_info + 5; k.gend = a.tile_info + 6;
+  }
+  if (a.mode == 1) return a.gather ? launch_conv_t<true, 1>(k, n_cu, s) : launch_conv_t<false, 1>(k, n_cu, s);
+  return a.gather ? launch_conv_t<true, 0>(k, n_cu, s) : launch_conv_t<false, 0>(k, n_cu, s);
 }
 
 hipError_t launch_conv_setup(int32_t* tile_info, const int64_t* go, hipStream_t s) {

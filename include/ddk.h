@@ -45,6 +45,10 @@ typedef struct ddk_config {
   int32_t lm_embedding_dim;            /* 1280 when esm_embeddings_path is set, else 0 */
   float tr_sigma_min, tr_sigma_max, rot_sigma_min, rot_sigma_max, tor_sigma_min, tor_sigma_max;
   int32_t device;                      /* HIP device ordinal */
+  /* all-atom confidence model (models/all_atom_score_model.py through get_model(..., confidence_mode=True)): */
+  int32_t all_atoms;                   /* 1: AAScoreModel in confidence_mode (sh_lmax=2 FCTP, OldAtomEncoder, 9 convs/layer) */
+  int32_t num_confidence_outputs;      /* len(rmsd_classification_cutoff)+1 when it is a list, else 1 */
+  int32_t confidence_no_batchnorm;
 } ddk_config;
 
 /* ---- lifetime ---------------------------------------------------------------------------- */

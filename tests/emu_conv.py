@@ -7,6 +7,7 @@ import numpy as np
 
 NS, NV, XW, NE = 24, 6, 84, 72
 F_A, F_C, F_T1O, F_T1E, F_PQ, F_STRIDE = 0, 24, 48, 84, 120, 132
+F_T2O, F_T2E, F_STRIDE2 = 132, 156, 180       # l<=2 tensor product of the confidence model (mode 1)
 OFF_P, OFF_Q, OFF_C = 24, 42, 60
 T_RA, T_RT, T_TV = range(3)
 FL_NONE, FL_S, FL_V = range(3)
@@ -31,14 +32,18 @@ def mfma(a, b, Dl):
     return out
 
 
-def emulate(ctx, layer, x_pad, src, dst, group_offsets, edge_attr, sh):
-    """returns sum[N, XW] (pre-mean) in float64."""
+def emulate(ctx, layer, x_pad, src, dst, group_offsets, edge_attr, sh, mode=0, slots=None):
+    """returns sum[N, n_slots, XW] squeezed to [N, XW] when slots is None (pre-mean) in float64.
+    mode 1: l<=2 FCTP layer of the confidence model (9 groups, extra F parts); slots[g] = accumulator slot of group g."""
     N = x_pad.shape[0]
-    out = np.zeros((N, XW), np.float64)
+    n_groups = len(group_offsets) - 1
+    n_slots = 1 if slots is None else max(slots) + 1
+    out_all = np.zeros((N, n_slots, XW), np.float64)
     tiles = ctx.export(f'conv.{layer}.tiles', np.int32).reshape(-1, 4)
     n_tiles = len(tiles)
     inv_s3, inv_s2 = 1 / np.sqrt(3.0), 1 / np.sqrt(2.0)
-    for g in range(4):
+    for g in range(n_groups):
+        out = out_all[:, 0 if slots is None else slots[g]]
         w1p = ctx.export(f'conv.{layer}.w1p.{g}').reshape(3, 9, 64, 4).astype(np.float64)
         b1p = ctx.export(f'conv.{layer}.b1p.{g}').reshape(3, 2, 16).astype(np.float64)
         w2p = ctx.export(f'conv.{layer}.w2p.{g}').reshape(n_tiles, 9, 64, 4).astype(np.float64)
@@ -62,7 +67,7 @@ def emulate(ctx, layer, x_pad, src, dst, group_offsets, edge_attr, sh):
                 else:
                     h[:, 32:36] = np.maximum(D[:, :4], 0)
             # F rows (per edge; both halves see the same row)
-            F = np.zeros((32, F_STRIDE))
+            F = np.zeros((32, F_STRIDE2 if mode == 1 else F_STRIDE))
             for i in range(32):
                 ee = e[i]
                 xr = x_pad[dst[ee]]
@@ -80,6 +85,13 @@ def emulate(ctx, layer, x_pad, src, dst, group_offsets, edge_attr, sh):
                     for c in range(3):
                         F[i, F_T1O + 12 * (r // 4) + 4 * c + r % 4] = t1o[r, c]
                         F[i, F_T1E + 12 * (r // 4) + 4 * c + r % 4] = t1e[r, c]
+                if mode == 1:      # (v^ v^T - I/3) p with v^ = sh[1:4]/sqrt3
+                    vh = v / np.sqrt(3.0)
+                    for base, blk in ((F_T2O, p), (F_T2E, q)):
+                        t2 = vh[None] * (blk @ vh)[:, None] - blk / 3.0
+                        for r in range(NV):
+                            for c in range(3):
+                                F[i, base + 12 * (r // 4) + 4 * c + r % 4] = t2[r, c]
             s0l, vl = sh[e, 0], sh[e, 1:4]
             accA = np.zeros((64, 4))
             accV = np.zeros((64, 4, 3))
@@ -111,7 +123,7 @@ def emulate(ctx, layer, x_pad, src, dst, group_offsets, edge_attr, sh):
                                 np.add.at(out, (sn[valid], chan[valid] + c), (accA[:, rq] * vl[:, c] + accV[:, rq, c])[valid])
                     accA[:] = 0
                     accV[:] = 0
-    return out
+    return out_all[:, 0] if slots is None else out_all
 
 
 def finalize(ctx, layer, summed, deg, x_pad, dout, with_bn=True):

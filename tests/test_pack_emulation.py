@@ -83,3 +83,38 @@ def test_packing_by_lane_emulation(built, golden, l):
     deg = np.bincount(src, minlength=N)
     out = emu_conv.finalize(ctx, l, summed, deg, x_pad, z['out'].shape[1])
     assert rel_err(out, z['out']) < 5e-6
+
+
+@pytest.mark.parametrize('l', range(5))
+def test_confidence_layer_packing_by_lane_emulation(built, l):
+    """l<=2 e3nn FullyConnectedTensorProduct layers of the confidence model: packed weights (instruction
+    offsets, path coefficients, wigner constants, extra 1x2->1 rows) -> emulated wave algorithm == oracle conv layer."""
+    from disco_diffdock_amd.runtime import Context
+    from oracle import confidence_ref as cr
+    import emu_conv
+    cfg = cr.ConfidenceModelConfig()
+    P = {k: v for k, v in cr.random_state_dict(cfg, seed=40 + l).items() if k.startswith('conv_layers.')}
+    ctx = Context(device=-1, all_atoms=1, embedding_scale=10000.0, num_confidence_outputs=2)
+    ctx.load_state_dict(P)
+    i_irr, o_irr = cfg.conv_irreps(l)
+    din, dout = smr.irreps_dim(i_irr), smr.irreps_dim(o_irr)
+    g = torch.Generator().manual_seed(l)
+    N, per = 12, 7
+    from oracle import e3nn_lite as o3
+    offs = [per * k for k in range(10)]
+    E = offs[-1]
+    node = torch.randn(N, din, generator=g)
+    ei = torch.randint(0, N, (2, E), generator=g)
+    ea = torch.randn(E, 72, generator=g)
+    vec = torch.randn(E, 3, generator=g)
+    sh9 = o3.spherical_harmonics(cfg.sh_irreps, vec, normalize=True, normalization='component')
+    x_pad = np.zeros((N, 84)); x_pad[:, :din] = node.numpy()
+    summed = emu_conv.emulate(ctx, l, x_pad, ei[0].numpy(), ei[1].numpy(), offs, ea.numpy().astype(np.float64),
+                              sh9[:, :4].numpy().astype(np.float64), mode=1, slots=list(range(9)))     # one accumulator slot per conv
+    bn_mean, bn_scale, bn_bias = (ctx.export(f'conv.{l}.bn_{k}').reshape(9, 84) for k in ('mean', 'scale', 'bias'))
+    for k in range(9):
+        sl = slice(offs[k], offs[k + 1])
+        want = cr.conv_layer(P, f'conv_layers.{9 * l + k}', cfg, l, node, ei[:, sl], ea[sl], sh9[sl], out_nodes=N).numpy()
+        deg = np.bincount(ei[0, sl].numpy(), minlength=N)
+        got = (summed[:, k] / np.maximum(deg, 1)[:, None] - bn_mean[k]) * bn_scale[k] + bn_bias[k]
+        assert rel_err(got[:, :dout], want) < 5e-6, (l, k)

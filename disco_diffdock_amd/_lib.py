@@ -28,6 +28,11 @@ class ddk_complex_desc(C.Structure):
                 ('mask_rotate', C.c_void_p), ('rec_x', C.c_void_p), ('rec_pos', C.c_void_p), ('rec_edge_index', C.c_void_p)]
 
 
+class ddk_atoms_desc(C.Structure):
+    _fields_ = [('n_atom', C.c_int32), ('n_atom_edges', C.c_int32), ('atom_x', C.c_void_p), ('atom_pos', C.c_void_p),
+                ('atom_edge_index', C.c_void_p), ('atom_rec_index', C.c_void_p)]
+
+
 _lib = None
 
 # every symbol include/ddk.h declares (tests check that the library exports all of them)
@@ -35,7 +40,8 @@ SYMBOLS = ['ddk_create', 'ddk_destroy', 'ddk_last_error', 'ddk_version', 'ddk_lo
            'ddk_set_score_norm_tables', 'ddk_tp_forward', 'ddk_conv_forward', 'ddk_complex_create', 'ddk_complex_destroy',
            'ddk_score_forward', 'ddk_se3_update', 'ddk_sample', 'ddk_last_graph_stats', 'ddk_last_node_features',
            'ddk_profile_enable', 'ddk_profile_read', 'ddk_set_latents', 'ddk_set_guidance',
-           'ddk_set_keep_receptor_features', 'ddk_randomize_position']
+           'ddk_set_keep_receptor_features', 'ddk_randomize_position', 'ddk_complex_set_atoms',
+           'ddk_confidence_forward']
 
 
 def lib():
@@ -64,6 +70,8 @@ def lib():
     L.ddk_score_forward.argtypes = [vp, vp, i32, vp, f32, f32, f32, vp, vp, vp, vp]
     L.ddk_se3_update.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp]
     L.ddk_randomize_position.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp]
+    L.ddk_complex_set_atoms.argtypes = [vp, vp, vp, vp, vp, i32]
+    L.ddk_confidence_forward.argtypes = [vp, vp, i32, vp, vp, vp]
     L.ddk_sample.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]
     L.ddk_last_graph_stats.argtypes = [vp, vp, vp, vp]
     L.ddk_last_node_features.argtypes = [vp, vp, i32, vp, vp, vp]
@@ -83,3 +91,6 @@ def _declare_debug(L):
     import ctypes as C
     L.ddk_debug_read_edges.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_int64]
+    L.ddk_debug_conf_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ddk_debug_conf_nodes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    L.ddk_debug_conf_edges.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -1,0 +1,693 @@
+// All-atom confidence model: models/all_atom_score_model.py in confidence_mode as get_model builds it
+// from workdir/paper_confidence_model/model_parameters.yml (utils/model_utils.py:25-68): three node types (ligand atoms,
+// receptor atoms, residues), nine tensor-product convolutions per layer with the l<=2 e3nn FullyConnectedTensorProduct,
+// OldAtomEncoder node embeddings, BatchNorm per conv, scatter-mean pooled ligand scalars -> confidence_predictor MLP.
+//
+// The forward always runs at t = 0 (utils/sampling.py:236 set_time(..., 0, 0, 0); in confidence_mode complex_t is used as sigma
+// directly, all_atom_score_model.py:205-207), so every sigma-embedding product is a constant of the model and everything that
+// does not depend on the ligand pose is a constant of the complex:
+//   * host, once per model:   sigma-embedding halves of all first layers, folded BatchNorm1d of the predictor;
+//   * host, once per complex: the three node embeddings, and edge embedding + spherical harmonics of the static edge sets
+//                             (atom-atom, atom->residue and its flip), replicated for max_batch samples;
+//   * device, per forward:    ligand radius graph + bonds, ligand-residue edges (cutoff 3*0+20 A) and their flip, receptor edges
+//                             (the score model's graph / edge-feature kernels with this model's weights), ligand-atom edges
+//                             within 5 A and their flip (conf_la_kernel), then num_conv_layers launches of the fused conv
+//                             kernel in its l<=2 mode over the nine edge groups
+//                                 [ll | lr | la | aa | al | ar | rr | rl | ra]  =  conv_layers.{9l + 0..8}
+//                             with three accumulator slots per node (one per conv feeding that node type), conf_finalize
+//                             (mean, BatchNorm of each conv, sum, residual) and the pooled head.
+// Node numbering: [ligand b*n_lig+i | atom Bm*n_lig + b*n_atom + a | residue Bm*(n_lig+n_atom) + b*n_rec + r] with
+// Bm = max_batch, so the replicated static edge sets are valid for every B <= Bm.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "model.h"
+
+namespace ddk {
+
+static const int LIG_DIMS_C[16] = {119, 4, 12, 12, 8, 10, 6, 6, 2, 8, 2, 2, 2, 2, 2, 2};   // process_mols.py:62-79
+static const int ATOM_DIMS_C[4] = {38, 119, 23, 38};                                        // process_mols.py:81-86
+static const int REC_DIM_C = 38;
+constexpr int CONF_MAX_OUT = 8;
+
+struct HostMlp {   // Linear(in, NS) -> ReLU -> Linear(NS, NS) with the sigma-embedding columns folded into the first bias
+  std::vector<float> w1d, w1b, b1s, w2, b2;   // [NS][DE], [NS][4] or empty, [NS], [NS][NS], [NS]
+  std::vector<float> offset; float coeff = 0.f;
+};
+
+struct ConfModel {
+  EdgeMlpDev lig_edge, rec_edge, lr_edge, la_edge;   // device copies for the dynamic edge sets
+  StepParams sp;                                     // t = 0 constants in the layout the shared edge-feature kernel expects
+  float la_sigb[NS];
+  HostMlp h_rec, h_atom, h_ar;                       // host copies for the per-complex static precompute
+  // OldAtomEncoder pieces (host)
+  std::vector<float> lig_tables, atom_tables, rec_table;
+  std::vector<int> lig_off, atom_off;
+  std::vector<float> lig_const, atom_const;          // linear(sigma_emb(0)) + bias  [NS]
+  std::vector<float> rec_lin_w, rec_lin_b;           // linear over ESM[:32]
+  std::vector<float> rec_lm_w, rec_lm_b;             // lm_embedding_layer [NS][lm + NS]
+  float emb0[SIG];
+  // confidence_predictor (device): W0 [NS][2NS], affine0 [NS] x2, W4 [NS][NS], affine4, W8 [n_out][NS], b8
+  float *w0 = nullptr, *s0 = nullptr, *t0 = nullptr, *w4 = nullptr, *s4 = nullptr, *t4 = nullptr, *w8 = nullptr, *b8 = nullptr;
+  int n_out = 1;
+  bool ready = false;
+};
+
+struct ConfComplex {
+  int n_atom = 0, E_aa = 0;
+  float* atom_pos = nullptr;
+  float *lig_x0 = nullptr, *atom_x0 = nullptr, *rec_x0 = nullptr;   // [n, NS]
+  int64_t cap4 = 0, cap_la = 0, cap_total = 0, off_la = 0, off_al = 0, off_aa = 0, off_ar = 0, off_ra = 0;
+  int32_t *e_src = nullptr, *e_dst = nullptr, *e_aux = nullptr;
+  float *e_emb = nullptr, *e_sh = nullptr;
+  int32_t* gtab = nullptr;     // [0..8] gbeg, [9..17] gend, [18] la counter, [19] overflow flag
+  int32_t* deg_scratch = nullptr;
+  float *xa = nullptr, *xb = nullptr, *sum3 = nullptr;
+  int32_t* deg3 = nullptr;
+  int64_t n_nodes = 0;         // Bm * (n_lig + n_atom + n_rec)
+};
+
+static const HostTensor* getw(ddk_ctx* ctx, const std::string& name, std::initializer_list<int64_t> shape) {
+  auto it = ctx->weights.find(name);
+  if (it == ctx->weights.end()) { ctx->err = "missing state_dict key: " + name; return nullptr; }
+  if (it->second.shape != std::vector<int64_t>(shape)) { ctx->err = "shape mismatch for " + name; return nullptr; }
+  return &it->second;
+}
+static std::vector<float> colsc(const HostTensor* t, int c0, int c1) {
+  const int rows = (int)t->shape[0], nc = (int)t->shape[1];
+  std::vector<float> o((size_t)rows * (c1 - c0));
+  for (int r = 0; r < rows; ++r)
+    for (int c = c0; c < c1; ++c) o[(size_t)r * (c1 - c0) + (c - c0)] = t->data[(size_t)r * nc + c];
+  return o;
+}
+
+// [bond(n_bond) | sigma(32) | dist(32)] -> NS first layer; sigma part folded with emb0 into the bias
+static bool load_mlp(ddk_ctx* ctx, const char* name, int n_bond, const char* expansion, float stop, const float* emb0, HostMlp& h,
+                     EdgeMlpDev* dev) {
+  const HostTensor* w0 = getw(ctx, std::string(name) + ".0.weight", {NS, n_bond + SIG + DE});
+  const HostTensor* b0 = getw(ctx, std::string(name) + ".0.bias", {NS});
+  const HostTensor* w3 = getw(ctx, std::string(name) + ".3.weight", {NS, NS});
+  const HostTensor* b3 = getw(ctx, std::string(name) + ".3.bias", {NS});
+  if (!w0 || !b0 || !w3 || !b3) return false;
+  h.w1b = n_bond ? colsc(w0, 0, n_bond) : std::vector<float>();
+  h.w1d = colsc(w0, n_bond + SIG, n_bond + SIG + DE);
+  const std::vector<float> ws = colsc(w0, n_bond, n_bond + SIG);
+  h.b1s.assign(NS, 0.f);
+  for (int o = 0; o < NS; ++o) {
+    float a = b0->data[o];
+    for (int k = 0; k < SIG; ++k) a += ws[(size_t)o * SIG + k] * emb0[k];
+    h.b1s[o] = a;
+  }
+  h.w2 = w3->data; h.b2 = b3->data;
+  h.offset.resize(DE);
+  auto it = ctx->weights.find(std::string(expansion) + "_distance_expansion.offset");
+  if (it != ctx->weights.end() && it->second.data.size() == (size_t)DE) h.offset = it->second.data;
+  else for (int k = 0; k < DE; ++k) h.offset[k] = stop * (float)k / (float)(DE - 1);
+  const double d = (double)(h.offset[1] - h.offset[0]);
+  h.coeff = (float)(-0.5 / (d * d));
+  if (dev) {
+    dev->w1d = dev_upload(ctx, h.w1d);
+    dev->w1b = n_bond ? dev_upload(ctx, h.w1b) : nullptr;
+    dev->w2 = dev_upload(ctx, h.w2);
+    dev->b2 = dev_upload(ctx, h.b2);
+    dev->w1l = nullptr; dev->unc = nullptr;
+    dev->coeff = h.coeff; dev->step = h.offset[1] - h.offset[0];
+    dev->offset = dev_upload(ctx, h.offset);
+    if (!dev->w1d || !dev->w2 || !dev->b2 || !dev->offset) return false;
+  }
+  return true;
+}
+
+// host evaluation of an edge MLP on one edge vector (static edge sets): emb[NS], sh[4]
+static void host_edge(const HostMlp& m, float vx, float vy, float vz, float* emb, float* sh) {
+  const float d = sqrtf(vx * vx + vy * vy + vz * vz);
+  const float inv = 1.7320508075688772f / fmaxf(d, 1e-12f);
+  sh[0] = 1.0f; sh[1] = vx * inv; sh[2] = vy * inv; sh[3] = vz * inv;
+  float gs[DE], h[NS];
+  for (int k = 0; k < DE; ++k) { const float t = d - m.offset[k]; gs[k] = expf(m.coeff * (t * t)); }
+  for (int o = 0; o < NS; ++o) {
+    float a = m.b1s[o];
+    for (int k = 0; k < DE; ++k) a += m.w1d[(size_t)o * DE + k] * gs[k];
+    h[o] = fmaxf(a, 0.0f);
+  }
+  for (int o = 0; o < NS; ++o) {
+    float a = m.b2[o];
+    for (int k = 0; k < NS; ++k) a += m.w2[(size_t)o * NS + k] * h[k];
+    emb[o] = a;
+  }
+}
+
+int conf_model_finalize(ddk_ctx* ctx) {
+  conf_model_destroy(ctx);
+  if (ctx->host_only || ctx->weights.find("lig_node_embedding.linear.weight") == ctx->weights.end()) return DDK_OK;
+  const ddk_config& c = ctx->cfg;
+  if (c.num_confidence_outputs < 1 || c.num_confidence_outputs > CONF_MAX_OUT) return fail(ctx, DDK_ERR_INVALID, "num_confidence_outputs out of range");
+  if (c.num_conv_layers < 3) return fail(ctx, DDK_ERR_INVALID, "confidence model: num_conv_layers >= 3 is implemented (2*ns pooled scalars)");
+  ConfModel* M = new ConfModel();
+  ctx->conf_model = M;
+  const int lm = c.lm_embedding_dim;
+#define GET(var, name, ...) const HostTensor* var = getw(ctx, name, {__VA_ARGS__}); if (!var) return DDK_ERR_INVALID
+  // sinusoidal_embedding(embedding_scale * 0, 32) = [sin 0 ... | cos 0 ...]
+  for (int k = 0; k < SIG / 2; ++k) { M->emb0[k] = 0.0f; M->emb0[SIG / 2 + k] = 1.0f; }
+  // ---- OldAtomEncoder (models/layers.py:81-116) -------------------------------------------------
+  int off = 0;
+  for (int i = 0; i < 16; ++i) {
+    GET(t, "lig_node_embedding.atom_embedding_list." + std::to_string(i) + ".weight", LIG_DIMS_C[i], NS);
+    M->lig_off.push_back(off); M->lig_tables.insert(M->lig_tables.end(), t->data.begin(), t->data.end()); off += LIG_DIMS_C[i];
+  }
+  off = 0;
+  for (int i = 0; i < 4; ++i) {
+    GET(t, "atom_node_embedding.atom_embedding_list." + std::to_string(i) + ".weight", ATOM_DIMS_C[i], NS);
+    M->atom_off.push_back(off); M->atom_tables.insert(M->atom_tables.end(), t->data.begin(), t->data.end()); off += ATOM_DIMS_C[i];
+  }
+  auto lin_const = [&](const char* pre, std::vector<float>& out) -> bool {   // linear(sigma_emb(0)) + bias
+    const HostTensor* w = getw(ctx, std::string(pre) + ".linear.weight", {NS, SIG});
+    const HostTensor* b = getw(ctx, std::string(pre) + ".linear.bias", {NS});
+    if (!w || !b) return false;
+    out.assign(NS, 0.f);
+    for (int o = 0; o < NS; ++o) {
+      float a = b->data[o];
+      for (int k = 0; k < SIG; ++k) a += w->data[(size_t)o * SIG + k] * M->emb0[k];
+      out[o] = a;
+    }
+    return true;
+  };
+  if (!lin_const("lig_node_embedding", M->lig_const) || !lin_const("atom_node_embedding", M->atom_const)) return DDK_ERR_INVALID;
+  {
+    GET(rt, "rec_node_embedding.atom_embedding_list.0.weight", REC_DIM_C, NS);
+    GET(rw, "rec_node_embedding.linear.weight", NS, SIG);
+    GET(rb, "rec_node_embedding.linear.bias", NS);
+    M->rec_table = rt->data; M->rec_lin_w = rw->data; M->rec_lin_b = rb->data;
+    if (lm > 0) {
+      if (lm < SIG) return fail(ctx, DDK_ERR_INVALID, "lm_embedding_dim < sigma_embed_dim");
+      GET(lw, "rec_node_embedding.lm_embedding_layer.weight", NS, lm + NS);
+      GET(lb, "rec_node_embedding.lm_embedding_layer.bias", NS);
+      M->rec_lm_w = lw->data; M->rec_lm_b = lb->data;
+    }
+  }
+  // ---- edge embedding MLPs ----------------------------------------------------------------------
+  HostMlp tmp;
+  if (!load_mlp(ctx, "lig_edge_embedding", 4, "lig", c.lig_max_radius, M->emb0, tmp, &M->lig_edge)) return DDK_ERR_INVALID;
+  memcpy(M->sp.lig_edge_sigb, tmp.b1s.data(), NS * sizeof(float));
+  if (!load_mlp(ctx, "rec_edge_embedding", 0, "rec", c.rec_max_radius, M->emb0, M->h_rec, &M->rec_edge)) return DDK_ERR_INVALID;
+  memcpy(M->sp.rec_edge_sigb, M->h_rec.b1s.data(), NS * sizeof(float));
+  if (!load_mlp(ctx, "lr_edge_embedding", 0, "cross", c.cross_max_distance, M->emb0, tmp, &M->lr_edge)) return DDK_ERR_INVALID;
+  memcpy(M->sp.cross_edge_sigb, tmp.b1s.data(), NS * sizeof(float));
+  if (!load_mlp(ctx, "la_edge_embedding", 0, "cross", c.cross_max_distance, M->emb0, tmp, &M->la_edge)) return DDK_ERR_INVALID;
+  memcpy(M->la_sigb, tmp.b1s.data(), NS * sizeof(float));
+  if (!load_mlp(ctx, "atom_edge_embedding", 0, "lig", c.lig_max_radius, M->emb0, M->h_atom, nullptr)) return DDK_ERR_INVALID;   // :382 lig expansion
+  if (!load_mlp(ctx, "ar_edge_embedding", 0, "rec", c.rec_max_radius, M->emb0, M->h_ar, nullptr)) return DDK_ERR_INVALID;
+  M->sp.tr_sigma = 0.0f; M->sp.rot_sigma = 0.0f; M->sp.tor_sigma = 0.0f;
+  M->sp.cross_cutoff = c.dynamic_max_cross ? 20.0f : c.cross_max_distance;       // 3 * complex_t['tr'] + 20 with complex_t = 0
+  // ---- confidence_predictor: Linear, BN1d, ReLU, Dropout, Linear, BN1d, ReLU, Dropout, Linear (:143-153) ----
+  {
+    M->n_out = c.num_confidence_outputs;
+    GET(w0, "confidence_predictor.0.weight", NS, 2 * NS);
+    GET(b0, "confidence_predictor.0.bias", NS);
+    GET(w4, "confidence_predictor.4.weight", NS, NS);
+    GET(b4, "confidence_predictor.4.bias", NS);
+    GET(w8, "confidence_predictor.8.weight", M->n_out, NS);
+    GET(b8, "confidence_predictor.8.bias", M->n_out);
+    auto affine = [&](int idx, const HostTensor* lin_b, std::vector<float>& s, std::vector<float>& t) -> bool {
+      s.assign(NS, 1.f); t = lin_b->data;     // y = s * (W x) + t
+      if (c.confidence_no_batchnorm) return true;
+      const std::string p = "confidence_predictor." + std::to_string(idx);
+      const HostTensor *g = getw(ctx, p + ".weight", {NS}), *be = getw(ctx, p + ".bias", {NS}), *mu = getw(ctx, p + ".running_mean", {NS}),
+                       *var = getw(ctx, p + ".running_var", {NS});
+      if (!g || !be || !mu || !var) return false;
+      for (int o = 0; o < NS; ++o) {
+        s[o] = g->data[o] / sqrtf(var->data[o] + 1e-5f);
+        t[o] = (lin_b->data[o] - mu->data[o]) * s[o] + be->data[o];
+      }
+      return true;
+    };
+    std::vector<float> s0, t0, s4, t4;
+    if (!affine(1, b0, s0, t0) || !affine(5, b4, s4, t4)) return DDK_ERR_INVALID;
+    M->w0 = dev_upload(ctx, w0->data); M->s0 = dev_upload(ctx, s0); M->t0 = dev_upload(ctx, t0);
+    M->w4 = dev_upload(ctx, w4->data); M->s4 = dev_upload(ctx, s4); M->t4 = dev_upload(ctx, t4);
+    M->w8 = dev_upload(ctx, w8->data); M->b8 = dev_upload(ctx, b8->data);
+    if (!M->w0 || !M->s0 || !M->t0 || !M->w4 || !M->s4 || !M->t4 || !M->w8 || !M->b8) return fail(ctx, DDK_ERR_NOMEM, "alloc");
+  }
+#undef GET
+  for (int l = 0; l < c.num_conv_layers; ++l)
+    if (!ctx->conv[l].has_weights) return fail(ctx, DDK_ERR_INVALID, "confidence checkpoint lacks conv_layers." + std::to_string(9 * l));
+  M->ready = true;
+  return DDK_OK;
+}
+
+void conf_model_destroy(ddk_ctx* ctx) {
+  if (ctx->conf_model) { delete (ConfModel*)ctx->conf_model; ctx->conf_model = nullptr; }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------------------------
+struct LaArgs {
+  const float* lig_pos;    // [B, n_lig, 3]
+  const float* atom_pos;   // [n_atom, 3]
+  int B, n_lig, n_atom, atom_node_base;
+  float r2;
+  EdgeMlpDev mlp;
+  float sigb[NS];
+  int32_t* gtab;           // [18] counter, [19] overflow
+  int64_t off_la, off_al, cap;
+  int32_t *e_src, *e_dst;
+  float *e_emb, *e_sh;
+};
+
+// ligand-atom edges: radius(atom.pos, lig.pos, lig_max_radius) (all_atom_score_model.py:413-420) -> group la (src ligand atom,
+// dst receptor atom) and its flip al (src receptor atom, dst ligand atom) with the SAME edge embedding and spherical harmonics
+// (vector atom - ligand for both, :232-238); one wave per ligand atom, the wave reserves a contiguous range of the group.
+__global__ __launch_bounds__(256) void conf_la_kernel(LaArgs A) {
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = wave; i < A.n_lig; i += 4) {
+    const float* lp = A.lig_pos + ((size_t)b * A.n_lig + i) * 3;
+    const float lx = lp[0], ly = lp[1], lz = lp[2];
+    for (int j0 = 0; j0 < A.n_atom; j0 += 64) {
+      const int j = j0 + lane;
+      float vx = 0.f, vy = 0.f, vz = 0.f;
+      bool in = false;
+      if (j < A.n_atom) {
+        vx = A.atom_pos[3 * j] - lx; vy = A.atom_pos[3 * j + 1] - ly; vz = A.atom_pos[3 * j + 2] - lz;
+        in = vx * vx + vy * vy + vz * vz < A.r2;
+      }
+      const unsigned long long mask = __ballot(in);
+      if (mask == 0ull) continue;
+      int base = 0;
+      if (lane == 0) base = atomicAdd(A.gtab + 18, __popcll(mask));
+      base = __shfl(base, 0, 64);
+      if (!in) continue;
+      const int64_t p = base + __popcll(mask & ((1ull << lane) - 1ull));
+      if (p >= A.cap) { A.gtab[19] = 1; continue; }
+      const float d = sqrtf(vx * vx + vy * vy + vz * vz);
+      const float inv = 1.7320508075688772f / fmaxf(d, 1e-12f);
+      const float4 shv = make_float4(1.0f, vx * inv, vy * inv, vz * inv);
+      float gs[DE], h[NS];
+#pragma unroll
+      for (int k = 0; k < DE; ++k) { const float t = d - A.mlp.offset[k]; gs[k] = expf(A.mlp.coeff * (t * t)); }
+#pragma unroll 1
+      for (int o = 0; o < NS; ++o) {
+        float a = A.sigb[o];
+#pragma unroll
+        for (int k = 0; k < DE; ++k) a += A.mlp.w1d[o * DE + k] * gs[k];
+        h[o] = fmaxf(a, 0.0f);
+      }
+      const int ln = b * A.n_lig + i, an = A.atom_node_base + b * A.n_atom + j;
+      const int64_t e1 = A.off_la + p, e2 = A.off_al + p;
+      A.e_src[e1] = ln; A.e_dst[e1] = an;
+      A.e_src[e2] = an; A.e_dst[e2] = ln;
+      *reinterpret_cast<float4*>(A.e_sh + 4 * e1) = shv;
+      *reinterpret_cast<float4*>(A.e_sh + 4 * e2) = shv;
+#pragma unroll 1
+      for (int o = 0; o < NS; ++o) {
+        float a = A.mlp.b2[o];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) a += A.mlp.w2[o * NS + k] * h[k];
+        A.e_emb[e1 * NS + o] = a;
+        A.e_emb[e2 * NS + o] = a;
+      }
+    }
+  }
+}
+
+// group table of one forward: [0..8] gbeg, [9..17] gend for [ll lr la aa al ar rr rl ra] from the shared graph kernel's info
+// table (go[0..4] of its [ll | lr | rr | rl] list), the la counter and the static set sizes
+__global__ void conf_gtab_kernel(int32_t* gtab, const int32_t* info, int B, int E_aa, int n_atom, int off_la, int off_al, int off_aa,
+                                 int off_ar, int off_ra, int cap_la, int mask) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int go0 = info[5], go1 = info[6], go2 = info[7], go3 = info[8], go4 = info[9];
+  const int n_la = min(gtab[18], cap_la);
+  const int beg[9] = {go0, go1, off_la, off_aa, off_al, off_ar, go2, go3, off_ra};
+  const int end[9] = {go1, go2, off_la + n_la, off_aa + B * E_aa, off_al + n_la, off_ar + B * n_atom, go3, go4, off_ra + B * n_atom};
+  for (int g = 0; g < 9; ++g) { gtab[g] = beg[g]; gtab[9 + g] = ((mask >> g) & 1) ? end[g] : beg[g]; }
+}
+
+// in-degree of every (node, slot): slot = group % 3
+__global__ void conf_deg_kernel(const int32_t* gtab, const int32_t* e_src, int32_t* deg3, int64_t cap_total) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= cap_total) return;
+  for (int g = 0; g < 9; ++g)
+    if (e >= gtab[g] && e < gtab[9 + g]) { atomicAdd(deg3 + (size_t)e_src[e] * 3 + (g % 3), 1); return; }
+}
+
+// initial node features: static embedding broadcast over the samples, zero padded to XW
+__global__ void conf_node_init_kernel(const float* lig_x0, const float* atom_x0, const float* rec_x0, int B, int Bm, int n_lig, int n_atom,
+                                      int n_rec, float* x) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n = (int64_t)Bm * (n_lig + n_atom + n_rec);
+  if (i >= n * XW) return;
+  const int64_t node = i / XW;
+  const int c = (int)(i % XW);
+  float v = 0.0f;
+  if (c < NS) {
+    const int64_t a0 = (int64_t)Bm * n_lig, r0 = a0 + (int64_t)Bm * n_atom;
+    if (node < a0) v = lig_x0[(node % n_lig) * NS + c];
+    else if (node < r0) v = atom_x0[((node - a0) % n_atom) * NS + c];
+    else v = rec_x0[((node - r0) % n_rec) * NS + c];
+  }
+  x[i] = v;
+}
+
+// x_out = pad(x_in) + sum over the 3 convs feeding the node type of BN_conv(sum / max(deg,1))   (all_atom_score_model.py:37-50,272-279)
+__global__ void conf_finalize_kernel(const float* sum3, const int32_t* deg3, const float* x_in, const float* bn_mean, const float* bn_scale,
+                                     const float* bn_bias, int64_t n_nodes, int64_t n_update, int64_t atom0, int64_t rec0, int dout, float* x_out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes * XW) return;
+  const int64_t node = i / XW;
+  const int c = (int)(i % XW);
+  float v = x_in[i];
+  if (node < n_update && c < dout) {
+    const int type = node < atom0 ? 0 : (node < rec0 ? 1 : 2);
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const int g = 3 * type + s;
+      const int d = deg3[node * 3 + s];
+      const float m = sum3[(node * 3 + s) * XW + c] / (float)(d > 1 ? d : 1);
+      v += (m - bn_mean[g * XW + c]) * bn_scale[g * XW + c] + bn_bias[g * XW + c];
+    }
+  }
+  x_out[i] = v;
+}
+
+struct HeadCArgs {
+  const float* x; int B, n_lig, n_out;
+  const float *w0, *s0, *t0, *w4, *s4, *t4, *w8, *b8;
+  float* out;
+};
+// scatter_mean of [x[:, :ns] | x[:, -ns:]] over each graph's ligand atoms, then the predictor MLP (:281-284)
+__global__ __launch_bounds__(64) void conf_head_kernel(HeadCArgs A) {
+  __shared__ float pooled[2 * NS], h1[NS], h2[NS];
+  const int b = blockIdx.x, t = threadIdx.x;
+  if (t < 2 * NS) {
+    const int col = t < NS ? t : (XW - NS) + (t - NS);
+    float s = 0.0f;
+    for (int i = 0; i < A.n_lig; ++i) s += A.x[((size_t)b * A.n_lig + i) * XW + col];
+    pooled[t] = s / (float)A.n_lig;
+  }
+  __syncthreads();
+  if (t < NS) {
+    float a = 0.0f;
+    for (int k = 0; k < 2 * NS; ++k) a += A.w0[t * 2 * NS + k] * pooled[k];
+    h1[t] = fmaxf(a * A.s0[t] + A.t0[t], 0.0f);
+  }
+  __syncthreads();
+  if (t < NS) {
+    float a = 0.0f;
+    for (int k = 0; k < NS; ++k) a += A.w4[t * NS + k] * h1[k];
+    h2[t] = fmaxf(a * A.s4[t] + A.t4[t], 0.0f);
+  }
+  __syncthreads();
+  if (t < A.n_out) {
+    float a = A.b8[t];
+    for (int k = 0; k < NS; ++k) a += A.w8[t * NS + k] * h2[k];
+    A.out[(size_t)b * A.n_out + t] = a;
+  }
+}
+
+void conf_complex_free(ddk_complex* cx) {
+  if (cx && cx->conf) { delete cx->conf; cx->conf = nullptr; }   // device arrays live in cx->allocs
+}
+
+template <typename T>
+static T* cxu(ddk_complex* cx, const T* src, size_t n) {
+  T* p = nullptr;
+  if (hipMalloc((void**)&p, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr;
+  cx->allocs.push_back(p);
+  if (n && src && hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  return p;
+}
+
+}  // namespace ddk
+
+using namespace ddk;
+
+extern "C" {
+
+int ddk_complex_set_atoms(ddk_ctx* ctx, ddk_complex* cx, const ddk_atoms_desc* d, const int32_t* lig_x, const float* rec_x, int32_t rec_feat_dim) {
+  if (!ctx || !cx || !d || !lig_x || !rec_x) return DDK_ERR_INVALID;
+  ConfModel* M = (ConfModel*)ctx->conf_model;
+  if (!ctx->cfg.all_atoms || !M || !M->ready) return fail(ctx, DDK_ERR_STATE, "ddk_complex_set_atoms needs a finalised all-atom confidence model context");
+  if (cx->conf) return fail(ctx, DDK_ERR_STATE, "atoms already set for this complex");
+  const ddk_config& c = ctx->cfg;
+  const int n_lig = cx->n_lig, n_rec = cx->n_rec, n_atom = d->n_atom, E_aa = d->n_atom_edges, lm = c.lm_embedding_dim;
+  if (n_atom < 1 || n_atom > (1 << 20)) return fail(ctx, DDK_ERR_INVALID, "n_atom out of range");
+  if (rec_feat_dim != 1 + lm) return fail(ctx, DDK_ERR_INVALID, "receptor feature width != 1 + lm_embedding_dim");
+  hipSetDevice(c.device);
+  ConfComplex* K = new ConfComplex();
+  cx->conf = K;
+  K->n_atom = n_atom; K->E_aa = E_aa;
+  const int64_t Bm = cx->max_batch;
+  // ---- node embeddings (OldAtomEncoder at t = 0) --------------------------------------------------
+  std::vector<float> lx((size_t)n_lig * NS), ax((size_t)n_atom * NS), rx((size_t)n_rec * NS);
+  for (int i = 0; i < n_lig; ++i)
+    for (int o = 0; o < NS; ++o) {
+      float a = M->lig_const[o];
+      for (int f = 0; f < 16; ++f) {
+        const int v = lig_x[(size_t)i * 16 + f];
+        if (v < 0 || v >= LIG_DIMS_C[f]) return fail(ctx, DDK_ERR_INVALID, "ligand categorical feature out of range");
+        a += M->lig_tables[(size_t)(M->lig_off[f] + v) * NS + o];
+      }
+      lx[(size_t)i * NS + o] = a;
+    }
+  for (int i = 0; i < n_atom; ++i)
+    for (int o = 0; o < NS; ++o) {
+      float a = M->atom_const[o];
+      for (int f = 0; f < 4; ++f) {
+        const int v = d->atom_x[(size_t)i * 4 + f];
+        if (v < 0 || v >= ATOM_DIMS_C[f]) return fail(ctx, DDK_ERR_INVALID, "receptor-atom categorical feature out of range");
+        a += M->atom_tables[(size_t)(M->atom_off[f] + v) * NS + o];
+      }
+      ax[(size_t)i * NS + o] = a;
+    }
+  for (int j = 0; j < n_rec; ++j) {
+    const float* xr = rec_x + (size_t)j * rec_feat_dim;      // [res id | ESM(lm)]; node_attr = [x | sigma_emb]
+    const int res = (int)xr[0];
+    if (res < 0 || res >= REC_DIM_C) return fail(ctx, DDK_ERR_INVALID, "residue id out of range");
+    float emb[NS];
+    for (int o = 0; o < NS; ++o) {
+      // OldAtomEncoder quirk (layers.py:112): the "scalar feature" slice x[:, 1:1+32] is ESM[:32] when lm features are present
+      double a = M->rec_lin_b[o] + M->rec_table[(size_t)res * NS + o];
+      for (int k = 0; k < SIG; ++k) a += (double)M->rec_lin_w[(size_t)o * SIG + k] * (lm > 0 ? xr[1 + k] : M->emb0[k]);
+      emb[o] = (float)a;
+    }
+    if (lm > 0) {   // lm_embedding_layer(cat([emb, x[:, -lm:]])) with x[:, -lm:] = [ESM[32:] | sigma_emb(0)]
+      for (int o = 0; o < NS; ++o) {
+        const float* w = M->rec_lm_w.data() + (size_t)o * (lm + NS);
+        double a = M->rec_lm_b[o];
+        for (int k = 0; k < NS; ++k) a += (double)w[k] * emb[k];
+        for (int k = 0; k < lm - SIG; ++k) a += (double)w[NS + k] * xr[1 + SIG + k];
+        for (int k = 0; k < SIG; ++k) a += (double)w[NS + lm - SIG + k] * M->emb0[k];
+        rx[(size_t)j * NS + o] = (float)a;
+      }
+    } else {
+      for (int o = 0; o < NS; ++o) rx[(size_t)j * NS + o] = emb[o];
+    }
+  }
+  K->lig_x0 = cxu(cx, lx.data(), lx.size()); K->atom_x0 = cxu(cx, ax.data(), ax.size()); K->rec_x0 = cxu(cx, rx.data(), rx.size());
+  K->atom_pos = cxu(cx, d->atom_pos, (size_t)n_atom * 3);
+  // ---- receptor-edge first layer with THIS model's rec_edge_embedding (the shared edge-feature kernel reads cx->rr_pre1) ----
+  {
+    std::vector<int32_t> ei((size_t)2 * cx->E_rr);
+    if (hipMemcpy(ei.data(), cx->rr_src, (size_t)cx->E_rr * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(ei.data() + cx->E_rr, cx->rr_dst, (size_t)cx->E_rr * 4, hipMemcpyDeviceToHost) != hipSuccess)
+      return fail(ctx, DDK_ERR_HIP, "receptor edge read-back failed");
+    std::vector<float> rp((size_t)n_rec * 3), pre1((size_t)cx->E_rr * NS);
+    if (hipMemcpy(rp.data(), cx->rec_pos, rp.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(ctx, DDK_ERR_HIP, "rec_pos read-back failed");
+    for (int k = 0; k < cx->E_rr; ++k) {
+      const int a = ei[k], b = ei[cx->E_rr + k];
+      const float vx = rp[3 * b] - rp[3 * a], vy = rp[3 * b + 1] - rp[3 * a + 1], vz = rp[3 * b + 2] - rp[3 * a + 2];
+      const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
+      float gs[DE];
+      for (int q = 0; q < DE; ++q) { const float t = dist - M->h_rec.offset[q]; gs[q] = expf(M->h_rec.coeff * (t * t)); }
+      for (int o = 0; o < NS; ++o) {
+        float a2 = 0.0f;
+        for (int q = 0; q < DE; ++q) a2 += M->h_rec.w1d[(size_t)o * DE + q] * gs[q];
+        pre1[(size_t)k * NS + o] = a2;
+      }
+    }
+    if (hipMemcpy(cx->rr_pre1, pre1.data(), pre1.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(ctx, DDK_ERR_HIP, "rr_pre1 upload failed");
+    // static sets need rec_pos on the host below
+    // ---- edge arrays: [4-group region of the shared graph kernel | la | al | aa | ar | ra] -------------
+    K->cap4 = cx->edge_cap;
+    K->cap_la = Bm * (int64_t)n_lig * 96 + 64;       // <= 96 receptor atoms within 5 A of a ligand atom (1.2 A spacing bound ~ 300)
+    K->off_la = K->cap4; K->off_al = K->off_la + K->cap_la; K->off_aa = K->off_al + K->cap_la;
+    K->off_ar = K->off_aa + Bm * E_aa; K->off_ra = K->off_ar + Bm * n_atom; K->cap_total = K->off_ra + Bm * n_atom;
+    if (K->cap_total >= ((int64_t)1 << 31)) return fail(ctx, DDK_ERR_INVALID, "edge capacity exceeds int32 (reduce max_batch)");
+    K->e_src = cxu<int32_t>(cx, nullptr, K->cap_total); K->e_dst = cxu<int32_t>(cx, nullptr, K->cap_total);
+    K->e_aux = cxu<int32_t>(cx, nullptr, K->cap4);
+    K->e_emb = cxu<float>(cx, nullptr, K->cap_total * NS); K->e_sh = cxu<float>(cx, nullptr, K->cap_total * 4);
+    if (!K->e_src || !K->e_dst || !K->e_aux || !K->e_emb || !K->e_sh) return fail(ctx, DDK_ERR_NOMEM, "device allocation failed (confidence edge arrays)");
+    // static sets (atom-atom; atom->residue and its flip), replicated for Bm samples
+    const int64_t atom_base = Bm * n_lig, rec_base = Bm * ((int64_t)n_lig + n_atom);
+    const int64_t n_static = Bm * ((int64_t)E_aa + 2 * n_atom);
+    std::vector<int32_t> ssrc((size_t)n_static), sdst((size_t)n_static);
+    std::vector<float> semb((size_t)n_static * NS), ssh((size_t)n_static * 4);
+    std::vector<float> emb1((size_t)(E_aa + n_atom) * NS), sh1((size_t)(E_aa + n_atom) * 4);
+    for (int k = 0; k < E_aa; ++k) {
+      const int a = d->atom_edge_index[k], b = d->atom_edge_index[E_aa + k];
+      if (a < 0 || a >= n_atom || b < 0 || b >= n_atom) return fail(ctx, DDK_ERR_INVALID, "atom edge index out of range");
+      host_edge(M->h_atom, d->atom_pos[3 * b] - d->atom_pos[3 * a], d->atom_pos[3 * b + 1] - d->atom_pos[3 * a + 1],
+                d->atom_pos[3 * b + 2] - d->atom_pos[3 * a + 2], emb1.data() + (size_t)k * NS, sh1.data() + (size_t)k * 4);
+    }
+    for (int i = 0; i < n_atom; ++i) {
+      if (d->atom_rec_index[i] != i) return fail(ctx, DDK_ERR_INVALID, "atom_rec_index row 0 must be arange(n_atom) (process_mols.py:472)");
+      const int r = d->atom_rec_index[n_atom + i];
+      if (r < 0 || r >= n_rec) return fail(ctx, DDK_ERR_INVALID, "atom residue index out of range");
+      host_edge(M->h_ar, rp[3 * r] - d->atom_pos[3 * i], rp[3 * r + 1] - d->atom_pos[3 * i + 1], rp[3 * r + 2] - d->atom_pos[3 * i + 2],
+                emb1.data() + (size_t)(E_aa + i) * NS, sh1.data() + (size_t)(E_aa + i) * 4);
+    }
+    for (int64_t b = 0; b < Bm; ++b) {
+      for (int k = 0; k < E_aa; ++k) {          // aa: src = row 0, dst = row 1
+        const int64_t p = b * E_aa + k;
+        ssrc[p] = (int32_t)(atom_base + b * n_atom + d->atom_edge_index[k]);
+        sdst[p] = (int32_t)(atom_base + b * n_atom + d->atom_edge_index[E_aa + k]);
+        memcpy(&semb[p * NS], &emb1[(size_t)k * NS], NS * 4); memcpy(&ssh[p * 4], &sh1[(size_t)k * 4], 16);
+      }
+      for (int i = 0; i < n_atom; ++i) {        // ar: src atom, dst residue ; ra: the flip with the same features
+        const int64_t p1 = Bm * E_aa + b * n_atom + i, p2 = Bm * ((int64_t)E_aa + n_atom) + b * n_atom + i;
+        const int32_t an = (int32_t)(atom_base + b * n_atom + i), rn = (int32_t)(rec_base + b * n_rec + d->atom_rec_index[n_atom + i]);
+        ssrc[p1] = an; sdst[p1] = rn; ssrc[p2] = rn; sdst[p2] = an;
+        memcpy(&semb[p1 * NS], &emb1[(size_t)(E_aa + i) * NS], NS * 4); memcpy(&ssh[p1 * 4], &sh1[(size_t)(E_aa + i) * 4], 16);
+        memcpy(&semb[p2 * NS], &emb1[(size_t)(E_aa + i) * NS], NS * 4); memcpy(&ssh[p2 * 4], &sh1[(size_t)(E_aa + i) * 4], 16);
+      }
+    }
+    if (hipMemcpy(K->e_src + K->off_aa, ssrc.data(), ssrc.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(K->e_dst + K->off_aa, sdst.data(), sdst.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(K->e_emb + K->off_aa * NS, semb.data(), semb.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(K->e_sh + K->off_aa * 4, ssh.data(), ssh.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+      return fail(ctx, DDK_ERR_HIP, "static edge upload failed");
+  }
+  K->n_nodes = Bm * ((int64_t)n_lig + n_atom + n_rec);
+  K->gtab = cxu<int32_t>(cx, nullptr, 32);
+  K->deg_scratch = cxu<int32_t>(cx, nullptr, K->n_nodes);
+  K->xa = cxu<float>(cx, nullptr, K->n_nodes * XW); K->xb = cxu<float>(cx, nullptr, K->n_nodes * XW);
+  K->sum3 = cxu<float>(cx, nullptr, K->n_nodes * 3 * XW);
+  K->deg3 = cxu<int32_t>(cx, nullptr, K->n_nodes * 3);
+  if (!K->lig_x0 || !K->atom_x0 || !K->rec_x0 || !K->atom_pos || !K->gtab || !K->deg_scratch || !K->xa || !K->xb || !K->sum3 || !K->deg3)
+    return fail(ctx, DDK_ERR_NOMEM, "device allocation failed in ddk_complex_set_atoms");
+  return DDK_OK;
+}
+
+int ddk_confidence_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* lig_pos, float* out, void* stream) {
+  if (!ctx) return DDK_ERR_INVALID;
+  if (ctx->host_only) return fail(ctx, DDK_ERR_STATE, "host-only context (device < 0) cannot launch kernels");
+  ConfModel* M = (ConfModel*)ctx->conf_model;
+  if (!ctx->finalized || !M || !M->ready) return fail(ctx, DDK_ERR_STATE, "confidence model weights not loaded / finalised");
+  if (!cx || !cx->conf) return fail(ctx, DDK_ERR_STATE, "ddk_complex_set_atoms has not run for this complex");
+  if (B < 1 || B > cx->max_batch || !lig_pos || !out) return fail(ctx, DDK_ERR_INVALID, "bad batch / null argument");
+  const ddk_config& c = ctx->cfg;
+  ConfComplex* K = cx->conf;
+  hipStream_t s = (hipStream_t)stream;
+  const int n_lig = cx->n_lig, n_rec = cx->n_rec, n_atom = K->n_atom;
+  const int64_t Bm = cx->max_batch;
+  const int64_t atom_base = Bm * n_lig, rec_base = Bm * ((int64_t)n_lig + n_atom);
+  hipError_t e;
+#define CK(x, what) do { e = (x); if (e != hipSuccess) return hip_fail(ctx, e, what); } while (0)
+  static const int dbg_mask = [] { const char* e = getenv("DDK_CONF_GROUP_MASK"); return e ? atoi(e) : 0x1ff; }();   // development aid
+  static const int dbg_from = [] { const char* e = getenv("DDK_CONF_MASK_FROM_LAYER"); return e ? atoi(e) : 0; }();
+  // ---- dynamic graphs ------------------------------------------------------------------------------
+  GraphArgs G;
+  G.lig_pos = lig_pos; G.rec_pos = cx->rec_pos; G.bond_src = cx->bond_src; G.bond_dst = cx->bond_dst;
+  G.rr_src = cx->rr_src; G.rr_dst = cx->rr_dst; G.rr_outdeg = cx->rr_outdeg;
+  G.B = B; G.n_lig = n_lig; G.n_rec = n_rec; G.M = cx->M; G.E_rr = cx->E_rr;
+  G.lig_r2 = c.lig_max_radius * c.lig_max_radius; G.cross_cutoff = M->sp.cross_cutoff;
+  G.counts = cx->counts; G.offs = cx->offs; G.info = cx->info; G.e_src = K->e_src; G.e_dst = K->e_dst; G.e_aux = K->e_aux;
+  G.deg = K->deg_scratch; G.rec_node_base = (int)rec_base;
+  CK(launch_graph(G, K->cap4, s), "graph");
+  EdgeFeatArgs EF;
+  EF.lig_pos = lig_pos; EF.rec_pos = cx->rec_pos; EF.bond_attr = cx->bond_attr; EF.rr_pre1 = cx->rr_pre1; EF.rr_sh = cx->rr_sh;
+  EF.e_src = K->e_src; EF.e_dst = K->e_dst; EF.e_aux = K->e_aux; EF.info = cx->info; EF.e_emb = K->e_emb; EF.e_sh = K->e_sh;
+  EF.lig = M->lig_edge; EF.rec = M->rec_edge; EF.cross = M->lr_edge; EF.sp = M->sp;
+  EF.n_lig_total = B * n_lig; EF.rec_node_base = (int)rec_base; EF.n_rec = n_rec;
+  EF.lig_latent = nullptr; EF.rec_latent = nullptr; EF.unconditional = 0.0f; EF.latent_dim = 0;
+  CK(launch_edge_features(EF, K->cap4, s), "edge features");
+  CK(hipMemsetAsync(K->gtab + 18, 0, 2 * sizeof(int32_t), s), "la counter");
+  LaArgs LA;
+  LA.lig_pos = lig_pos; LA.atom_pos = K->atom_pos; LA.B = B; LA.n_lig = n_lig; LA.n_atom = n_atom; LA.atom_node_base = (int)atom_base;
+  LA.r2 = c.lig_max_radius * c.lig_max_radius; LA.mlp = M->la_edge; memcpy(LA.sigb, M->la_sigb, sizeof(LA.sigb));
+  LA.gtab = K->gtab; LA.off_la = K->off_la; LA.off_al = K->off_al; LA.cap = K->cap_la;
+  LA.e_src = K->e_src; LA.e_dst = K->e_dst; LA.e_emb = K->e_emb; LA.e_sh = K->e_sh;
+  hipLaunchKernelGGL(conf_la_kernel, dim3(B), dim3(256), 0, s, LA);
+  CK(hipGetLastError(), "la graph");
+  hipLaunchKernelGGL(conf_gtab_kernel, dim3(1), dim3(64), 0, s, K->gtab, cx->info, B, K->E_aa, n_atom, (int)K->off_la, (int)K->off_al,
+                     (int)K->off_aa, (int)K->off_ar, (int)K->off_ra, (int)K->cap_la, dbg_from > 0 ? 0x1ff : dbg_mask);
+  CK(hipGetLastError(), "group table");
+  CK(hipMemsetAsync(K->deg3, 0, (size_t)K->n_nodes * 3 * sizeof(int32_t), s), "deg3");
+  hipLaunchKernelGGL(conf_deg_kernel, dim3((unsigned)((K->cap_total + 255) / 256)), dim3(256), 0, s, K->gtab, K->e_src, K->deg3, K->cap_total);
+  CK(hipGetLastError(), "degrees");
+  // ---- node features and the conv stack ----------------------------------------------------------
+  float *xin = K->xa, *xout = K->xb;
+  const int64_t tot = K->n_nodes * XW;
+  hipLaunchKernelGGL(conf_node_init_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, K->lig_x0, K->atom_x0, K->rec_x0, B, (int)Bm,
+                     n_lig, n_atom, n_rec, xin);
+  CK(hipGetLastError(), "node init");
+  static const int dbg_layers = [] { const char* e = getenv("DDK_CONF_MAX_LAYERS"); return e ? atoi(e) : 1000; }();   // development aid
+  for (int l = 0; l < c.num_conv_layers && l < dbg_layers; ++l) {
+    const ConvLayerDev& L = ctx->conv[l];
+    if (dbg_from > 0 && l == dbg_from) {   // development aid: restrict the groups from this layer on
+      hipLaunchKernelGGL(conf_gtab_kernel, dim3(1), dim3(64), 0, s, K->gtab, cx->info, B, K->E_aa, n_atom, (int)K->off_la, (int)K->off_al,
+                         (int)K->off_aa, (int)K->off_ar, (int)K->off_ra, (int)K->cap_la, dbg_mask);
+    }
+    const bool last = l == c.num_conv_layers - 1;      // all_atom_score_model.py:241 "last layer optimisation": ligand updates only
+    CK(hipMemsetAsync(K->sum3, 0, (size_t)(last ? atom_base : K->n_nodes) * 3 * XW * sizeof(float), s), "memset sum3");
+    CK(hipMemsetAsync(cx->info + 10 + (l % 8), 0, sizeof(int32_t), s), "counter reset");
+    ConvLaunch a;
+    a.x = xin; a.src = K->e_src; a.dst = K->e_dst; a.edge_attr = K->e_emb; a.sh = K->e_sh; a.sum = K->sum3;
+    a.tile_info = cx->info; a.counter = cx->info + 10 + (l % 8); a.gather = 1;
+    a.mode = 1; a.n_groups = 9; a.n_active = last ? 3 : 9; a.n_slots = 3;
+    a.slots = 0;
+    for (int g = 0; g < 9; ++g) a.slots |= (uint32_t)(g % 3) << (2 * g);
+    a.gbeg = K->gtab; a.gend = K->gtab + 9;
+    CK(launch_conv_fused(L, a, ctx->n_cu, s), "conv_fused (confidence)");
+    hipLaunchKernelGGL(conf_finalize_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, K->sum3, K->deg3, xin, L.bn_mean, L.bn_scale,
+                       L.bn_bias, K->n_nodes, last ? atom_base : K->n_nodes, atom_base, rec_base, L.dout, xout);
+    CK(hipGetLastError(), "conf finalize");
+    float* t = xin; xin = xout; xout = t;
+  }
+  cx->x_last = xin;
+  cx->last_B = B;
+  HeadCArgs H;
+  H.x = xin; H.B = B; H.n_lig = n_lig; H.n_out = M->n_out;
+  H.w0 = M->w0; H.s0 = M->s0; H.t0 = M->t0; H.w4 = M->w4; H.s4 = M->s4; H.t4 = M->t4; H.w8 = M->w8; H.b8 = M->b8; H.out = out;
+  hipLaunchKernelGGL(conf_head_kernel, dim3(B), dim3(64), 0, s, H);
+  CK(hipGetLastError(), "confidence head");
+#undef CK
+  return DDK_OK;
+}
+
+// Test hook: edge counts of the nine groups of the last confidence forward ([ll lr la aa al ar rr rl ra]) + la overflow flag.
+int ddk_debug_conf_counts(ddk_ctx* ctx, ddk_complex* cx, int32_t* out10) {
+  if (!ctx || !cx || !cx->conf || !out10) return DDK_ERR_INVALID;
+  int32_t g[32];
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(g, cx->conf->gtab, sizeof(g), hipMemcpyDeviceToHost) != hipSuccess)
+    return fail(ctx, DDK_ERR_HIP, "gtab read-back failed");
+  for (int k = 0; k < 9; ++k) out10[k] = g[9 + k] - g[k];
+  out10[9] = g[19];
+  return DDK_OK;
+}
+
+// Test hook: all node features [n_nodes, XW] after the last confidence forward (device numbering) and the per-slot degrees.
+int ddk_debug_conf_nodes(ddk_ctx* ctx, ddk_complex* cx, float* x, int32_t* deg3, int64_t n_nodes) {
+  if (!ctx || !cx || !cx->conf || !cx->x_last) return DDK_ERR_INVALID;
+  if (n_nodes != cx->conf->n_nodes) return fail(ctx, DDK_ERR_INVALID, "node count");
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(x, cx->x_last, (size_t)n_nodes * XW * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(deg3, cx->conf->deg3, (size_t)n_nodes * 12, hipMemcpyDeviceToHost) != hipSuccess)
+    return fail(ctx, DDK_ERR_HIP, "copy failed");
+  return DDK_OK;
+}
+
+// Test hook: raw edge arrays [off, off+n) of the last confidence forward and the group table (18 ints).
+int ddk_debug_conf_edges(ddk_ctx* ctx, ddk_complex* cx, int64_t off, int64_t n, int32_t* src, int32_t* dst, float* emb, float* sh, int32_t* gtab18) {
+  if (!ctx || !cx || !cx->conf) return DDK_ERR_INVALID;
+  ConfComplex* K = cx->conf;
+  if (hipDeviceSynchronize() != hipSuccess) return fail(ctx, DDK_ERR_HIP, "sync failed");
+  if (gtab18 && hipMemcpy(gtab18, K->gtab, 18 * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(ctx, DDK_ERR_HIP, "copy failed");
+  if (n > 0 && (off < 0 || off + n > K->cap_total)) return fail(ctx, DDK_ERR_INVALID, "range");
+  if (n > 0 && (hipMemcpy(src, K->e_src + off, n * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(dst, K->e_dst + off, n * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy(emb, K->e_emb + off * NS, n * NS * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(sh, K->e_sh + off * 4, n * 16, hipMemcpyDeviceToHost) != hipSuccess))
+    return fail(ctx, DDK_ERR_HIP, "copy failed");
+  return DDK_OK;
+}
+
+}  // extern "C"

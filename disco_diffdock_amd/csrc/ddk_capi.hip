@@ -353,6 +353,8 @@ static int build_conv_layer(ddk_ctx* ctx, int mode, int l, ConvLayerDev& L) {
 }
 
 int model_finalize(ddk_ctx* ctx);   // model.hip
+int conf_model_finalize(ddk_ctx* ctx);   // conf.hip
+void conf_model_destroy(ddk_ctx* ctx);
 void model_destroy(ddk_ctx* ctx);   // model.hip
 
 }  // namespace ddk
@@ -392,6 +394,7 @@ void ddk_destroy(ddk_ctx* ctx) {
   if (!ctx->host_only) {
     hipSetDevice(ctx->cfg.device);
     model_destroy(ctx);
+    conf_model_destroy(ctx);
     for (auto& r : ctx->prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     if (ctx->prof_edges) hipHostFree(ctx->prof_edges);
     for (void* p : ctx->dev_allocs) hipFree(p);
@@ -429,7 +432,7 @@ int ddk_finalize_weights(ddk_ctx* ctx) {
     int rc = build_conv_layer(ctx, ctx->cfg.all_atoms ? 1 : 0, l, ctx->conv[l]);
     if (rc != DDK_OK) return rc;
   }
-  int rc = model_finalize(ctx);
+  int rc = ctx->cfg.all_atoms ? conf_model_finalize(ctx) : model_finalize(ctx);
   if (rc != DDK_OK) return rc;
   ctx->finalized = true;
   return DDK_OK;
@@ -463,6 +466,11 @@ int ddk_tp_forward(ddk_ctx* ctx, int32_t layer, const float* x_dst, const float*
 int ddk_conv_forward(ddk_ctx* ctx, int32_t layer, const float* x, int64_t N, const int32_t* edge_src,
                      const int32_t* edge_dst, const int64_t* go, const float* edge_attr, const float* sh, float* out,
                      void* stream) {
+  // all-atom (confidence) contexts: `layer` is the index of ONE reference conv (conv_layers.{layer}, all_atom_score_model.py:37-50,
+  // residual=False): every edge belongs to it, out = BatchNorm(scatter_mean(...))
+  const bool aa = ctx && ctx->cfg.all_atoms;
+  const int conv_k = aa ? layer % 9 : 0;
+  if (aa) layer /= 9;
   int rc = check_launchable(ctx, layer);
   if (rc) return rc;
   if (!go || go[0] != 0 || go[1] < go[0] || go[2] < go[1] || go[3] < go[2] || go[4] < go[3])
@@ -487,7 +495,19 @@ int ddk_conv_forward(ddk_ctx* ctx, int32_t layer, const float* x, int64_t N, con
     ConvLaunch a;
     a.x = ws.xpad; a.src = edge_src; a.dst = edge_dst; a.edge_attr = edge_attr; a.sh = sh; a.sum = ws.sum;
     a.tile_info = ws.tile_info; a.counter = ws.tile_info + 10; a.gather = 0;
+    if (aa) {
+      int32_t gt[18];
+      for (int g = 0; g < 9; ++g) { gt[g] = 0; gt[9 + g] = g == conv_k ? (int32_t)E : 0; }
+      CK(hipMemcpyAsync(ws.tile_info + 32, gt, sizeof(gt), hipMemcpyHostToDevice, s), "group table");
+      CK(hipStreamSynchronize(s), "group table");    // gt lives on this stack frame
+      a.mode = 1; a.n_groups = 9; a.n_active = 9; a.n_slots = 1; a.slots = 0; a.gbeg = ws.tile_info + 32; a.gend = ws.tile_info + 41;
+    }
     CK(launch_conv_fused(L, a, ctx->n_cu, s), "conv_fused");
+  }
+  if (aa) {
+    CK(launch_node_finalize(ws.sum, ws.deg, nullptr, L.bn_mean + conv_k * XW, L.bn_scale + conv_k * XW, L.bn_bias + conv_k * XW, N, L.dout, L.dout, out, s),
+       "node_finalize");
+    return DDK_OK;
   }
   // with no edges the reference returns zeros + residual (tensor_layers.py:149-151): BatchNorm is skipped
   if (E > 0)

@@ -34,7 +34,7 @@ static_assert(F_STRIDE == 132 && NV == 6, "F row layout");
 
 // F-row extension of the confidence model's l<=2 tensor product (e3nn FullyConnectedTensorProduct with sh 0e+1o+2e on the
 // same 0e/1o/1e/0o node irreps): the 1o(x)2e->1o and 1e(x)2e->1e paths contract p / q with the symmetric traceless
-// v^ v^T - I/3, i.e. 6 more vector rows per block (two quads, component-major like T1O/T1E).
+// v^ v^T - |v^|^2 I/3 (|v^| = 1, or 0 for a zero-length edge), i.e. 6 more vector rows per block (two quads, component-major like T1O/T1E).
 constexpr int F_T2O = F_STRIDE;            // 6 rows x xyz (+2 pad rows): v^ (v^.p) - p/3
 constexpr int F_T2E = F_T2O + 24;          // same with q
 constexpr int F_STRIDE2 = F_T2E + 24;      // 180 floats: 16-B slot = 13*row mod 16 -> conflict free
@@ -131,6 +131,7 @@ struct ddk_ctx {
   std::vector<void*> dev_allocs;
   // packed small weights for the non-conv kernels live in model.hip (opaque here)
   void* model = nullptr;
+  void* conf_model = nullptr;   // conf.hip
   // profiling (ddk_profile_enable / ddk_profile_read)
   bool prof = false;
   struct ProfRec { hipEvent_t a, b; int layer; int slot; int64_t skipped = 0; bool lig_only = false; };   // skipped: edges not evaluated (layer-0 rec-rec dedup)

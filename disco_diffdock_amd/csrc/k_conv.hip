@@ -344,12 +344,14 @@ __global__ __launch_bounds__(64 * ConvTraits<MODE>::WAVES) void conv_fused_kerne
         Pc[0] = (py * vz - pz * vy) * inv_s2;
         Pc[4] = (pz * vx - px * vz) * inv_s2;
         Pc[8] = (px * vy - py * vx) * inv_s2;
-        if (MODE == 1) {   // 1o(x)2e->1o / 1e(x)2e->1e: (v^ v^T - I/3) p with v^ = sh[1:4]/sqrt3  (constants folded into the packed weights)
-          const float dv = (px * vx + py * vy + pz * vz) * (1.0f / 3.0f);     // (v^.p) |v| / sqrt3 ... v = sqrt3 v^
+        if (MODE == 1) {   // 1o(x)2e->1o / 1e(x)2e->1e: (v^ v^T - |v^|^2 I/3) p with v^ = sh[1:4]/sqrt3  (constants folded into the packed weights)
+          // v = sqrt3 v^ ; |v^| is 1, or 0 for a zero-length edge (a C-alpha atom and its own residue: Y2 = 0 there)
+          const float dv = (px * vx + py * vy + pz * vz) * (1.0f / 3.0f);
+          const float n3 = (vx * vx + vy * vy + vz * vz) * (1.0f / 9.0f);       // |v^|^2 / 3
           float* P2 = Fr + (hh ? F_T2E : F_T2O) + 12 * (m >> 2) + (m & 3);
-          P2[0] = dv * vx - px * (1.0f / 3.0f);
-          P2[4] = dv * vy - py * (1.0f / 3.0f);
-          P2[8] = dv * vz - pz * (1.0f / 3.0f);
+          P2[0] = dv * vx - px * n3;
+          P2[4] = dv * vy - py * n3;
+          P2[8] = dv * vz - pz * n3;
         }
       }
       if (MODE == 1) {     // pad rows 6,7 of the second quad (their weights are zero; keep them finite)

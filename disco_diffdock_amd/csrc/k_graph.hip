@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(GraphArgs G) {
     odeg[j] = od;
   }
   __syncthreads();
-  const int lig0 = b * n_lig, rec0 = G.B * n_lig + b * n_rec;
+  const int lig0 = b * n_lig, rec0 = (G.rec_node_base >= 0 ? G.rec_node_base : G.B * n_lig) + b * n_rec;
   // degrees (scatter 'mean' divisor: all incoming groups together, tensor_layers.py:159)
   for (int i = tid; i < n_lig; i += 256) G.deg[lig0 + i] = bdeg[i] + odeg[i] + c_lr[i];
   for (int j = tid; j < n_rec; j += 256) G.deg[rec0 + j] = G.rr_outdeg[j] + c_rl[j];
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void edge_features_kernel(EdgeFeatArgs A) {
     } else {   // cross edges: vec = rec - lig for BOTH directions (score_model.py:387, 220-223)
       const int ln = g == 1 ? sn : dn, rn = g == 1 ? dn : sn;
       const float* pl = A.lig_pos + 3 * (size_t)ln;
-      const float* pr = A.rec_pos + 3 * (size_t)((rn - A.n_lig_total) % A.n_rec);
+      const float* pr = A.rec_pos + 3 * (size_t)((rn - (A.rec_node_base >= 0 ? A.rec_node_base : A.n_lig_total)) % A.n_rec);
       vx = pr[0] - pl[0]; vy = pr[1] - pl[1]; vz = pr[2] - pl[2];
     }
     const float d = sqrtf(vx * vx + vy * vy + vz * vz);

@@ -92,6 +92,7 @@ struct GraphArgs {
   int32_t* e_dst;
   int32_t* e_aux;
   int32_t* deg;             // [B*(n_lig+n_rec)]
+  int rec_node_base = -1;   // node id of sample 0's first residue (-1: B*n_lig, the score model's [lig | rec] numbering)
 };
 
 struct EdgeFeatArgs {
@@ -109,6 +110,7 @@ struct EdgeFeatArgs {
   EdgeMlpDev lig, rec, cross;
   StepParams sp;
   int n_lig_total;         // B*n_lig
+  int rec_node_base = -1;  // -1: n_lig_total
   int n_rec;
   const float* lig_latent; // [B*n_lig, latent_dim] or null
   const float* rec_latent; // [B*n_rec, latent_dim] or null
@@ -158,6 +160,11 @@ struct RandPosArgs {
 };
 hipError_t launch_randomize(const RandPosArgs& A, hipStream_t s);
 
+int conf_model_finalize(ddk_ctx* ctx);   // conf.hip (all-atom confidence model)
+void conf_complex_free(ddk_complex* cx);
+void conf_model_destroy(ddk_ctx* ctx);
+struct ConfComplex;
+
 hipError_t launch_graph(const GraphArgs& G, int64_t edge_cap, hipStream_t s);
 hipError_t launch_edge_features(const EdgeFeatArgs& A, int64_t edge_cap, hipStream_t s);
 struct NodeEmbedArgs {
@@ -193,5 +200,6 @@ struct ddk_complex {
   float* x_last = nullptr;    // node features after the conv stack of the last forward
   int last_B = 0;
   bool keep_rec = false, last_full = false;   // last conv layer: all groups (true) or ligand-side groups only
+  ddk::ConfComplex* conf = nullptr;   // all-atom level (ddk_complex_set_atoms), owned
   std::vector<void*> allocs;
 };

@@ -481,6 +481,7 @@ void ddk_complex_destroy(ddk_ctx* ctx, ddk_complex* cx) {
   if (ctx) hipSetDevice(ctx->cfg.device);
   for (void* p : cx->allocs)
     if (p) hipFree(p);
+  conf_complex_free(cx);
   delete cx;
 }
 

@@ -220,6 +220,60 @@ class Complex:
                    'ddk_se3_update')
         return out
 
+    def set_atoms(self, atom_x, atom_pos, atom_edge_index, atom_rec_index, lig_x=None, rec_x=None):
+        """Receptor-atom level of the confidence model's graph (data['atom'] of datasets_utils/process_mols.py:474-477)."""
+        f = lambda a, dt: np.ascontiguousarray(a.detach().cpu().numpy() if torch.is_tensor(a) else a, dtype=dt)
+        at = dict(atom_x=f(atom_x, np.int32), atom_pos=f(atom_pos, np.float32), atom_edge_index=f(atom_edge_index, np.int32),
+                  atom_rec_index=f(atom_rec_index, np.int32))
+        self.n_atom = at['atom_x'].shape[0]
+        d = _lib.ddk_atoms_desc(n_atom=self.n_atom, n_atom_edges=at['atom_edge_index'].shape[1],
+                                **{k: v.ctypes.data_as(C.c_void_p) for k, v in at.items()})
+        lig_x = self.arr['lig_x'] if lig_x is None else f(lig_x, np.int32)
+        rec_x = self.arr['rec_x'] if rec_x is None else f(rec_x, np.float32)
+        self.ctx._check(self.ctx.L.ddk_complex_set_atoms(self.ctx.h, self.h, C.byref(d), lig_x.ctypes.data_as(C.c_void_p),
+                                                         rec_x.ctypes.data_as(C.c_void_p), rec_x.shape[1]), 'ddk_complex_set_atoms')
+
+    def confidence_forward(self, pos):
+        """confidence_model(batch) for B poses of this complex -> [B, num_confidence_outputs] (device)."""
+        pos = pos.contiguous().float().reshape(-1, self.n_lig, 3)
+        B = pos.shape[0]
+        out = torch.empty((B, int(self.ctx.cfg.num_confidence_outputs)), dtype=torch.float32, device=pos.device)
+        self.ctx._check(self.ctx.L.ddk_confidence_forward(self.ctx.h, self.h, B, _ptr(pos), _ptr(out), _stream()), 'ddk_confidence_forward')
+        return out
+
+    def confidence_counts(self):
+        out = (C.c_int32 * 10)()
+        self.ctx._check(self.ctx.L.ddk_debug_conf_counts(self.ctx.h, self.h, out), 'ddk_debug_conf_counts')
+        v = list(out)
+        if v[9]:
+            raise RuntimeError('ddk: ligand-atom edge capacity overflow')
+        return dict(zip(('ll', 'lr', 'la', 'aa', 'al', 'ar', 'rr', 'rl', 'ra'), v[:9]))
+
+    def confidence_nodes(self):
+        n = self.max_batch * (self.n_lig + self.n_atom + self.n_rec)
+        x, deg = np.zeros((n, 84), np.float32), np.zeros((n, 3), np.int32)
+        self.ctx._check(self.ctx.L.ddk_debug_conf_nodes(self.ctx.h, self.h, x.ctypes.data_as(C.c_void_p), deg.ctypes.data_as(C.c_void_p), n), 'ddk_debug_conf_nodes')
+        return x, deg
+
+    def confidence_edges(self):
+        """test hook: {group: (src, dst, emb, sh)} of the last confidence forward (node ids in the device numbering)."""
+        gt = (C.c_int32 * 18)()
+        self.ctx._check(self.ctx.L.ddk_debug_conf_edges(self.ctx.h, self.h, 0, 0, None, None, None, None, gt), 'ddk_debug_conf_edges')
+        out = {}
+        for k, name in enumerate(('ll', 'lr', 'la', 'aa', 'al', 'ar', 'rr', 'rl', 'ra')):
+            n = gt[9 + k] - gt[k]
+            src, dst = np.zeros(n, np.int32), np.zeros(n, np.int32)
+            emb, sh = np.zeros((n, 24), np.float32), np.zeros((n, 4), np.float32)
+            p = lambda a: a.ctypes.data_as(C.c_void_p)
+            self.ctx._check(self.ctx.L.ddk_debug_conf_edges(self.ctx.h, self.h, gt[k], n, p(src), p(dst), p(emb), p(sh), None), 'ddk_debug_conf_edges')
+            out[name] = (src, dst, emb, sh)
+        return out
+
+    def lig_node_features(self, B, device):
+        lig = torch.empty((B * self.n_lig, 84), dtype=torch.float32, device=device)
+        self.ctx._check(self.ctx.L.ddk_last_node_features(self.ctx.h, self.h, B, _ptr(lig), None, _stream()), 'ddk_last_node_features')
+        return lig
+
     def randomize_position(self, pos0, rot, tor=None, tr=None):
         """utils/sampling.py:12-34 for B = rot.shape[0] copies of the conformer pos0 [n_lig,3]; returns [B,n_lig,3]."""
         ctx = self.ctx

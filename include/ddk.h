@@ -106,6 +106,24 @@ typedef struct ddk_complex_desc {
 int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* desc, int32_t max_batch, ddk_complex** out);
 void ddk_complex_destroy(ddk_ctx* ctx, ddk_complex* cx);
 
+/* ---- all-atom confidence model (models/all_atom_score_model.py in confidence_mode; context created with all_atoms = 1 and
+ *      the reference's confidence checkpoint keys): the receptor-atom level of the graph (datasets_utils/process_mols.py:383-477),
+ *      HOST pointers; ddk_complex_set_atoms also needs the complex's ligand ids and receptor features again because the node
+ *      embeddings of this model (OldAtomEncoder, models/layers.py:81-116) are computed here. */
+typedef struct ddk_atoms_desc {
+  int32_t n_atom, n_atom_edges;
+  const int32_t* atom_x;          /* [n_atom, 4]   data['atom'].x */
+  const float* atom_pos;          /* [n_atom, 3] */
+  const int32_t* atom_edge_index; /* [2, n_atom_edges]  data['atom','atom'].edge_index */
+  const int32_t* atom_rec_index;  /* [2, n_atom]        data['atom','receptor'].edge_index (row 0 = arange) */
+} ddk_atoms_desc;
+int ddk_complex_set_atoms(ddk_ctx* ctx, ddk_complex* cx, const ddk_atoms_desc* atoms, const int32_t* lig_x, const float* rec_x,
+                          int32_t rec_feat_dim);
+
+/* confidence_model(batch) -> [B, num_confidence_outputs]  (utils/sampling.py:230-243 with set_time(..., 0, 0, 0);
+ * models/all_atom_score_model.py:203-284): lig_pos [B, n_lig, 3] DEVICE, out [B, num_confidence_outputs] DEVICE. */
+int ddk_confidence_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* lig_pos, float* out, void* stream);
+
 /* ---- DisCo latent conditioning (models/score_model.py:170-184, 209-215, 329-337, 358-366, 392-402; latent_vocab == 1):
  *      lig_latent [B*n_lig, latent_dim], rec_latent [B*n_rec, latent_dim] (data['ligand'|'receptor'].latent_h, DEVICE,
  *      caller-owned, must stay valid for the following forwards) and the value of data[...].unconditional.

@@ -96,7 +96,7 @@ def _intra_graph(pos, edge_index, sigma_emb, stop, cfg, dtype, extra=None):
     return torch.cat(attr, 1), _sh(vec, cfg)
 
 
-def confidence_forward(P, cfg, data, dtype=torch.float32, return_intermediates=False):
+def confidence_forward(P, cfg, data, dtype=torch.float32, return_intermediates=False, stop_after=None, group_mask=0x1ff, mask_from=0):
     """all_atom_score_model.py:203-284 in confidence_mode (complex_t is used as sigma directly, :205-207)."""
     ns = cfg.ns
     lig, rec, atom = data['ligand'], data['receptor'], data['atom']
@@ -143,11 +143,23 @@ def confidence_forward(P, cfg, data, dtype=torch.float32, return_intermediates=F
     la_attr = mlp2(la_attr, P, 'la_edge_embedding', 0, 3)
     ar_attr = mlp2(ar_attr, P, 'ar_edge_embedding', 0, 3)
 
+    edge_sets = dict(ll=(ll_index, ll_attr, ll_sh), lr=(lr_index, lr_attr, lr_sh), la=(la_index, la_attr, la_sh), aa=(aa_index, aa_attr, aa_sh),
+                     ar=(ar_index, ar_attr, ar_sh), rr=(rr_index, rr_attr, rr_sh))
+    x0 = dict(lig=lig_x, atom=atom_x, rec=rec_x)
     flip = lambda ei: torch.flip(ei, dims=[0])
     cat3 = lambda e, a, b: torch.cat([e, a[:, :ns], b[:, :ns]], -1)
     L = cfg.num_conv_layers
     for l in range(L):
-        cv = lambda k, *a, **kw: conv_layer(P, f'conv_layers.{9 * l + k}', cfg, l, *a, **kw)
+        if stop_after is not None and l >= stop_after:
+            break
+        def cv(k, x, ei, ea, sh_, **kw):
+            if l >= mask_from and not (group_mask >> k) & 1:      # development aid: conv k sees no edges -> BatchNorm of zeros
+                n_out = kw.get('out_nodes') or x.shape[0]
+                o_irr = cfg.conv_irreps(l)[1]
+                z0 = torch.zeros((n_out, irreps_dim(o_irr)), dtype=x.dtype)
+                pre = f'conv_layers.{9 * l + k}.batch_norm'
+                return o3.batch_norm_eval(z0, o_irr, P[f'{pre}.weight'], P[f'{pre}.bias'], P[f'{pre}.running_mean'], P[f'{pre}.running_var'], 1e-5) if cfg.batch_norm else z0
+            return conv_layer(P, f'conv_layers.{9 * l + k}', cfg, l, x, ei, ea, sh_, **kw)
         n_l, n_a, n_r = lig_x.shape[0], atom_x.shape[0], rec_x.shape[0]
         lig_update = cv(0, lig_x, ll_index, cat3(ll_attr, lig_x[ll_index[0]], lig_x[ll_index[1]]), ll_sh)
         lr_update = cv(1, rec_x, lr_index, cat3(lr_attr, lig_x[lr_index[0]], rec_x[lr_index[1]]), lr_sh, out_nodes=n_l)
@@ -175,7 +187,7 @@ def confidence_forward(P, cfg, data, dtype=torch.float32, return_intermediates=F
         h = torch.relu(h)
     conf = F.linear(h, P['confidence_predictor.8.weight'], P['confidence_predictor.8.bias']).squeeze(dim=-1)
     if return_intermediates:
-        return conf, dict(lig_node_attr=lig_x, atom_node_attr=atom_x, rec_node_attr=rec_x, pooled=pooled,
+        return conf, dict(lig_node_attr=lig_x, atom_node_attr=atom_x, rec_node_attr=rec_x, pooled=pooled, edge_sets=edge_sets, x0=x0,
                           counts=dict(ll=ll_index.shape[1], lr=lr_index.shape[1], la=la_index.shape[1], aa=aa_index.shape[1],
                                       ar=ar_index.shape[1], rr=rr_index.shape[1]))
     return conf

@@ -88,7 +88,7 @@ def emulate(ctx, layer, x_pad, src, dst, group_offsets, edge_attr, sh, mode=0, s
                 if mode == 1:      # (v^ v^T - I/3) p with v^ = sh[1:4]/sqrt3
                     vh = v / np.sqrt(3.0)
                     for base, blk in ((F_T2O, p), (F_T2E, q)):
-                        t2 = vh[None] * (blk @ vh)[:, None] - blk / 3.0
+                        t2 = vh[None] * (blk @ vh)[:, None] - blk * (vh @ vh) / 3.0     # |v^| = 0 for zero-length edges
                         for r in range(NV):
                             for c in range(3):
                                 F[i, base + 12 * (r // 4) + 4 * c + r % 4] = t2[r, c]

@@ -543,3 +543,21 @@ def test_randomize_position_device_wrapper(dev, golden):
         assert torch.allclose(torch.linalg.norm(p[bonds[0]] - p[bonds[1]], dim=1), d0[bonds[0], bonds[1]], atol=1e-4)
     with pytest.raises(RuntimeError, match='cuda'):
         randomize_position_device(gl, False, False, 19.0, torch.device('cpu'))
+
+
+def test_confidence_model_golden(dev, golden):
+    """ddk_confidence_forward == the reference's all-atom confidence model (golden produced by
+    models/all_atom_score_model.py through get_model on the stand-ins) on the same poses; ligand features after the conv stack too."""
+    from oracle import confidence_ref as cr
+    from disco_diffdock_amd.runtime import Context, Complex
+    z, c = golden('confidence_paper_model'), complex_from_npz(golden('complex_confidence'))
+    cfg = cr.ConfidenceModelConfig()
+    ctx = Context(device=0, all_atoms=1, embedding_scale=10000.0, num_confidence_outputs=2)
+    ctx.load_state_dict(cr.random_state_dict(cfg, seed=int(z['seed'])))
+    B = int(z['B'])
+    cx = Complex(ctx, c, max_batch=B)
+    cx.set_atoms(c['atom_x'], c['atom_pos'], c['atom_edge_index'], c['atom_rec_index'])
+    conf = cx.confidence_forward(T(z['pos']).to(dev))
+    lig = cx.lig_node_features(B, dev)
+    assert rel_err(lig.cpu(), z['lig_node_attr']) < 1e-4
+    assert rel_err(conf.cpu(), z['confidence']) < 1e-4

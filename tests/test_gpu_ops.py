@@ -111,3 +111,30 @@ def test_fused_conv_equals_unfused_boundary(dev):
     ref = e3nn_lite.batch_norm_eval((summed / cnt).cpu(), o_irr, Pl['batch_norm.weight'], Pl['batch_norm.bias'],
                                     Pl['batch_norm.running_mean'], Pl['batch_norm.running_var']) + node
     assert rel_err(fused.cpu(), ref) < 2e-5
+
+
+@pytest.mark.parametrize('l', range(5))
+def test_confidence_conv_layer_vs_oracle(dev, l):
+    """One conv of the all-atom confidence model (e3nn FCTP with sh 0e+1o+2e, BatchNorm, no residual)
+    through ddk_conv_forward in an all-atom context == the oracle's conv layer."""
+    from oracle import confidence_ref as cr, e3nn_lite as o3
+    from disco_diffdock_amd.runtime import Context
+    cfg = cr.ConfidenceModelConfig()
+    P = {k: v for k, v in cr.random_state_dict(cfg, seed=60 + l).items() if k.startswith('conv_layers.')}
+    ctx = Context(device=0, all_atoms=1, embedding_scale=10000.0, num_confidence_outputs=2)
+    ctx.load_state_dict(P)
+    i_irr, o_irr = cfg.conv_irreps(l)
+    din, dout = smr.irreps_dim(i_irr), smr.irreps_dim(o_irr)
+    g = torch.Generator().manual_seed(l)
+    N, E = 300, 5000
+    node = torch.randn(N, din, generator=g)
+    src = torch.sort(torch.randint(0, N, (E,), generator=g)).values
+    dst = torch.randint(0, N, (E,), generator=g)
+    ea = torch.randn(E, 72, generator=g)
+    vec = torch.randn(E, 3, generator=g)
+    vec[::7] = 0.0                      # zero-length edges (a C-alpha atom and its own residue): Y1 = Y2 = 0
+    sh9 = o3.spherical_harmonics(cfg.sh_irreps, vec, normalize=True, normalization='component')
+    for k in (0, 4, 8):
+        want = cr.conv_layer(P, f'conv_layers.{9 * l + k}', cfg, l, node, torch.stack([src, dst]), ea, sh9, out_nodes=N)
+        got = ctx.conv_forward(9 * l + k, node.to(dev), src.to(dev), dst.to(dev), [0, E, E, E, E], ea.to(dev), sh9[:, :4].contiguous().to(dev), dout)
+        assert rel_err(got.cpu(), want) < 1e-5, (l, k)

@@ -107,6 +107,7 @@ def test_confidence_layer_packing_by_lane_emulation(built, l):
     ei = torch.randint(0, N, (2, E), generator=g)
     ea = torch.randn(E, 72, generator=g)
     vec = torch.randn(E, 3, generator=g)
+    vec[::5] = 0.0                      # zero-length edges: Y1 = Y2 = 0
     sh9 = o3.spherical_harmonics(cfg.sh_irreps, vec, normalize=True, normalization='component')
     x_pad = np.zeros((N, 84)); x_pad[:, :din] = node.numpy()
     summed = emu_conv.emulate(ctx, l, x_pad, ei[0].numpy(), ei[1].numpy(), offs, ea.numpy().astype(np.float64),

@@ -97,6 +97,11 @@ def from_arrays(c, loader_style=True):
     d['receptor', 'rec_contact', 'receptor'].edge_index = torch.as_tensor(c['rec_edge_index']).long()
     d.original_center = torch.as_tensor(c.get('original_center', np.zeros((1, 3), np.float32))).float()
     d.name = c.get('name', 'complex')
+    if 'atom_x' in c:      # all-atom receptor level of the confidence model's graphs (process_mols.py:474-477)
+        d['atom'].x = torch.as_tensor(c['atom_x']).long()
+        d['atom'].pos = torch.as_tensor(c['atom_pos']).float()
+        d['atom', 'atom_contact', 'atom'].edge_index = torch.as_tensor(c['atom_edge_index']).long()
+        d['atom', 'atom_rec_contact', 'receptor'].edge_index = torch.as_tensor(c['atom_rec_index']).long()
     return d
 
 

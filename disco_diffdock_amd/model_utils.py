@@ -8,10 +8,13 @@ from .score_model import TensorProductScoreModel, ModelWrapper
 
 
 def get_model(args, device, t_to_sigma, no_parallel=False, confidence_mode=False):
-    if 'all_atoms' in args and args.all_atoms:
-        raise RuntimeError('ddk: the all-atom (confidence) model is outside the accelerated hot path')
+    if getattr(args, 'all_atoms', False):
+        if not confidence_mode:
+            raise RuntimeError('ddk: the all-atom model is implemented in confidence_mode only (the all-atom SCORE model is outside the hot path)')
+        from .confidence import ConfidenceModel       # utils/model_utils.py:26-27 -> AAScoreModel
+        return ConfidenceModel(args, device)
     if confidence_mode:
-        raise RuntimeError('ddk: confidence_mode is outside the accelerated hot path')
+        raise RuntimeError('ddk: confidence_mode is implemented for all-atom checkpoints (all_atoms: true) only')
     g = lambda k, d: getattr(args, k, d)
     if g('latent_dim', 0) > 0 and g('latent_vocab', 0) != 1:
         raise RuntimeError('ddk: latent conditioning is implemented for the equivariant-latent models (latent_vocab == 1) only')

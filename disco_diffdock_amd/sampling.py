@@ -2,7 +2,7 @@
 (sampling.py:49-54,249) and ``randomize_position`` (:12-46).  The 20-step loop itself - score model forward,
 SDE perturbation, SE(3)/torsion update, Kabsch re-alignment - runs inside libddk.so (``ddk_sample``) without any
 host synchronisation; this file only prepares the per-step host scalars exactly as the reference computes them.
-Options outside the accelerated path (confidence model, AR/latent models, classifier-free guidance, visualisation)
+Options outside the accelerated path (visualisation, the oracle latent encoder)
 raise instead of silently doing something else."""
 import copy
 
@@ -150,8 +150,14 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
              compute_ar_accuracy=False, noise=None):
     """``noise`` (extra, optional): list with one tensor [steps, b, 6+R] per batch of N(0,1) draws (tr xyz, rot xyz,
     torsions) to replace the device generator - used by the parity tests (the reference never seeds its RNGs)."""
-    if confidence_model is not None or visualization_list is not None:
-        raise RuntimeError('ddk: the confidence model and visualisation are outside the accelerated hot path')
+    if visualization_list is not None:
+        raise RuntimeError('ddk: visualisation is outside the accelerated hot path')
+    confidence, confidence_loader = None, None
+    if confidence_model is not None:      # utils/sampling.py:59-62
+        if confidence_data_list is None:
+            raise RuntimeError('ddk: the confidence model needs confidence_data_list (all-atom graphs; the score graphs carry no atoms)')
+        confidence_loader = iter(DataLoader(confidence_data_list, batch_size=batch_size))
+        confidence = []
     latent_model = use_latent and getattr(model_args, 'latent_dim', 0) > 0
     if classifier_free_guidance_weight != 0.0 and not latent_model:
         raise RuntimeError('ddk: classifier-free guidance needs the latent-conditioned model (sampling.py:119-135)')
@@ -199,6 +205,12 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
                     if R:
                         z[t_idx, :, 6:] = torch.normal(mean=0, std=1, size=(b * R,), device=device).reshape(b, R)
             cx.sample(pos, t_arr, sc, nc, z)
+            if confidence_model is not None:   # utils/sampling.py:230-243: final poses into the all-atom graphs, t = 0
+                cbatch = next(confidence_loader)
+                cbatch['ligand'].pos = pos.reshape(-1, 3)
+                cbatch.complex_t = {k: torch.zeros(b, device=device) for k in ('tr', 'rot', 'tor')}
+                out = confidence_model(cbatch)
+                confidence.append(out[0] if type(out) is tuple else out)
             len_lig = pos.shape[1]
             flat = pos.reshape(-1, 3)
             len_rec = len(batch['receptor'].pos) // b
@@ -220,4 +232,6 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
                             lat_pos.append(d_i['receptor'].pos[idx:idx + 1].detach().cpu() + d_i.original_center.detach().cpu())
                     d_i.latent_str = lat_str
                     d_i.latent_pos = torch.cat(lat_pos, dim=0)
-    return data_list, None
+    if confidence_model is not None:          # utils/sampling.py:245-247
+        confidence = torch.nan_to_num(torch.cat(confidence, dim=0), nan=-1000)
+    return data_list, confidence

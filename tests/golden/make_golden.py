@@ -341,6 +341,31 @@ def confidence_golden():
     save('confidence_paper_model', pos=pos_in, confidence=conf, lig_node_attr=inter['lig_node_attr'], B=Bs, seed=31,
          n_tensors=len(P), n_elements=n_el, counts=np.asarray([inter['counts'][k] for k in ('ll', 'lr', 'la', 'aa', 'ar', 'rr')]))
     save('complex_confidence', **{k: v for k, v in c.items() if k != 'name'})
+    # ---- reference sampling() with confidence_model / confidence_data_list (utils/sampling.py:59-62,230-249): DiffDock-S score model
+    #      (seed 7, as in main()) for 2 reverse steps, then the confidence model on the final poses
+    from oracle import score_model_ref as smr
+    with open(os.path.join(REF, 'workdir', 'diffdockS_score_model', 'model_parameters.yml')) as f:
+        sargs = Namespace(**yaml.full_load(f))
+    s_t2s = partial(diffusion_utils.t_to_sigma, args=sargs)
+    smodel = get_model(sargs, torch.device('cpu'), s_t2s, no_parallel=True)
+    sm = smodel.score_model if hasattr(smodel, 'score_model') else smodel
+    sm.load_state_dict(smr.random_state_dict(smr.ScoreModelConfig.from_namespace(sargs), seed=7), strict=True)
+    smodel.eval()
+    steps = 2
+    sched = diffusion_utils.get_t_schedule(steps)
+    dl = [to_graph(c) for _ in range(Bs)]
+    cdl = [graph() for _ in range(Bs)]
+    rng = np.random.default_rng(29)
+    for d_ in dl:
+        p = d_['ligand'].pos
+        d_['ligand'].pos = p - p.mean(0, keepdim=True) + pocket + torch.from_numpy(rng.normal(0, 1.0, size=(1, 3))).float()
+    pos0 = torch.cat([d_['ligand'].pos for d_ in dl])
+    torch.manual_seed(77)
+    out_list, conf2 = ref_sampling.sampling(dl, smodel, steps, sched, sched, sched, torch.device('cpu'), s_t2s, sargs, batch_size=Bs,
+                                            no_final_step_noise=True, use_latent=False, confidence_model=cm, confidence_data_list=cdl,
+                                            confidence_model_args=cargs, temp_sampling=1.0, temp_psi=0.0, temp_sigma_data=0.5)
+    save('trajectory_confidence', pos0=pos0, pos_out=torch.cat([d_['ligand'].pos for d_ in out_list]), confidence=conf2, steps=steps,
+         seed=77, score_seed=7, conf_seed=31)
 
 
 if __name__ == '__main__':

@@ -561,3 +561,40 @@ def test_confidence_model_golden(dev, golden):
     lig = cx.lig_node_features(B, dev)
     assert rel_err(lig.cpu(), z['lig_node_attr']) < 1e-4
     assert rel_err(conf.cpu(), z['confidence']) < 1e-4
+
+
+CONF_ARGS = Namespace(all_atoms=True, ns=24, nv=6, num_conv_layers=5, sigma_embed_dim=32, distance_embed_dim=32, cross_distance_embed_dim=32,
+                      max_radius=5.0, cross_max_distance=80, dynamic_max_cross=True, embedding_type='sinusoidal', embedding_scale=10000,
+                      scale_by_sigma=True, no_torsion=False, no_batch_norm=False, dropout=0.1, use_second_order_repr=False,
+                      esm_embeddings_path='data/esm2_3billion_embeddings.pt', rmsd_classification_cutoff=[2.0], confidence_no_batchnorm=False,
+                      tr_sigma_min=0.1, tr_sigma_max=34.0, rot_sigma_min=0.03, rot_sigma_max=1.55, tor_sigma_min=0.0314, tor_sigma_max=3.14)
+
+
+def test_sampling_with_confidence_golden(dev, model7, golden):
+    """utils/sampling.py:59-62,230-249: the reference's sampling(confidence_model=..., confidence_data_list=...) - DiffDock-S reverse
+    diffusion followed by the all-atom confidence model on the final poses - reproduced through get_model(confidence_mode=True)."""
+    from functools import partial
+    from oracle import confidence_ref as cr
+    from disco_diffdock_amd.sampling import sampling
+    from disco_diffdock_amd.model_utils import get_model
+    from disco_diffdock_amd.data import from_arrays
+    from disco_diffdock_amd.diffusion_utils import t_to_sigma, get_t_schedule
+    z, c = golden('trajectory_confidence'), complex_from_npz(golden('complex_confidence'))
+    cm = get_model(CONF_ARGS, dev, partial(t_to_sigma, args=CONF_ARGS), no_parallel=True, confidence_mode=True)
+    cm.load_state_dict(cr.random_state_dict(cr.ConfidenceModelConfig(), seed=int(z['conf_seed'])), strict=True)
+    cm.eval()
+    n = len(c['lig_pos'])
+    B, steps = len(z['pos0']) // n, int(z['steps'])
+    score_only = {k: v for k, v in c.items() if not k.startswith('atom_')}
+    dl, cdl = [from_arrays(score_only) for _ in range(B)], [from_arrays(c) for _ in range(B)]
+    for i, d in enumerate(dl):
+        d['ligand'].pos = T(z['pos0'][i * n:(i + 1) * n])
+    sched = get_t_schedule(steps)
+    noise = [_ref_noise(int(z['seed']), steps, B, int(c['edge_mask'].sum()))]
+    out, conf = sampling(dl, model7, steps, sched, sched, sched, dev, partial(t_to_sigma, args=ARGS_S), ARGS_S, batch_size=B,
+                         no_final_step_noise=True, use_latent=False, noise=noise, confidence_model=cm, confidence_data_list=cdl,
+                         confidence_model_args=CONF_ARGS, temp_sampling=1.0, temp_psi=0.0, temp_sigma_data=0.5)
+    assert rel_err(torch.cat([d['ligand'].pos for d in out]).cpu(), z['pos_out']) < 1e-4
+    assert tuple(conf.shape) == z['confidence'].shape and rel_err(conf.cpu(), z['confidence']) < 1e-4
+    with pytest.raises(RuntimeError, match='confidence_data_list'):
+        sampling(dl, model7, steps, sched, sched, sched, dev, partial(t_to_sigma, args=ARGS_S), ARGS_S, batch_size=B, confidence_model=cm)

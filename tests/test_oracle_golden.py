@@ -295,3 +295,30 @@ def test_confidence_model_golden(golden):
     assert [inter['counts'][k] for k in ('ll', 'lr', 'la', 'aa', 'ar', 'rr')] == list(z['counts'])
     assert rel_err(inter['lig_node_attr'], z['lig_node_attr']) < 1e-5
     assert rel_err(conf, z['confidence']) < 1e-5
+
+
+def test_sampling_with_confidence_golden(golden, tables):
+    """Reference sampling(confidence_model=..., confidence_data_list=...) == oracle sampler followed by the oracle confidence model."""
+    from oracle import confidence_ref as cr, graph_lite
+    z, c = golden('trajectory_confidence'), complex_from_npz(golden('complex_confidence'))
+    cfg = _cfg_for('diffdockS_score_model')
+    P = smr.random_state_dict(cfg, seed=int(z['score_seed']))
+    n = len(c['lig_pos'])
+    B, steps = len(z['pos0']) // n, int(z['steps'])
+    dl = [to_graph(c) for _ in range(B)]
+    for i, d in enumerate(dl):
+        d['ligand'].pos = T(z['pos0'][i * n:(i + 1) * n])
+    sched = spr.get_t_schedule(steps)
+    torch.manual_seed(int(z['seed']))
+    out, _ = spr.sampling(dl, P, cfg, tables[0], tables[1], steps, sched, sched, sched, batch_size=B, no_final_step_noise=True,
+                          temp_sampling=1.0, temp_psi=0.0, temp_sigma_data=0.5)
+    pos = torch.cat([d['ligand'].pos for d in out])
+    assert rel_err(pos, z['pos_out']) < 1e-4
+    ccfg = cr.ConfidenceModelConfig()
+    b = graph_lite.collate([graph_lite.add_atoms(to_graph(c), c['atom_x'], c['atom_pos'], c['atom_edge_index'], c['atom_rec_index']) for _ in range(B)])
+    b['ligand'].pos = pos.float()
+    for nt in ('ligand', 'receptor', 'atom'):
+        b[nt].node_t = {k: torch.zeros(b[nt].num_nodes) for k in ('tr', 'rot', 'tor')}
+    b.complex_t = {k: torch.zeros(B) for k in ('tr', 'rot', 'tor')}
+    conf = cr.confidence_forward(cr.random_state_dict(ccfg, seed=int(z['conf_seed'])), ccfg, b)
+    assert rel_err(conf, z['confidence']) < 1e-4

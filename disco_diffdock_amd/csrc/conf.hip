@@ -314,13 +314,13 @@ __global__ __launch_bounds__(256) void conf_la_kernel(LaArgs A) {
 // group table of one forward: [0..8] gbeg, [9..17] gend for [ll lr la aa al ar rr rl ra] from the shared graph kernel's info
 // table (go[0..4] of its [ll | lr | rr | rl] list), the la counter and the static set sizes
 __global__ void conf_gtab_kernel(int32_t* gtab, const int32_t* info, int B, int E_aa, int n_atom, int off_la, int off_al, int off_aa,
-                                 int off_ar, int off_ra, int cap_la, int mask) {
+                                 int off_ar, int off_ra, int cap_la) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const int go0 = info[5], go1 = info[6], go2 = info[7], go3 = info[8], go4 = info[9];
   const int n_la = min(gtab[18], cap_la);
   const int beg[9] = {go0, go1, off_la, off_aa, off_al, off_ar, go2, go3, off_ra};
   const int end[9] = {go1, go2, off_la + n_la, off_aa + B * E_aa, off_al + n_la, off_ar + B * n_atom, go3, go4, off_ra + B * n_atom};
-  for (int g = 0; g < 9; ++g) { gtab[g] = beg[g]; gtab[9 + g] = ((mask >> g) & 1) ? end[g] : beg[g]; }
+  for (int g = 0; g < 9; ++g) { gtab[g] = beg[g]; gtab[9 + g] = end[g]; }
 }
 
 // in-degree of every (node, slot): slot = group % 3
@@ -584,8 +584,6 @@ int ddk_confidence_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float
   const int64_t atom_base = Bm * n_lig, rec_base = Bm * ((int64_t)n_lig + n_atom);
   hipError_t e;
 #define CK(x, what) do { e = (x); if (e != hipSuccess) return hip_fail(ctx, e, what); } while (0)
-  static const int dbg_mask = [] { const char* e = getenv("DDK_CONF_GROUP_MASK"); return e ? atoi(e) : 0x1ff; }();   // development aid
-  static const int dbg_from = [] { const char* e = getenv("DDK_CONF_MASK_FROM_LAYER"); return e ? atoi(e) : 0; }();
   // ---- dynamic graphs ------------------------------------------------------------------------------
   GraphArgs G;
   G.lig_pos = lig_pos; G.rec_pos = cx->rec_pos; G.bond_src = cx->bond_src; G.bond_dst = cx->bond_dst;
@@ -611,7 +609,7 @@ int ddk_confidence_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float
   hipLaunchKernelGGL(conf_la_kernel, dim3(B), dim3(256), 0, s, LA);
   CK(hipGetLastError(), "la graph");
   hipLaunchKernelGGL(conf_gtab_kernel, dim3(1), dim3(64), 0, s, K->gtab, cx->info, B, K->E_aa, n_atom, (int)K->off_la, (int)K->off_al,
-                     (int)K->off_aa, (int)K->off_ar, (int)K->off_ra, (int)K->cap_la, dbg_from > 0 ? 0x1ff : dbg_mask);
+                     (int)K->off_aa, (int)K->off_ar, (int)K->off_ra, (int)K->cap_la);
   CK(hipGetLastError(), "group table");
   CK(hipMemsetAsync(K->deg3, 0, (size_t)K->n_nodes * 3 * sizeof(int32_t), s), "deg3");
   hipLaunchKernelGGL(conf_deg_kernel, dim3((unsigned)((K->cap_total + 255) / 256)), dim3(256), 0, s, K->gtab, K->e_src, K->deg3, K->cap_total);
@@ -622,13 +620,8 @@ int ddk_confidence_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float
   hipLaunchKernelGGL(conf_node_init_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, K->lig_x0, K->atom_x0, K->rec_x0, B, (int)Bm,
                      n_lig, n_atom, n_rec, xin);
   CK(hipGetLastError(), "node init");
-  static const int dbg_layers = [] { const char* e = getenv("DDK_CONF_MAX_LAYERS"); return e ? atoi(e) : 1000; }();   // development aid
-  for (int l = 0; l < c.num_conv_layers && l < dbg_layers; ++l) {
+  for (int l = 0; l < c.num_conv_layers; ++l) {
     const ConvLayerDev& L = ctx->conv[l];
-    if (dbg_from > 0 && l == dbg_from) {   // development aid: restrict the groups from this layer on
-      hipLaunchKernelGGL(conf_gtab_kernel, dim3(1), dim3(64), 0, s, K->gtab, cx->info, B, K->E_aa, n_atom, (int)K->off_la, (int)K->off_al,
-                         (int)K->off_aa, (int)K->off_ar, (int)K->off_ra, (int)K->cap_la, dbg_mask);
-    }
     const bool last = l == c.num_conv_layers - 1;      // all_atom_score_model.py:241 "last layer optimisation": ligand updates only
     CK(hipMemsetAsync(K->sum3, 0, (size_t)(last ? atom_base : K->n_nodes) * 3 * XW * sizeof(float), s), "memset sum3");
     CK(hipMemsetAsync(cx->info + 10 + (l % 8), 0, sizeof(int32_t), s), "counter reset");

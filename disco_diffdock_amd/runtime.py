@@ -239,6 +239,7 @@ class Complex:
         B = pos.shape[0]
         out = torch.empty((B, int(self.ctx.cfg.num_confidence_outputs)), dtype=torch.float32, device=pos.device)
         self.ctx._check(self.ctx.L.ddk_confidence_forward(self.ctx.h, self.h, B, _ptr(pos), _ptr(out), _stream()), 'ddk_confidence_forward')
+        self.confidence_counts()      # one host sync per confidence batch: fails loudly if the ligand-atom edge capacity overflowed
         return out
 
     def confidence_counts(self):

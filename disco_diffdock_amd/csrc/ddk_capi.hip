@@ -342,6 +342,55 @@ static int build_conv_layer(ddk_ctx* ctx, int mode, int l, ConvLayerDev& L) {
       return fail(ctx, DDK_ERR_NOMEM, "device allocation failed while packing conv weights");
     if (hipMemcpy(L.tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice) != hipSuccess)
       return fail(ctx, DDK_ERR_HIP, "tile table upload failed");
+    if (mode == 0 && c.conv_f16x3) {   // error-compensated f16 split of the same (scaled) weights
+      auto split = [](float v, uint16_t& hi, uint16_t& lo) {
+        const _Float16 h = (_Float16)v;
+        const _Float16 l = (_Float16)((v - (float)h) * 2048.0f);
+        memcpy(&hi, &h, 2); memcpy(&lo, &l, 2);
+      };
+      std::vector<uint8_t> w2h((size_t)NG * L.n_tiles * W2H_TILE_BYTES, 0);
+      std::vector<uint16_t> w1h((size_t)NG * 3 * (W1H_TILE_BYTES / 2), 0);
+      for (int g = 0; g < NG; ++g) {
+        const float* w2 = w2all.data() + g * w2sz;    // fp32 fragment order: [t][s/4][lane][s&3], s = register of the lane half
+        const float* w1 = w1all.data() + g * w1sz;
+        for (int t = 0; t < L.n_tiles; ++t) {
+          uint8_t* rec = w2h.data() + ((size_t)g * L.n_tiles + t) * W2H_TILE_BYTES;
+          uint16_t* hi = (uint16_t*)rec; uint16_t* lo = (uint16_t*)(rec + W2H_FRAG_BYTES);
+          for (int s = 0; s < 5; ++s)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int i = 0; i < 8; ++i) {
+                const int r = 8 * s + i;
+                float v = r < 36 ? w2[(((size_t)t * 9 + r / 4) * 64 + lane) * 4 + (r & 3)] : 0.f;
+                if (r == 36 && lane < 32) {      // K slot 36 of lane half 0 multiplies the constant 1: the bias of tile row `lane`
+                  const float* b2t = b2all.data() + g * b2sz + (size_t)t * 32;   // [hh][16] in D-register order
+                  for (int hh2 = 0; hh2 < 2; ++hh2)
+                    for (int rr = 0; rr < 16; ++rr)
+                      if (d_row(rr, hh2) == lane) v = b2t[hh2 * 16 + rr];
+                }
+                split(v, hi[(s * 64 + lane) * 8 + i], lo[(s * 64 + lane) * 8 + i]);
+              }
+          memcpy(rec + 2 * W2H_FRAG_BYTES, b2all.data() + g * b2sz + (size_t)t * 32, 128);
+          memcpy(rec + 2 * W2H_FRAG_BYTES + 128, &tiles[t], 8);
+        }
+        for (int T = 0; T < 3; ++T) {
+          uint16_t* hi = w1h.data() + ((size_t)g * 3 + T) * (W1H_TILE_BYTES / 2);
+          uint16_t* lo = hi + W2H_FRAG_BYTES / 2;
+          for (int s = 0; s < 5; ++s)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int i = 0; i < 8; ++i) {
+                const int r = 8 * s + i;
+                const float v = r < 36 ? w1[(((size_t)T * 9 + r / 4) * 64 + lane) * 4 + (r & 3)] : 0.f;
+                split(v, hi[(s * 64 + lane) * 8 + i], lo[(s * 64 + lane) * 8 + i]);
+              }
+        }
+      }
+      L.w2h = (uint8_t*)dev_alloc(ctx, w2h.size());
+      L.w1h = (uint16_t*)dev_alloc(ctx, w1h.size() * 2);
+      if (!L.w2h || !L.w1h) return fail(ctx, DDK_ERR_NOMEM, "device allocation failed while packing conv weights (f16 split)");
+      if (hipMemcpy(L.w2h, w2h.data(), w2h.size(), hipMemcpyHostToDevice) != hipSuccess ||
+          hipMemcpy(L.w1h, w1h.data(), w1h.size() * 2, hipMemcpyHostToDevice) != hipSuccess)
+        return fail(ctx, DDK_ERR_HIP, "f16 weight upload failed");
+    }
     L.w1p[0] = d1; L.b1p[0] = db1; L.w2r[0] = d2;    // group-major contiguous: group g at + g * stride
     for (int g = 1; g < 4; ++g) {
       L.w1p[g] = d1 + g * w1sz;

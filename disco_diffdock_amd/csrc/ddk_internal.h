@@ -54,6 +54,14 @@ template <> struct ConvTraits<1> { static constexpr int WAVES = 6, FS = F_STRIDE
 template <int MODE> constexpr size_t conv_lds_bytes() { return (size_t)(ConvTraits<MODE>::WAVES * 32 * ConvTraits<MODE>::FS + 2 * W2_TILE_FLOATS + 16) * 4; }
 static_assert(conv_lds_bytes<1>() <= 160 * 1024, "LDS budget (l<=2)");
 constexpr int CONV_MAX_GROUPS = 9;
+// 3 x f16 mode (ddk_config.conv_f16x3): W2 tile record = hi fragments [5][64][8] fp16 | lo*2^11 fragments [5][64][8] fp16 |
+// bias [2][16] f32 | tile descriptor (2 x int32) | pad ; element (s, lane, i) of a fragment set = weight of tile row lane&31 for the
+// hidden unit held by register 8*s+i of lane half lane>>5 (zero for registers >= 36: K = 72 padded to 80)
+constexpr int W2H_FRAG_BYTES = 5 * 64 * 8 * 2;                      // 5,120
+constexpr int W2H_TILE_BYTES = 2 * W2H_FRAG_BYTES + 128 + 16;       // 10,384 = 649 x 16 B
+constexpr int W1H_TILE_BYTES = 2 * W2H_FRAG_BYTES;                  // GEMM1: hi + lo fragments of one 32-row tile
+constexpr size_t CONV_H_LDS_BYTES = (size_t)CONV_WAVES * 32 * F_STRIDE * 4 + 2 * W2H_TILE_BYTES + 64;   // 156,000 B
+static_assert(CONV_H_LDS_BYTES <= 160 * 1024 && W2H_TILE_BYTES % 16 == 0, "LDS budget (3 x f16)");
 
 // One W2 "tile" = 32 weight rows x 72 hidden units = one burst of 36 v_mfma_f32_32x32x2_f32 per 32 edges.
 // Tile row rho = 8*rq + 4*hh + j (rq = accumulator quad 0..3, hh = lane half, j = 0..3) holds the weight that multiplies
@@ -88,6 +96,8 @@ struct ConvLayerDev {          // device copies for one TensorProductConvLayer w
   float* b1p[4] = {};          // [3][2][16]
   float* w2r[4] = {};          // [n_tiles][W2_TILE_FLOATS]: per tile the fragments [9][64][4], the bias [2][16], the TileDesc words
   TileDesc* tiles = nullptr;   // [n_tiles]
+  uint16_t* w1h = nullptr;     // 3 x f16 mode: [groups][3][W1H_TILE_BYTES/2]
+  uint8_t* w2h = nullptr;      // 3 x f16 mode: [groups][n_tiles][W2H_TILE_BYTES]
   int n_cols = 0;              // flush columns (8 output channels each); col_start[c] = first tile of column c, col_start[n_cols] = n_tiles
   int col_start[17] = {};
   float* bn_mean = nullptr;    // [XW]  running_mean on 0e channels, 0 elsewhere
@@ -174,6 +184,7 @@ struct ConvLaunch {
   const int32_t* gend = nullptr;
 };
 hipError_t launch_conv_fused(const ConvLayerDev& L, const ConvLaunch& a, int n_cu, hipStream_t s);
+hipError_t launch_conv_fused_h(const ConvLayerDev& L, const ConvLaunch& a, int n_cu, hipStream_t s);   // k_conv_h.hip (3 x f16)
 hipError_t launch_conv_setup(int32_t* tile_info, const int64_t* group_offsets_host, hipStream_t s);
 hipError_t launch_pad_rows(const float* x, int64_t n, int din, float* xpad, hipStream_t s);
 hipError_t launch_count_deg(const int32_t* src, int64_t E, int32_t* deg, hipStream_t s);

@@ -33,51 +33,9 @@
 // Roofline: MFMA-bound (2*72*(72+W) flop per edge vs ~650 B per edge of HBM traffic), see DESIGN.md.
 #include <stdlib.h>
 
-#include "ddk_internal.h"
+#include "k_conv_common.h"
 
 namespace ddk {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct ConvKArgs {
-  const float* x;
-  const int32_t* src;
-  const int32_t* dst;
-  const float* edge_attr;
-  const float* sh;
-  float* sum;
-  const int32_t* tile_info;
-  int32_t* counter;
-  const float* w1p;   // [4][3][9][64][4]
-  const float* b1p;   // [4][3][2][16]
-  const float* w2r;   // [4][n_tiles][W2_TILE_FLOATS]
-  const TileDesc* tiles;  // [n_tiles]
-  int n_tiles;
-  int n_cols;         // flush columns; col_start[c] .. col_start[c+1] = tiles of column c
-  int col_start[17];
-  int g2_limit;       // >= 0: evaluate only the first g2_limit edges of group 2 (see ConvLaunch)
-  float* sum_g2;
-  int g2_node_off;
-  int n_groups, n_active, n_slots;   // edge groups [gbeg[g], gend[g]); the first n_active run; sum row = (node*n_slots + slot(g))
-  uint32_t slots;
-  const int32_t* gbeg;
-  const int32_t* gend;
-};
-
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
-
-#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
-
-// tile descriptors are wave-uniform: read them through the constant address space (s_load -> SGPRs)
-typedef const int32_t __attribute__((address_space(4))) cint32;
-struct TileQ { int w0, chan0; };
-__device__ __forceinline__ TileQ load_tile(const TileDesc* p) {
-  cint32* q = (cint32*)(uintptr_t)p;
-  TileQ r;
-  r.w0 = q[0]; r.chan0 = q[1];
-  return r;
-}
 
 __device__ __forceinline__ void load_frags(float4 (&a)[9], f32x16& B, const float* w, const float* b) {
 #pragma unroll
@@ -102,53 +60,6 @@ __device__ __forceinline__ f32x16 burst(const float4 (&a)[9], const float (&h)[3
     D = MFMA(a[s4].w, h[4 * s4 + 3], D);
   }
   return D;
-}
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f32x4 ldv4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-#define D_LO(D, rq) (f32x2{(D)[4 * (rq)], (D)[4 * (rq) + 1]})
-#define D_HI(D, rq) (f32x2{(D)[4 * (rq) + 2], (D)[4 * (rq) + 3]})
-#define V_LO(f) __builtin_shufflevector(f, f, 0, 1)
-#define V_HI(f) __builtin_shufflevector(f, f, 2, 3)
-
-// kind-specialised tensor-product epilogue of one W2 tile (wave-uniform branch).  Every accumulator is a register PAIR
-// {sum over even rows j, sum over odd rows j} so that the whole epilogue is v_pk_fma_f32 on adjacent registers
-// (D[4rq+j], D[4rq+j+1]) x (f[j], f[j+1]) without any shuffling moves; the pair is added up when the column is flushed.
-__device__ __forceinline__ void tile_epilogue(int kind, const f32x16& D, f32x4 f0, f32x4 f1, f32x4 f2, f32x2 (&accA)[4],
-                                              f32x2 (&accV)[4][3]) {
-  if (kind == T_TV) {   // f0/f1/f2 = x/y/z components of the 4 feature rows
-#pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {
-      const f32x2 dl = D_LO(D, rq), dh = D_HI(D, rq);
-      accV[rq][0] = __builtin_elementwise_fma(dh, V_HI(f0), __builtin_elementwise_fma(dl, V_LO(f0), accV[rq][0]));
-      accV[rq][1] = __builtin_elementwise_fma(dh, V_HI(f1), __builtin_elementwise_fma(dl, V_LO(f1), accV[rq][1]));
-      accV[rq][2] = __builtin_elementwise_fma(dh, V_HI(f2), __builtin_elementwise_fma(dl, V_LO(f2), accV[rq][2]));
-    }
-  } else if (kind == T_RA) {
-#pragma unroll
-    for (int rq = 0; rq < 4; ++rq) accA[rq] = __builtin_elementwise_fma(D_LO(D, rq), V_LO(f0), accA[rq]);
-#pragma unroll
-    for (int rq = 0; rq < 4; ++rq) accA[rq] = __builtin_elementwise_fma(D_HI(D, rq), V_HI(f0), accA[rq]);
-  } else {
-#pragma unroll
-    for (int rq = 0; rq < 4; ++rq) accV[rq][0] = __builtin_elementwise_fma(D_LO(D, rq), V_LO(f0), accV[rq][0]);
-#pragma unroll
-    for (int rq = 0; rq < 4; ++rq) accV[rq][0] = __builtin_elementwise_fma(D_HI(D, rq), V_HI(f0), accV[rq][0]);
-  }
-}
-
-// control words of the 5-step segmented scan over runs of equal edge_src (identical for every channel of an edge tile)
-struct SegCtl { bool m1, m2, m4, m8, m16, tail, valid; };
-__device__ __forceinline__ void seg_add(float* dst, float xv, const SegCtl& c) {
-  xv = c.valid ? xv : 0.0f;
-  float up;
-  up = __shfl_up(xv, 1, 32);  if (c.m1) xv += up;
-  up = __shfl_up(xv, 2, 32);  if (c.m2) xv += up;
-  up = __shfl_up(xv, 4, 32);  if (c.m4) xv += up;
-  up = __shfl_up(xv, 8, 32);  if (c.m8) xv += up;
-  up = __shfl_up(xv, 16, 32); if (c.m16) xv += up;
-  if (c.tail) unsafeAtomicAdd(dst, xv);
 }
 
 // LDS fragments of one staged W2 tile -> registers (lane-contiguous 16-B reads: conflict free)
@@ -371,6 +282,9 @@ __global__ __launch_bounds__(64 * ConvTraits<MODE>::WAVES) void conv_fused_kerne
     f32x16 B0, B1;
     lds_frags(a0, B0, ring, lane, hh);
     int2 tqv = *reinterpret_cast<const int2*>(ring + 2336);
+    // every wave must have taken tile t_begin out of stage 0 before the first iteration's publication of tile t_begin+2 overwrites it
+    // (a fast wave reaches that store one burst after this point; the second wave of a SIMD can still be reading)
+    __syncthreads();
     TileQ tq;
     tq.w0 = __builtin_amdgcn_readfirstlane(tqv.x); tq.chan0 = __builtin_amdgcn_readfirstlane(tqv.y);
 #define PSUM(p) ((p).x + (p).y)
@@ -509,7 +423,9 @@ static hipError_t launch_conv_t(const ConvKArgs& k, int n_cu, hipStream_t s) {
 }
 
 hipError_t launch_conv_fused(const ConvLayerDev& L, const ConvLaunch& a, int n_cu, hipStream_t s) {
+  if (L.w2h != nullptr && a.mode == 0) return launch_conv_fused_h(L, a, n_cu, s);   // ddk_config.conv_f16x3
   ConvKArgs k;
+  k.w1h = nullptr; k.w2h = nullptr;
   k.x = a.x; k.src = a.src; k.dst = a.dst; k.edge_attr = a.edge_attr; k.sh = a.sh; k.sum = a.sum;
   k.tile_info = a.tile_info; k.counter = a.counter;
   k.w1p = L.w1p[0]; k.b1p = L.b1p[0]; k.w2r = L.w2r[0]; k.tiles = L.tiles; k.n_tiles = L.n_tiles;

@@ -1,0 +1,99 @@
+// Device helpers shared by the fused conv kernels (k_conv.hip: fp32 MFMA; k_conv_h.hip: error-compensated 3 x f16 MFMA).
+#pragma once
+#include "ddk_internal.h"
+
+namespace ddk {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvKArgs {
+  const float* x;
+  const int32_t* src;
+  const int32_t* dst;
+  const float* edge_attr;
+  const float* sh;
+  float* sum;
+  const int32_t* tile_info;
+  int32_t* counter;
+  const float* w1p;   // [4][3][9][64][4]
+  const float* b1p;   // [4][3][2][16]
+  const float* w2r;   // [4][n_tiles][W2_TILE_FLOATS]
+  const TileDesc* tiles;  // [n_tiles]
+  const uint16_t* w1h;   // 3 x f16 mode: [groups][3][2][5][64][8] fp16 (hi, lo*2^11) GEMM1 fragments
+  const uint8_t* w2h;    // 3 x f16 mode: [groups][n_tiles][W2H_TILE_BYTES] tile records
+  int n_tiles;
+  int n_cols;         // flush columns; col_start[c] .. col_start[c+1] = tiles of column c
+  int col_start[17];
+  int g2_limit;       // >= 0: evaluate only the first g2_limit edges of group 2 (see ConvLaunch)
+  float* sum_g2;
+  int g2_node_off;
+  int n_groups, n_active, n_slots;   // edge groups [gbeg[g], gend[g]); the first n_active run; sum row = (node*n_slots + slot(g))
+  uint32_t slots;
+  const int32_t* gbeg;
+  const int32_t* gend;
+};
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// tile descriptors are wave-uniform: read them through the constant address space (s_load -> SGPRs)
+typedef const int32_t __attribute__((address_space(4))) cint32;
+struct TileQ { int w0, chan0; };
+__device__ __forceinline__ TileQ load_tile(const TileDesc* p) {
+  cint32* q = (cint32*)(uintptr_t)p;
+  TileQ r;
+  r.w0 = q[0]; r.chan0 = q[1];
+  return r;
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 ldv4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+#define D_LO(D, rq) (f32x2{(D)[4 * (rq)], (D)[4 * (rq) + 1]})
+#define D_HI(D, rq) (f32x2{(D)[4 * (rq) + 2], (D)[4 * (rq) + 3]})
+#define V_LO(f) __builtin_shufflevector(f, f, 0, 1)
+#define V_HI(f) __builtin_shufflevector(f, f, 2, 3)
+
+// kind-specialised tensor-product epilogue of one W2 tile (wave-uniform branch).  Every accumulator is a register PAIR
+// {sum over even rows j, sum over odd rows j} so that the whole epilogue is v_pk_fma_f32 on adjacent registers
+// (D[4rq+j], D[4rq+j+1]) x (f[j], f[j+1]) without any shuffling moves; the pair is added up when the column is flushed.
+__device__ __forceinline__ void tile_epilogue(int kind, const f32x16& D, f32x4 f0, f32x4 f1, f32x4 f2, f32x2 (&accA)[4],
+                                              f32x2 (&accV)[4][3]) {
+  if (kind == T_TV) {   // f0/f1/f2 = x/y/z components of the 4 feature rows
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const f32x2 dl = D_LO(D, rq), dh = D_HI(D, rq);
+      accV[rq][0] = __builtin_elementwise_fma(dh, V_HI(f0), __builtin_elementwise_fma(dl, V_LO(f0), accV[rq][0]));
+      accV[rq][1] = __builtin_elementwise_fma(dh, V_HI(f1), __builtin_elementwise_fma(dl, V_LO(f1), accV[rq][1]));
+      accV[rq][2] = __builtin_elementwise_fma(dh, V_HI(f2), __builtin_elementwise_fma(dl, V_LO(f2), accV[rq][2]));
+    }
+  } else if (kind == T_RA) {
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) accA[rq] = __builtin_elementwise_fma(D_LO(D, rq), V_LO(f0), accA[rq]);
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) accA[rq] = __builtin_elementwise_fma(D_HI(D, rq), V_HI(f0), accA[rq]);
+  } else {
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) accV[rq][0] = __builtin_elementwise_fma(D_LO(D, rq), V_LO(f0), accV[rq][0]);
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) accV[rq][0] = __builtin_elementwise_fma(D_HI(D, rq), V_HI(f0), accV[rq][0]);
+  }
+}
+
+// control words of the 5-step segmented scan over runs of equal edge_src (identical for every channel of an edge tile)
+struct SegCtl { bool m1, m2, m4, m8, m16, tail, valid; };
+__device__ __forceinline__ void seg_add(float* dst, float xv, const SegCtl& c) {
+  xv = c.valid ? xv : 0.0f;
+  float up;
+  up = __shfl_up(xv, 1, 32);  if (c.m1) xv += up;
+  up = __shfl_up(xv, 2, 32);  if (c.m2) xv += up;
+  up = __shfl_up(xv, 4, 32);  if (c.m4) xv += up;
+  up = __shfl_up(xv, 8, 32);  if (c.m8) xv += up;
+  up = __shfl_up(xv, 16, 32); if (c.m16) xv += up;
+  if (c.tail) unsafeAtomicAdd(dst, xv);
+}
+
+
+}  // namespace ddk

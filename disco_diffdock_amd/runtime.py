@@ -16,7 +16,8 @@ DEFAULTS = dict(ns=24, nv=6, num_conv_layers=5, sigma_embed_dim=32, distance_emb
                 dynamic_max_cross=1, embedding_scale=1000.0, scale_by_sigma=1, no_torsion=0, batch_norm=1,
                 latent_dim=0, latent_vocab=0, latent_droprate=0.0, lm_embedding_dim=1280,
                 tr_sigma_min=0.1, tr_sigma_max=19.0, rot_sigma_min=0.03, rot_sigma_max=1.55,
-                tor_sigma_min=0.03, tor_sigma_max=3.14, device=0, all_atoms=0, num_confidence_outputs=1, confidence_no_batchnorm=0)
+                tor_sigma_min=0.03, tor_sigma_max=3.14, device=0, all_atoms=0, num_confidence_outputs=1, confidence_no_batchnorm=0,
+                conv_f16x3=0)
 
 
 def config_from_args(args, device=0):
@@ -54,6 +55,8 @@ class Context:
     def __init__(self, device=0, **cfg):
         self.L = _lib.lib()
         d = dict(DEFAULTS)
+        if os.environ.get('DDK_CONV_F16X3'):      # select the error-compensated 3 x f16 conv kernel for every context of this process
+            d['conv_f16x3'] = int(os.environ['DDK_CONV_F16X3'])
         d.update(cfg)
         d['device'] = device
         self.cfg = SimpleNamespace(**d)

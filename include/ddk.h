@@ -49,6 +49,10 @@ typedef struct ddk_config {
   int32_t all_atoms;                   /* 1: AAScoreModel in confidence_mode (sh_lmax=2 FCTP, OldAtomEncoder, 9 convs/layer) */
   int32_t num_confidence_outputs;      /* len(rmsd_classification_cutoff)+1 when it is a list, else 1 */
   int32_t confidence_no_batchnorm;
+  /* 1: the radial-MLP GEMMs of the fused conv kernel run as an error-compensated 3 x f16 product on the f16 matrix pipe
+   *    (w = w_hi + w_lo/2^11, h = h_hi + h_lo/2^11, fp32 accumulation; the dropped lo.lo term is 2^-22 relative) instead of the
+   *    fp32 MFMA.  Same fp32-level accuracy; 0 (default) keeps the plain fp32 MFMA. */
+  int32_t conv_f16x3;
 } ddk_config;
 
 /* ---- lifetime ---------------------------------------------------------------------------- */

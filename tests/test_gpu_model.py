@@ -598,3 +598,28 @@ def test_sampling_with_confidence_golden(dev, model7, golden):
     assert tuple(conf.shape) == z['confidence'].shape and rel_err(conf.cpu(), z['confidence']) < 1e-4
     with pytest.raises(RuntimeError, match='confidence_data_list'):
         sampling(dl, model7, steps, sched, sched, sched, dev, partial(t_to_sigma, args=ARGS_S), ARGS_S, batch_size=B, confidence_model=cm)
+
+
+@pytest.mark.parametrize('t', [1.0, 0.05])
+def test_score_model_golden_f16x3(dev, golden, t):
+    """The opt-in 3 x f16 conv kernel (ddk_config.conv_f16x3) against the reference-produced score goldens, same 1e-4 bar."""
+    from functools import partial
+    from disco_diffdock_amd.model_utils import get_model
+    from disco_diffdock_amd.diffusion_utils import t_to_sigma
+    tag = 'diffdockS_score_model'
+    z = golden(f'score_{tag}_t{t}')
+    c = complex_from_npz(golden(f'complex_{tag}'))
+    model = get_model(ARGS_S, dev, partial(t_to_sigma, args=ARGS_S), no_parallel=True)
+    sm = model.score_model
+    sm.ctx.close()
+    from disco_diffdock_amd.runtime import Context
+    sm.cfg['conv_f16x3'] = 1
+    sm.ctx = Context(device=0, **sm.cfg)
+    sm.load_state_dict(smr.random_state_dict(CFG, seed=7), strict=True)
+    B = int(z['B'])
+    b = _dev_batch(c, B, z['pos'], dev, t)
+    tr, rot, tor = sm(b, keep_receptor_features=True)
+    lig, rec = sm.last_complex.node_features(B, dev)
+    assert rel_err(lig.cpu(), z['lig_node_attr']) < 1e-4 and rel_err(rec.cpu(), z['rec_node_attr']) < 1e-4
+    errs = {name: rel_err(a.cpu(), z[name]) for name, a in (('tr', tr), ('rot', rot), ('tor', tor))}
+    assert max(errs.values()) < 1e-4, errs

@@ -138,3 +138,28 @@ def test_confidence_conv_layer_vs_oracle(dev, l):
         want = cr.conv_layer(P, f'conv_layers.{9 * l + k}', cfg, l, node, torch.stack([src, dst]), ea, sh9, out_nodes=N)
         got = ctx.conv_forward(9 * l + k, node.to(dev), src.to(dev), dst.to(dev), [0, E, E, E, E], ea.to(dev), sh9[:, :4].contiguous().to(dev), dout)
         assert rel_err(got.cpu(), want) < 1e-5, (l, k)
+
+
+@pytest.mark.parametrize('l,N,splits,sort_src', [
+    (0, 50, [0, 100, 1000, 1777, 3001], True),
+    (1, 300, [0, 0, 2049, 2049, 4100], False),
+    (3, 400, [0, 1500, 6000, 9000, 12345], True),
+    (4, 400, [0, 33, 64, 4000, 4031], False),
+])
+def test_conv_layer_f16x3_vs_oracle(dev, l, N, splits, sort_src):
+    """Opt-in mode ddk_config.conv_f16x3: the radial-MLP GEMMs as an error-compensated 3 x f16 product (f32 accumulation) must meet
+    the SAME bar as the fp32 MFMA path against the fp64 oracle, and repeated launches must agree (no timing dependence)."""
+    from disco_diffdock_amd.runtime import Context
+    i_irr, o_irr = CFG.conv_irreps(l)
+    Pl = smr.random_conv_layer_params(CFG, l, 40 + l, True)
+    node, ei, ea, sh = _random_case(l, N, splits, 7 + l, sort_src)
+    ctx = Context(device=0, conv_f16x3=1)
+    ctx.load_state_dict({f'conv_layers.{l}.{k}': v for k, v in Pl.items()})
+    dout = smr.irreps_dim(o_irr)
+    P = {'L.' + k: v.double() for k, v in Pl.items()}
+    ref = smr.tp_conv_layer(P, 'L', node.double(), ei, [ea.double()[splits[i]:splits[i + 1]] for i in range(4)], sh.double(),
+                            i_irr, '1x0e+1x1o', o_irr, residual=True, batch_norm=True, faster=True, edge_groups=4)
+    args = (l, node.to(dev), ei[0].to(dev), ei[1].to(dev), splits, ea.to(dev), sh.to(dev), dout)
+    for _ in range(5):
+        out = ctx.conv_forward(*args).cpu()
+        assert rel_err(out, ref) < 1e-5

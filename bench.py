@@ -215,7 +215,7 @@ def main():
                                    'README low-temperature sampling, no_final_step_noise; 1 step = 1 complex',
                        'samples_per_complex': SAMPLES, 'inference_steps': STEPS, 'complexes_per_gpu': N_COMPLEXES,
                        'parallelism': f'complexes sharded over {world} process(es), one per GPU, final RCCL pose gather'},
-            'roofline': {'bound': 'mfma', 'kernel': 'ddk::conv_fused_kernel<true>', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS,
+            'roofline': {'bound': 'mfma', 'kernel': 'ddk::conv_fused_kernel<true, 0>', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS,
                          'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': pmc_traffic(),
                          'traffic_source': 'profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over this '
                                            'command, bytes per conv_fused launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 FETCH correction)',

@@ -297,7 +297,7 @@ class FullyConnectedTensorProduct(_TPBase):
             w = weight[..., off:off + n].reshape(weight.shape[:-1] + shape)
             c = wigner_3j(self.irreps_in1[i1].ir.l, self.irreps_in2[i2].ir.l, self.irreps_out[io].ir.l, x1.dtype)
             outs[io] = outs[io] + coeff * torch.einsum('...uvw,ijk,...ui,...vj->...wk', w, c, b1[i1], b2[i2])
-        return torch.cat([o.reshape(o.shape[:-2] + (-1,)) for o in outs], dim=-1)
+        return torch.cat([o.reshape(o.shape[:-2] + (o.shape[-2] * o.shape[-1],)) for o in outs], dim=-1)   # (explicit size: works for 0 edges)
 
 
 class FullTensorProduct(_TPBase):

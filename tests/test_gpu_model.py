@@ -623,3 +623,37 @@ def test_score_model_golden_f16x3(dev, golden, t):
     assert rel_err(lig.cpu(), z['lig_node_attr']) < 1e-4 and rel_err(rec.cpu(), z['rec_node_attr']) < 1e-4
     errs = {name: rel_err(a.cpu(), z[name]) for name, a in (('tr', tr), ('rot', rot), ('tor', tor))}
     assert max(errs.values()) < 1e-4, errs
+
+
+@pytest.mark.parametrize('shift,B,max_batch', [(0.0, 1, 1), (0.0, 2, 5), (60.0, 3, 3)])
+def test_confidence_model_vs_oracle_edge_cases(dev, golden, shift, B, max_batch):
+    """Confidence model against the CPU oracle: a single pose, fewer poses than max_batch (node numbering uses max_batch strides), and a
+    ligand far outside the receptor (no ligand-atom and no ligand-residue edges: empty edge groups, BatchNorm of zeros)."""
+    from oracle import confidence_ref as cr, graph_lite
+    from disco_diffdock_amd.runtime import Context, Complex
+    c = complex_from_npz(golden('complex_confidence'))
+    cfg = cr.ConfidenceModelConfig()
+    P = cr.random_state_dict(cfg, seed=5)
+    rng = np.random.default_rng(3)
+    n = len(c['lig_pos'])
+    pocket = c['atom_pos'][17]
+    lig0 = c['lig_pos'] - c['lig_pos'].mean(0, keepdims=True)
+    pos = np.stack([lig0 + pocket + shift + rng.normal(0, 1.0, size=(1, 3)) for _ in range(B)]).astype(np.float32)
+    b = graph_lite.collate([graph_lite.add_atoms(to_graph(c), c['atom_x'], c['atom_pos'], c['atom_edge_index'], c['atom_rec_index']) for _ in range(B)])
+    b['ligand'].pos = T(pos.reshape(-1, 3))
+    for nt in ('ligand', 'receptor', 'atom'):
+        b[nt].node_t = {k: torch.zeros(b[nt].num_nodes) for k in ('tr', 'rot', 'tor')}
+    b.complex_t = {k: torch.zeros(B) for k in ('tr', 'rot', 'tor')}
+    want, inter = cr.confidence_forward(P, cfg, b, return_intermediates=True)
+    if shift:
+        assert inter['counts']['la'] == 0 and inter['counts']['lr'] == 0
+    ctx = Context(device=0, all_atoms=1, embedding_scale=10000.0, num_confidence_outputs=2)
+    ctx.load_state_dict(P)
+    cx = Complex(ctx, c, max_batch=max_batch)
+    cx.set_atoms(c['atom_x'], c['atom_pos'], c['atom_edge_index'], c['atom_rec_index'])
+    got = cx.confidence_forward(T(pos).to(dev))
+    cnt = cx.confidence_counts()
+    assert all(cnt[k] == inter['counts'][k] for k in ('ll', 'lr', 'la', 'rr'))
+    assert rel_err(got.cpu(), want.reshape(B, -1)) < 1e-4
+    with pytest.raises(RuntimeError, match='batch'):
+        cx.confidence_forward(T(np.repeat(pos[:1], max_batch + 1, 0)).to(dev))

@@ -34,3 +34,21 @@ def gather_poses(poses, n_lig, samples, device):
         dist.all_reduce(own, op=dist.ReduceOp.SUM)
     assert bool((own == 1).all()), 'every complex must be owned by exactly one rank'
     return {i: buf[i, :, :n_lig[i]].clone() for i in range(n)}
+
+
+def shard_samples(n_samples, rank, world):
+    """Large-pocket layout of SURVEY.md §8(e): the samples of ONE complex are independent given the latent, so rank r takes the
+    contiguous slice [lo, hi) of the n_samples poses (receptor replicated on every rank, ``Complex(max_batch=hi-lo)``)."""
+    base, extra = divmod(n_samples, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def gather_samples(pos, n_samples, rank, world, device):
+    """pos: this rank's [hi-lo, n_lig, 3] slice -> on every rank the full [n_samples, n_lig, 3] (disjoint slots, one all_reduce)."""
+    lo, hi = shard_samples(n_samples, rank, world)
+    buf = torch.zeros((n_samples,) + tuple(pos.shape[1:]), dtype=torch.float32, device=device)
+    buf[lo:hi] = pos.to(device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    return buf

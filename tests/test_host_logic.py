@@ -94,10 +94,24 @@ def _worker(rank, world, port, tmp):
     mine = shard_indices([n * 100 for n in n_lig], rank, world)
     poses = {i: torch.full((S, n_lig[i], 3), float(i)) + torch.arange(S).reshape(S, 1, 1) for i in mine}
     full = gather_poses(poses, n_lig, S, device=torch.device('cpu'))
+    # sample-level sharding of one complex (large-pocket layout): 7 poses over the ranks
+    from disco_diffdock_amd.distributed import shard_samples, gather_samples
+    lo, hi = shard_samples(7, rank, world)
+    whole = torch.arange(7 * 4 * 3, dtype=torch.float32).reshape(7, 4, 3)
+    got = gather_samples(whole[lo:hi], 7, rank, world, torch.device('cpu'))
     if rank == 0:
         ok = all(torch.equal(full[i], torch.full((S, n_lig[i], 3), float(i)) + torch.arange(S).reshape(S, 1, 1)) for i in range(len(n_lig)))
+        ok = ok and torch.equal(got, whole)
         open(os.path.join(tmp, 'ok'), 'w').write(str(ok))
     dist.destroy_process_group()
+
+
+def test_shard_samples_partition():
+    from disco_diffdock_amd.distributed import shard_samples
+    for n, world in ((40, 8), (7, 2), (3, 8), (1, 1)):
+        parts = [shard_samples(n, r, world) for r in range(world)]
+        assert parts[0][0] == 0 and parts[-1][1] == n and all(parts[r][1] == parts[r + 1][0] for r in range(world - 1))
+        assert max(b - a for a, b in parts) - min(b - a for a, b in parts) <= 1
 
 
 def test_gloo_world2_shard_and_gather(tmp_path):

@@ -401,18 +401,26 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
       ls[(size_t)i * NS + o] = (float)a;
     }
   }
+  std::vector<float> w_esm_t((size_t)lm * NS);      // [lm][NS]: the 24 outputs of one feature are contiguous -> the inner loop vectorises
+  for (int o = 0; has_model && o < NS; ++o)
+    for (int k = 0; k < lm; ++k) w_esm_t[(size_t)k * NS + o] = H.rec_w_esm[(size_t)o * lm + k];
   for (int j = 0; has_model && j < n_rec; ++j) {
     const float* xr = d->rec_x + (size_t)j * d->rec_feat_dim;
     const int res = (int)xr[0];
     if (res < 0 || res >= REC_DIM) return fail(ctx, DDK_ERR_INVALID, "residue id out of range");
     const float* emb = H.rec_table.data() + (size_t)res * NS;
+    double acc[NS];
     for (int o = 0; o < NS; ++o) {
       double a = H.rec_b[o];
       for (int k = 0; k < NS; ++k) a += (double)H.rec_w_emb[(size_t)o * NS + k] * emb[k];
-      const float* w = H.rec_w_esm.data() + (size_t)o * lm;
-      for (int k = 0; k < lm; ++k) a += (double)w[k] * xr[1 + k];
-      rs[(size_t)j * NS + o] = (float)a;
+      acc[o] = a;
     }
+    for (int k = 0; k < lm; ++k) {
+      const double xk = xr[1 + k];
+      const float* w = w_esm_t.data() + (size_t)k * NS;
+      for (int o = 0; o < NS; ++o) acc[o] += (double)w[o] * xk;
+    }
+    for (int o = 0; o < NS; ++o) rs[(size_t)j * NS + o] = (float)acc[o];
   }
   cx->lig_node_static = cx_upload(cx, ls.data(), ls.size());
   cx->rec_node_static = cx_upload(cx, rs.data(), rs.size());

@@ -10,6 +10,24 @@
 
 namespace ddk {
 
+// dot product of a 16-B aligned global weight row with an LDS activation row: all N/4 128-bit loads of the row are issued
+// before the first use (the heads are L2-latency bound: few threads, long dependent chains), four independent accumulators
+template <int N>
+__device__ __forceinline__ float row_dot(const float* __restrict__ w, const float* act) {
+  const float4* w4 = reinterpret_cast<const float4*>(w);
+  float4 r[N / 4];
+#pragma unroll
+  for (int i = 0; i < N / 4; ++i) r[i] = w4[i];
+  float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+#pragma unroll
+  for (int i = 0; i < N / 4; ++i) {
+    a0 = fmaf(r[i].x, act[4 * i + 0], a0); a1 = fmaf(r[i].y, act[4 * i + 1], a1);
+    a2 = fmaf(r[i].z, act[4 * i + 2], a2); a3 = fmaf(r[i].w, act[4 * i + 3], a3);
+  }
+  __builtin_amdgcn_sched_barrier(0);   // one row in flight at a time: keeps the register count of the unrolled callers in check
+  return (a0 + a1) + (a2 + a3);
+}
+
 
 __device__ __forceinline__ void smear(float d, const EdgeMlpDev& m, float* gs) {
 #pragma unroll
@@ -104,9 +122,7 @@ __device__ void center_head_block(const HeadArgs& A, int b) {
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
       const int o = 6 * p + q;
-      float a = A.md.fc_b0[o];
-#pragma unroll
-      for (int k = 0; k < 2 * NS; ++k) a += A.md.fc_w0[o * 2 * NS + k] * act[el][k];
+      const float a = A.md.fc_b0[o] + row_dot<2 * NS>(A.md.fc_w0 + o * 2 * NS, act[el]);
       h6[q] = fmaxf(a, 0.0f);
     }
     __syncthreads();
@@ -116,10 +132,7 @@ __device__ void center_head_block(const HeadArgs& A, int b) {
     // 144 per-edge weights, rows p, p+8, ...: accumulate the six FCTP paths (see the weight layout above)
     float sA = 0.f, sF = 0.f, vB[3] = {}, vC[3] = {}, vD[3] = {}, vE[3] = {};
     auto wrow = [&](int row) {
-      float wv = A.md.fc_b4[row];
-#pragma unroll
-      for (int k = 0; k < 2 * NS; ++k) wv += A.md.fc_w4[row * 2 * NS + k] * act[el][k];
-      return wv;
+      return A.md.fc_b4[row] + row_dot<2 * NS>(A.md.fc_w4 + row * 2 * NS, act[el]);
     };
     // rows of a path are dealt round-robin to the 8 threads of the edge; every row of a thread has w = row & 1 = p & 1
 #pragma unroll 1
@@ -275,9 +288,7 @@ __device__ void torsion_head_block(const HeadArgs& A, int b, int r) {
 #pragma unroll
   for (int q = 0; q < 9; ++q) {
     const int o = 9 * p + q;
-    float a = A.md.tb_b0[o];
-#pragma unroll 8
-    for (int j = 0; j < NE; ++j) a += A.md.tb_w0[o * NE + j] * act[el][j];
+    const float a = A.md.tb_b0[o] + row_dot<NE>(A.md.tb_w0 + o * NE, act[el]);
     h9[q] = fmaxf(a, 0.0f);
   }
   __syncthreads();
@@ -297,9 +308,7 @@ __device__ void torsion_head_block(const HeadArgs& A, int b, int r) {
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
         const int row = path * (NV * NS) + uu * NS + 3 * p + q;
-        float a = A.md.tb_b4[row];
-#pragma unroll 8
-        for (int j = 0; j < NE; ++j) a += A.md.tb_w4[row * NE + j] * act[el][j];
+        const float a = A.md.tb_b4[row] + row_dot<NE>(A.md.tb_w4 + row * NE, act[el]);
         o3[q] += a * dt;
       }
     }

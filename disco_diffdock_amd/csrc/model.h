@@ -159,6 +159,8 @@ struct RandPosArgs {
   float* pos_out;
 };
 hipError_t launch_randomize(const RandPosArgs& A, hipStream_t s);
+hipError_t launch_pose_metrics(const float* pos, const float* ref, const uint8_t* mask, const float* rec_pos, int B, int n_lig, int n_rec,
+                               float* out, hipStream_t s);
 
 int conf_model_finalize(ddk_ctx* ctx);   // conf.hip (all-atom confidence model)
 void conf_complex_free(ddk_complex* cx);

@@ -531,6 +531,16 @@ int ddk_randomize_position(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float
   return DDK_OK;
 }
 
+int ddk_pose_metrics(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* pos, const float* ref_pos, const uint8_t* atom_mask, float* out,
+                     void* stream) {
+  if (!ctx) return DDK_ERR_INVALID;
+  if (ctx->host_only) return fail(ctx, DDK_ERR_STATE, "host-only context (device < 0) cannot launch kernels");
+  if (!cx || B < 1 || !pos || !ref_pos || !out) return fail(ctx, DDK_ERR_INVALID, "ddk_pose_metrics: bad complex / batch / null argument");
+  hipError_t e = launch_pose_metrics(pos, ref_pos, atom_mask, cx->rec_pos, B, cx->n_lig, cx->n_rec, out, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(ctx, e, "pose_metrics launch");
+  return DDK_OK;
+}
+
 int ddk_sample(ddk_ctx* ctx, ddk_complex* cx, int32_t B, int32_t steps, const float* t, const float* score_coeff,
                const float* noise_coeff, const float* noise, float* pos, void* stream) {
   int rc = check_model(ctx, cx, B);

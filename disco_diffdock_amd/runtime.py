@@ -278,6 +278,16 @@ class Complex:
         self.ctx._check(self.ctx.L.ddk_last_node_features(self.ctx.h, self.h, B, _ptr(lig), None, _stream()), 'ddk_last_node_features')
         return lig
 
+    def pose_metrics(self, pos, ref_pos, atom_mask=None):
+        """evaluate.py:297-338 for B poses: tensor [B,4] = rmsd, centroid distance, min cross distance, min self distance."""
+        pos = pos.contiguous().float().reshape(-1, self.n_lig, 3)
+        ref = ref_pos.contiguous().float().reshape(self.n_lig, 3).to(pos.device)
+        m = None if atom_mask is None else atom_mask.to(pos.device).to(torch.uint8).contiguous()
+        out = torch.empty((pos.shape[0], 4), dtype=torch.float32, device=pos.device)
+        self.ctx._check(self.ctx.L.ddk_pose_metrics(self.ctx.h, self.h, pos.shape[0], _ptr(pos), _ptr(ref), _ptr(m), _ptr(out), _stream()),
+                        'ddk_pose_metrics')
+        return out
+
     def randomize_position(self, pos0, rot, tor=None, tr=None):
         """utils/sampling.py:12-34 for B = rot.shape[0] copies of the conformer pos0 [n_lig,3]; returns [B,n_lig,3]."""
         ctx = self.ctx

@@ -167,6 +167,17 @@ int ddk_se3_update(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* pos, c
 int ddk_randomize_position(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* pos0, const float* tor, const float* rot,
                            const float* tr, float* pos_out, void* stream);
 
+/* ---- pose metrics of evaluate.py:297-338 for B poses of one complex, one launch:
+ *      out[b] = { rmsd, centroid_distance, min_cross_distance, min_self_distance } with
+ *        rmsd = sqrt(mean_i |pos_i - ref_i|^2)                    (the symmetry-uncorrected fallback of evaluate.py:313)
+ *        centroid_distance = |mean_i pos_i - mean_i ref_i|         (:315)
+ *        min_cross_distance = min over residues r, atoms i of |rec_pos_r - pos_i|   (:331-332)
+ *        min_self_distance  = min over atom pairs i != j of |pos_i - pos_j|          (:333-335)
+ *      all over the atoms with atom_mask[i] != 0 (filterHs, evaluate.py:297).  pos [B,n_lig,3], ref_pos [n_lig,3] (already minus
+ *      original_center), atom_mask [n_lig] uint8 (NULL = all atoms), out [B,4]; all DEVICE pointers. */
+int ddk_pose_metrics(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* pos, const float* ref_pos, const uint8_t* atom_mask,
+                     float* out, void* stream);
+
 /* ---- a1-a2: the reverse-diffusion loop of sampling()  utils/sampling.py:105-198 for one batch:
  *      per step  perturb = score_coeff*score + noise_coeff*z  (coefficients are the host scalars of
  *      sampling.py:137-192, including the low-temperature variant), then ddk_se3_update.

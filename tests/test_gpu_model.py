@@ -657,3 +657,26 @@ def test_confidence_model_vs_oracle_edge_cases(dev, golden, shift, B, max_batch)
     assert rel_err(got.cpu(), want.reshape(B, -1)) < 1e-4
     with pytest.raises(RuntimeError, match='batch'):
         cx.confidence_forward(T(np.repeat(pos[:1], max_batch + 1, 0)).to(dev))
+
+
+def test_pose_metrics(dev, golden):
+    """evaluate.py:297-338 (uncorrected RMSD :313, centroid distance :315, min cross distance :331-332, min self distance :333-335,
+    heavy-atom filter :297) restated in numpy here vs ddk_pose_metrics."""
+    from disco_diffdock_amd.runtime import Complex
+    from disco_diffdock_amd.tensor_layers import _shape_context
+    c = complex_from_npz(golden('complex_diffdockS_score_model'))
+    B, n = 5, len(c['lig_pos'])
+    rng = np.random.default_rng(2)
+    pos = np.stack([c['lig_pos'] + rng.normal(0, 2.0, size=(1, 3)) + rng.normal(0, 0.3, size=(n, 3)) for _ in range(B)]).astype(np.float32)
+    ref = c['lig_pos'].astype(np.float32)
+    for mask in (None, rng.random(n) > 0.3):
+        f = np.ones(n, bool) if mask is None else mask
+        ligand_pos, orig = pos[:, f], ref[None, f]
+        rmsd = np.sqrt(((ligand_pos - orig) ** 2).sum(axis=2).mean(axis=1))
+        cen = np.linalg.norm(ligand_pos.mean(axis=1) - orig.mean(axis=1), axis=1)
+        cross = np.linalg.norm(c['rec_pos'][None, :, None, :] - ligand_pos[:, None, :, :], axis=-1).min(axis=(1, 2))
+        sd = np.linalg.norm(ligand_pos[:, :, None, :] - ligand_pos[:, None, :, :], axis=-1)
+        sd = np.where(np.eye(sd.shape[2]), np.inf, sd).min(axis=(1, 2))
+        cx = Complex(_shape_context(0), c, max_batch=B)
+        got = cx.pose_metrics(T(pos).to(dev), T(ref), None if mask is None else T(mask)).cpu().numpy()
+        assert np.allclose(got, np.stack([rmsd, cen, cross, sd], 1), rtol=1e-5, atol=1e-5)

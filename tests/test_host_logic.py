@@ -133,6 +133,7 @@ def test_graph_cache_roundtrip(tmp_path):
     from disco_diffdock_amd import graph_cache, synthetic
     from disco_diffdock_amd.data import from_arrays
     cs = [synthetic.make_complex(s, n_res=n, esm_dim=8) for s, n in ((0, 40), (1, 17), (2, 64))]
+    synthetic.add_receptor_atoms(cs[1], np.random.default_rng(1))        # one complex carries the all-atom level of the confidence graphs
     path = tmp_path / 'graphs.ddkg'
     assert graph_cache.save_complexes(path, cs) == 3
     back = graph_cache.load_complexes(path)
@@ -140,7 +141,10 @@ def test_graph_cache_roundtrip(tmp_path):
     for a, b in zip(cs, back):
         for k in ('lig_x', 'lig_pos', 'bond_index', 'bond_attr', 'edge_mask', 'mask_rotate', 'rec_x', 'rec_pos', 'rec_edge_index', 'original_center'):
             assert np.array_equal(np.asarray(a[k]).reshape(np.asarray(b[k]).shape), b[k]), k
+        for k in ('atom_x', 'atom_pos', 'atom_edge_index', 'atom_rec_index'):
+            assert (k in a) == (k in b) and (k not in a or np.array_equal(np.asarray(a[k]), b[k])), k
         g = from_arrays(b)
+        assert ('atom' in g) == ('atom_x' in a)
         assert g['ligand'].pos.shape == (a['lig_pos'].shape[0], 3) and g['receptor'].x.shape == a['rec_x'].shape
     raw = path.read_bytes()
     (tmp_path / 'bad_magic').write_bytes(b'XXXX' + raw[4:])

@@ -339,3 +339,67 @@ def random_score_model_state_dict(seed=0):
             fan_in = shape[1] if name.endswith('weight') else spec[name[:-4] + 'weight'][1]
             P[name] = (torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(fan_in)
     return P
+
+
+def confidence_state_dict_spec(ns=24, nv=6, num_conv_layers=5, sigma=32, dist=32, lm=1280, n_out=2):
+    """name -> shape of the all-atom confidence model's state_dict (models/all_atom_score_model.py in confidence_mode as
+    get_model builds it from workdir/paper_confidence_model; 430 tensors / 4 773 122 elements).  Used for random-init benches."""
+    spec = {}
+
+    def lin(name, o, i):
+        spec[f'{name}.weight'] = (o, i)
+        spec[f'{name}.bias'] = (o,)
+
+    for pre, dims, has_lm in (('lig_node_embedding', LIG_FEATURE_DIMS, False), ('rec_node_embedding', REC_RESIDUE_FEATURE_DIMS, True),
+                              ('atom_node_embedding', REC_ATOM_FEATURE_DIMS, False)):
+        for i, d in enumerate(dims):
+            spec[f'{pre}.atom_embedding_list.{i}.weight'] = (d, ns)
+        lin(f'{pre}.linear', ns, sigma)
+        if has_lm and lm:
+            lin(f'{pre}.lm_embedding_layer', ns, lm + ns)
+    lin('lig_edge_embedding.0', ns, 4 + sigma + dist)
+    lin('lig_edge_embedding.3', ns, ns)
+    for k in ('rec', 'atom', 'lr', 'ar', 'la'):
+        lin(f'{k}_edge_embedding.0', ns, sigma + dist)
+        lin(f'{k}_edge_embedding.3', ns, ns)
+    for k in ('lig', 'rec', 'cross'):
+        spec[f'{k}_distance_expansion.offset'] = (dist,)
+    seq = [(ns, 0, 0, 0), (ns, nv, 0, 0), (ns, nv, nv, 0), (ns, nv, nv, ns)]
+    for l in range(num_conv_layers):
+        i_, o_ = seq[min(l, 3)], seq[min(l + 1, 3)]
+        # e3nn FullyConnectedTensorProduct(in, 0e+1o+2e, out) weight count: paths (in irrep, sh l, out irrep) allowed by parity / triangle
+        irr = ((0, 1), (1, -1), (1, 1), (0, -1))
+        W = sum(i_[a] * o_[c] for a in range(4) for (sl, sp) in ((0, 1), (1, -1), (2, 1)) for c in range(4)
+                if i_[a] and o_[c] and irr[a][1] * sp == irr[c][1] and abs(irr[a][0] - sl) <= irr[c][0] <= irr[a][0] + sl)
+        nf = sum(o_)
+        for k in range(9):
+            lin(f'conv_layers.{9 * l + k}.fc.0', 3 * ns, 3 * ns)
+            lin(f'conv_layers.{9 * l + k}.fc.3', W, 3 * ns)
+            for nm, sh in (('weight', nf), ('bias', o_[0]), ('running_mean', o_[0]), ('running_var', nf)):
+                spec[f'conv_layers.{9 * l + k}.batch_norm.{nm}'] = (sh,)
+    lin('confidence_predictor.0', ns, 2 * ns)
+    lin('confidence_predictor.4', ns, ns)
+    lin('confidence_predictor.8', n_out, ns)
+    for i in (1, 5):
+        for k in ('weight', 'bias', 'running_mean', 'running_var'):
+            spec[f'confidence_predictor.{i}.{k}'] = (ns,)
+    return spec
+
+
+def random_confidence_state_dict(seed=0, **kw):
+    import math
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    spec, P = confidence_state_dict_spec(**kw), {}
+    stops = {'lig': 5.0, 'rec': 30.0, 'cross': 80.0}
+    for name, shape in spec.items():
+        if name.endswith('distance_expansion.offset'):
+            P[name] = torch.linspace(0.0, stops[name.split('_')[0]], shape[0])
+        elif 'atom_embedding_list' in name:
+            P[name] = (torch.rand(shape, generator=g) * 2 - 1) * math.sqrt(6.0 / (shape[0] + shape[1]))
+        elif '.batch_norm.' in name or (name.startswith('confidence_predictor') and name.split('.')[1] in ('1', '5')):
+            P[name] = torch.randn(shape, generator=g) * 0.1 if name.endswith(('running_mean', 'bias')) else torch.rand(shape, generator=g) + 0.5
+        else:
+            fan_in = shape[1] if name.endswith('weight') else spec[name[:-4] + 'weight'][1]
+            P[name] = (torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(fan_in)
+    return P

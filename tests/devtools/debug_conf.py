@@ -1,12 +1,12 @@
 """Development aid: confidence model on the device vs the oracle, stage by stage."""
 import sys, os
 import numpy as np, torch
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), '..', '..')))
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), '..')))
-sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), '..', 'tests')))
 from oracle import confidence_ref as cr, graph_lite
 from helpers import complex_from_npz, to_graph, rel_err
 from disco_diffdock_amd.runtime import Context, Complex
-G = os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden')
+G = os.path.join(os.path.dirname(__file__), '..', 'golden')
 z, c = np.load(os.path.join(G, 'confidence_paper_model.npz')), complex_from_npz(np.load(os.path.join(G, 'complex_confidence.npz')))
 cfg = cr.ConfidenceModelConfig()
 nl = int(sys.argv[1]) if len(sys.argv) > 1 else 5

@@ -1,7 +1,7 @@
 import sys, os
 import numpy as np, torch
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), '..', '..')))
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), '..')))
-sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), '..', 'tests')))
 from oracle import confidence_ref as cr, e3nn_lite as o3, score_model_ref as smr
 from helpers import rel_err
 from disco_diffdock_amd.runtime import Context

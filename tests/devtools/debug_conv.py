@@ -1,14 +1,14 @@
 """Development aid: per-column error of the fused conv kernel against a golden conv-layer case."""
 import sys, os
 import numpy as np, torch
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), '..', '..')))
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), '..')))
-sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), '..', 'tests')))
 from oracle import score_model_ref as smr
 CFG = smr.ScoreModelConfig()
 T = torch.from_numpy
 from disco_diffdock_amd.tensor_layers import TensorProductConvLayer
 l, bn = int(sys.argv[1]), int(sys.argv[2])
-z = np.load(os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden', f'conv_layer_l{l}_bn{bn}.npz'))
+z = np.load(os.path.join(os.path.dirname(__file__), '..', 'golden', f'conv_layer_l{l}_bn{bn}.npz'))
 dev = torch.device('cuda:0')
 i_irr, o_irr = CFG.conv_irreps(l)
 layer = TensorProductConvLayer(i_irr, '1x0e+1x1o', o_irr, 72, hidden_features=72, residual=True, batch_norm=bool(bn), dropout=0.1, faster=True, edge_groups=4).eval()

@@ -1,7 +1,7 @@
 import sys, os
 import numpy as np, torch
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), '..', '..')))
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), '..')))
-sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), '..', 'tests')))
 from oracle import score_model_ref as smr
 from disco_diffdock_amd.runtime import Context
 CFG = smr.ScoreModelConfig()

@@ -2,7 +2,7 @@
 import os, sys
 import numpy as np
 import torch
-ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..', '..'))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from oracle import score_model_ref as smr, sampler_ref as spr
 from helpers import batch_of, rel_err

@@ -155,3 +155,12 @@ def test_graph_cache_roundtrip(tmp_path):
     bad = dict(cs[0]); bad['rec_pos'] = bad['rec_pos'][:-1]
     with pytest.raises(ValueError, match='rec_pos'):
         graph_cache.save_complexes(tmp_path / 'x', [bad])
+
+
+def test_product_confidence_spec_equals_reference_layout():
+    """The product-side random-init layout of the confidence model == the oracle's (pinned by the reference's strict load)."""
+    from disco_diffdock_amd import synthetic
+    from oracle import confidence_ref as cr
+    a = {k: tuple(v) for k, v in synthetic.confidence_state_dict_spec().items()}
+    b = {k: tuple(v) for k, v in cr.state_dict_spec(cr.ConfidenceModelConfig()).items()}
+    assert a == b and len(a) == 430 and sum(int(np.prod(v)) for v in a.values()) == 4773122

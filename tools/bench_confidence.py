@@ -4,13 +4,12 @@ import numpy as np, torch
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), '..')))
 from disco_diffdock_amd import synthetic
 from disco_diffdock_amd.runtime import Context, Complex
-from oracle import confidence_ref as cr      # weights only (random init in the reference's state_dict layout)
 dev = torch.device('cuda:0')
 B = 40
 c = synthetic.make_complex(0, n_res=300)
 synthetic.add_receptor_atoms(c, np.random.default_rng(0))
 ctx = Context(device=0, all_atoms=1, embedding_scale=10000.0, num_confidence_outputs=2)
-ctx.load_state_dict(cr.random_state_dict(cr.ConfidenceModelConfig(), seed=1))
+ctx.load_state_dict(synthetic.random_confidence_state_dict(seed=1))
 t0 = time.time()
 cx = Complex(ctx, c, max_batch=B)
 cx.set_atoms(c['atom_x'], c['atom_pos'], c['atom_edge_index'], c['atom_rec_index'])

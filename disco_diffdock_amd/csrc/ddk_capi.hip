@@ -1,6 +1,8 @@
 // C-ABI entry points (include/ddk.h): context, checkpoint loading, weight packing into MFMA fragment
 // order, and the operator-level entry points (ddk_tp_forward, ddk_conv_forward).
 #include <math.h>
+#include <algorithm>
+#include <cmath>
 #include <string.h>
 
 #include "ddk_internal.h"
@@ -350,9 +352,21 @@ static int build_conv_layer(ddk_ctx* ctx, int mode, int l, ConvLayerDev& L) {
       };
       std::vector<uint8_t> w2h((size_t)NG * L.n_tiles * W2H_TILE_BYTES, 0);
       std::vector<uint16_t> w1h((size_t)NG * 3 * (W1H_TILE_BYTES / 2), 0);
+      // exact power-of-two range scaling: max|w| of a group is brought into [2^13, 2^14) so that neither half of the split leaves
+      // the fp16 range whatever the scale of the checkpoint (the kernel scales the activations per edge the same way)
+      auto range_scale = [](const float* v, size_t n, const float* v2, size_t n2) {
+        float m = 0.f;
+        for (size_t i = 0; i < n; ++i) m = std::max(m, std::fabs(v[i]));
+        for (size_t i = 0; i < n2; ++i) m = std::max(m, std::fabs(v2[i]));
+        int e = 0;
+        std::frexp(std::max(m, 0x1p-40f), &e);      // m = f * 2^e, f in [0.5, 1)
+        return std::ldexp(1.0f, 14 - e);
+      };
       for (int g = 0; g < NG; ++g) {
         const float* w2 = w2all.data() + g * w2sz;    // fp32 fragment order: [t][s/4][lane][s&3], s = register of the lane half
         const float* w1 = w1all.data() + g * w1sz;
+        const float sc1 = range_scale(w1, w1sz, nullptr, 0), sc2 = range_scale(w2, w2sz, b2all.data() + g * b2sz, b2sz);
+        L.w1s[g] = sc1; L.w2s[g] = sc2;
         for (int t = 0; t < L.n_tiles; ++t) {
           uint8_t* rec = w2h.data() + ((size_t)g * L.n_tiles + t) * W2H_TILE_BYTES;
           uint16_t* hi = (uint16_t*)rec; uint16_t* lo = (uint16_t*)(rec + W2H_FRAG_BYTES);
@@ -367,7 +381,7 @@ static int build_conv_layer(ddk_ctx* ctx, int mode, int l, ConvLayerDev& L) {
                     for (int rr = 0; rr < 16; ++rr)
                       if (d_row(rr, hh2) == lane) v = b2t[hh2 * 16 + rr];
                 }
-                split(v, hi[(s * 64 + lane) * 8 + i], lo[(s * 64 + lane) * 8 + i]);
+                split(v * sc2, hi[(s * 64 + lane) * 8 + i], lo[(s * 64 + lane) * 8 + i]);
               }
           memcpy(rec + 2 * W2H_FRAG_BYTES, b2all.data() + g * b2sz + (size_t)t * 32, 128);
           memcpy(rec + 2 * W2H_FRAG_BYTES + 128, &tiles[t], 8);
@@ -380,7 +394,7 @@ static int build_conv_layer(ddk_ctx* ctx, int mode, int l, ConvLayerDev& L) {
               for (int i = 0; i < 8; ++i) {
                 const int r = 8 * s + i;
                 const float v = r < 36 ? w1[(((size_t)T * 9 + r / 4) * 64 + lane) * 4 + (r & 3)] : 0.f;
-                split(v, hi[(s * 64 + lane) * 8 + i], lo[(s * 64 + lane) * 8 + i]);
+                split(v * sc1, hi[(s * 64 + lane) * 8 + i], lo[(s * 64 + lane) * 8 + i]);
               }
         }
       }

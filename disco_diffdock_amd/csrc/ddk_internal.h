@@ -98,6 +98,7 @@ struct ConvLayerDev {          // device copies for one TensorProductConvLayer w
   TileDesc* tiles = nullptr;   // [n_tiles]
   uint16_t* w1h = nullptr;     // 3 x f16 mode: [groups][3][W1H_TILE_BYTES/2]
   uint8_t* w2h = nullptr;      // 3 x f16 mode: [groups][n_tiles][W2H_TILE_BYTES]
+  float w1s[4] = {1, 1, 1, 1}, w2s[4] = {1, 1, 1, 1};   // 3 x f16 mode: power-of-two range scale of the packed W1 / (W2, b2) of each group
   int n_cols = 0;              // flush columns (8 output channels each); col_start[c] = first tile of column c, col_start[n_cols] = n_tiles
   int col_start[17] = {};
   float* bn_mean = nullptr;    // [XW]  running_mean on 0e channels, 0 elsewhere

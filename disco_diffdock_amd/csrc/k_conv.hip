@@ -426,6 +426,7 @@ hipError_t launch_conv_fused(const ConvLayerDev& L, const ConvLaunch& a, int n_c
   if (L.w2h != nullptr && a.mode == 0) return launch_conv_fused_h(L, a, n_cu, s);   // ddk_config.conv_f16x3
   ConvKArgs k;
   k.w1h = nullptr; k.w2h = nullptr;
+  for (int g = 0; g < 4; ++g) { k.w1s[g] = 1.0f; k.w1u[g] = 1.0f; k.w2u[g] = 1.0f; }
   k.x = a.x; k.src = a.src; k.dst = a.dst; k.edge_attr = a.edge_attr; k.sh = a.sh; k.sum = a.sum;
   k.tile_info = a.tile_info; k.counter = a.counter;
   k.w1p = L.w1p[0]; k.b1p = L.b1p[0]; k.w2r = L.w2r[0]; k.tiles = L.tiles; k.n_tiles = L.n_tiles;

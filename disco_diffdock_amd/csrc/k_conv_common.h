@@ -21,6 +21,7 @@ struct ConvKArgs {
   const TileDesc* tiles;  // [n_tiles]
   const uint16_t* w1h;   // 3 x f16 mode: [groups][3][2][5][64][8] fp16 (hi, lo*2^11) GEMM1 fragments
   const uint8_t* w2h;    // 3 x f16 mode: [groups][n_tiles][W2H_TILE_BYTES] tile records
+  float w1s[4], w1u[4], w2u[4];   // 3 x f16 mode: weight range scale of GEMM1 (and its inverse), inverse weight scale of GEMM2
   int n_tiles;
   int n_cols;         // flush columns; col_start[c] .. col_start[c+1] = tiles of column c
   int col_start[17];

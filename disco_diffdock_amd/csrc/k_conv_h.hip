@@ -46,6 +46,15 @@ __device__ __forceinline__ f32x16 burst_h(const f16x8 (&ah)[5], const f16x8 (&al
   return Dm;
 }
 
+// Exact power-of-two range scaling of the split operands: returns 2^(13 - floor(log2 max(m, 2^-40))), i.e. max|x| lands in
+// [2^13, 2^14) -- inside the fp16 range, with the 11 + 11 bits of the hi/lo split above the fp16 subnormals for everything within
+// 2^-27 of the maximum -- and its inverse.  Without it a hidden unit above 65504 would overflow and tiny checkpoints would lose bits.
+__device__ __forceinline__ float range_scale(float m, float& inv) {
+  const uint32_t eb = max((__float_as_uint(m) >> 23) & 0xffu, 87u);   // biased exponent; 0 and subnormals map to the 2^-40 floor
+  inv = __uint_as_float((eb - 13u) << 23);
+  return __uint_as_float((267u - eb) << 23);
+}
+
 // scalar-accumulator epilogue (the f16 pipe does not compete with the VALU for issue: fewer registers beat fewer instructions here)
 __device__ __forceinline__ void tile_epilogue_s(int kind, const f32x16& D, const float* Fp, f32x4 f0, float (&accA)[4], float (&accV)[4][3]) {
   if (kind == T_TV) {
@@ -188,41 +197,26 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_fused_h_kernel(ConvKArgs
     }
     // h = relu(W1 in + b1) as an error-compensated 3 x f16 product (see the header)
     f16x8 hhi[5], hlo[5];
+    float osc;        // GEMM2 outputs of this edge are (s2 h) x (w2s W2): the factor that takes a flushed sum back
     {
       f16x8 bhi[5], blo[5];
+      float m1 = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 36; ++j) m1 = fmaxf(m1, fabsf(bin[j]));
+      m1 = fmaxf(m1, __shfl_xor(m1, 32));          // both lane halves hold K slices of the same edge
+      float inv1;
+      const float s1 = range_scale(m1, inv1);
 #pragma unroll
       for (int s = 0; s < 5; ++s)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const float v = 8 * s + i < 36 ? bin[(8 * s + i) % 36] : 0.0f;
+          const float v = 8 * s + i < 36 ? bin[(8 * s + i) % 36] * s1 : 0.0f;
           const _Float16 t = (_Float16)v;
           bhi[s][i] = t; blo[s][i] = (_Float16)((v - (float)t) * 2048.0f);
         }
-#ifdef DDK_H_GEMM1_FP32
-      float h[36];
-      {
-        const float* w1 = A.w1p + (size_t)g * (3 * 9 * 64 * 4);
-        const float* b1 = A.b1p + (size_t)g * (3 * 2 * 16);
-#pragma unroll
-        for (int T = 0; T < 3; ++T) {
-          f32x16 acc;
-          const float* bp = b1 + (T * 2 + hh) * 16;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { const float4 b = ld4(bp + 4 * j); acc[4 * j + 0] = b.x; acc[4 * j + 1] = b.y; acc[4 * j + 2] = b.z; acc[4 * j + 3] = b.w; }
-          const float* wp = w1 + ((size_t)T * 9 * 64 + lane) * 4;
-#pragma unroll
-          for (int s4 = 0; s4 < 9; ++s4) {
-            const float4 a = ld4(wp + s4 * 64 * 4);
-            acc = MFMA(a.x, bin[4 * s4 + 0], acc); acc = MFMA(a.y, bin[4 * s4 + 1], acc);
-            acc = MFMA(a.z, bin[4 * s4 + 2], acc); acc = MFMA(a.w, bin[4 * s4 + 3], acc);
-          }
-          if (T < 2) { _Pragma("unroll") for (int r = 0; r < 16; ++r) h[16 * T + r] = fmaxf(acc[r], 0.0f); }
-          else { _Pragma("unroll") for (int r = 0; r < 4; ++r) h[32 + r] = fmaxf(acc[r], 0.0f); }
-        }
-      }
-#else
       const uint16_t* w1 = A.w1h + (size_t)g * 3 * (W1H_TILE_BYTES / 2);
       const float* b1 = A.b1p + (size_t)g * (3 * 2 * 16);
+      const float bsc = s1 * A.w1s[g], usc = inv1 * A.w1u[g];   // the accumulators hold (s1 in) x (w1s W1): bias in, result out of that scale
       float h[36];
 #pragma unroll
       for (int T = 0; T < 3; ++T) {
@@ -231,7 +225,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_fused_h_kernel(ConvKArgs
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float4 b = ld4(bp + 4 * j);
-          am[4 * j + 0] = b.x; am[4 * j + 1] = b.y; am[4 * j + 2] = b.z; am[4 * j + 3] = b.w;
+          am[4 * j + 0] = b.x * bsc; am[4 * j + 1] = b.y * bsc; am[4 * j + 2] = b.z * bsc; am[4 * j + 3] = b.w * bsc;
           ac[4 * j + 0] = 0.0f; ac[4 * j + 1] = 0.0f; ac[4 * j + 2] = 0.0f; ac[4 * j + 3] = 0.0f;
         }
         const uint16_t* wt = w1 + (size_t)T * (W1H_TILE_BYTES / 2) + lane * 8;
@@ -245,19 +239,25 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_fused_h_kernel(ConvKArgs
         }
         if (T < 2) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) h[16 * T + r] = fmaxf(fmaf(ac[r], 1.0f / 2048.0f, am[r]), 0.0f);
+          for (int r = 0; r < 16; ++r) h[16 * T + r] = fmaxf(fmaf(ac[r], 1.0f / 2048.0f, am[r]), 0.0f) * usc;
         } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) h[32 + r] = fmaxf(fmaf(ac[r], 1.0f / 2048.0f, am[r]), 0.0f);
+          for (int r = 0; r < 4; ++r) h[32 + r] = fmaxf(fmaf(ac[r], 1.0f / 2048.0f, am[r]), 0.0f) * usc;
         }
       }
-#endif
+      float m2 = 1.0f;                                 // the constant 1 of the bias slot takes part in the range
+#pragma unroll
+      for (int j = 0; j < 36; ++j) m2 = fmaxf(m2, h[j]);
+      m2 = fmaxf(m2, __shfl_xor(m2, 32));
+      float inv2;
+      const float s2 = range_scale(m2, inv2);
+      osc = inv2 * A.w2u[g];
 #pragma unroll
       for (int s = 0; s < 5; ++s)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           // K slot 36 of lane half 0 is the constant 1: its weight column holds the bias of the tile row (K = 72 is padded to 80 anyway)
-          const float v = 8 * s + i < 36 ? h[(8 * s + i) % 36] : ((8 * s + i == 36 && hh == 0) ? 1.0f : 0.0f);
+          const float v = 8 * s + i < 36 ? h[(8 * s + i) % 36] * s2 : ((8 * s + i == 36 && hh == 0) ? s2 : 0.0f);
           const _Float16 t = (_Float16)v;
           hhi[s][i] = t; hlo[s][i] = (_Float16)((v - (float)t) * 2048.0f);
         }
@@ -369,13 +369,13 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_fused_h_kernel(ConvKArgs
         _Pragma("unroll") for (int rq = 0; rq < 4; ++rq) { \
           if (rq < nrq) { \
             if (fl == FL_S) { \
-              seg_add(node_row + chan0 + 2 * rq + hh, fmaf(PSUM(accA[rq]), s0, PSUM(accV[rq][0])), seg); \
+              seg_add(node_row + chan0 + 2 * rq + hh, osc * fmaf(PSUM(accA[rq]), s0, PSUM(accV[rq][0])), seg); \
             } else { \
               float* d = node_row + chan0 + 3 * (2 * rq + hh); \
-              const float sa = PSUM(accA[rq]); \
-              seg_add(d + 0, fmaf(sa, vx, PSUM(accV[rq][0])), seg); \
-              seg_add(d + 1, fmaf(sa, vy, PSUM(accV[rq][1])), seg); \
-              seg_add(d + 2, fmaf(sa, vz, PSUM(accV[rq][2])), seg); \
+              const float sa = osc * PSUM(accA[rq]); \
+              seg_add(d + 0, fmaf(sa, vx, osc * PSUM(accV[rq][0])), seg); \
+              seg_add(d + 1, fmaf(sa, vy, osc * PSUM(accV[rq][1])), seg); \
+              seg_add(d + 2, fmaf(sa, vz, osc * PSUM(accV[rq][2])), seg); \
             } \
           } \
           accA[rq] = 0.0f; accV[rq][0] = 0.0f; accV[rq][1] = 0.0f; accV[rq][2] = 0.0f; \
@@ -418,6 +418,7 @@ hipError_t launch_conv_fused_h(const ConvLayerDev& L, const ConvLaunch& a, int n
   k.x = a.x; k.src = a.src; k.dst = a.dst; k.edge_attr = a.edge_attr; k.sh = a.sh; k.sum = a.sum;
   k.tile_info = a.tile_info; k.counter = a.counter;
   k.w1p = L.w1p[0]; k.b1p = L.b1p[0]; k.w2r = nullptr; k.w1h = L.w1h; k.w2h = L.w2h; k.tiles = L.tiles; k.n_tiles = L.n_tiles;
+  for (int g = 0; g < 4; ++g) { k.w1s[g] = L.w1s[g]; k.w1u[g] = 1.0f / L.w1s[g]; k.w2u[g] = 1.0f / L.w2s[g]; }
   k.n_cols = L.n_cols;
   for (int c = 0; c <= L.n_cols; ++c) k.col_start[c] = L.col_start[c];
   k.g2_limit = a.g2_limit; k.sum_g2 = a.sum_g2; k.g2_node_off = a.g2_node_off;

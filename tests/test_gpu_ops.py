@@ -163,3 +163,40 @@ def test_conv_layer_f16x3_vs_oracle(dev, l, N, splits, sort_src):
     for _ in range(5):
         out = ctx.conv_forward(*args).cpu()
         assert rel_err(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize('in_scale,w1_scale,w2_scale', [
+    (1e4, 1e2, 1e-6),       # inputs and hidden units (~1e6) far above the fp16 maximum 65504, W2 far below the fp16 normal range 6.1e-5
+    (1e-4, 1e-2, 1e6),      # tiny inputs, W1 and hidden units (~1e-6); W2 above the fp16 maximum
+    (1.0, 1e6, 1e-6),       # W1 above, W2 below
+])
+def test_conv_layer_f16x3_range(dev, in_scale, w1_scale, w2_scale):
+    """The 3 x f16 split must not depend on the SCALE of a checkpoint or of the features: operands are range-scaled by exact powers of
+    two (weights per group at pack time, activations per edge in the kernel), so operands far outside the fp16 range meet the same bar.
+    (The three scales multiply to 1, so the messages stay O(1) next to the residual and the batch-norm statistics.)"""
+    from disco_diffdock_amd.runtime import Context
+    l, N, splits = 3, 300, [0, 700, 2500, 4000, 5555]
+    i_irr, o_irr = CFG.conv_irreps(l)
+    Pl = smr.random_conv_layer_params(CFG, l, 77, True)
+    for k in list(Pl):
+        if k.startswith('fc.') and k.endswith('.0.weight'):
+            Pl[k] = Pl[k] * w1_scale
+        if k.startswith('fc.') and k.endswith('.0.bias'):
+            Pl[k] = Pl[k] * (w1_scale * in_scale)
+        if k.startswith('fc.') and k.endswith('.4.weight'):     # (.4.bias stays O(0.1) like the W2 h it is added to)
+            Pl[k] = Pl[k] * w2_scale
+    node, ei, ea, sh = _random_case(l, N, splits, 11, True)
+    ea = ea * in_scale
+    P = {'L.' + k: v.double() for k, v in Pl.items()}
+    ref = smr.tp_conv_layer(P, 'L', node.double(), ei, [ea.double()[splits[i]:splits[i + 1]] for i in range(4)], sh.double(),
+                            i_irr, '1x0e+1x1o', o_irr, residual=True, batch_norm=True, faster=True, edge_groups=4)
+    assert 0.05 < float(ref.abs().max()) < 1e3
+    args = (l, node.to(dev), ei[0].to(dev), ei[1].to(dev), splits, ea.to(dev), sh.to(dev), smr.irreps_dim(o_irr))
+    err = {}
+    for mode in (1, 0):
+        ctx = Context(device=0, conv_f16x3=mode)
+        ctx.load_state_dict({f'conv_layers.{l}.{k}': v for k, v in Pl.items()})
+        out = ctx.conv_forward(*args).cpu()
+        assert torch.isfinite(out).all()
+        err[mode] = rel_err(out, ref)
+    assert err[1] < 1e-5 and err[1] < 4 * err[0] + 1e-6, err

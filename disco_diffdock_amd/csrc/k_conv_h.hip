@@ -339,6 +339,21 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_fused_h_kernel(ConvKArgs
 #else
 #define DDK_FLUSH_COND ((w0 >> 2) & 3)
 #endif
+#ifdef DDK_EXP_NOSTREAM      /* tiles are not fetched: the ring keeps the first two */
+#define DDK_STAGE_LOAD (void)rec2;
+#define DDK_STAGE_STORE (void)stg;
+#else
+#define DDK_STAGE_LOAD const float4 st0 = ld4(rec2 + 4 * tid); \
+      float4 st1 = make_float4(0.f, 0.f, 0.f, 0.f);   /* (a copy of st0 here would wait for the load) */ \
+      if (second) st1 = ld4(rec2 + 4 * (tid + 64 * WAVES));
+#define DDK_STAGE_STORE *reinterpret_cast<float4*>(stg + 4 * tid) = st0; \
+      if (second) *reinterpret_cast<float4*>(stg + 4 * (tid + 64 * WAVES)) = st1;
+#endif
+#ifdef DDK_EXP_NOFRAGS       /* the fragment registers are not refreshed from the ring */
+#define DDK_FRAGS(ANH, ANL, T)
+#else
+#define DDK_FRAGS(ANH, ANL, T) lds_frags_h(ANH, ANL, ring + (((T) + 1 - t_begin) & 1) * STAGE_F, lane);
+#endif
 #ifdef DDK_EXP_NOBARRIER
 #define DDK_TILE_BARRIER
 #else
@@ -352,12 +367,10 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_fused_h_kernel(ConvKArgs
       const int w0 = tq.w0, chan0 = tq.chan0; \
       const int t2 = min((T) + 2, t_end - 1); \
       const float* rec2 = wrec + (size_t)t2 * STAGE_F; \
-      const float4 st0 = ld4(rec2 + 4 * tid); \
-      float4 st1 = make_float4(0.f, 0.f, 0.f, 0.f);   /* (a copy of st0 here would wait for the load) */ \
-      if (second) st1 = ld4(rec2 + 4 * (tid + 64 * WAVES)); \
+      DDK_STAGE_LOAD \
       const float* Fp = Fr + (w0 >> 16); \
       const f32x4 f0 = ldv4(Fp); \
-      lds_frags_h(ANH, ANL, ring + (((T) + 1 - t_begin) & 1) * STAGE_F, lane); \
+      DDK_FRAGS(ANH, ANL, T) \
       tqv = *reinterpret_cast<const int2*>(ring + (((T) + 1 - t_begin) & 1) * STAGE_F + (2 * W2H_FRAG_BYTES + 128) / 4); \
       __builtin_amdgcn_sched_barrier(0); \
       const f32x16 D = burst_h(ACH, ACL, hhi, hlo, 0); \
@@ -382,8 +395,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_fused_h_kernel(ConvKArgs
         } \
       } \
       float* stg = ring + (((T) - t_begin) & 1) * STAGE_F; \
-      *reinterpret_cast<float4*>(stg + 4 * tid) = st0; \
-      if (second) *reinterpret_cast<float4*>(stg + 4 * (tid + 64 * WAVES)) = st1; \
+      DDK_STAGE_STORE \
       tq.w0 = __builtin_amdgcn_readfirstlane(tqv.x); tq.chan0 = __builtin_amdgcn_readfirstlane(tqv.y); \
       DDK_TILE_BARRIER \
     }
@@ -400,6 +412,9 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_fused_h_kernel(ConvKArgs
 #undef DDK_EPILOGUE
 #undef DDK_FLUSH_COND
 #undef DDK_TILE_BARRIER
+#undef DDK_STAGE_LOAD
+#undef DDK_STAGE_STORE
+#undef DDK_FRAGS
   }
 }
 

@@ -3,6 +3,7 @@
     python -m disco_diffdock_amd.build            # incremental
     python -m disco_diffdock_amd.build --force
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -21,24 +22,49 @@ def _hipcc():
     return 'hipcc'
 
 
+def _digest(paths, extra=''):
+    h = hashlib.sha256(extra.encode())
+    for p in paths:
+        h.update(os.path.basename(p).encode())
+        with open(p, 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _stamp_ok(path, digest):
+    try:
+        with open(path + '.stamp') as f:
+            return f.read().strip() == digest
+    except OSError:
+        return False
+
+
 def build(force=False, verbose=True):
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, '..', 'include', 'ddk.h')]
-    newest = max(os.path.getmtime(d) for d in deps)
-    objs = []
+    """Incremental and CONTENT based (a stamp with the hash of the source, every header and the flags sits next to each object):
+    file times do not survive the copy to the GPU box, and a rebuild there must only happen when something really changed."""
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')) + [os.path.join(HERE, '..', 'include', 'ddk.h')]
+    objs, relink = [], force or not os.path.exists(LIB)
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace('.hip', '.o'))
         objs.append(o)
-        if force or not os.path.exists(o) or os.path.getmtime(o) < newest:
+        dg = _digest([s] + headers, ' '.join(FLAGS))
+        if force or not os.path.exists(o) or not _stamp_ok(o, dg):
             cmd = [_hipcc()] + FLAGS + ['-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd), flush=True)
             subprocess.check_call(cmd)
-    if force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
+            with open(o + '.stamp', 'w') as f:
+                f.write(dg)
+            relink = True
+    ldg = _digest([o + '.stamp' for o in objs])
+    if relink or not _stamp_ok(LIB, ldg):
         cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
+        with open(LIB + '.stamp', 'w') as f:
+            f.write(ldg)
     return LIB
 
 

@@ -187,13 +187,15 @@ def test_sampling_vs_oracle(dev, tables):
     assert rel_err(a, r) < 1e-4
 
 
-def test_equivariance_and_batch_consistency_full_size(dev):
-    """BASELINE config-2 shape (40 samples, 300 residues): rotating + translating the whole complex rotates tr/rot and
-    leaves tor unchanged; permuting the samples of the batch permutes the outputs."""
+@pytest.mark.parametrize('n_res,t,min_edges', [(300, 0.4, 500000), (2000, 0.4, 2000000), (2000, 1.0, 5000000)])
+def test_equivariance_and_batch_consistency_full_size(dev, n_res, t, min_edges):
+    """BASELINE config-2 shape (40 samples, 300 residues) and config-5 shape (2000 residues; at t = 1 every ligand-residue pair is a
+    cross edge): rotating + translating the whole complex rotates tr/rot and leaves tor unchanged; permuting the samples of the batch
+    permutes the outputs."""
     from scipy.spatial.transform import Rotation
     from disco_diffdock_amd import synthetic
     from disco_diffdock_amd.runtime import Context, Complex
-    c = synthetic.make_complex(2, n_res=300)
+    c = synthetic.make_complex(2, n_res=n_res)
     P = smr.random_state_dict(CFG, seed=3)
     ctx = Context(device=0)
     ctx.load_state_dict(P)
@@ -201,11 +203,13 @@ def test_equivariance_and_batch_consistency_full_size(dev):
     rng = np.random.default_rng(0)
     pos = np.stack([c['lig_pos'] + rng.normal(0, 4.0, size=(1, 3)) + rng.normal(0, 0.3, size=c['lig_pos'].shape) for _ in range(B)]).astype(np.float32)
     cx = Complex(ctx, c, B)
-    tr0, rot0, tor0 = [x.double().cpu() for x in cx.score_forward(T(pos).to(dev), 0.4, 0.4, 0.4)]
+    tr0, rot0, tor0 = [x.double().cpu() for x in cx.score_forward(T(pos).to(dev), t, t, t)]
     st = cx.graph_stats()
-    assert st['E_rr'] == B * c['rec_edge_index'].shape[1] and st['E_lr'] == st['E_rl'] and st['E'] > 500000
+    assert st['E_rr'] == B * c['rec_edge_index'].shape[1] and st['E_lr'] == st['E_rl'] and st['E'] > min_edges
+    if t == 1.0:       # cutoff 3 sigma_tr + 20 = 77 A: every ligand atom sees every residue of the 40 A ball
+        assert st['E_lr'] == B * len(c['lig_pos']) * n_res
     perm = rng.permutation(B)
-    tr1, rot1, tor1 = [x.double().cpu() for x in cx.score_forward(T(pos[perm]).to(dev), 0.4, 0.4, 0.4)]
+    tr1, rot1, tor1 = [x.double().cpu() for x in cx.score_forward(T(pos[perm]).to(dev), t, t, t)]
     R = cx.R
     assert rel_err(tr1, tr0[perm]) < 1e-5 and rel_err(rot1, rot0[perm]) < 1e-5
     assert rel_err(tor1.reshape(B, R), tor0.reshape(B, R)[perm]) < 1e-5
@@ -215,7 +219,7 @@ def test_equivariance_and_batch_consistency_full_size(dev):
     c2['rec_pos'] = (c['rec_pos'].astype(np.float64) @ Rm.T + shift).astype(np.float32)
     pos2 = (pos.astype(np.float64) @ Rm.T + shift).astype(np.float32)
     cx2 = Complex(ctx, c2, B)
-    tr2, rot2, tor2 = [x.double().cpu() for x in cx2.score_forward(T(pos2).to(dev), 0.4, 0.4, 0.4)]
+    tr2, rot2, tor2 = [x.double().cpu() for x in cx2.score_forward(T(pos2).to(dev), t, t, t)]
     Rt = torch.from_numpy(Rm)
     assert rel_err(tr0 @ Rt.T, tr2) < 2e-4
     assert rel_err(rot0 @ Rt.T, rot2) < 2e-4

@@ -116,11 +116,13 @@ __global__ __launch_bounds__(64 * ConvTraits<MODE>::WAVES) void conv_fused_kerne
   const int split = rest > 0 ? max(1, min(A.n_cols, nwg / rest)) : 1;
   const int n_units = full + rest * split;
 
+  // work queue: the first unit of workgroup w is w itself; every later one comes from the device counter (zeroed by the caller),
+  // fetched by thread 0 at the START of the previous unit so that the atomic's round trip hides under that unit's tile loop
+  int unit = blockIdx.x;
   for (;;) {
-    if (tid == 0) *blk_slot = atomicAdd(A.counter, 1);
-    __syncthreads();
-    const int unit = __builtin_amdgcn_readfirstlane(*blk_slot);
     if (unit >= n_units) break;
+    int unit_next = 0;
+    if (tid == 0) unit_next = nwg + atomicAdd(A.counter, 1);
     int blk = unit, t_begin = 0, t_end = n_tiles;
     if (unit >= full) {
       const int r = unit - full, c = r % split;
@@ -360,6 +362,11 @@ __global__ __launch_bounds__(64 * ConvTraits<MODE>::WAVES) void conv_fused_kerne
 #undef DDK_EPILOGUE
 #undef DDK_FLUSH_COND
 #undef DDK_TILE_BARRIER
+    // hand the next unit to the workgroup; this barrier also retires the ring (every wave has finished reading it) before the next
+    // unit's staging writes
+    if (tid == 0) *blk_slot = unit_next;
+    __syncthreads();
+    unit = __builtin_amdgcn_readfirstlane(*blk_slot);
   }
 }
 

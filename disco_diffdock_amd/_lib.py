@@ -41,7 +41,7 @@ SYMBOLS = ['ddk_create', 'ddk_destroy', 'ddk_last_error', 'ddk_version', 'ddk_lo
            'ddk_score_forward', 'ddk_se3_update', 'ddk_sample', 'ddk_last_graph_stats', 'ddk_last_node_features',
            'ddk_profile_enable', 'ddk_profile_read', 'ddk_set_latents', 'ddk_set_guidance',
            'ddk_set_keep_receptor_features', 'ddk_randomize_position', 'ddk_complex_set_atoms',
-           'ddk_confidence_forward', 'ddk_pose_metrics']
+           'ddk_confidence_forward', 'ddk_pose_metrics', 'ddk_build_graph']
 
 
 def lib():
@@ -75,6 +75,7 @@ def lib():
     L.ddk_pose_metrics.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp]
     L.ddk_sample.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]
     L.ddk_last_graph_stats.argtypes = [vp, vp, vp, vp]
+    L.ddk_build_graph.argtypes = [vp, vp, C.c_int32, vp, C.c_float, vp, vp, C.c_int64, vp, vp]
     L.ddk_last_node_features.argtypes = [vp, vp, i32, vp, vp, vp]
     L.ddk_set_latents.argtypes = [vp, vp, vp, vp, f32]
     L.ddk_set_guidance.argtypes = [vp, vp, f32, f32, f32]

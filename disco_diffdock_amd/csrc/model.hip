@@ -248,6 +248,19 @@ static T* cx_upload(ddk_complex* cx, const T* src, size_t n) {
   return p;
 }
 
+// a6-a8 + the merge of score_model.py:218-225: counts, offsets and the sorted edge list of B poses into the complex' workspace
+static hipError_t build_graph(ddk_ctx* ctx, ddk_complex* cx, int B, const float* lig_pos, float cross_cutoff, hipStream_t s) {
+  const ddk_config& c = ctx->cfg;
+  GraphArgs G;
+  G.lig_pos = lig_pos; G.rec_pos = cx->rec_pos; G.bond_src = cx->bond_src; G.bond_dst = cx->bond_dst;
+  G.rr_src = cx->rr_src; G.rr_dst = cx->rr_dst; G.rr_outdeg = cx->rr_outdeg;
+  G.B = B; G.n_lig = cx->n_lig; G.n_rec = cx->n_rec; G.M = cx->M; G.E_rr = cx->E_rr;
+  G.lig_r2 = c.lig_max_radius * c.lig_max_radius; G.cross_cutoff = cross_cutoff;
+  G.counts = cx->counts; G.offs = cx->offs; G.info = cx->info; G.e_src = cx->e_src; G.e_dst = cx->e_dst; G.e_aux = cx->e_aux;
+  G.deg = cx->deg;
+  return launch_graph(G, cx->edge_cap, s);
+}
+
 static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float* lig_pos, const StepParams& sp,
                               float* tr_out, float* rot_out, float* tor_out, hipStream_t s) {
   const ddk_config& c = ctx->cfg;
@@ -256,14 +269,7 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
   const int64_t N = (int64_t)B * (n_lig + n_rec);
   hipError_t e;
 #define CK(x, what) do { e = (x); if (e != hipSuccess) return hip_fail(ctx, e, what); } while (0)
-  GraphArgs G;
-  G.lig_pos = lig_pos; G.rec_pos = cx->rec_pos; G.bond_src = cx->bond_src; G.bond_dst = cx->bond_dst;
-  G.rr_src = cx->rr_src; G.rr_dst = cx->rr_dst; G.rr_outdeg = cx->rr_outdeg;
-  G.B = B; G.n_lig = n_lig; G.n_rec = n_rec; G.M = cx->M; G.E_rr = cx->E_rr;
-  G.lig_r2 = c.lig_max_radius * c.lig_max_radius; G.cross_cutoff = sp.cross_cutoff;
-  G.counts = cx->counts; G.offs = cx->offs; G.info = cx->info; G.e_src = cx->e_src; G.e_dst = cx->e_dst; G.e_aux = cx->e_aux;
-  G.deg = cx->deg;
-  CK(launch_graph(G, cx->edge_cap, s), "graph build");
+  CK(build_graph(ctx, cx, B, lig_pos, sp.cross_cutoff, s), "graph build");
   EdgeFeatArgs F;
   F.lig_pos = lig_pos; F.rec_pos = cx->rec_pos; F.bond_attr = cx->bond_attr; F.rr_pre1 = cx->rr_pre1; F.rr_sh = cx->rr_sh;
   F.e_src = cx->e_src; F.e_dst = cx->e_dst; F.e_aux = cx->e_aux; F.info = cx->info; F.e_emb = cx->e_emb; F.e_sh = cx->e_sh;
@@ -500,6 +506,25 @@ int ddk_score_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* lig
   StepParams sp;
   if ((rc = make_step_params(ctx, t_tr, t_rot, t_tor, sp))) return rc;
   return score_forward_impl(ctx, cx, B, lig_pos, sp, tr_out, rot_out, tor_out, (hipStream_t)stream);
+}
+
+int ddk_build_graph(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* lig_pos, float t_tr, int32_t* edge_src_out,
+                    int32_t* edge_dst_out, int64_t cap, int32_t* group_offsets_out, void* stream) {
+  int rc = check_model(ctx, cx, B);
+  if (rc) return rc;
+  if (!lig_pos || !edge_src_out || !edge_dst_out || !group_offsets_out) return fail(ctx, DDK_ERR_INVALID, "ddk_build_graph: null argument");
+  const int64_t cap_b = (int64_t)B * ((int64_t)cx->M + (int64_t)cx->n_lig * (LIG_CAP - 1) + 2LL * cx->n_lig * cx->n_rec + cx->E_rr);
+  const int64_t need = cap_b < cx->edge_cap ? cap_b : cx->edge_cap;
+  if (cap < need) return fail(ctx, DDK_ERR_INVALID, "ddk_build_graph: cap " + std::to_string(cap) + " is below the worst case " + std::to_string(need) + " of this batch");
+  StepParams sp;
+  if ((rc = make_step_params(ctx, t_tr, t_tr, t_tr, sp))) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = build_graph(ctx, cx, B, lig_pos, sp.cross_cutoff, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(edge_src_out, cx->e_src, (size_t)need * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(edge_dst_out, cx->e_dst, (size_t)need * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(group_offsets_out, cx->info + 5, 5 * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
+  if (e != hipSuccess) return hip_fail(ctx, e, "ddk_build_graph");
+  return DDK_OK;
 }
 
 int ddk_se3_update(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* pos, const float* tr, const float* rot,

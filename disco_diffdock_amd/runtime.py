@@ -45,6 +45,12 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _need_cuda(t):
+    if not t.is_cuda:
+        raise RuntimeError('ddk: device tensors only (no CPU path exists); got a tensor on ' + str(t.device))
+    return t
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
@@ -202,7 +208,7 @@ class Complex:
     # ---- model.score_model(batch) ------------------------------------------------------------------
     def score_forward(self, pos, t_tr, t_rot, t_tor):
         ctx = self.ctx
-        pos = pos.contiguous().float().reshape(-1, self.n_lig, 3)
+        pos = _need_cuda(pos).contiguous().float().reshape(-1, self.n_lig, 3)
         B = pos.shape[0]
         dev = pos.device
         tr = torch.empty((B, 3), dtype=torch.float32, device=dev)
@@ -317,6 +323,22 @@ class Complex:
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         ctx._check(ctx.L.ddk_sample(ctx.h, self.h, B, steps, p(t), p(sc), p(nc), _ptr(noise), _ptr(pos), _stream()), 'ddk_sample')
         return pos
+
+    def build_graph(self, pos, t_tr):
+        """score_model.py:310-408 + :218-225 alone: ``(edge_index [2, E] int32, group_offsets [5])`` of the merged graph of the B poses
+        ``pos`` [B, n_lig, 3] at diffusion time t_tr; groups [lig-lig | lig->rec | rec-rec | rec->lig], each sorted by row 0 (the
+        receiving node, tensor_layers.py:159); nodes numbered [all ligand atoms | all residues]."""
+        pos = _need_cuda(pos).contiguous().float().reshape(-1, self.n_lig, 3)
+        B = pos.shape[0]
+        cap = B * (self.M + self.n_lig * 32 + 2 * self.n_lig * self.n_rec + self.E_rr)
+        src = torch.empty(cap, dtype=torch.int32, device=pos.device)
+        dst = torch.empty(cap, dtype=torch.int32, device=pos.device)
+        off = torch.empty(5, dtype=torch.int32, device=pos.device)
+        self.ctx._check(self.ctx.L.ddk_build_graph(self.ctx.h, self.h, B, _ptr(pos), float(t_tr), _ptr(src), _ptr(dst), cap, _ptr(off),
+                                                   _stream()), 'ddk_build_graph')
+        off = off.cpu()
+        E = int(off[4])
+        return torch.stack([src[:E], dst[:E]]), off
 
     def graph_stats(self):
         out = (C.c_int64 * 8)()

@@ -187,6 +187,18 @@ int ddk_pose_metrics(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* pos,
 int ddk_sample(ddk_ctx* ctx, ddk_complex* cx, int32_t B, int32_t steps, const float* t, const float* score_coeff,
                const float* noise_coeff, const float* noise, float* pos, void* stream);
 
+/* ---- graph construction alone (score_model.py:310-344 build_lig_conv_graph, :346-373 build_rec_conv_graph, :375-408
+ *      build_cross_conv_graph, merged as in :218-225): for B poses of the complex at diffusion time t_tr, the ONE edge list the
+ *      conv layers consume, in the reference's group order [lig-lig | lig->rec | rec-rec | rec->lig(flipped)], every group sorted
+ *      by edge_src.  Row convention of tensor_layers.py:147-159: edge_src = node that RECEIVES the message (scatter index),
+ *      edge_dst = node whose features enter the tensor product; node numbering [ligand atoms of all samples | residues of all
+ *      samples].  lig-lig = covalent bonds + radius_graph(lig_max_radius, <= 32 neighbours); cross cutoff = 3 sigma_tr(t_tr) + 20
+ *      (dynamic_max_cross) or cross_max_distance.  edge_src_out / edge_dst_out: device [cap] int32; group_offsets_out: device [5]
+ *      int32 (offsets of the four groups, [4] = E).  DDK_ERR_INVALID when cap is below the complex' worst case
+ *      (ddk_last_graph_stats out[7]); no host synchronisation inside. */
+int ddk_build_graph(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* lig_pos, float t_tr, int32_t* edge_src_out,
+                    int32_t* edge_dst_out, int64_t cap, int32_t* group_offsets_out, void* stream);
+
 /* ---- introspection for tests / benches ------------------------------------------------------ */
 /* Copies the last forward's per-stage edge counts into out[8] (HOST): E_ll, E_lr, E_rr, E_rl, tiles, ... */
 int ddk_last_graph_stats(ddk_ctx* ctx, ddk_complex* cx, int64_t* out, void* stream);

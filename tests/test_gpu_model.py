@@ -684,3 +684,36 @@ def test_pose_metrics(dev, golden):
         cx = Complex(_shape_context(0), c, max_batch=B)
         got = cx.pose_metrics(T(pos).to(dev), T(ref), None if mask is None else T(mask)).cpu().numpy()
         assert np.allclose(got, np.stack([rmsd, cen, cross, sd], 1), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('t', [1.0, 0.3, 0.0])
+def test_build_graph_vs_oracle(dev, t):
+    """ddk_build_graph (score_model.py:310-408, 218-225 alone) against the oracle's graph builders: same edge multisets per group (the
+    reference order inside a group is torch_cluster's, ours is sorted by the receiving node), group order and node numbering of the
+    merged graph, every group sorted by edge_src."""
+    from disco_diffdock_amd import synthetic
+    from disco_diffdock_amd.runtime import Context, Complex
+    c = synthetic.make_complex(12, n_res=60, n_lig=23)
+    ctx = Context(device=0)
+    ctx.load_state_dict(smr.random_state_dict(CFG, seed=2))
+    B = 3
+    rng = np.random.default_rng(3)
+    pos = np.stack([c['lig_pos'] + rng.normal(0, 3.0, size=(1, 3)) for _ in range(B)]).astype(np.float32)
+    cx = Complex(ctx, c, B)
+    ei, off = cx.build_graph(T(pos).to(dev), t)
+    ei, off = ei.cpu().long(), [int(v) for v in off]
+    b = batch_of(c, B, pos)
+    spr.set_time(b, t, t, t, B)
+    g = smr.embed(smr.random_state_dict(CFG, seed=2), CFG, b, return_graph=True)[-1]
+    s1, s2, s3 = g['splits']
+    ref_ei = g['edge_index']
+    bounds = [0, s1, s2, s3, ref_ei.shape[1]]
+    from collections import Counter     # lig-lig is a MULTISET: a covalent bond inside the radius appears as bond edge and as radius edge
+    want = {k: Counter(zip(ref_ei[0, bounds[k]:bounds[k + 1]].tolist(), ref_ei[1, bounds[k]:bounds[k + 1]].tolist())) for k in range(4)}
+    assert off[0] == 0 and off[4] == ei.shape[1] == ref_ei.shape[1]
+    for k in range(4):
+        sl = ei[:, off[k]:off[k + 1]]
+        assert Counter(zip(sl[0].tolist(), sl[1].tolist())) == want[k], k
+        assert bool((sl[0, 1:] >= sl[0, :-1]).all()), k
+    with pytest.raises(RuntimeError):
+        cx.build_graph(T(pos), t)          # CPU tensor: no CPU path

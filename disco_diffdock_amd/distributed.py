@@ -36,6 +36,31 @@ def gather_poses(poses, n_lig, samples, device):
     return {i: buf[i, :, :n_lig[i]].clone() for i in range(n)}
 
 
+def gather_confidences(conf, n_complexes, device):
+    """conf: {complex index: tensor [samples] or [samples, k]} (the confidence model's output for this rank's complexes,
+    evaluate.py:317-325 ranks poses by it) -> on every rank the full {index: tensor}; rides with the pose gather (disjoint slots)."""
+    shape = None
+    for v in conf.values():
+        shape = tuple(v.shape)
+    meta = torch.zeros(3, dtype=torch.int64, device=device)       # a rank without complexes learns the shape from the others
+    if shape is not None:
+        meta[0], meta[1], meta[2] = len(shape), shape[0], (shape[1] if len(shape) > 1 else 1)
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if multi:
+        dist.all_reduce(meta, op=dist.ReduceOp.MAX)
+    nd, S, k = [int(v) for v in meta.tolist()]
+    buf = torch.zeros((n_complexes, S, k), dtype=torch.float32, device=device)
+    own = torch.zeros(n_complexes, dtype=torch.float32, device=device)
+    for i, v in conf.items():
+        buf[i] = v.to(device).float().reshape(S, k)
+        own[i] = 1.0
+    if multi:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        dist.all_reduce(own, op=dist.ReduceOp.SUM)
+    assert bool((own == 1).all()), 'every complex must be owned by exactly one rank'
+    return {i: (buf[i, :, 0] if nd == 1 else buf[i]).clone() for i in range(n_complexes)}
+
+
 def shard_samples(n_samples, rank, world):
     """Large-pocket layout of SURVEY.md §8(e): the samples of ONE complex are independent given the latent, so rank r takes the
     contiguous slice [lo, hi) of the n_samples poses (receptor replicated on every rank, ``Complex(max_batch=hi-lo)``)."""

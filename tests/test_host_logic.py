@@ -99,7 +99,13 @@ def _worker(rank, world, port, tmp):
     lo, hi = shard_samples(7, rank, world)
     whole = torch.arange(7 * 4 * 3, dtype=torch.float32).reshape(7, 4, 3)
     got = gather_samples(whole[lo:hi], 7, rank, world, torch.device('cpu'))
+    from disco_diffdock_amd.distributed import gather_confidences
+    conf = gather_confidences({i: torch.tensor([[i + 0.5 * s, -i] for s in range(S)]) for i in mine}, len(n_lig), torch.device('cpu'))
+    conf1 = gather_confidences({i: torch.arange(S) * 1.0 + 10 * i for i in mine}, len(n_lig), torch.device('cpu'))
+    okc = all(torch.equal(conf[i], torch.tensor([[i + 0.5 * s, -i] for s in range(S)])) and torch.equal(conf1[i], torch.arange(S) * 1.0 + 10 * i)
+              for i in range(len(n_lig)))
     if rank == 0:
+        assert okc
         ok = all(torch.equal(full[i], torch.full((S, n_lig[i], 3), float(i)) + torch.arange(S).reshape(S, 1, 1)) for i in range(len(n_lig)))
         ok = ok and torch.equal(got, whole)
         open(os.path.join(tmp, 'ok'), 'w').write(str(ok))

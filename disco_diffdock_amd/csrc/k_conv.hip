@@ -7,10 +7,10 @@
 //     sum = scatter_sum(m, src)       wave-level segmented reduction + fp32 atomics on the segment tails
 // (mean / BatchNorm / residual are applied by node_finalize_kernel below.)
 //
-// Mapping onto CDNA4 (one 64-lane wave == one workgroup, 32 edges per wave iteration):
+// Mapping onto CDNA4 (one persistent 8-wave workgroup per CU; work unit = 256 consecutive edges of one edge group, 32 per wave):
 //   * both GEMMs run on the fp32 matrix cores: v_mfma_f32_32x32x2_f32, D[row][col] with
 //       rows  = 32 output features of the GEMM (hidden units / per-edge weights)   -> A operand = packed weights
-//       cols  = the 32 edges of the tile                                           -> B operand = per-edge activations
+//       cols  = the 32 edges of the wave                                           -> B operand = per-edge activations
 //     so lane l always "owns" edge (l & 31); lane-half (l >> 5) selects the K pair of the A/B operands and
 //     the 4-row groups of D.  The hidden vector h = relu(W1 e + b1) therefore comes out of GEMM1 already in
 //     the register layout GEMM2 needs for its B operand (the K order of GEMM2 is permuted at weight-packing
@@ -22,11 +22,13 @@
 //     the algebra allows:
 //       - tile row 8*rq + 4*hh + j = weight of TP input row (row0 + j) for output channel 8*col + 2*rq + hh: all four
 //         accumulator quads of a tile consume the SAME four feature rows (one 16-B / 48-B LDS read of the per-edge "F row")
-//         and the tile kind (scalar rows -> 4 fma per quad, vector rows -> 12) is wave-uniform: one scalar branch per tile;
+//         and the tile kind (scalar rows -> 2 v_pk_fma per quad, vector rows -> 6) is wave-uniform: one scalar branch per tile;
 //       - the a*s0 / a(x)v / c*s0 / c(x)v rows accumulate the plain dot product; s0 or v is applied once per channel when
-//         the column is flushed; the 1/sqrt(n_in) of tensor_layers.py:89-92 and the bias are folded into the packed W2 / C operand;
-//       - the next tile's fragments (9 x 16 B of W2 + 4 x 16 B of bias per lane, L2 resident) are requested in one batch
-//         BEFORE the burst into a second register set.
+//         the column is flushed; the 1/sqrt(n_in) of tensor_layers.py:89-92 and the bias are folded into the packed W2 / C operand.
+//   * the 9.4 KB record of a W2 tile (fragments + bias + descriptor) is fetched from L2 ONCE per workgroup and handed to the eight
+//     waves through a 2-stage LDS ring (private per-wave streams cap the loop near 100 TFLOP/s, probe5): during tile t every
+//     thread requests its 16-32 B of tile t+2, the waves read tile t+1 from the ring into a second register set, and the share of
+//     tile t+2 is published into the stage tile t came from, one barrier per tile.
 //   * when a column (8 output channels) finishes, each value is reduced over runs of equal edge_src inside the wave with a
 //     5-step segmented scan and only the run tails issue global fp32 atomics.
 //

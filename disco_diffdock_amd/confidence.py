@@ -56,7 +56,7 @@ class ConfidenceModel(nn.Module):
 
     def complex_for(self, batch):
         """Complex (+ atoms) in this model's context for a batch of B copies of one all-atom complex graph."""
-        from .score_model import arrays_from_batch, _fingerprint
+        from .score_model import arrays_from_batch, _fingerprint, _first_view
         B = batch.num_graphs
         key = (id(self.ctx),) + _fingerprint(batch, B) + (batch['atom'].num_nodes,)
         cx = _conf_cache.get(key)
@@ -64,11 +64,12 @@ class ConfidenceModel(nn.Module):
             if len(_conf_cache) > 4:
                 _conf_cache.clear()
             arr = arrays_from_batch(batch, B)
-            n_a = batch['atom'].num_nodes // B
-            E_aa = batch['atom', 'atom'].num_edges // B
+            g, B0 = _first_view(batch, B)          # the first graph itself when the batch knows it (no concatenation of the 40 copies)
+            n_a = g['atom'].num_nodes // B0
+            E_aa = g['atom', 'atom'].num_edges // B0
             cx = Complex(self.ctx, arr, max_batch=B)
-            cx.set_atoms(batch['atom'].x[:n_a].cpu(), batch['atom'].pos[:n_a].cpu(), batch['atom', 'atom'].edge_index[:, :E_aa].cpu(),
-                         batch['atom', 'receptor'].edge_index[:, :n_a].cpu())
+            cx.set_atoms(g['atom'].x[:n_a].cpu(), g['atom'].pos[:n_a].cpu(), g['atom', 'atom'].edge_index[:, :E_aa].cpu(),
+                         g['atom', 'receptor'].edge_index[:, :n_a].cpu())
             _conf_cache[key] = cx
         return cx, B
 

@@ -59,6 +59,8 @@ class HeteroData:
 
     def to(self, device):
         for st in self._stores.values():
+            if isinstance(st, _LazyStorage):
+                st.materialise_all()
             for k, v in list(st.__dict__.items()):
                 if torch.is_tensor(v):
                     st.__dict__[k] = v.to(device)
@@ -74,7 +76,9 @@ class HeteroData:
         """shallow copy with its own storages (tensors are shared): rebinding attributes on the copy leaves the original intact"""
         new = HeteroData()
         for k, st in self._stores.items():
-            new._stores[k] = Storage(**st.__dict__)
+            cp = type(st).__new__(type(st))          # keeps a collated batch's stores lazy
+            cp.__dict__.update(st.__dict__)
+            new._stores[k] = cp
         for k, v in self.__dict__.items():
             if not k.startswith('_'):
                 new.__dict__[k] = v
@@ -105,32 +109,79 @@ def from_arrays(c, loader_style=True):
     return d
 
 
+class _LazyStorage(Storage):
+    """Store of a collated batch: an attribute is concatenated over the graphs the first time it is read.  A sampling() batch holds
+    copies of ONE complex (utils/sampling.py:57), whose receptor features ([n_rec, 1281] per copy) the device path never reads from
+    the batch - eager collation spent 10 ms per 40-sample batch copying them."""
+
+    def __init__(self, srcs, kind, off_src=None, off_dst=None):
+        self.__dict__['_srcs'] = srcs
+        self.__dict__['_kind'] = kind
+        self.__dict__['_off'] = (off_src, off_dst)
+
+    def _materialise(self, k):
+        srcs, kind = self.__dict__['_srcs'], self.__dict__['_kind']
+        if k == 'batch' and kind == 'node':
+            v = torch.cat([torch.full((st.num_nodes,), i, dtype=torch.long) for i, st in enumerate(srcs)])
+        elif k in srcs[0].__dict__:
+            vals = [st.__dict__[k] for st in srcs]
+            if k == 'edge_index' and kind == 'edge':
+                o0, o1 = self.__dict__['_off']
+                vals = [v + torch.tensor([[int(o0[i])], [int(o1[i])]], dtype=v.dtype, device=v.device) for i, v in enumerate(vals)]
+                v = torch.cat(vals, 1)
+            else:
+                v = torch.cat(vals, 0) if torch.is_tensor(vals[0]) else list(vals)
+        else:
+            raise AttributeError(k)
+        self.__dict__[k] = v
+        return v
+
+    def __getattr__(self, k):          # only reached when k is not materialised yet
+        if k.startswith('_'):
+            raise AttributeError(k)
+        return self._materialise(k)
+
+    def __contains__(self, k):
+        return k in self.__dict__ or k in self.__dict__['_srcs'][0].__dict__ or (k == 'batch' and self.__dict__['_kind'] == 'node')
+
+    def keys(self):
+        ks = [k for k in self.__dict__['_srcs'][0].__dict__ if not k.startswith('_')]
+        ks += [k for k in self.__dict__ if not k.startswith('_') and k not in ks]
+        if self.__dict__['_kind'] == 'node' and 'batch' not in ks:
+            ks.append('batch')
+        return ks
+
+    def materialise_all(self):
+        for k in self.keys():
+            getattr(self, k)
+        return self
+
+    @property
+    def num_nodes(self):
+        return sum(st.num_nodes for st in self.__dict__['_srcs'])
+
+    @property
+    def num_edges(self):
+        return sum(st.num_edges for st in self.__dict__['_srcs'])
+
+
 def collate(data_list):
+    """Batch of graphs with the accessors of a PyG ``Batch`` (concatenated node/edge attributes, offset edge_index, ``.batch``,
+    ``num_graphs``); attributes are concatenated lazily on first access.  ``batch.first`` is the first graph itself."""
     batch = HeteroData()
     first = data_list[0]
     offs = {nt: np.cumsum([0] + [d[nt].num_nodes for d in data_list]) for nt in first.node_types}
     for nt in first.node_types:
-        st = batch[nt]
-        for k in first[nt].keys():
-            vals = [getattr(d[nt], k) for d in data_list]
-            setattr(st, k, torch.cat(vals, 0) if torch.is_tensor(vals[0]) else list(vals))
-        st.batch = torch.cat([torch.full((d[nt].num_nodes,), i, dtype=torch.long) for i, d in enumerate(data_list)])
+        batch._stores[nt] = _LazyStorage([d[nt] for d in data_list], 'node')
     for et in first.edge_types:
-        st = batch[et]
-        for k in first[et].keys():
-            vals = [getattr(d[et], k) for d in data_list]
-            if k == 'edge_index':
-                vals = [v + torch.tensor([[int(offs[et[0]][i])], [int(offs[et[1]][i])]], dtype=v.dtype, device=v.device)
-                        for i, v in enumerate(vals)]
-                setattr(st, k, torch.cat(vals, 1))
-            else:
-                setattr(st, k, torch.cat(vals, 0) if torch.is_tensor(vals[0]) else list(vals))
+        batch._stores[et] = _LazyStorage([d[et] for d in data_list], 'edge', offs[et[0]], offs[et[1]])
     for k, v in first.__dict__.items():
         if k.startswith('_'):
             continue
         vals = [d.__dict__[k] for d in data_list]
         batch.__dict__[k] = torch.cat(vals, 0) if torch.is_tensor(v) else list(vals)
     batch.num_graphs = len(data_list)
+    batch.first = first
     return batch
 
 

@@ -180,7 +180,10 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
             cx, _ = complex_for_batch(batch, device, ctx=score_model.ctx)
             latent_h = None
             if latent_model:   # utils/sampling.py:69-103: AR decoding on the ar_pos pose, then the latents condition every step
-                batch = batch.to(device)
+                lig_st = batch['ligand']      # only the poses go to the device: the encoder's score-model copy takes everything else
+                lig_st.pos = lig_st.pos.to(device)      # from the cached ddk_complex (a batch.to(device) moved 61 MB of ESM features)
+                if 'ar_pos' in lig_st:
+                    lig_st.ar_pos = lig_st.ar_pos.to(device)
                 temp_lig_pos = batch['ligand'].pos
                 if 'ar_pos' in batch['ligand']:
                     batch['ligand'].pos = batch['ligand'].ar_pos
@@ -188,6 +191,7 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
                 batch['ligand'].pos = temp_lig_pos
                 batch['ligand'].latent_h, batch['receptor'].latent_h = latent_h
                 cx.set_latents(latent_h[0], latent_h[1], 0.0)
+                lat_cpu = (latent_h[0].cpu(), latent_h[1].cpu())     # for the bookkeeping below, fetched before the sampler is enqueued
                 cx.set_guidance(classifier_free_guidance_weight, cfg_start, cfg_end)
             elif score_model.cfg['latent_dim'] > 0:
                 raise RuntimeError('ddk: a latent-conditioned score model was given but use_latent / model_args.latent_dim disable the latents')
@@ -213,19 +217,22 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
                 confidence.append(out[0] if type(out) is tuple else out)
             len_lig = pos.shape[1]
             flat = pos.reshape(-1, 3)
-            len_rec = len(batch['receptor'].pos) // b
+            len_rec = batch['receptor'].num_nodes // b
+            flat_cpu = None
             for i in range(b):
                 d_i = data_list[batch_id * batch_size + i]
                 d_i['ligand'].pos = flat[i * len_lig:len_lig * (i + 1)]
-                if latent_model:   # latent bookkeeping of utils/sampling.py:205-221
-                    lig_lat, rec_lat = latent_h[0][i * len_lig:len_lig * (i + 1)], latent_h[1][i * len_rec:len_rec * (i + 1)]
+                if latent_model:   # latent bookkeeping of utils/sampling.py:205-221 (on host copies: one read-back, not 6 syncs per pose)
+                    lig_lat, rec_lat = lat_cpu[0][i * len_lig:len_lig * (i + 1)], lat_cpu[1][i * len_rec:len_rec * (i + 1)]
                     lat_str, lat_pos = "", []
                     for j in range(model_args.latent_dim):
                         assert torch.sum(lig_lat[:, j]) + torch.sum(rec_lat[:, j]) == 1
                         if torch.sum(lig_lat[:, j]) == 1:
                             idx = int(torch.argmax(lig_lat[:, j]))
                             lat_str += 'L' + str(idx)
-                            lat_pos.append(d_i['ligand'].pos[idx:idx + 1].detach().cpu() + d_i.original_center.detach().cpu())
+                            if flat_cpu is None:
+                                flat_cpu = flat.detach().cpu()
+                            lat_pos.append(flat_cpu[i * len_lig + idx:i * len_lig + idx + 1] + d_i.original_center.detach().cpu())
                         else:
                             idx = int(torch.argmax(rec_lat[:, j]))
                             lat_str += 'R' + str(idx)

@@ -11,7 +11,18 @@ _complex_cache = {}
 _default_ctx = {}
 
 
+def _first_view(batch, B):
+    """(graph, 1) for batches that know their first graph (our collate), else (batch, B): slices below take 1/B of every array"""
+    first = getattr(batch, 'first', None)
+    return (first, 1) if first is not None else (batch, B)
+
+
 def _fingerprint(batch, B):
+    batch, B0 = _first_view(batch, B)
+    return (B,) + _fingerprint_of(batch, B0)[1:]
+
+
+def _fingerprint_of(batch, B):
     lig, rec = batch['ligand'], batch['receptor']
     n_l, n_r = lig.num_nodes // B, rec.num_nodes // B
     x0 = lig.x[:n_l]
@@ -22,6 +33,7 @@ def _fingerprint(batch, B):
 
 def arrays_from_batch(batch, B, mask_rotate=None):
     """Slice the first graph out of a batch of B copies of one complex (utils/sampling.py:57, Appendix A.10)."""
+    batch, B = _first_view(batch, B)
     lig, rec = batch['ligand'], batch['receptor']
     n_l, n_r = lig.num_nodes // B, rec.num_nodes // B
     M = batch['ligand', 'ligand'].num_edges // B

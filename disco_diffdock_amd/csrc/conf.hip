@@ -411,9 +411,8 @@ void conf_complex_free(ddk_complex* cx) {
 
 template <typename T>
 static T* cxu(ddk_complex* cx, const T* src, size_t n) {
-  T* p = nullptr;
-  if (hipMalloc((void**)&p, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr;
-  cx->allocs.push_back(p);
+  T* p = (T*)cx_alloc(cx, n * sizeof(T));
+  if (!p) return nullptr;
   if (n && src && hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
   return p;
 }

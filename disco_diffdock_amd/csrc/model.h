@@ -203,5 +203,28 @@ struct ddk_complex {
   int last_B = 0;
   bool keep_rec = false, last_full = false;   // last conv layer: all groups (true) or ligand-side groups only
   ddk::ConfComplex* conf = nullptr;   // all-atom level (ddk_complex_set_atoms), owned
-  std::vector<void*> allocs;
+  std::vector<void*> allocs;          // arena chunks (hipFree'd by ddk_complex_destroy)
+  char* chunk = nullptr;              // current chunk: bump allocation, 256-B aligned
+  size_t chunk_cap = 0, chunk_off = 0, reserve_hint = 0;
+  bool oom = false;                   // a chunk allocation failed (checked once at the end of the creating call)
 };
+
+namespace ddk {
+// Device memory of a complex comes from a few large chunks instead of one hipMalloc per array (34 + of them per complex, each a
+// driver call; and every hipFree synchronises the device, which stalls a caller that drops complexes while the GPU is busy).
+inline void cx_reserve(ddk_complex* cx, size_t bytes) { cx->reserve_hint = bytes; }
+inline void* cx_alloc(ddk_complex* cx, size_t bytes) {
+  const size_t need = ((bytes ? bytes : 4) + 255) & ~(size_t)255;
+  if (!cx->chunk || cx->chunk_off + need > cx->chunk_cap) {
+    size_t cap = need > cx->reserve_hint ? need : cx->reserve_hint;
+    if (cap < ((size_t)1 << 20)) cap = (size_t)1 << 20;
+    void* p = nullptr;
+    if (hipMalloc(&p, cap) != hipSuccess) { cx->oom = true; return nullptr; }
+    cx->allocs.push_back(p);
+    cx->chunk = (char*)p; cx->chunk_cap = cap; cx->chunk_off = 0; cx->reserve_hint = 0;
+  }
+  void* r = cx->chunk + cx->chunk_off;
+  cx->chunk_off += need;
+  return r;
+}
+}  // namespace ddk

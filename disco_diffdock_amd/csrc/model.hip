@@ -241,9 +241,8 @@ static int make_step_params(ddk_ctx* ctx, float t_tr, float t_rot, float t_tor, 
 
 template <typename T>
 static T* cx_upload(ddk_complex* cx, const T* src, size_t n) {
-  T* p = nullptr;
-  if (hipMalloc((void**)&p, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr;
-  cx->allocs.push_back(p);
+  T* p = (T*)cx_alloc(cx, n * sizeof(T));
+  if (!p) return nullptr;
   if (n && src && hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
   return p;
 }
@@ -373,6 +372,14 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
   cx->n_lig = d->n_lig; cx->n_rec = d->n_rec; cx->M = d->n_bond_edges; cx->R = d->n_rot; cx->E_rr = d->n_rec_edges;
   cx->max_batch = max_batch;
   const int n_lig = d->n_lig, n_rec = d->n_rec, M = d->n_bond_edges, lm = c.lm_embedding_dim;
+  {   // one chunk for everything this function allocates (sizes below mirror the uploads / workspaces; 256 B of slack per array)
+    const size_t E0 = (size_t)d->n_rec_edges, Bm0 = (size_t)max_batch, R0 = (size_t)(d->n_rot > 0 ? d->n_rot : 1);
+    const size_t cap0 = Bm0 * ((size_t)M + (size_t)n_lig * (LIG_CAP - 1) + 2 * (size_t)n_lig * n_rec + E0) + 64, N0 = Bm0 * (size_t)(n_lig + n_rec);
+    size_t need = (size_t)M * 24 + R0 * 8 + R0 * n_lig + (size_t)n_rec * 12 + (size_t)(n_lig + n_rec) * NS * 4 + E0 * (8 + NS * 4 + 16) + (size_t)n_rec * 4;
+    need += cap0 * (12 + NS * 4 + 16) + N0 * 4 + Bm0 * 16 + 256 + 3 * N0 * XW * 4 + (size_t)n_rec * XW * 4 + Bm0 * n_lig * 12 + 2 * Bm0 * (6 + R0) * 4;
+    if (c.latent_dim > 0) need += N0 * c.latent_dim * 4;
+    cx_reserve(cx, need + 64 * 256);
+  }
   // ---- topology ------------------------------------------------------------------------------
   std::vector<int32_t> ru, rv;
   for (int m = 0; m < M; ++m) {
@@ -483,9 +490,7 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
     cx->zero_lat = cx_upload<float>(cx, nullptr, N * c.latent_dim);
     if (cx->zero_lat) hipMemset(cx->zero_lat, 0, (size_t)N * c.latent_dim * sizeof(float));
   }
-  for (void* p : cx->allocs)
-    if (!p) return fail(ctx, DDK_ERR_NOMEM, "device allocation failed in ddk_complex_create");
-  if (!cx->bond_src || !cx->rr_sh || !cx->scores) return fail(ctx, DDK_ERR_NOMEM, "device allocation failed in ddk_complex_create");
+  if (cx->oom || !cx->bond_src || !cx->rr_sh || !cx->scores) return fail(ctx, DDK_ERR_NOMEM, "device allocation failed in ddk_complex_create");
   hipMemset(cx->info, 0, 64 * sizeof(int32_t));
   return DDK_OK;
 }

@@ -36,6 +36,28 @@ __device__ void build_lig_adj(const float* lp, int n_lig, float r2, unsigned (*a
   }
 }
 
+// In-place exclusive prefix sum of a[0..n) in LDS by a 256-thread block (thread t owns a contiguous chunk; wave shuffles across
+// the chunk totals); tmp: 8 ints of LDS.  Ends with a barrier.  (A single thread walking 2000 residues took 85 us.)
+__device__ void block_exclusive_scan(int* a, int n, int* tmp) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (n + 255) / 256;
+  const int beg = min(tid * per, n), end = min(beg + per, n);
+  int s = 0;
+  for (int k = beg; k < end; ++k) s += a[k];
+  int v = s;
+#pragma unroll
+  for (int d = 1; d < 64; d *= 2) {
+    const int t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  if (lane == 63) tmp[wave] = v;
+  __syncthreads();
+  int base = v - s;                     // exclusive prefix inside the wave
+  for (int w = 0; w < wave; ++w) base += tmp[w];
+  for (int k = beg; k < end; ++k) { const int t = a[k]; a[k] = base; base += t; }
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void graph_count_kernel(GraphArgs G) {
   extern __shared__ float smem[];
   float* lp = smem;                              // [MAX_LIG*3]
@@ -96,7 +118,7 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(GraphArgs G) {
   float* rp = lp + MAX_LIG * 3;                       // [n_rec*3]
   int* c_rl = reinterpret_cast<int*>(rp + 3 * G.n_rec);   // [n_rec] -> exclusive prefix
   __shared__ unsigned adj[MAX_LIG][MAX_LIG / 32];
-  __shared__ int bdeg[MAX_LIG], odeg[MAX_LIG], c_lr[MAX_LIG], ll_pre[MAX_LIG], lr_pre[MAX_LIG];
+  __shared__ int bdeg[MAX_LIG], odeg[MAX_LIG], c_lr[MAX_LIG], ll_pre[MAX_LIG], lr_pre[MAX_LIG], scan_tmp[8];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (G.info[24]) return;   // capacity overflow: reported by the host wrapper
   const int n_lig = G.n_lig, n_rec = G.n_rec;
@@ -107,12 +129,20 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(GraphArgs G) {
   __syncthreads();
   build_lig_adj(lp, n_lig, G.lig_r2, adj);
   for (int m = tid; m < G.M; m += 256) atomicAdd(&bdeg[G.bond_src[m]], 1);
-  for (int idx = tid; idx < n_lig * n_rec; idx += 256) {
-    const int i = idx / n_rec, j = idx - i * n_rec;
-    if (cross_within(lp + 3 * i, rp + 3 * j, G.cross_cutoff)) {
-      atomicAdd(&c_lr[i], 1);
-      atomicAdd(&c_rl[j], 1);
+  // cross-edge counts without LDS atomics (at t ~ 1 every pair is an edge: 2 x n_lig x n_rec atomics on n_lig + n_rec addresses
+  // serialised): per ligand atom one wave + ballots, per residue one thread
+  for (int i = wave; i < n_lig; i += 4) {
+    int cnt = 0;
+    for (int j0 = 0; j0 < n_rec; j0 += 64) {
+      const int j = j0 + lane;
+      cnt += __popcll(__ballot(j < n_rec && cross_within(lp + 3 * i, rp + 3 * j, G.cross_cutoff)));
     }
+    if (lane == 0) c_lr[i] = cnt;
+  }
+  for (int j = tid; j < n_rec; j += 256) {
+    int cnt = 0;
+    for (int i = 0; i < n_lig; ++i) cnt += cross_within(lp + 3 * i, rp + 3 * j, G.cross_cutoff) ? 1 : 0;
+    c_rl[j] = cnt;
   }
   __syncthreads();
   for (int j = tid; j < n_lig; j += 256) {
@@ -133,11 +163,7 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(GraphArgs G) {
       lr_pre[i] = c; c += c_lr[i];
     }
   }
-  if (tid == 64) {   // exclusive prefix of the per-residue rec->lig counts (in place)
-    int a = 0;
-    for (int j = 0; j < n_rec; ++j) { const int t = c_rl[j]; c_rl[j] = a; a += t; }
-  }
-  __syncthreads();
+  block_exclusive_scan(c_rl, n_rec, scan_tmp);   // exclusive prefix of the per-residue rec->lig counts (in place; ends with a barrier)
   const int g1 = G.info[6], g2 = G.info[7], g3 = G.info[8];
   // ---- group 0: lig-lig, sorted by src: bonds of the atom (bond order) then radius edges (ascending dst)
   for (int j = tid; j < n_lig; j += 256) {

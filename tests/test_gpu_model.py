@@ -717,3 +717,11 @@ def test_build_graph_vs_oracle(dev, t):
         assert bool((sl[0, 1:] >= sl[0, :-1]).all()), k
     with pytest.raises(RuntimeError):
         cx.build_graph(T(pos), t)          # CPU tensor: no CPU path
+    # a too small caller buffer is refused before anything is written (C ABI level)
+    import ctypes as C
+    small = torch.zeros(16, dtype=torch.int32, device=dev)
+    off5 = torch.zeros(5, dtype=torch.int32, device=dev)
+    p = T(pos).to(dev)
+    rc = ctx.L.ddk_build_graph(ctx.h, cx.h, B, C.c_void_p(p.data_ptr()), C.c_float(t), C.c_void_p(small.data_ptr()), C.c_void_p(small.data_ptr()),
+                               C.c_int64(16), C.c_void_p(off5.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc != 0 and b'worst case' in ctx.L.ddk_last_error(ctx.h) and int(small.abs().sum()) == 0

@@ -181,11 +181,17 @@ def make_ligand(rng, n_atoms=None):
     for _ in range(k2):
         cur, d = grow(cur, d)
     heavy = list(range(len(pos)))
+    failed = 0
     while len(pos) < n_atoms:
         parent = int(rng.choice(heavy))
         try:
             grow(parent, None)
+            failed = 0
         except RuntimeError:
+            failed += 1
+            if failed >= 8:       # the backbone is saturated (large n_atoms): let the side chains grow on (never reached for 20-40 atoms)
+                heavy = list(range(len(pos)))
+                failed = 0
             continue
     n = len(pos)
     pos = np.asarray(pos)

@@ -1,0 +1,60 @@
+"""Development aid: randomised parity sweep of ddk_score_forward against the CPU oracle over small complexes of varied shape
+(ligand size, receptor size, batch, diffusion time, ligand placement incl. far away from the receptor, compressed ligands whose
+neighbour caps bind).  Prints the worst relative error per output and the case that produced it."""
+import os, sys
+import numpy as np, torch
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..', '..'))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from oracle import score_model_ref as smr, sampler_ref as spr
+from helpers import batch_of, rel_err
+from disco_diffdock_amd import synthetic
+from disco_diffdock_amd.runtime import Context, Complex
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+dev = torch.device('cuda:0')
+d = os.path.join(ROOT, 'disco_diffdock_amd', 'data')
+tables = (np.load(os.path.join(d, 'so3_exp_score_norms.npy')), np.load(os.path.join(d, 'torus_score_norm_seed0.npy')))
+CFG = smr.ScoreModelConfig(latent_vocab=64)
+worst = {}
+rng = np.random.default_rng(2024)
+for case in range(N):
+    seed = int(rng.integers(1 << 30))
+    n_res = int(rng.choice([5, 17, 40, 64, 97]))
+    n_lig = int(rng.choice([12, 18, 25, 33, 48]))
+    B = int(rng.choice([1, 2, 3, 5]))
+    t = float(rng.choice([1.0, 0.9, 0.5, 0.2, 0.03, 0.0]))
+    place = rng.choice(['pocket', 'far', 'compressed', 'spread'])
+    c = synthetic.make_complex(seed % 100000, n_res=n_res, n_lig=n_lig)
+    P = smr.random_state_dict(CFG, seed=seed % 1000)
+    base = c['lig_pos'].astype(np.float64)
+    cen = base.mean(0, keepdims=True)
+    pos = []
+    for b in range(B):
+        if place == 'far':
+            p = base + np.array([[150.0, -80.0, 60.0]])
+        elif place == 'compressed':          # many atoms inside 5 A: radius-graph / bond-centre caps bind
+            p = cen + 0.35 * (base - cen)
+        elif place == 'spread':
+            p = base + rng.normal(0, 12.0, size=(1, 3))
+        else:
+            p = base + rng.normal(0, 2.0, size=(1, 3)) + rng.normal(0, 0.2, size=base.shape)
+        pos.append(p)
+    pos = np.stack(pos).astype(np.float32)
+    ctx = Context(device=0)
+    ctx.load_state_dict(P)
+    cx = Complex(ctx, c, B)
+    tr, rot, tor = cx.score_forward(torch.from_numpy(pos).to(dev), t, t, t)
+    st = cx.graph_stats()
+    bt = batch_of(c, B, pos)
+    spr.set_time(bt, t, t, t, B)
+    tr_r, rot_r, tor_r = smr.score_model_forward(P, CFG, bt, tables[0], tables[1])
+    errs = dict(tr=rel_err(tr.cpu(), tr_r), rot=rel_err(rot.cpu(), rot_r), tor=rel_err(tor.cpu(), tor_r) if tor_r.numel() else 0.0)
+    desc = f'case {case}: seed={seed} n_res={n_res} n_lig={len(c["lig_pos"])} R={cx.R} B={B} t={t} {place} E={st["E"]} E_lr={st["E_lr"]}'
+    for k, v in errs.items():
+        if not np.isfinite(v) or v > worst.get(k, (-1, ''))[0]:
+            worst[k] = (float(v), desc)
+    flag = '' if max(errs.values()) < 1e-4 else '   <-- ABOVE 1e-4'
+    print(desc, ' '.join(f'{k}={v:.2e}' for k, v in errs.items()), flag, flush=True)
+    cx.close(); ctx.close()
+print('worst:', worst)

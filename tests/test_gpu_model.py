@@ -725,3 +725,35 @@ def test_build_graph_vs_oracle(dev, t):
     rc = ctx.L.ddk_build_graph(ctx.h, cx.h, B, C.c_void_p(p.data_ptr()), C.c_float(t), C.c_void_p(small.data_ptr()), C.c_void_p(small.data_ptr()),
                                C.c_int64(16), C.c_void_p(off5.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc != 0 and b'worst case' in ctx.L.ddk_last_error(ctx.h) and int(small.abs().sum()) == 0
+
+
+@pytest.mark.parametrize('case', range(10))
+def test_randomised_shapes_vs_oracle(dev, tables, case):
+    """Randomised sweep over shapes the fixed cases do not hit together (5-97 residues, 12-48 ligand atoms, batch 1-5, t in [0, 1],
+    ligand in the pocket / far from the receptor (no cross edges) / compressed so that the neighbour caps bind / spread out):
+    tr, rot, tor against the oracle at the north-star bar.  (tests/devtools/fuzz_parity.py runs longer sweeps of the same kind.)"""
+    from disco_diffdock_amd import synthetic
+    from disco_diffdock_amd.runtime import Context, Complex
+    rng = np.random.default_rng(9000 + case)
+    seed = int(rng.integers(100000))
+    n_res, n_lig = int(rng.choice([5, 17, 40, 64, 97])), int(rng.choice([12, 18, 25, 33, 48]))
+    B, t = int(rng.choice([1, 2, 3, 5])), float(rng.choice([1.0, 0.9, 0.5, 0.2, 0.03, 0.0]))
+    place = ['pocket', 'far', 'compressed', 'spread'][case % 4]
+    c = synthetic.make_complex(seed, n_res=n_res, n_lig=n_lig)
+    P = smr.random_state_dict(CFG, seed=seed % 1000)
+    base = c['lig_pos'].astype(np.float64)
+    cen = base.mean(0, keepdims=True)
+    pos = np.stack([{'far': base + np.array([[150.0, -80.0, 60.0]]), 'compressed': cen + 0.35 * (base - cen),
+                     'spread': base + rng.normal(0, 12.0, size=(1, 3)),
+                     'pocket': base + rng.normal(0, 2.0, size=(1, 3)) + rng.normal(0, 0.2, size=base.shape)}[place] for _ in range(B)]).astype(np.float32)
+    ctx = Context(device=0)
+    ctx.load_state_dict(P)
+    cx = Complex(ctx, c, B)
+    tr, rot, tor = cx.score_forward(T(pos).to(dev), t, t, t)
+    if place == 'far':
+        assert cx.graph_stats()['E_lr'] == 0
+    b = batch_of(c, B, pos)
+    spr.set_time(b, t, t, t, B)
+    tr_r, rot_r, tor_r = smr.score_model_forward(P, CFG, b, tables[0], tables[1])
+    assert rel_err(tr.cpu(), tr_r) < 1e-4 and rel_err(rot.cpu(), rot_r) < 1e-4
+    assert tor.numel() == tor_r.numel() and (tor_r.numel() == 0 or rel_err(tor.cpu(), tor_r) < 1e-4)

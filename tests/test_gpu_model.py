@@ -185,6 +185,15 @@ def test_sampling_vs_oracle(dev, tables):
     a = torch.cat([d['ligand'].pos for d in out]).cpu()
     r = torch.cat([d['ligand'].pos for d in ref])
     assert rel_err(a, r) < 1e-4
+    # the README DiffDock-S command samples 40 poses in batches of 10 (--batch_size 10): batches are independent, so two batches of 2
+    # with the noise split the same way reproduce the single batch of 4
+    dl2 = [from_arrays(c) for _ in range(B)]
+    for d, p in zip(dl2, start):
+        d['ligand'].pos = T(p).float()
+    out2, _ = sampling(dl2, model, steps, sched, sched, sched, dev, partial(t_to_sigma, args=ARGS_S), ARGS_S, batch_size=2,
+                       no_final_step_noise=True, noise=[z[:, :2].contiguous(), z[:, 2:].contiguous()], **README_S)
+    a2 = torch.cat([d['ligand'].pos for d in out2]).cpu()
+    assert rel_err(a2, a) < 1e-5
 
 
 @pytest.mark.parametrize('n_res,t,min_edges', [(300, 0.4, 500000), (2000, 0.4, 2000000), (2000, 1.0, 5000000)])

@@ -123,8 +123,8 @@ class _LazyStorage(Storage):
         srcs, kind = self.__dict__['_srcs'], self.__dict__['_kind']
         if k == 'batch' and kind == 'node':
             v = torch.cat([torch.full((st.num_nodes,), i, dtype=torch.long) for i, st in enumerate(srcs)])
-        elif k in srcs[0].__dict__:
-            vals = [st.__dict__[k] for st in srcs]
+        elif k in self._src_keys():
+            vals = [getattr(st, k) for st in srcs]     # (generic accessors: the sources may be PyG storages)
             if k == 'edge_index' and kind == 'edge':
                 o0, o1 = self.__dict__['_off']
                 vals = [v + torch.tensor([[int(o0[i])], [int(o1[i])]], dtype=v.dtype, device=v.device) for i, v in enumerate(vals)]
@@ -136,16 +136,19 @@ class _LazyStorage(Storage):
         self.__dict__[k] = v
         return v
 
+    def _src_keys(self):
+        return [k for k in self.__dict__['_srcs'][0].keys() if not str(k).startswith('_')]
+
     def __getattr__(self, k):          # only reached when k is not materialised yet
         if k.startswith('_'):
             raise AttributeError(k)
         return self._materialise(k)
 
     def __contains__(self, k):
-        return k in self.__dict__ or k in self.__dict__['_srcs'][0].__dict__ or (k == 'batch' and self.__dict__['_kind'] == 'node')
+        return k in self.__dict__ or k in self._src_keys() or (k == 'batch' and self.__dict__['_kind'] == 'node')
 
     def keys(self):
-        ks = [k for k in self.__dict__['_srcs'][0].__dict__ if not k.startswith('_')]
+        ks = self._src_keys()
         ks += [k for k in self.__dict__ if not k.startswith('_') and k not in ks]
         if self.__dict__['_kind'] == 'node' and 'batch' not in ks:
             ks.append('batch')
@@ -174,7 +177,7 @@ def collate(data_list):
     for nt in first.node_types:
         batch._stores[nt] = _LazyStorage([d[nt] for d in data_list], 'node')
     for et in first.edge_types:
-        batch._stores[et] = _LazyStorage([d[et] for d in data_list], 'edge', offs[et[0]], offs[et[1]])
+        batch._stores[HeteroData._key(et)] = _LazyStorage([d[et] for d in data_list], 'edge', offs[et[0]], offs[et[-1]])   # PyG edge types are 3-tuples
     for k, v in first.__dict__.items():
         if k.startswith('_'):
             continue

@@ -170,3 +170,65 @@ def test_product_confidence_spec_equals_reference_layout():
     a = {k: tuple(v) for k, v in synthetic.confidence_state_dict_spec().items()}
     b = {k: tuple(v) for k, v in cr.state_dict_spec(cr.ConfidenceModelConfig()).items()}
     assert a == b and len(a) == 430 and sum(int(np.prod(v)) for v in a.values()) == 4773122
+
+
+def test_collate_accepts_pyg_style_graphs():
+    """The reference hands torch_geometric HeteroData to sampling(): stores keep their tensors in a mapping (not in __dict__), edge
+    types are 3-tuples.  A minimal stand-in with exactly those accessors must collate to the same batch as our own container."""
+    import numpy as np
+    import torch
+    from disco_diffdock_amd import synthetic
+    from disco_diffdock_amd.data import from_arrays, collate
+
+    class Store:
+        def __init__(self, **kw):
+            object.__setattr__(self, '_mapping', dict(kw))
+
+        def keys(self):
+            return list(self._mapping)
+
+        def __getattr__(self, k):
+            try:
+                return object.__getattribute__(self, '_mapping')[k]
+            except KeyError:
+                raise AttributeError(k)
+
+        def __contains__(self, k):
+            return k in self._mapping
+
+        @property
+        def num_nodes(self):
+            return self._mapping['pos'].shape[0]
+
+        @property
+        def num_edges(self):
+            return self._mapping['edge_index'].shape[1]
+
+    class PygLike:
+        def __init__(self, g):
+            self._node = {nt: Store(**{k: getattr(g[nt], k) for k in g[nt].keys()}) for nt in g.node_types}
+            names = {('ligand', 'ligand'): 'lig_bond', ('receptor', 'receptor'): 'rec_contact'}
+            self._edge = {(et[0], names[et], et[1]): Store(**{k: getattr(g[et], k) for k in g[et].keys()}) for et in g.edge_types}
+
+        node_types = property(lambda self: list(self._node))
+        edge_types = property(lambda self: list(self._edge))
+
+        def __getitem__(self, key):
+            if isinstance(key, tuple):
+                for et, st in self._edge.items():
+                    if (et[0], et[-1]) == (key[0], key[-1]):
+                        return st
+                raise KeyError(key)
+            return self._node[key]
+
+    c = synthetic.make_complex(5, n_res=30, n_lig=20)
+    own = [from_arrays(c) for _ in range(3)]
+    for i, g in enumerate(own):
+        g['ligand'].pos = g['ligand'].pos + float(i)
+    a, b = collate(own), collate([PygLike(g) for g in own])
+    assert a.num_graphs == b.num_graphs == 3
+    for nt, k in (('ligand', 'pos'), ('ligand', 'x'), ('ligand', 'batch'), ('receptor', 'pos'), ('receptor', 'batch')):
+        assert torch.equal(getattr(a[nt], k), getattr(b[nt], k)), (nt, k)
+    for et in (('ligand', 'ligand'), ('receptor', 'receptor')):
+        assert torch.equal(a[et].edge_index, b[et].edge_index) and a[et].num_edges == b[et].num_edges
+    assert a['ligand'].num_nodes == b['ligand'].num_nodes == 3 * len(c['lig_pos'])

@@ -16,6 +16,13 @@ __device__ __forceinline__ bool cross_within(const float* lp, const float* rp, f
   return dx * dx + dy * dy + dz * dz < 1.0f;
 }
 
+// the same test on coordinates that were divided by c ONCE when they were staged in LDS (bit-identical quotients; the six IEEE
+// divisions per pair were ~90 % of the instructions of the counting / fill loops)
+__device__ __forceinline__ bool cross_within_scaled(const float* lps, const float* rps) {
+  const float dx = rps[0] - lps[0], dy = rps[1] - lps[1], dz = rps[2] - lps[2];
+  return dx * dx + dy * dy + dz * dz < 1.0f;
+}
+
 __device__ __forceinline__ float dist2(const float* a, const float* b) {
   const float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
   return dx * dx + dy * dy + dz * dz;
@@ -63,10 +70,11 @@ __global__ __launch_bounds__(256) void graph_count_kernel(GraphArgs G) {
   float* lp = smem;                              // [MAX_LIG*3]
   float* rp = lp + MAX_LIG * 3;                  // [n_rec*3]
   __shared__ unsigned adj[MAX_LIG][MAX_LIG / 32];
+  __shared__ float lps[MAX_LIG * 3];             // ligand coordinates / cross cutoff
   __shared__ int s_cnt[2];
   const int b = blockIdx.x, tid = threadIdx.x;
-  for (int i = tid; i < G.n_lig * 3; i += 256) lp[i] = G.lig_pos[(size_t)b * G.n_lig * 3 + i];
-  for (int i = tid; i < G.n_rec * 3; i += 256) rp[i] = G.rec_pos[i];
+  for (int i = tid; i < G.n_lig * 3; i += 256) { const float v = G.lig_pos[(size_t)b * G.n_lig * 3 + i]; lp[i] = v; lps[i] = v / G.cross_cutoff; }
+  for (int i = tid; i < G.n_rec * 3; i += 256) rp[i] = G.rec_pos[i] / G.cross_cutoff;      // only the cross test reads the residues here
   if (tid < 2) s_cnt[tid] = 0;
   __syncthreads();
   build_lig_adj(lp, G.n_lig, G.lig_r2, adj);
@@ -76,7 +84,7 @@ __global__ __launch_bounds__(256) void graph_count_kernel(GraphArgs G) {
     for (int w = 0; w < MAX_LIG / 32; ++w) c_ll += __popc(adj[i][w]);
   for (int idx = tid; idx < G.n_lig * G.n_rec; idx += 256) {
     const int i = idx / G.n_rec, j = idx - i * G.n_rec;
-    c_lr += cross_within(lp + 3 * i, rp + 3 * j, G.cross_cutoff) ? 1 : 0;
+    c_lr += cross_within_scaled(lps + 3 * i, rp + 3 * j) ? 1 : 0;
   }
   atomicAdd(&s_cnt[0], c_ll);
   atomicAdd(&s_cnt[1], c_lr);
@@ -112,6 +120,8 @@ __global__ void graph_scan_kernel(GraphArgs G, int64_t edge_cap) {
   G.info[24] = ((int64_t)go[4] > edge_cap) ? 1 : 0;
 }
 
+constexpr int FILL_SLICES = 4;
+
 __global__ __launch_bounds__(256) void graph_fill_kernel(GraphArgs G) {
   extern __shared__ float smem[];
   float* lp = smem;                                   // [MAX_LIG*3]
@@ -119,11 +129,14 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(GraphArgs G) {
   int* c_rl = reinterpret_cast<int*>(rp + 3 * G.n_rec);   // [n_rec] -> exclusive prefix
   __shared__ unsigned adj[MAX_LIG][MAX_LIG / 32];
   __shared__ int bdeg[MAX_LIG], odeg[MAX_LIG], c_lr[MAX_LIG], ll_pre[MAX_LIG], lr_pre[MAX_LIG], scan_tmp[8];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // FILL_SLICES workgroups per sample: each repeats the (cheap) counting / prefix phase and writes one slice of the edge list --
+  // one workgroup per sample left 216 CUs idle while 256 threads issued ~300 scattered stores each
+  const int b = blockIdx.x, slice = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (G.info[24]) return;   // capacity overflow: reported by the host wrapper
   const int n_lig = G.n_lig, n_rec = G.n_rec;
-  for (int i = tid; i < n_lig * 3; i += 256) lp[i] = G.lig_pos[(size_t)b * n_lig * 3 + i];
-  for (int i = tid; i < n_rec * 3; i += 256) rp[i] = G.rec_pos[i];
+  __shared__ float lps[MAX_LIG * 3];             // ligand coordinates / cross cutoff
+  for (int i = tid; i < n_lig * 3; i += 256) { const float v = G.lig_pos[(size_t)b * n_lig * 3 + i]; lp[i] = v; lps[i] = v / G.cross_cutoff; }
+  for (int i = tid; i < n_rec * 3; i += 256) rp[i] = G.rec_pos[i] / G.cross_cutoff;      // only the cross test reads the residues here
   for (int i = tid; i < MAX_LIG; i += 256) { bdeg[i] = 0; c_lr[i] = 0; }
   for (int j = tid; j < n_rec; j += 256) c_rl[j] = 0;
   __syncthreads();
@@ -135,13 +148,13 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(GraphArgs G) {
     int cnt = 0;
     for (int j0 = 0; j0 < n_rec; j0 += 64) {
       const int j = j0 + lane;
-      cnt += __popcll(__ballot(j < n_rec && cross_within(lp + 3 * i, rp + 3 * j, G.cross_cutoff)));
+      cnt += __popcll(__ballot(j < n_rec && cross_within_scaled(lps + 3 * i, rp + 3 * j)));
     }
     if (lane == 0) c_lr[i] = cnt;
   }
   for (int j = tid; j < n_rec; j += 256) {
     int cnt = 0;
-    for (int i = 0; i < n_lig; ++i) cnt += cross_within(lp + 3 * i, rp + 3 * j, G.cross_cutoff) ? 1 : 0;
+    for (int i = 0; i < n_lig; ++i) cnt += cross_within_scaled(lps + 3 * i, rp + 3 * j) ? 1 : 0;
     c_rl[j] = cnt;
   }
   __syncthreads();
@@ -153,8 +166,10 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(GraphArgs G) {
   __syncthreads();
   const int lig0 = b * n_lig, rec0 = (G.rec_node_base >= 0 ? G.rec_node_base : G.B * n_lig) + b * n_rec;
   // degrees (scatter 'mean' divisor: all incoming groups together, tensor_layers.py:159)
-  for (int i = tid; i < n_lig; i += 256) G.deg[lig0 + i] = bdeg[i] + odeg[i] + c_lr[i];
-  for (int j = tid; j < n_rec; j += 256) G.deg[rec0 + j] = G.rr_outdeg[j] + c_rl[j];
+  if (slice == 0) {
+    for (int i = tid; i < n_lig; i += 256) G.deg[lig0 + i] = bdeg[i] + odeg[i] + c_lr[i];
+    for (int j = tid; j < n_rec; j += 256) G.deg[rec0 + j] = G.rr_outdeg[j] + c_rl[j];
+  }
   __syncthreads();
   if (tid == 0) {
     int a = 0, c = 0;
@@ -166,7 +181,7 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(GraphArgs G) {
   block_exclusive_scan(c_rl, n_rec, scan_tmp);   // exclusive prefix of the per-residue rec->lig counts (in place; ends with a barrier)
   const int g1 = G.info[6], g2 = G.info[7], g3 = G.info[8];
   // ---- group 0: lig-lig, sorted by src: bonds of the atom (bond order) then radius edges (ascending dst)
-  for (int j = tid; j < n_lig; j += 256) {
+  for (int j = tid; slice == 0 && j < n_lig; j += 256) {
     int pos = G.offs[2 * b] + ll_pre[j];
     for (int m = 0; m < G.M; ++m)
       if (G.bond_src[m] == j) {
@@ -178,11 +193,11 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(GraphArgs G) {
       }
   }
   // ---- group 1: lig->rec, sorted by ligand atom then residue: one wave per ligand atom, ballot compaction
-  for (int i = wave; i < n_lig; i += 4) {
+  for (int i = wave + 4 * slice; i < n_lig; i += 4 * FILL_SLICES) {
     int pos = g1 + G.offs[2 * b + 1] + lr_pre[i];
     for (int j0 = 0; j0 < n_rec; j0 += 64) {
       const int j = j0 + lane;
-      const bool in = j < n_rec && cross_within(lp + 3 * i, rp + 3 * j, G.cross_cutoff);
+      const bool in = j < n_rec && cross_within_scaled(lps + 3 * i, rp + 3 * j);
       const unsigned long long mask = __ballot(in);
       if (in) {
         const int p = pos + __popcll(mask & ((1ull << lane) - 1ull));
@@ -192,15 +207,15 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(GraphArgs G) {
     }
   }
   // ---- group 3: rec->lig (flipped cross edges), sorted by residue then ligand atom
-  for (int j = tid; j < n_rec; j += 256) {
+  for (int j = tid + 256 * slice; j < n_rec; j += 256 * FILL_SLICES) {
     int pos = g3 + G.offs[2 * b + 1] + c_rl[j];
     for (int i = 0; i < n_lig; ++i)
-      if (cross_within(lp + 3 * i, rp + 3 * j, G.cross_cutoff)) {
+      if (cross_within_scaled(lps + 3 * i, rp + 3 * j)) {
         G.e_src[pos] = rec0 + j; G.e_dst[pos] = lig0 + i; G.e_aux[pos] = -1; ++pos;
       }
   }
   // ---- group 2: static receptor edges of this sample
-  for (int k = tid; k < G.E_rr; k += 256) {
+  for (int k = tid + 256 * slice; k < G.E_rr; k += 256 * FILL_SLICES) {
     const int pos = g2 + b * G.E_rr + k;
     G.e_src[pos] = rec0 + G.rr_src[k]; G.e_dst[pos] = rec0 + G.rr_dst[k]; G.e_aux[pos] = k;
   }
@@ -324,7 +339,7 @@ hipError_t launch_graph(const GraphArgs& G, int64_t edge_cap, hipStream_t s) {
   const size_t lds = (size_t)(MAX_LIG * 3 + G.n_rec * 3) * 4 + (size_t)G.n_rec * 4;
   hipLaunchKernelGGL(graph_count_kernel, dim3(G.B), dim3(256), lds, s, G);
   hipLaunchKernelGGL(graph_scan_kernel, dim3(1), dim3(64), 0, s, G, edge_cap);
-  hipLaunchKernelGGL(graph_fill_kernel, dim3(G.B), dim3(256), lds, s, G);
+  hipLaunchKernelGGL(graph_fill_kernel, dim3(G.B, FILL_SLICES), dim3(256), lds, s, G);
   return hipGetLastError();
 }
 

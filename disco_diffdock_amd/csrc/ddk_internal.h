@@ -189,10 +189,11 @@ hipError_t launch_conv_fused_h(const ConvLayerDev& L, const ConvLaunch& a, int n
 hipError_t launch_conv_setup(int32_t* tile_info, const int64_t* group_offsets_host, hipStream_t s);
 hipError_t launch_pad_rows(const float* x, int64_t n, int din, float* xpad, hipStream_t s);
 hipError_t launch_count_deg(const int32_t* src, int64_t E, int32_t* deg, hipStream_t s);
-hipError_t launch_node_finalize(const float* sum, const int32_t* deg, const float* x_in /*[N,XW] or null*/,
+hipError_t launch_node_finalize(float* sum, const int32_t* deg, const float* x_in /*[N,XW] or null*/,
                                 const float* bn_mean, const float* bn_scale, const float* bn_bias, int64_t n, int dout,
                                 int out_stride, float* out, hipStream_t s, const float* sum_rr0 = nullptr,
-                                int64_t n_lig_total = 0, int n_rec = 1);
+                                int64_t n_lig_total = 0, int n_rec = 1, int clear_sum = 0, float* zero_extra = nullptr,
+                                int64_t n_extra = 0);
 // k_tp.hip
 hipError_t launch_tp_forward(const ConvLayerDev& L, const float* x_dst, const float* sh, const float* w, int64_t E,
                              float* out, hipStream_t s);

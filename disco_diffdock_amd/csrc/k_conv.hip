@@ -402,10 +402,15 @@ __global__ void count_deg_kernel(const int32_t* src, int64_t E, int32_t* deg) {
 
 // scatter 'mean' divisor, e3nn BatchNorm (eval) and the residual of tensor_layers.py:159-166:
 //   out = ((sum/max(deg,1) - mean) * scale + bias) + pad(x_in)
-__global__ void node_finalize_kernel(const float* sum, const int32_t* deg, const float* x_in, const float* bn_mean,
+// (clear_sum: every accumulator that is read is zeroed behind the read, so the next layer / forward finds a clean buffer without a
+// hipMemsetAsync of [N, 84] per layer; zero_extra: a second buffer to clear - the shared layer-0 rec-rec rows, read by every sample
+// of layer 0's finalize and therefore cleared one launch later)
+__global__ void node_finalize_kernel(float* sum, const int32_t* deg, const float* x_in, const float* bn_mean,
                                      const float* bn_scale, const float* bn_bias, int64_t n, int dout, int out_stride,
-                                     float* out, const float* sum_rr0, int64_t n_lig_total, int n_rec) {
+                                     float* out, const float* sum_rr0, int64_t n_lig_total, int n_rec, int clear_sum,
+                                     float* zero_extra, int64_t n_extra) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (zero_extra != nullptr && i < n_extra) zero_extra[i] = 0.0f;
   if (i >= n * out_stride) return;
   const int64_t r = i / out_stride;
   const int c = (int)(i % out_stride);
@@ -413,6 +418,7 @@ __global__ void node_finalize_kernel(const float* sum, const int32_t* deg, const
   if (c < dout) {
     const int d = deg[r];
     float sv = sum[r * XW + c];
+    if (clear_sum) sum[r * XW + c] = 0.0f;
     if (sum_rr0 != nullptr && r >= n_lig_total) sv += sum_rr0[((r - n_lig_total) % n_rec) * XW + c];   // shared layer-0 rec-rec messages
     v = sv / (float)(d > 1 ? d : 1);
     v = (v - bn_mean[c]) * bn_scale[c] + bn_bias[c];
@@ -470,13 +476,15 @@ hipError_t launch_count_deg(const int32_t* src, int64_t E, int32_t* deg, hipStre
   return hipGetLastError();
 }
 
-hipError_t launch_node_finalize(const float* sum, const int32_t* deg, const float* x_in, const float* bn_mean,
+hipError_t launch_node_finalize(float* sum, const int32_t* deg, const float* x_in, const float* bn_mean,
                                 const float* bn_scale, const float* bn_bias, int64_t n, int dout, int out_stride,
-                                float* out, hipStream_t s, const float* sum_rr0, int64_t n_lig_total, int n_rec) {
-  const int64_t tot = n * out_stride;
+                                float* out, hipStream_t s, const float* sum_rr0, int64_t n_lig_total, int n_rec, int clear_sum,
+                                float* zero_extra, int64_t n_extra) {
+  int64_t tot = n * out_stride;
+  if (zero_extra != nullptr && n_extra > tot) tot = n_extra;
   if (tot == 0) return hipSuccess;
   hipLaunchKernelGGL(node_finalize_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, sum, deg, x_in, bn_mean,
-                     bn_scale, bn_bias, n, dout, out_stride, out, sum_rr0, n_lig_total, n_rec);
+                     bn_scale, bn_bias, n, dout, out_stride, out, sum_rr0, n_lig_total, n_rec, clear_sum, zero_extra, n_extra);
   return hipGetLastError();
 }
 

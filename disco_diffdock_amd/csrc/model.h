@@ -201,6 +201,7 @@ struct ddk_complex {
   float* sum_rr0 = nullptr;   // [n_rec, XW] layer-0 rec-rec messages shared by all samples
   float* x_last = nullptr;    // node features after the conv stack of the last forward
   int last_B = 0;
+  bool sum_clean = false;             // the accumulators are all zero (the last forward completed; node_finalize clears behind itself)
   bool keep_rec = false, last_full = false;   // last conv layer: all groups (true) or ligand-side groups only
   ddk::ConfComplex* conf = nullptr;   // all-atom level (ddk_complex_set_atoms), owned
   std::vector<void*> allocs;          // arena chunks (hipFree'd by ddk_complex_destroy)

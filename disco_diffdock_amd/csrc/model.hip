@@ -308,9 +308,15 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
   NE_.x = xin; NE_.lig_latent = cx->lig_latent; NE_.rec_latent = cx->rec_latent; NE_.lig_w_lat = M->dev.lig_w_lat; NE_.rec_w_lat = M->dev.rec_w_lat;
   NE_.lig_unc = M->dev.lig_node_unc; NE_.rec_unc = M->dev.rec_node_unc; NE_.unconditional = cx->unconditional; NE_.latent_dim = c.latent_dim;
   CK(launch_node_embed(NE_, s), "node embed");
+  // accumulators: node_finalize zeroes what it reads, so a forward that ran to its end leaves them clean for the next one
+  if (!cx->sum_clean) {
+    CK(hipMemsetAsync(cx->sum, 0, (size_t)cx->max_batch * (n_lig + n_rec) * XW * sizeof(float), s), "memset sum");
+    CK(hipMemsetAsync(cx->sum_rr0, 0, (size_t)n_rec * XW * sizeof(float), s), "memset sum_rr0");
+  }
+  cx->sum_clean = false;
+  bool rr0_dirty = false;
   for (int l = 0; l < c.num_conv_layers; ++l) {
     const ConvLayerDev& L = ctx->conv[l];
-    CK(hipMemsetAsync(cx->sum, 0, (size_t)N * XW * sizeof(float), s), "memset sum");
     ConvLaunch a;
     a.x = xin; a.src = cx->e_src; a.dst = cx->e_dst; a.edge_attr = cx->e_emb; a.sh = cx->e_sh; a.sum = cx->sum;
     a.tile_info = cx->info; a.counter = cx->info + 10 + (l % 8); a.gather = 1;
@@ -318,7 +324,7 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
     // (no latents) -> evaluate the rec-rec messages once, exact in real arithmetic
     const bool dedup = (l == 0 && c.latent_dim == 0 && B > 1 && cx->E_rr > 0);
     if (dedup) {
-      CK(hipMemsetAsync(cx->sum_rr0, 0, (size_t)n_rec * XW * sizeof(float), s), "memset sum_rr0");
+      rr0_dirty = true;
       a.g2_limit = cx->E_rr; a.sum_g2 = cx->sum_rr0; a.g2_node_off = B * n_lig;
     }
     // last layer: only ligand rows are read downstream (heads) unless the caller asked for the receptor rows
@@ -337,13 +343,17 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
       CK(hipEventRecord(pr.b, s), "event record");
       ctx->prof_recs.push_back(pr);
     }
+    const bool clear_rr0 = rr0_dirty && !dedup;     // one launch after the layer whose finalize read the shared rows
     CK(launch_node_finalize(cx->sum, cx->deg, xin, L.bn_mean, L.bn_scale, L.bn_bias, lig_only ? (int64_t)B * n_lig : N, L.dout, XW, xout, s,
-                            dedup ? cx->sum_rr0 : nullptr, (int64_t)B * n_lig, n_rec), "node_finalize");
+                            dedup ? cx->sum_rr0 : nullptr, (int64_t)B * n_lig, n_rec, 1, clear_rr0 ? cx->sum_rr0 : nullptr,
+                            clear_rr0 ? (int64_t)n_rec * XW : 0), "node_finalize");
+    if (clear_rr0) rr0_dirty = false;
     float* t = xin; xin = xout; xout = t;
   }
   cx->x_last = xin;
   cx->last_B = B;
   cx->last_full = cx->keep_rec;
+  cx->sum_clean = !rr0_dirty;       // (a one-layer model leaves the shared rows to the memset of the next forward)
   if (ctx->prof && ctx->prof_slots + 1 < ctx->prof_cap) {
     CK(hipMemcpyAsync(ctx->prof_edges + ctx->prof_slots + 1, cx->info + 7, sizeof(int32_t), hipMemcpyDeviceToHost, s), "profile edge count");   // group_off[2] = edges of groups 0+1
     CK(hipMemcpyAsync(ctx->prof_edges + ctx->prof_slots, cx->info + 23, sizeof(int32_t), hipMemcpyDeviceToHost, s), "profile edge count");

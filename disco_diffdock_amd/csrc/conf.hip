@@ -261,7 +261,9 @@ struct LaArgs {
 // (vector atom - ligand for both, :232-238); one wave per ligand atom, the wave reserves a contiguous range of the group.
 __global__ __launch_bounds__(256) void conf_la_kernel(LaArgs A) {
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int i = wave; i < A.n_lig; i += 4) {
+  // grid (B, LA_SLICES): the ligand atoms of a sample are dealt out over LA_SLICES workgroups (edge order inside the group is free:
+  // every wave appends one contiguous run per ligand atom)
+  for (int i = wave + 4 * blockIdx.y; i < A.n_lig; i += 4 * gridDim.y) {
     const float* lp = A.lig_pos + ((size_t)b * A.n_lig + i) * 3;
     const float lx = lp[0], ly = lp[1], lz = lp[2];
     for (int j0 = 0; j0 < A.n_atom; j0 += 64) {
@@ -605,7 +607,7 @@ int ddk_confidence_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float
   LA.r2 = c.lig_max_radius * c.lig_max_radius; LA.mlp = M->la_edge; memcpy(LA.sigb, M->la_sigb, sizeof(LA.sigb));
   LA.gtab = K->gtab; LA.off_la = K->off_la; LA.off_al = K->off_al; LA.cap = K->cap_la;
   LA.e_src = K->e_src; LA.e_dst = K->e_dst; LA.e_emb = K->e_emb; LA.e_sh = K->e_sh;
-  hipLaunchKernelGGL(conf_la_kernel, dim3(B), dim3(256), 0, s, LA);
+  hipLaunchKernelGGL(conf_la_kernel, dim3(B, 8), dim3(256), 0, s, LA);
   CK(hipGetLastError(), "la graph");
   hipLaunchKernelGGL(conf_gtab_kernel, dim3(1), dim3(64), 0, s, K->gtab, cx->info, B, K->E_aa, n_atom, (int)K->off_la, (int)K->off_al,
                      (int)K->off_aa, (int)K->off_ar, (int)K->off_ra, (int)K->cap_la);

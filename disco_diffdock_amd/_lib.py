@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get('DDK_LIB') or os.path.join(_HERE, 'libddk.so')   # DDK_LIB: kernel-experiment builds (tools/build_variant.py)
+LIB_PATH = os.environ.get('DDK_LIB') or os.path.join(_HERE, 'libddk.so')   # DDK_LIB: an alternative build of the library (kernel experiments)
 
 
 class ddk_config(C.Structure):
@@ -42,6 +42,9 @@ SYMBOLS = ['ddk_create', 'ddk_destroy', 'ddk_last_error', 'ddk_version', 'ddk_lo
            'ddk_profile_enable', 'ddk_profile_read', 'ddk_set_latents', 'ddk_set_guidance',
            'ddk_set_keep_receptor_features', 'ddk_randomize_position', 'ddk_complex_set_atoms',
            'ddk_confidence_forward', 'ddk_pose_metrics', 'ddk_build_graph']
+
+# test hooks (include/ddk_debug.h): not part of the drop-in boundary
+DEBUG_SYMBOLS = ['ddk_debug_export', 'ddk_debug_read_edges', 'ddk_debug_conf_counts', 'ddk_debug_conf_nodes', 'ddk_debug_conf_edges']
 
 
 def lib():

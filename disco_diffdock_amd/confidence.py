@@ -58,7 +58,15 @@ class ConfidenceModel(nn.Module):
         """Complex (+ atoms) in this model's context for a batch of B copies of one all-atom complex graph."""
         from .score_model import arrays_from_batch, _fingerprint, _first_view
         B = batch.num_graphs
-        key = (id(self.ctx),) + _fingerprint(batch, B) + (batch['atom'].num_nodes,)
+        g0, B00 = _first_view(batch, B)
+        n_a0, E_aa0 = g0['atom'].num_nodes // B00, g0['atom', 'atom'].num_edges // B00
+        import hashlib
+        from .score_model import _bytes_of
+        ha = hashlib.blake2b(digest_size=16)
+        for a in (g0['atom'].x[:n_a0], g0['atom'].pos[:n_a0], g0['atom', 'atom'].edge_index[:, :E_aa0], g0['atom', 'receptor'].edge_index[:, :n_a0]):
+            ha.update(_bytes_of(a))
+            ha.update(b'|')
+        key = (id(self.ctx),) + _fingerprint(batch, B) + (n_a0, ha.hexdigest())
         cx = _conf_cache.get(key)
         if cx is None or cx.max_batch < B:
             if len(_conf_cache) > 4:

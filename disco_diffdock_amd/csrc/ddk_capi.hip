@@ -447,6 +447,8 @@ int ddk_create(const ddk_config* cfg, ddk_ctx** out) {
   e = hipGetDeviceProperties(&prop, cfg->device);
   if (e != hipSuccess) return hip_fail(ctx, e, "hipGetDeviceProperties");
   ctx->n_cu = prop.multiProcessorCount;
+  e = conv_prepare_device();
+  if (e != hipSuccess) return hip_fail(ctx, e, "hipFuncSetAttribute(dynamic LDS)");
   ctx->ws.tile_info = (int32_t*)dev_alloc(ctx, 64 * sizeof(int32_t));
   if (!ctx->ws.tile_info) return fail(ctx, DDK_ERR_NOMEM, "hipMalloc failed");
   return DDK_OK;
@@ -559,10 +561,7 @@ int ddk_conv_forward(ddk_ctx* ctx, int32_t layer, const float* x, int64_t N, con
     a.x = ws.xpad; a.src = edge_src; a.dst = edge_dst; a.edge_attr = edge_attr; a.sh = sh; a.sum = ws.sum;
     a.tile_info = ws.tile_info; a.counter = ws.tile_info + 10; a.gather = 0;
     if (aa) {
-      int32_t gt[18];
-      for (int g = 0; g < 9; ++g) { gt[g] = 0; gt[9 + g] = g == conv_k ? (int32_t)E : 0; }
-      CK(hipMemcpyAsync(ws.tile_info + 32, gt, sizeof(gt), hipMemcpyHostToDevice, s), "group table");
-      CK(hipStreamSynchronize(s), "group table");    // gt lives on this stack frame
+      CK(launch_conv_one_group(ws.tile_info + 32, 9, conv_k, E, s), "group table");
       a.mode = 1; a.n_groups = 9; a.n_active = 9; a.n_slots = 1; a.slots = 0; a.gbeg = ws.tile_info + 32; a.gend = ws.tile_info + 41;
     }
     CK(launch_conv_fused(L, a, ctx->n_cu, s), "conv_fused");

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/ddk.h"
+#include "../../include/ddk_debug.h"
 
 namespace ddk {
 
@@ -186,7 +187,10 @@ struct ConvLaunch {
 };
 hipError_t launch_conv_fused(const ConvLayerDev& L, const ConvLaunch& a, int n_cu, hipStream_t s);
 hipError_t launch_conv_fused_h(const ConvLayerDev& L, const ConvLaunch& a, int n_cu, hipStream_t s);   // k_conv_h.hip (3 x f16)
+hipError_t conv_prepare_device();     // per-device kernel attributes (dynamic LDS opt-in), called by ddk_create
+hipError_t conv_prepare_device_h();   // k_conv_h.hip
 hipError_t launch_conv_setup(int32_t* tile_info, const int64_t* group_offsets_host, hipStream_t s);
+hipError_t launch_conv_one_group(int32_t* gt, int n_groups, int k, int64_t E, hipStream_t s);
 hipError_t launch_pad_rows(const float* x, int64_t n, int din, float* xpad, hipStream_t s);
 hipError_t launch_count_deg(const int32_t* src, int64_t E, int32_t* deg, hipStream_t s);
 hipError_t launch_node_finalize(float* sum, const int32_t* deg, const float* x_in /*[N,XW] or null*/,

@@ -292,22 +292,9 @@ __global__ __launch_bounds__(64 * ConvTraits<MODE>::WAVES) void conv_fused_kerne
     TileQ tq;
     tq.w0 = __builtin_amdgcn_readfirstlane(tqv.x); tq.chan0 = __builtin_amdgcn_readfirstlane(tqv.y);
 #define PSUM(p) ((p).x + (p).y)
-// timing ablations (tools/build_variant.py -DDDK_EXP_...): wrong results, never built into libddk.so
-#ifdef DDK_EXP_NOEPI
-#define DDK_EPILOGUE accA[0] += f32x2{D[0] + D[5] + D[10] + D[15], f0.x + f1.x + f2.x};
-#else
 #define DDK_EPILOGUE tile_epilogue(w0 & 3, D, f0, f1, f2, accA, accV);
-#endif
-#ifdef DDK_EXP_NOFLUSH
-#define DDK_FLUSH_COND (((w0 >> 2) & 3) && t2 + 1 > t_end)
-#else
 #define DDK_FLUSH_COND ((w0 >> 2) & 3)
-#endif
-#ifdef DDK_EXP_NOBARRIER
-#define DDK_TILE_BARRIER
-#else
 #define DDK_TILE_BARRIER __syncthreads();
-#endif
 // one W2 tile: (1) request this thread's share of tile t+2 from L2 and the descriptor of tile t+1, (2) read tile t+1's
 // fragments from the ring into the other register set, (3) the uninterrupted 36-MFMA burst of tile t, (4) epilogue and,
 // at the end of a column, the flush, (5) publish tile t+2 into the ring stage tile t came from, (6) barrier.
@@ -351,9 +338,6 @@ __global__ __launch_bounds__(64 * ConvTraits<MODE>::WAVES) void conv_fused_kerne
       tq.w0 = __builtin_amdgcn_readfirstlane(tqv.x); tq.chan0 = __builtin_amdgcn_readfirstlane(tqv.y);       \
       DDK_TILE_BARRIER                                                                                         \
     }
-#ifdef DDK_EXP_REPEAT2
-    for (int rep = 0; rep < 2; ++rep)
-#endif
     for (int t = t_begin; t < t_end; t += 2) {
       DDK_TILE(t, a0, B0, a1, B1)
       if (t + 1 >= t_end) break;
@@ -385,6 +369,12 @@ __global__ void conv_setup_kernel(int32_t* tile_info, int g0, int g1, int g2, in
     for (int g = 0; g < 5; ++g) tile_info[5 + g] = go[g];
     tile_info[10] = 0;
   }
+}
+
+// group table of a single-conv launch (ddk_conv_forward on an all-atom context): gbeg[g] = 0, gend[g] = E for g == k else 0
+__global__ void conv_one_group_kernel(int32_t* gt, int n_groups, int k, int E) {
+  const int g = threadIdx.x;
+  if (g < n_groups) { gt[g] = 0; gt[n_groups + g] = g == k ? E : 0; }
 }
 
 __global__ void pad_rows_kernel(const float* x, int64_t n, int din, float* xpad) {
@@ -430,11 +420,25 @@ __global__ void node_finalize_kernel(float* sum, const int32_t* deg, const float
 template <bool GATHER, int MODE>
 static hipError_t launch_conv_t(const ConvKArgs& k, int n_cu, hipStream_t s) {
   // one persistent workgroup per CU (its F rows + the W2 ring fill the LDS), dynamic block queue
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fused_kernel<GATHER, MODE>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv_lds_bytes<MODE>());
-  if (attr != hipSuccess) return attr;
   hipLaunchKernelGGL((conv_fused_kernel<GATHER, MODE>), dim3(n_cu), dim3(64 * ConvTraits<MODE>::WAVES), conv_lds_bytes<MODE>(), s, k);
   return hipGetLastError();
+}
+
+template <bool GATHER, int MODE>
+static hipError_t conv_attr_t() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fused_kernel<GATHER, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)conv_lds_bytes<MODE>());
+}
+
+// opt the fused kernels into > 64 KB of dynamic LDS on the CURRENT device (ddk_create calls this after hipSetDevice: the attribute
+// is per device, and a failure is reported by that context instead of being cached for the process)
+hipError_t conv_prepare_device() {
+  hipError_t e = conv_attr_t<true, 0>();
+  if (e == hipSuccess) e = conv_attr_t<false, 0>();
+  if (e == hipSuccess) e = conv_attr_t<true, 1>();
+  if (e == hipSuccess) e = conv_attr_t<false, 1>();
+  if (e == hipSuccess) e = conv_prepare_device_h();
+  return e;
 }
 
 hipError_t launch_conv_fused(const ConvLayerDev& L, const ConvLaunch& a, int n_cu, hipStream_t s) {
@@ -460,6 +464,11 @@ hipError_t launch_conv_fused(const ConvLayerDev& L, const ConvLaunch& a, int n_c
 hipError_t launch_conv_setup(int32_t* tile_info, const int64_t* go, hipStream_t s) {
   hipLaunchKernelGGL(conv_setup_kernel, dim3(1), dim3(64), 0, s, tile_info, (int)go[0], (int)go[1], (int)go[2], (int)go[3],
                      (int)go[4]);
+  return hipGetLastError();
+}
+
+hipError_t launch_conv_one_group(int32_t* gt, int n_groups, int k, int64_t E, hipStream_t s) {
+  hipLaunchKernelGGL(conv_one_group_kernel, dim3(1), dim3(64), 0, s, gt, n_groups, k, (int)E);
   return hipGetLastError();
 }
 

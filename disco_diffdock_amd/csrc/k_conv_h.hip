@@ -330,37 +330,15 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_fused_h_kernel(ConvKArgs
     TileQ tq;
     tq.w0 = __builtin_amdgcn_readfirstlane(tqv.x); tq.chan0 = __builtin_amdgcn_readfirstlane(tqv.y);
 #define PSUM(p) (p)
-// timing ablations (tools/build_variant.py -DDDK_EXP_...): wrong results, never built into libddk.so
-#ifdef DDK_EXP_NOEPI
-#define DDK_EPILOGUE accA[0] += D[0] + D[5] + D[10] + D[15] + f0.x;
-#else
 #define DDK_EPILOGUE tile_epilogue_s(w0 & 3, D, Fp, f0, accA, accV);
-#endif
-#ifdef DDK_EXP_NOFLUSH
-#define DDK_FLUSH_COND (((w0 >> 2) & 3) && t2 + 1 > t_end)
-#else
 #define DDK_FLUSH_COND ((w0 >> 2) & 3)
-#endif
-#ifdef DDK_EXP_NOSTREAM      /* tiles are not fetched: the ring keeps the first two */
-#define DDK_STAGE_LOAD (void)rec2;
-#define DDK_STAGE_STORE (void)stg;
-#else
 #define DDK_STAGE_LOAD const float4 st0 = ld4(rec2 + 4 * tid); \
       float4 st1 = make_float4(0.f, 0.f, 0.f, 0.f);   /* (a copy of st0 here would wait for the load) */ \
       if (second) st1 = ld4(rec2 + 4 * (tid + 64 * WAVES));
 #define DDK_STAGE_STORE *reinterpret_cast<float4*>(stg + 4 * tid) = st0; \
       if (second) *reinterpret_cast<float4*>(stg + 4 * (tid + 64 * WAVES)) = st1;
-#endif
-#ifdef DDK_EXP_NOFRAGS       /* the fragment registers are not refreshed from the ring */
-#define DDK_FRAGS(ANH, ANL, T)
-#else
 #define DDK_FRAGS(ANH, ANL, T) lds_frags_h(ANH, ANL, ring + (((T) + 1 - t_begin) & 1) * STAGE_F, lane);
-#endif
-#ifdef DDK_EXP_NOBARRIER
-#define DDK_TILE_BARRIER
-#else
 #define DDK_TILE_BARRIER __syncthreads();
-#endif
 // one W2 tile: (1) request this thread's share of tile t+2 from L2 and the descriptor of tile t+1, (2) read tile t+1's
 // fragments from the ring into the other register set, (3) the uninterrupted 36-MFMA burst of tile t, (4) epilogue and,
 // at the end of a column, the flush, (5) publish tile t+2 into the ring stage tile t came from, (6) barrier.
@@ -401,9 +379,6 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_fused_h_kernel(ConvKArgs
       tq.w0 = __builtin_amdgcn_readfirstlane(tqv.x); tq.chan0 = __builtin_amdgcn_readfirstlane(tqv.y); \
       DDK_TILE_BARRIER \
     }
-#ifdef DDK_EXP_REPEAT2
-    for (int rep = 0; rep < 2; ++rep)
-#endif
     for (int t = t_begin; t < t_end; t += 2) {
       DDK_TILE(t, a0h, a0l, a1h, a1l)
       if (t + 1 >= t_end) break;
@@ -428,11 +403,17 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_fused_h_kernel(ConvKArgs
 
 template <bool GATHER>
 static hipError_t launch_h_t(const ConvKArgs& k, int n_cu, hipStream_t s) {
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fused_h_kernel<GATHER>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)CONV_H_LDS_BYTES);
-  if (attr != hipSuccess) return attr;
   hipLaunchKernelGGL((conv_fused_h_kernel<GATHER>), dim3(n_cu), dim3(64 * CONV_WAVES), CONV_H_LDS_BYTES, s, k);
   return hipGetLastError();
+}
+
+hipError_t conv_prepare_device_h() {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fused_h_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)CONV_H_LDS_BYTES);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fused_h_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)CONV_H_LDS_BYTES);
+  return e;
 }
 
 hipError_t launch_conv_fused_h(const ConvLayerDev& L, const ConvLaunch& a, int n_cu, hipStream_t s) {

@@ -340,13 +340,8 @@ __device__ void torsion_head_block(const HeadArgs& A, int b, int r) {
 // one launch for both heads: blocks [0, B*R) = rotatable bonds, blocks [B*R, B*R + B) = graph centres
 __global__ __launch_bounds__(256, 2) void heads_kernel(HeadArgs A, int n_tor_blocks) {
   const int blk = blockIdx.x;
-  // (DDK_EXP_*: timing ablations for tools/build_variant.py, never built into libddk.so)
-#ifndef DDK_EXP_NO_TORSION
   if (blk < n_tor_blocks) torsion_head_block(A, blk / A.R, blk % A.R);
-#endif
-#ifndef DDK_EXP_NO_CENTER
   if (blk >= n_tor_blocks) center_head_block(A, blk - n_tor_blocks);
-#endif
 }
 
 hipError_t launch_heads(const HeadArgs& A, bool torsion, hipStream_t s) {

@@ -33,14 +33,13 @@ def get_timestep_embedding(embedding_type, embedding_dim, embedding_scale=10000)
 
 
 def set_time(complex_graphs, t_tr, t_rot, t_tor, batchsize, all_atoms, device):
-    for nt in ('ligand', 'receptor'):
+    types = ('ligand', 'receptor', 'atom') if all_atoms else ('ligand', 'receptor')
+    for nt in types:
         n = complex_graphs[nt].num_nodes
         complex_graphs[nt].node_t = {'tr': t_tr * torch.ones(n, device=device), 'rot': t_rot * torch.ones(n, device=device),
                                      'tor': t_tor * torch.ones(n, device=device)}
     complex_graphs.complex_t = {'tr': t_tr * torch.ones(batchsize, device=device), 'rot': t_rot * torch.ones(batchsize, device=device),
                                 'tor': t_tor * torch.ones(batchsize, device=device)}
-    if all_atoms:
-        raise NotImplementedError('all-atom (confidence model) graphs are outside the ddk hot path')
 
 
 def modify_conformer_batch(orig_pos, data, tr_update, rot_update, torsion_updates, mask_rotate):

@@ -4,12 +4,11 @@ SDE perturbation, SE(3)/torsion update, Kabsch re-alignment - runs inside libddk
 host synchronisation; this file only prepares the per-step host scalars exactly as the reference computes them.
 Options outside the accelerated path (visualisation, the oracle latent encoder)
 raise instead of silently doing something else."""
-import copy
-
 import numpy as np
 import torch
 
 from .data import DataLoader
+from .diffusion_utils import set_time
 from .score_model import complex_for_batch
 
 
@@ -21,47 +20,27 @@ def is_iterable(arr):
         return False
 
 
-def _modify_conformer_torsion_angles_np(pos, edge_index, mask_rotate, torsion_updates):
-    """utils/torsion.py:48-68 (numpy/scipy variant used for the initial randomisation)."""
+def randomize_position(data_list, no_torsion, no_random, tr_sigma_max, unbatched=False, ar_args=None, device=None):
+    """utils/sampling.py:12-46 with the reference's signature.  The random draws come from the reference's own RNG streams in
+    the reference's order; the geometry (torsion rotations, centring, random rotation, translation) runs on the GPU in one
+    ``ddk_randomize_position`` launch (:func:`randomize_position_device`).  Limitation (documented in INTEGRATION.md):
+    ``data_list`` must hold copies of ONE complex, which is what evaluate.py:232 passes; ``device`` defaults to the current
+    CUDA device."""
     from scipy.spatial.transform import Rotation as R
-    pos = copy.deepcopy(pos)
-    if type(pos) != np.ndarray:
-        pos = pos.cpu().numpy()
-    for idx_edge, e in enumerate(edge_index.cpu().numpy()):
-        if torsion_updates[idx_edge] == 0:
-            continue
-        u, v = e[0], e[1]
-        assert not mask_rotate[idx_edge, u] and mask_rotate[idx_edge, v]
-        rot_vec = pos[u] - pos[v]
-        rot_vec = rot_vec * torsion_updates[idx_edge] / np.linalg.norm(rot_vec)
-        rot_mat = R.from_rotvec(rot_vec).as_matrix()
-        pos[mask_rotate[idx_edge]] = (pos[mask_rotate[idx_edge]] - pos[v]) @ rot_mat.T + pos[v]
-    return torch.from_numpy(pos.astype(np.float32))
-
-
-def randomize_position(data_list, no_torsion, no_random, tr_sigma_max, unbatched=False, ar_args=None):
-    from scipy.spatial.transform import Rotation as R
-    if not no_torsion:
-        for g in data_list:
-            upd = np.random.uniform(low=-np.pi, high=np.pi, size=int(g['ligand'].edge_mask.sum()))
-            g['ligand'].pos = _modify_conformer_torsion_angles_np(
-                g['ligand'].pos, g['ligand', 'ligand'].edge_index.T[g['ligand'].edge_mask],
-                g['ligand'].mask_rotate[0] if not unbatched else g['ligand'].mask_rotate, upd)
-    for g in data_list:
-        center = torch.mean(g['ligand'].pos, dim=0, keepdim=True)
-        rot = torch.from_numpy(R.random().as_matrix()).float()
-        g['ligand'].pos = (g['ligand'].pos - center) @ rot.T
-        if not no_random:
-            g['ligand'].pos = g['ligand'].pos + torch.normal(mean=0, std=tr_sigma_max, size=(1, 3))
+    if device is None:
+        if not torch.cuda.is_available():
+            raise RuntimeError('ddk: randomize_position runs on the GPU only (no CPU fallback)')
+        device = torch.device('cuda', torch.cuda.current_device())
+    randomize_position_device(data_list, no_torsion, no_random, tr_sigma_max, device)
     if ar_args is not None:   # utils/sampling.py:36-46: the pose the AR model sees
         for g in data_list:
             if ar_args.no_randomness:
-                g['ligand'].ar_pos = torch.from_numpy(g['ligand'].orig_rdkit_pos[0]).float()
-                center = torch.mean(g['ligand'].ar_pos, dim=0, keepdim=True)
+                ar = torch.from_numpy(np.asarray(g['ligand'].orig_rdkit_pos[0])).float()
+                center = torch.mean(ar, dim=0, keepdim=True)
                 rot = torch.from_numpy(R.random().as_matrix()).float()
-                g['ligand'].ar_pos = (g['ligand'].ar_pos - center) @ rot.T
+                g['ligand'].ar_pos = ((ar - center) @ rot.T).to(device)
             else:
-                g['ligand'].ar_pos = copy.deepcopy(g['ligand'].pos)
+                g['ligand'].ar_pos = g['ligand'].pos.clone()
 
 
 def randomize_position_device(data_list, no_torsion, no_random, tr_sigma_max, device):
@@ -69,7 +48,7 @@ def randomize_position_device(data_list, no_torsion, no_random, tr_sigma_max, de
     (evaluate.py:232): the random draws are taken on the host from the reference's own RNG streams in the reference's
     order (np.random.uniform per graph, then scipy ``Rotation.random()`` and ``torch.normal`` per graph), the geometry of
     all N copies runs in one ``ddk_randomize_position`` launch, and every ``g['ligand'].pos`` becomes a view of the
-    resulting device tensor.  (The host function above remains the general fallback-free path for mixed lists.)"""
+    resulting device tensor."""
     from scipy.spatial.transform import Rotation as R
     from .data import collate
     from .score_model import complex_for_batch
@@ -202,8 +181,10 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
             elif no_random or ode:
                 z = None
             else:
-                z = torch.empty((inference_steps, b, 6 + cx.R), device=device)
+                z = torch.zeros((inference_steps, b, 6 + cx.R), device=device)
                 for t_idx in range(inference_steps):   # draw order of the reference: tr, rot, tor per step
+                    if not nc[t_idx].any():            # no_final_step_noise: the reference draws nothing there (sampling.py:146-164)
+                        continue
                     z[t_idx, :, 0:3] = torch.normal(mean=0, std=1, size=(b, 3), device=device)
                     z[t_idx, :, 3:6] = torch.normal(mean=0, std=1, size=(b, 3), device=device)
                     if R:
@@ -212,7 +193,7 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
             if confidence_model is not None:   # utils/sampling.py:230-243: final poses into the all-atom graphs, t = 0
                 cbatch = next(confidence_loader)
                 cbatch['ligand'].pos = pos.reshape(-1, 3)
-                cbatch.complex_t = {k: torch.zeros(b, device=device) for k in ('tr', 'rot', 'tor')}
+                set_time(cbatch, 0, 0, 0, b, confidence_model_args.all_atoms if confidence_model_args is not None else True, device)
                 out = confidence_model(cbatch)
                 confidence.append(out[0] if type(out) is tuple else out)
             len_lig = pos.shape[1]

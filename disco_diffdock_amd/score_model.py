@@ -17,18 +17,37 @@ def _first_view(batch, B):
     return (first, 1) if first is not None else (batch, B)
 
 
-def _fingerprint(batch, B):
+def _fingerprint(batch, B, mask_rotate=None):
     batch, B0 = _first_view(batch, B)
-    return (B,) + _fingerprint_of(batch, B0)[1:]
+    return (B,) + _fingerprint_of(batch, B0, mask_rotate)[1:]
 
 
-def _fingerprint_of(batch, B):
+def _bytes_of(a):
+    if torch.is_tensor(a):
+        a = a.detach().cpu().numpy()
+    return np.ascontiguousarray(a).tobytes()
+
+
+def _fingerprint_of(batch, B, mask_rotate=None):
+    """Content key of ONE complex: a digest over everything ``Complex`` uploads (atom features in atom order, bond topology and
+    types, rotatable-bond masks, receptor geometry / residue ids / edges and a slice + checksum of the ESM features).  Sums of
+    features are not enough: two ligands of the same composition (atom order reversed, regio-isomers) share every sum."""
+    import hashlib
     lig, rec = batch['ligand'], batch['receptor']
     n_l, n_r = lig.num_nodes // B, rec.num_nodes // B
-    x0 = lig.x[:n_l]
-    rp = rec.pos[:n_r]
-    return (B, n_l, n_r, int(x0.sum().item()), float(rp.double().sum().item()), float(rec.x[:n_r, 1:9].double().sum().item()),
-            batch['ligand', 'ligand'].num_edges // B, batch['receptor', 'receptor'].num_edges // B)
+    M, E = batch['ligand', 'ligand'].num_edges // B, batch['receptor', 'receptor'].num_edges // B
+    if mask_rotate is None:
+        mask_rotate = lig.mask_rotate
+        while isinstance(mask_rotate, (list, tuple)):
+            mask_rotate = mask_rotate[0]
+    h = hashlib.blake2b(digest_size=16)
+    for a in (lig.x[:n_l], batch['ligand', 'ligand'].edge_index[:, :M], batch['ligand', 'ligand'].edge_attr[:M], lig.edge_mask[:M],
+              np.asarray(mask_rotate.cpu() if torch.is_tensor(mask_rotate) else mask_rotate, dtype=np.uint8).reshape(-1),
+              rec.pos[:n_r], rec.x[:n_r, :17], batch['receptor', 'receptor'].edge_index[:, :E]):
+        h.update(_bytes_of(a))
+        h.update(b'|')
+    h.update(np.float64(rec.x[:n_r].double().sum().item()).tobytes())
+    return (B, n_l, n_r, M, E, h.hexdigest())
 
 
 def arrays_from_batch(batch, B, mask_rotate=None):
@@ -57,7 +76,7 @@ def complex_for_batch(batch, device, ctx=None, mask_rotate=None, need_model=True
             raise RuntimeError('ddk: no model context bound to this call')
         from .tensor_layers import _shape_context
         ctx = _shape_context(device.index or 0)
-    key = (id(ctx),) + _fingerprint(batch, B)
+    key = (id(ctx),) + _fingerprint(batch, B, mask_rotate)
     cx = _complex_cache.get(key)
     if cx is None or cx.max_batch < B:
         if len(_complex_cache) > 8:
@@ -100,11 +119,48 @@ class TensorProductScoreModel(nn.Module):
         self.no_torsion = no_torsion
         self._loaded = False
 
+    def expected_state_dict_spec(self):
+        """name -> shape of the reference ``score_model.state_dict()`` for this configuration: the tensors
+        ``ddk_finalize_weights`` consumes."""
+        from .synthetic import score_model_state_dict_spec
+        c = self.cfg
+        ns, sig, dist, lm = c['ns'], c['sigma_embed_dim'], c['distance_embed_dim'], c['lm_embedding_dim']
+        spec = dict(score_model_state_dict_spec(ns=ns, nv=c['nv'], num_conv_layers=c['num_conv_layers'], sigma=sig, dist=dist, lm=lm))
+        ld = c['latent_dim']
+        if ld > 0:      # DisCo: +latent_dim node columns, +2*latent_dim edge columns, unconditional embeddings (score_model.py:46-62)
+            spec['lig_node_embedding.additional_features_embedder.weight'] = (ns, ns + sig + ld)
+            spec['rec_node_embedding.additional_features_embedder.weight'] = (ns, ns + sig + lm + ld)
+            spec['lig_edge_embedding.0.weight'] = (ns, 4 + sig + dist + 2 * ld)
+            spec['rec_edge_embedding.0.weight'] = (ns, sig + dist + 2 * ld)
+            spec['cross_edge_embedding.0.weight'] = (ns, sig + c['cross_distance_embed_dim'] + 2 * ld)
+            if c['latent_droprate'] > 0:
+                for k in ('lig_node', 'rec_node', 'lig_edge', 'rec_edge', 'cross_edge'):
+                    spec[f'{k}_unconditional_embedding'] = (1, ns)
+        if not c['batch_norm']:
+            spec = {k: v for k, v in spec.items() if '.batch_norm.' not in k}
+        if c['no_torsion']:
+            spec = {k: v for k, v in spec.items() if not k.startswith(('final_edge_embedding', 'tor_bond_conv', 'tor_final_layer'))}
+        return spec
+
     # the parameters live in the ddk context (packed for the kernels), not in nn.Parameters
     def load_state_dict(self, state_dict, strict=True):
-        self.ctx.load_state_dict(state_dict)
+        """``nn.Module.load_state_dict`` semantics on the reference key set: with ``strict`` a missing, unexpected or mis-shaped
+        key raises; e3nn's internal ``*.tp.*`` buffers of real checkpoints are ignored."""
+        spec = self.expected_state_dict_spec()
+        have = {k: v for k, v in state_dict.items() if '.tp.' not in k}
+        missing = [k for k in spec if k not in have]
+        unexpected = [k for k in have if k not in spec]
+        bad = [f'{k}: checkpoint {tuple(have[k].shape)} vs model {spec[k]}' for k in spec
+               if k in have and tuple(have[k].shape) != tuple(spec[k])]
+        if bad:
+            raise RuntimeError('ddk score model: size mismatch for ' + '; '.join(bad))
+        if strict and (missing or unexpected):
+            raise RuntimeError(f'ddk score model: error(s) in loading state_dict: missing keys {missing}, unexpected keys {unexpected}')
+        if missing:      # non-strict: nothing on the device can run with a partial checkpoint
+            raise RuntimeError(f'ddk score model: the device path needs the complete checkpoint; missing {missing}')
+        self.ctx.load_state_dict({k: have[k] for k in spec})
         self._loaded = True
-        return self
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
 
     def eval(self):
         return self
@@ -159,3 +215,16 @@ class ModelWrapper(nn.Module):
 
     def forward(self, data):
         return self.score_model(data)
+
+    def load_state_dict(self, state_dict, strict=True):
+        """evaluate.py:164-171 loads either the wrapper's state_dict (keys ``score_model.*`` / ``encoder.*``) or the bare
+        score model's; the (oracle) latent encoder is outside the hot path, so its keys are reported as unexpected."""
+        wrapped = any(k.startswith('score_model.') for k in state_dict)
+        inner = {k[len('score_model.'):]: v for k, v in state_dict.items() if k.startswith('score_model.')} if wrapped else dict(state_dict)
+        extra = [k for k in state_dict if wrapped and not k.startswith('score_model.')]
+        if strict and extra and self.encoder is None:
+            enc = [k for k in extra if not k.startswith('encoder.')]
+            if enc:
+                raise RuntimeError(f'ddk: unexpected keys {enc}')
+        res = self.score_model.load_state_dict(inner, strict=strict)
+        return torch.nn.modules.module._IncompatibleKeys(list(res.missing_keys), list(res.unexpected_keys) + extra)

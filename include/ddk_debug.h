@@ -1,0 +1,34 @@
+/* ddk_debug.h — test hooks of libddk.so.  NOT part of the drop-in boundary (include/ddk.h): these entry points copy internal
+ * device arrays to HOST buffers for the parity tests, synchronise the device, and may change between rounds.  Nothing in the
+ * product path (sampling(), bench.py's timed region) calls them. */
+#ifndef DDK_DEBUG_H
+#define DDK_DEBUG_H
+
+#include "ddk.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Packed host-side arrays of a context ("conv.<l>.w1p.<g>", "conv.<l>.w2p.<g>", "conv.<l>.tiles", "conv.<l>.bn_scale", ...):
+ * returns the number of 32-bit words of the item (buf may be NULL to query) or a negative ddk_status. */
+int64_t ddk_debug_export(ddk_ctx* ctx, const char* what, void* buf, int64_t cap_words);
+
+/* Edge arrays of the last score-model forward of `cx` (counts via ddk_last_graph_stats): src/dst [n] int32, emb [n,24],
+ * sh [n,4], deg [n_nodes] int32; HOST pointers, any may be NULL. */
+int ddk_debug_read_edges(ddk_ctx* ctx, ddk_complex* cx, int64_t n, int32_t* src, int32_t* dst, float* emb, float* sh, int32_t* deg,
+                         int64_t n_nodes);
+
+/* Confidence model (conf.hip), last ddk_confidence_forward of `cx`:
+ *   counts: out[0..8] = edges of the nine groups [ll lr la aa al ar rr rl ra], out[9] = ligand-atom edge capacity overflow flag;
+ *   nodes:  x [n, 84] features after the conv stack and deg [n, 3] per-slot in-degrees, n = max_batch * (n_lig + n_atom + n_rec);
+ *   edges:  group table gt[18] (begin[9], end[9]) when gt != NULL, else n edges from `first`: src, dst, emb [n,24], sh [n,4]. */
+int ddk_debug_conf_counts(ddk_ctx* ctx, ddk_complex* cx, int32_t* out);
+int ddk_debug_conf_nodes(ddk_ctx* ctx, ddk_complex* cx, float* x, int32_t* deg, int64_t n);
+int ddk_debug_conf_edges(ddk_ctx* ctx, ddk_complex* cx, int64_t first, int64_t n, int32_t* src, int32_t* dst, float* emb, float* sh,
+                         int32_t* gt);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDK_DEBUG_H */

@@ -232,3 +232,52 @@ def test_collate_accepts_pyg_style_graphs():
     for et in (('ligand', 'ligand'), ('receptor', 'receptor')):
         assert torch.equal(a[et].edge_index, b[et].edge_index) and a[et].num_edges == b[et].num_edges
     assert a['ligand'].num_nodes == b['ligand'].num_nodes == 3 * len(c['lig_pos'])
+
+
+def _reversed_ligand(c):
+    """the same ligand with its atoms listed in reverse order: every feature SUM is unchanged, topology arrays are not"""
+    n = c['lig_x'].shape[0]
+    perm = np.arange(n)[::-1].copy()
+    inv = np.empty(n, np.int64)
+    inv[perm] = np.arange(n)
+    d = dict(c)
+    d['lig_x'] = c['lig_x'][perm]
+    d['lig_pos'] = c['lig_pos'][perm]
+    d['bond_index'] = inv[c['bond_index']]
+    d['mask_rotate'] = c['mask_rotate'][:, perm]
+    return d
+
+
+def test_complex_cache_key_is_a_content_hash():
+    """the process-global Complex cache key must tell two same-composition ligands on one receptor apart
+    (reversed atom order, changed bond types, a mask_rotate override) - sums of features collide."""
+    from disco_diffdock_amd import synthetic
+    from disco_diffdock_amd.data import collate, from_arrays
+    from disco_diffdock_amd.score_model import _fingerprint
+    c = synthetic.make_complex(3, n_res=40, n_lig=20)
+    key = lambda cc, **kw: _fingerprint(collate([from_arrays(cc) for _ in range(2)]), 2, **kw)
+    k0 = key(c)
+    assert k0 == key(dict(c))                                        # deterministic
+    assert k0 != key(_reversed_ligand(c))                            # equal sums, different atom order / bond_index / mask_rotate
+    c2 = dict(c); c2['bond_attr'] = np.roll(c['bond_attr'], 1, axis=1)
+    assert k0 != key(c2)
+    c3 = dict(c); c3['rec_x'] = c['rec_x'].copy(); c3['rec_x'][5, 700] += 1.0     # ESM feature outside the hashed slice: the checksum sees it
+    assert k0 != key(c3)
+    mr = np.array(c['mask_rotate'], dtype=bool).copy()
+    if mr.size:
+        mr[0, 0] = not mr[0, 0]
+        assert k0 != key(c, mask_rotate=mr)
+
+
+@pytest.mark.parametrize('lat', [dict(), dict(latent_dim=2, latent_vocab=1, latent_droprate=0.1)])
+def test_strict_state_dict_key_set(lat):
+    """load_state_dict(strict=True) validates against the reference key set (DiffDock-S: 171 tensors, DisCo-S: 176)."""
+    from types import SimpleNamespace
+    from oracle import score_model_ref as smr
+    from disco_diffdock_amd.score_model import TensorProductScoreModel
+    from disco_diffdock_amd.runtime import DEFAULTS
+    cfg = dict(DEFAULTS, **lat)
+    spec = TensorProductScoreModel.expected_state_dict_spec(SimpleNamespace(cfg=cfg))
+    ref = smr.state_dict_spec(smr.ScoreModelConfig(**(lat or dict(latent_vocab=64))))
+    assert {k: tuple(v) for k, v in spec.items()} == {k: tuple(v) for k, v in ref.items()}
+    assert len(spec) == (176 if lat else 171)

@@ -31,6 +31,13 @@ def test_library_exports_every_declared_symbol(built):
     for s in declared:
         assert hasattr(L, s), s
     assert b'gfx950' in _lib.lib().ddk_version()
+    # the test hooks bound by _lib.py are declared too (include/ddk_debug.h), and nothing else is bound
+    dbg = set(re.findall(r'\b(ddk_debug_[a-z0-9_]+)\s*\(', open(os.path.join(ROOT, 'include', 'ddk_debug.h')).read()))
+    assert dbg == set(_lib.DEBUG_SYMBOLS)
+    for s in dbg:
+        assert hasattr(L, s), s
+    bound = set(re.findall(r'L\.(ddk_[a-z0-9_]+)\.', open(os.path.join(ROOT, 'disco_diffdock_amd', '_lib.py')).read()))
+    assert bound <= declared | dbg, bound - declared - dbg
 
 
 def test_host_only_context_refuses_to_launch(built):

@@ -201,7 +201,8 @@ def main():
 
     if rank == 0:
         conv_ms = sum(p['ms'] for p in prof)
-        flops = sum(p['edges'] * (2 * 72 * (72 + W_LAYER[l]) + TP_FLOP[l]) for l, p in enumerate(prof))
+        fl = lambda key: sum(p[key] * (2 * 72 * (72 + W_LAYER[l]) + TP_FLOP[l]) for l, p in enumerate(prof))
+        flops_exec, flops, flops_full = fl('edges'), fl('edges_unpruned'), fl('edges_reference')
         byts = sum(p['edges'] * FUSED_BYTES[l] for l, p in enumerate(prof))
         launches = sum(p['launches'] for p in prof)
         achieved = flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
@@ -216,7 +217,11 @@ def main():
                        'samples_per_complex': SAMPLES, 'inference_steps': STEPS, 'complexes_per_gpu': N_COMPLEXES,
                        'parallelism': f'complexes sharded over {world} process(es), one per GPU, final RCCL pose gather'},
             'roofline': {'bound': 'mfma', 'kernel': 'ddk::conv_fused_kernel<true, 0>', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': pmc_traffic(),
+                         'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS,
+                         'achieved_executed': flops_exec / (conv_ms * 1e-3) / 1e12, 'frac_executed': flops_exec / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                         'achieved_full_reference': flops_full / (conv_ms * 1e-3) / 1e12,
+                         'edges_executed_over_unpruned': sum(p['edges'] for p in prof) / max(sum(p['edges_unpruned'] for p in prof), 1),
+                         'traffic': pmc_traffic(),
                          'traffic_source': 'profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over this '
                                            'command, bytes per conv_fused launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 FETCH correction)',
                          'algorithmic_bytes_per_launch': byts / max(launches, 1),
@@ -226,7 +231,9 @@ def main():
                          'algorithmic_hbm_frac_of_peak': (byts / (conv_ms * 1e-3) / 1e9) / PEAK_HBM_GBS if conv_ms > 0 else 0.0,
                          'conv_share_of_wall': conv_ms * 1e-3 / elapsed,
                          'per_layer': [{'layer': l, 'ms_per_launch': p['ms'] / max(p['launches'], 1),
-                                        'TFLOPs': p['edges'] * (2 * 72 * (72 + W_LAYER[l]) + TP_FLOP[l]) / max(p['ms'], 1e-9) / 1e9}
+                                        'TFLOPs': p['edges_unpruned'] * (2 * 72 * (72 + W_LAYER[l]) + TP_FLOP[l]) / max(p['ms'], 1e-9) / 1e9,
+                                        'TFLOPs_executed': p['edges'] * (2 * 72 * (72 + W_LAYER[l]) + TP_FLOP[l]) / max(p['ms'], 1e-9) / 1e9,
+                                        'edges_executed_frac': p['edges'] / max(p['edges_unpruned'], 1)}
                                        for l, p in enumerate(prof)]},
         }
         if world == 1 and not a.no_cpu_baseline:
@@ -238,7 +245,7 @@ def main():
             # 3 x f16 product on the f16 matrix pipe (fp32-level accuracy, every parity test passes unchanged)
             e2, prof2, final2, _, _ = measure(conv_f16x3=1)
             ms2 = sum(p['ms'] for p in prof2)
-            fl2 = sum(p['edges'] * (2 * 72 * (72 + W_LAYER[l]) + TP_FLOP[l]) for l, p in enumerate(prof2))
+            fl2 = sum(p['edges_unpruned'] * (2 * 72 * (72 + W_LAYER[l]) + TP_FLOP[l]) for l, p in enumerate(prof2))
             dev_max = max(float((final2[i] - final[i]).abs().max()) for i in final)
             out['alt_precision'] = {'mode': 'conv_f16x3 (error-compensated 3 x f16 MFMA, f32 accumulation; opt-in, ddk_config.conv_f16x3 = 1)',
                                     'value': a.steps / e2, 'unit': 'complexes/s', 'ms_per_step': 1e3 * e2 / a.steps,

@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void conf_la_kernel(LaArgs A) {
 __global__ void conf_gtab_kernel(int32_t* gtab, const int32_t* info, int B, int E_aa, int n_atom, int off_la, int off_al, int off_aa,
                                  int off_ar, int off_ra, int cap_la) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const int go0 = info[5], go1 = info[6], go2 = info[7], go3 = info[8], go4 = info[9];
+  const int go0 = info[I_GO], go1 = info[I_GO + 1], go2 = info[I_GO + 2], go3 = info[I_GO + 3], go4 = info[I_GO + 4];
   const int n_la = min(gtab[18], cap_la);
   const int beg[9] = {go0, go1, off_la, off_aa, off_al, off_ar, go2, go3, off_ra};
   const int end[9] = {go1, go2, off_la + n_la, off_aa + B * E_aa, off_al + n_la, off_ar + B * n_atom, go3, go4, off_ra + B * n_atom};
@@ -588,7 +588,7 @@ int ddk_confidence_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float
   // ---- dynamic graphs ------------------------------------------------------------------------------
   GraphArgs G;
   G.lig_pos = lig_pos; G.rec_pos = cx->rec_pos; G.bond_src = cx->bond_src; G.bond_dst = cx->bond_dst;
-  G.rr_src = cx->rr_src; G.rr_dst = cx->rr_dst; G.rr_outdeg = cx->rr_outdeg;
+  G.rr_src = cx->rr_src; G.rr_dst = cx->rr_dst; G.rr_outdeg = cx->rr_outdeg; G.rr_start = cx->rr_start;
   G.B = B; G.n_lig = n_lig; G.n_rec = n_rec; G.M = cx->M; G.E_rr = cx->E_rr;
   G.lig_r2 = c.lig_max_radius * c.lig_max_radius; G.cross_cutoff = M->sp.cross_cutoff;
   G.counts = cx->counts; G.offs = cx->offs; G.info = cx->info; G.e_src = K->e_src; G.e_dst = K->e_dst; G.e_aux = K->e_aux;
@@ -625,10 +625,10 @@ int ddk_confidence_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float
     const ConvLayerDev& L = ctx->conv[l];
     const bool last = l == c.num_conv_layers - 1;      // all_atom_score_model.py:241 "last layer optimisation": ligand updates only
     CK(hipMemsetAsync(K->sum3, 0, (size_t)(last ? atom_base : K->n_nodes) * 3 * XW * sizeof(float), s), "memset sum3");
-    CK(hipMemsetAsync(cx->info + 10 + (l % 8), 0, sizeof(int32_t), s), "counter reset");
+    CK(hipMemsetAsync(cx->info + I_CNT + (l % 8), 0, sizeof(int32_t), s), "counter reset");
     ConvLaunch a;
     a.x = xin; a.src = K->e_src; a.dst = K->e_dst; a.edge_attr = K->e_emb; a.sh = K->e_sh; a.sum = K->sum3;
-    a.tile_info = cx->info; a.counter = cx->info + 10 + (l % 8); a.gather = 1;
+    a.tile_info = cx->info; a.counter = cx->info + I_CNT + (l % 8); a.gather = 1;
     a.mode = 1; a.n_groups = 9; a.n_active = last ? 3 : 9; a.n_slots = 3;
     a.slots = 0;
     for (int g = 0; g < 9; ++g) a.slots |= (uint32_t)(g % 3) << (2 * g);

@@ -130,6 +130,8 @@ struct Workspace {     // per-launch scratch of the fused conv entry point
 
 }  // namespace ddk
 
+namespace ddk { constexpr int PROF_INTS = 8; }
+
 struct ddk_ctx {
   ddk_config cfg;
   std::string err;
@@ -146,9 +148,10 @@ struct ddk_ctx {
   void* conf_model = nullptr;   // conf.hip
   // profiling (ddk_profile_enable / ddk_profile_read)
   bool prof = false;
-  struct ProfRec { hipEvent_t a, b; int layer; int slot; int64_t skipped = 0; bool lig_only = false; };   // skipped: edges not evaluated (layer-0 rec-rec dedup)
+  bool prune = true;                // backward receptive-field pruning of the rec-rec messages (ddk_set_receptive_field_pruning)
+  struct ProfRec { hipEvent_t a, b; int layer; int slot; int tab = 0; int64_t r01_skipped = 0; bool lig_only = false; };   // tab: group table of the launch
   std::vector<ProfRec> prof_recs;
-  int32_t* prof_edges = nullptr;   // pinned host: total edges of forward #slot
+  int32_t* prof_edges = nullptr;   // pinned host: PROF_INTS edge counts of forward #slot (InfoSlot I_EXEC block)
   int prof_slots = 0, prof_cap = 0;
 };
 
@@ -171,14 +174,13 @@ struct ConvLaunch {
   int32_t* counter;          // device tile counter (zeroed by the caller)
   int gather;                // 1: edge_attr is edge_emb[E,24] and x[src][:24], x[dst][:24] are gathered
   // layer-0 receptor-receptor de-duplication (all samples of a batch share the receptor and, before the first conv,
-  // its node/edge features): only the first g2_limit edges of group 2 (sample 0) are evaluated, their messages go to
-  // sum_g2[(src - g2_node_off)] and node_finalize adds that row to every sample's copy.  g2_limit < 0: off.
-  int g2_limit = -1;
-  int lig_side_only = 0;     // 1: evaluate only groups 0 and 1 (messages into ligand nodes); the last layer's receptor rows are dead
+  // its node/edge features): group 2 of the launch's group table is the shared copy of the receptor edges (sample-0 numbering,
+  // graph_fill_kernel); its messages go to sum_g2[(src - g2_node_off)] and node_finalize adds that row to every sample's copy.
   float* sum_g2 = nullptr;
   int g2_node_off = 0;
-  // general form (confidence model): n_groups edge groups, group g occupies edges [gbeg[g], gend[g]) (device arrays), uses the
+  // n_groups edge groups, group g occupies edges [gbeg[g], gend[g]) (device arrays; null: tile_info[5 + g] .. tile_info[6 + g]), uses the
   // g-th radial MLP of the layer and accumulates into sum[(node * n_slots + slot(g)) * XW]; only the first n_active groups run
+  // (score model, last layer: 2 = the messages into ligand nodes; its receptor rows are dead)
   int mode = 0;              // ConvTraits MODE
   int n_groups = 4, n_active = 4, n_slots = 1;
   uint32_t slots = 0;        // 2 bits per group

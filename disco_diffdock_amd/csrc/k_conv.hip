@@ -85,7 +85,7 @@ __global__ __launch_bounds__(64 * ConvTraits<MODE>::WAVES) void conv_fused_kerne
   int* blk_slot = reinterpret_cast<int*>(ring + 2 * W2_TILE_FLOATS);
   const int el = lane & 31;
   const int hh = lane >> 5;
-  const bool g2_shared = A.g2_limit >= 0;                     // shortened group 2 (layer-0 rec-rec de-duplication)
+  const bool g2_shared = A.sum_g2 != nullptr;                 // group 2 is the shared rec-rec copy (layer-0 de-duplication): its own accumulator
   // work unit: a block of BLOCK_EDGES consecutive edges of ONE edge group (its radial-MLP weights are shared by the workgroup)
   // lane g < n_active keeps group g's edge range and its block range [pbeg, pend) of the work queue; a block index is mapped to
   // its group with one ballot (no dependent scalar loads per block)
@@ -93,7 +93,6 @@ __global__ __launch_bounds__(64 * ConvTraits<MODE>::WAVES) void conv_fused_kerne
   if (lane < A.n_active) {
     gb_v = A.gbeg[lane];
     ge_v = A.gend[lane];
-    if (g2_shared && lane == 2) ge_v = min(ge_v, gb_v + A.g2_limit);
   }
   const int nb_v = (ge_v - gb_v + BLOCK_EDGES - 1) / BLOCK_EDGES;
   int pend_v = nb_v;
@@ -451,12 +450,10 @@ hipError_t launch_conv_fused(const ConvLayerDev& L, const ConvLaunch& a, int n_c
   k.w1p = L.w1p[0]; k.b1p = L.b1p[0]; k.w2r = L.w2r[0]; k.tiles = L.tiles; k.n_tiles = L.n_tiles;
   k.n_cols = L.n_cols;
   for (int c = 0; c <= L.n_cols; ++c) k.col_start[c] = L.col_start[c];
-  k.g2_limit = a.g2_limit; k.sum_g2 = a.sum_g2; k.g2_node_off = a.g2_node_off;
-  if (a.gbeg) {
-    k.n_groups = a.n_groups; k.n_active = a.n_active; k.n_slots = a.n_slots; k.slots = a.slots; k.gbeg = a.gbeg; k.gend = a.gend;
-  } else {   // score model: 4 contiguous groups from the info table (go[g] .. go[g+1]), one accumulator slot
-    k.n_groups = 4; k.n_active = a.lig_side_only ? 2 : 4; k.n_slots = 1; k.slots = 0; k.gbeg = a.tile_info + 5; k.gend = a.tile_info + 6;
-  }
+  k.sum_g2 = a.sum_g2; k.g2_node_off = a.g2_node_off;
+  k.n_groups = a.n_groups; k.n_active = a.n_active; k.n_slots = a.n_slots; k.slots = a.slots;
+  if (a.gbeg) { k.gbeg = a.gbeg; k.gend = a.gend; }
+  else { k.gbeg = a.tile_info + 5; k.gend = a.tile_info + 6; }   // 4 contiguous groups go[g] .. go[g+1] (explicit-boundary entry point)
   if (a.mode == 1) return a.gather ? launch_conv_t<true, 1>(k, n_cu, s) : launch_conv_t<false, 1>(k, n_cu, s);
   return a.gather ? launch_conv_t<true, 0>(k, n_cu, s) : launch_conv_t<false, 0>(k, n_cu, s);
 }

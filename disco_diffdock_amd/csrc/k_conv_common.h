@@ -25,8 +25,7 @@ struct ConvKArgs {
   int n_tiles;
   int n_cols;         // flush columns; col_start[c] .. col_start[c+1] = tiles of column c
   int col_start[17];
-  int g2_limit;       // >= 0: evaluate only the first g2_limit edges of group 2 (see ConvLaunch)
-  float* sum_g2;
+  float* sum_g2;      // != null: group 2 is the shared rec-rec copy; its messages go to sum_g2[(src - g2_node_off)] (see ConvLaunch)
   int g2_node_off;
   int n_groups, n_active, n_slots;   // edge groups [gbeg[g], gend[g]); the first n_active run; sum row = (node*n_slots + slot(g))
   uint32_t slots;

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_fused_h_kernel(ConvKArgs
   int* blk_slot = reinterpret_cast<int*>(ring + 2 * STAGE_F);
   const int el = lane & 31;
   const int hh = lane >> 5;
-  const bool g2_shared = A.g2_limit >= 0;                     // shortened group 2 (layer-0 rec-rec de-duplication)
+  const bool g2_shared = A.sum_g2 != nullptr;                 // group 2 is the shared rec-rec copy (layer-0 de-duplication): its own accumulator
   // work unit: a block of BLOCK_EDGES consecutive edges of ONE edge group (its radial-MLP weights are shared by the workgroup)
   // lane g < n_active keeps group g's edge range and its block range [pbeg, pend) of the work queue; a block index is mapped to
   // its group with one ballot (no dependent scalar loads per block)
@@ -96,7 +96,6 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_fused_h_kernel(ConvKArgs
   if (lane < A.n_active) {
     gb_v = A.gbeg[lane];
     ge_v = A.gend[lane];
-    if (g2_shared && lane == 2) ge_v = min(ge_v, gb_v + A.g2_limit);
   }
   const int nb_v = (ge_v - gb_v + BLOCK_EDGES - 1) / BLOCK_EDGES;
   int pend_v = nb_v;
@@ -424,8 +423,10 @@ hipError_t launch_conv_fused_h(const ConvLayerDev& L, const ConvLaunch& a, int n
   for (int g = 0; g < 4; ++g) { k.w1s[g] = L.w1s[g]; k.w1u[g] = 1.0f / L.w1s[g]; k.w2u[g] = 1.0f / L.w2s[g]; }
   k.n_cols = L.n_cols;
   for (int c = 0; c <= L.n_cols; ++c) k.col_start[c] = L.col_start[c];
-  k.g2_limit = a.g2_limit; k.sum_g2 = a.sum_g2; k.g2_node_off = a.g2_node_off;
-  k.n_groups = 4; k.n_active = a.lig_side_only ? 2 : 4; k.n_slots = 1; k.slots = 0; k.gbeg = a.tile_info + 5; k.gend = a.tile_info + 6;
+  k.sum_g2 = a.sum_g2; k.g2_node_off = a.g2_node_off;
+  k.n_groups = 4; k.n_active = a.n_active; k.n_slots = 1; k.slots = 0;
+  if (a.gbeg) { k.gbeg = a.gbeg; k.gend = a.gend; }
+  else { k.gbeg = a.tile_info + 5; k.gend = a.tile_info + 6; }
   return a.gather ? launch_h_t<true>(k, n_cu, s) : launch_h_t<false>(k, n_cu, s);
 }
 

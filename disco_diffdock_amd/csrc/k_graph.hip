@@ -65,13 +65,65 @@ __device__ void block_exclusive_scan(int* a, int n, int* tmp) {
   __syncthreads();
 }
 
+// ---- backward receptive-field levels of the residues of one sample ---------------------------------------------------------
+// The heads read ligand rows only, so the LAST conv layer evaluates only the messages into ligand nodes; those read receptor rows
+// only at the residues that carry a cross edge in this sample (level A).  Walking back through the stack, conv layer L-2 therefore
+// has to produce only the level-A receptor rows: of its rec-rec messages only those RECEIVED by a level-A residue; they read the
+// rows of the sending residues, so layer L-3 has to produce level B = A + {senders of rec-rec edges into A}, layer L-4 level
+// C = B + {senders into B}.  Exact: a pruned message never reaches anything the heads read.  (Messages are received at edge_src
+// and sent from edge_dst, tensor_layers.py:153-159.)  lvl[j]: 0 = A, 1 = B \ A, 2 = C \ B, 3 = the rest.
+// On entry lvl[j] is 0 or 3 and a barrier has passed; ends with a barrier.
+__device__ void propagate_levels(uint8_t* lvl, const GraphArgs& G) {
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int k = threadIdx.x; k < G.E_rr; k += 256) {
+      const int r = G.rr_src[k], d = G.rr_dst[k];
+      if (lvl[r] == pass && lvl[d] == 3) lvl[d] = (uint8_t)(pass + 1);   // (concurrent writers store the same value)
+    }
+    __syncthreads();
+  }
+}
+
+// Per level: the number of static rec-rec edges received by the residues of that level (tot[0..3]) and, when pre != nullptr, for
+// every residue the count over the residues before it of the SAME level (pre[j]) - a 4-component block scan by 256 threads
+// (thread t owns a contiguous chunk; wave shuffles across the chunk totals).  tmp: [4 waves][4], tot: [4] in LDS.  Ends with a barrier.
+__device__ void level_scan(const uint8_t* lvl, const int32_t* outdeg, int n, int* pre, int (*tmp)[4], int* tot) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (n + 255) / 256;
+  const int beg = min(tid * per, n), end = min(beg + per, n);
+  int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  for (int k = beg; k < end; ++k) {
+    const int l = lvl[k], od = outdeg[k];
+    s0 += l == 0 ? od : 0; s1 += l == 1 ? od : 0; s2 += l == 2 ? od : 0; s3 += l == 3 ? od : 0;
+  }
+  int v0 = s0, v1 = s1, v2 = s2, v3 = s3;
+#pragma unroll
+  for (int d = 1; d < 64; d *= 2) {
+    const int t0 = __shfl_up(v0, d, 64), t1 = __shfl_up(v1, d, 64), t2 = __shfl_up(v2, d, 64), t3 = __shfl_up(v3, d, 64);
+    if (lane >= d) { v0 += t0; v1 += t1; v2 += t2; v3 += t3; }
+  }
+  if (lane == 63) { tmp[wave][0] = v0; tmp[wave][1] = v1; tmp[wave][2] = v2; tmp[wave][3] = v3; }
+  __syncthreads();
+  if (pre != nullptr) {
+    int b0 = v0 - s0, b1 = v1 - s1, b2 = v2 - s2, b3 = v3 - s3;     // exclusive prefix inside the wave
+    for (int w = 0; w < wave; ++w) { b0 += tmp[w][0]; b1 += tmp[w][1]; b2 += tmp[w][2]; b3 += tmp[w][3]; }
+    for (int k = beg; k < end; ++k) {
+      const int l = lvl[k], od = outdeg[k];
+      pre[k] = l == 0 ? b0 : (l == 1 ? b1 : (l == 2 ? b2 : b3));
+      b0 += l == 0 ? od : 0; b1 += l == 1 ? od : 0; b2 += l == 2 ? od : 0; b3 += l == 3 ? od : 0;
+    }
+  }
+  if (tid < 4) tot[tid] = tmp[0][tid] + tmp[1][tid] + tmp[2][tid] + tmp[3][tid];
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void graph_count_kernel(GraphArgs G) {
   extern __shared__ float smem[];
   float* lp = smem;                              // [MAX_LIG*3]
   float* rp = lp + MAX_LIG * 3;                  // [n_rec*3]
+  uint8_t* lvl = reinterpret_cast<uint8_t*>(rp + 3 * G.n_rec + G.n_rec);   // [n_rec] (behind the int array only the fill kernel uses)
   __shared__ unsigned adj[MAX_LIG][MAX_LIG / 32];
   __shared__ float lps[MAX_LIG * 3];             // ligand coordinates / cross cutoff
-  __shared__ int s_cnt[2];
+  __shared__ int s_cnt[2], lvl_tmp[4][4], lvl_tot[4];
   const int b = blockIdx.x, tid = threadIdx.x;
   for (int i = tid; i < G.n_lig * 3; i += 256) { const float v = G.lig_pos[(size_t)b * G.n_lig * 3 + i]; lp[i] = v; lps[i] = v / G.cross_cutoff; }
   for (int i = tid; i < G.n_rec * 3; i += 256) rp[i] = G.rec_pos[i] / G.cross_cutoff;      // only the cross test reads the residues here
@@ -82,42 +134,62 @@ __global__ __launch_bounds__(256) void graph_count_kernel(GraphArgs G) {
   int c_ll = 0, c_lr = 0;
   for (int i = tid; i < G.n_lig; i += 256)
     for (int w = 0; w < MAX_LIG / 32; ++w) c_ll += __popc(adj[i][w]);
-  for (int idx = tid; idx < G.n_lig * G.n_rec; idx += 256) {
-    const int i = idx / G.n_rec, j = idx - i * G.n_rec;
-    c_lr += cross_within_scaled(lps + 3 * i, rp + 3 * j) ? 1 : 0;
+  for (int j = tid; j < G.n_rec; j += 256) {
+    int cnt = 0;
+    for (int i = 0; i < G.n_lig; ++i) cnt += cross_within_scaled(lps + 3 * i, rp + 3 * j) ? 1 : 0;
+    c_lr += cnt;
+    lvl[j] = (G.prune && cnt == 0) ? 3 : 0;
   }
   atomicAdd(&s_cnt[0], c_ll);
   atomicAdd(&s_cnt[1], c_lr);
   __syncthreads();
-  if (tid < 2) G.counts[2 * b + tid] = s_cnt[tid];
+  if (G.prune) propagate_levels(lvl, G);
+  level_scan(lvl, G.rr_outdeg, G.n_rec, nullptr, lvl_tmp, lvl_tot);
+  if (tid < 2) G.counts[CNT_STRIDE * b + tid] = s_cnt[tid];
+  if (tid < 3) G.counts[CNT_STRIDE * b + 2 + tid] = lvl_tot[tid];
 }
 
-// info layout (int32): [0..4] conv tile_start, [5..9] group_off, [10..17] per-layer tile counters,
-// [18..22] edge-feature block_start (256 edges per block), [23] total edges, [24] overflow flag
+// one thread: prefixes over the samples, group offsets, the per-layer group tables (InfoSlot / GroupTable in model.h)
 __global__ void graph_scan_kernel(GraphArgs G, int64_t edge_cap) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  int ll = 0, lr = 0;
+  int ll = 0, lr = 0, ra = 0, rb = 0, rc = 0;
   for (int b = 0; b < G.B; ++b) {
-    G.offs[2 * b] = ll;
-    G.offs[2 * b + 1] = lr;
-    ll += G.M + G.counts[2 * b];
-    lr += G.counts[2 * b + 1];
+    int32_t* o = G.offs + CNT_STRIDE * b;
+    const int32_t* c = G.counts + CNT_STRIDE * b;
+    o[0] = ll; o[1] = lr; o[2] = ra; o[3] = rb; o[4] = rc; o[5] = b * G.E_rr - (ra + rb + rc);
+    ll += G.M + c[0];
+    lr += c[1];
+    ra += c[2]; rb += c[3]; rc += c[4];
   }
   int go[5];
   go[0] = 0; go[1] = ll; go[2] = ll + lr; go[3] = go[2] + G.B * G.E_rr; go[4] = go[3] + lr;
-  int ts = 0, bs = 0;
-  G.info[0] = 0;
-  G.info[18] = 0;
-  for (int g = 0; g < 4; ++g) {
-    ts += (go[g + 1] - go[g] + 31) / 32;
-    bs += (go[g + 1] - go[g] + 255) / 256;
-    G.info[g + 1] = ts;
-    G.info[19 + g] = bs;
+  const int seg[4] = {go[2], go[2] + ra, go[2] + ra + rb, go[2] + ra + rb + rc};     // first edge of the level segments of group 2
+  const int n_shared = G.shared_rr ? G.E_rr : 0;
+  int bs = 0;
+  G.info[I_FB] = 0;
+  for (int g = 0; g < 5; ++g) {
+    bs += ((g < 4 ? go[g + 1] - go[g] : n_shared) + 255) / 256;
+    G.info[I_FB + 1 + g] = bs;
   }
-  for (int g = 0; g < 5; ++g) G.info[5 + g] = go[g];
-  for (int k = 0; k < 8; ++k) G.info[10 + k] = 0;
-  G.info[23] = go[4];
-  G.info[24] = ((int64_t)go[4] > edge_cap) ? 1 : 0;
+  for (int g = 0; g < 5; ++g) G.info[I_GO + g] = go[g];
+  for (int k = 0; k < 8; ++k) G.info[I_CNT + k] = 0;
+  for (int l = 0; l < 4; ++l) G.info[I_SEG + l] = seg[l];
+  G.info[I_E] = go[4];
+  G.info[I_OVF] = ((int64_t)go[4] + n_shared > edge_cap) ? 1 : 0;
+  G.info[I_SHARED] = G.shared_rr ? go[4] : -1;
+  G.info[I_EXEC] = go[4];
+  G.info[I_EXEC + 1] = go[2];
+  for (int k = 0; k < N_TAB; ++k) {
+    int32_t* tb = G.info + I_TAB + 8 * k;
+    int tot = 0;
+    for (int g = 0; g < 4; ++g) { tb[g] = go[g]; tb[4 + g] = go[g + 1]; }
+    if (k == TAB_A) tb[4 + 2] = seg[1];
+    if (k == TAB_B) tb[4 + 2] = seg[2];
+    if (k == TAB_C) tb[4 + 2] = seg[3];
+    if (k == TAB_SHARED) { tb[2] = go[4]; tb[4 + 2] = go[4] + n_shared; }
+    for (int g = 0; g < 4; ++g) tot += tb[4 + g] - tb[g];
+    G.info[I_EXEC + 2 + k] = tot;
+  }
 }
 
 constexpr int FILL_SLICES = 4;
@@ -126,13 +198,14 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(GraphArgs G) {
   extern __shared__ float smem[];
   float* lp = smem;                                   // [MAX_LIG*3]
   float* rp = lp + MAX_LIG * 3;                       // [n_rec*3]
-  int* c_rl = reinterpret_cast<int*>(rp + 3 * G.n_rec);   // [n_rec] -> exclusive prefix
+  int* c_rl = reinterpret_cast<int*>(rp + 3 * G.n_rec);   // [n_rec] -> exclusive prefix; later the per-level prefix of the rec-rec edges
+  uint8_t* lvl = reinterpret_cast<uint8_t*>(c_rl + G.n_rec);   // [n_rec] receptive-field level of the residue
   __shared__ unsigned adj[MAX_LIG][MAX_LIG / 32];
-  __shared__ int bdeg[MAX_LIG], odeg[MAX_LIG], c_lr[MAX_LIG], ll_pre[MAX_LIG], lr_pre[MAX_LIG], scan_tmp[8];
+  __shared__ int bdeg[MAX_LIG], odeg[MAX_LIG], c_lr[MAX_LIG], ll_pre[MAX_LIG], lr_pre[MAX_LIG], scan_tmp[8], lvl_tmp[4][4], lvl_tot[4];
   // FILL_SLICES workgroups per sample: each repeats the (cheap) counting / prefix phase and writes one slice of the edge list --
   // one workgroup per sample left 216 CUs idle while 256 threads issued ~300 scattered stores each
   const int b = blockIdx.x, slice = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (G.info[24]) return;   // capacity overflow: reported by the host wrapper
+  if (G.info[I_OVF]) return;   // capacity overflow: reported by the host wrapper
   const int n_lig = G.n_lig, n_rec = G.n_rec;
   __shared__ float lps[MAX_LIG * 3];             // ligand coordinates / cross cutoff
   for (int i = tid; i < n_lig * 3; i += 256) { const float v = G.lig_pos[(size_t)b * n_lig * 3 + i]; lp[i] = v; lps[i] = v / G.cross_cutoff; }
@@ -156,6 +229,7 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(GraphArgs G) {
     int cnt = 0;
     for (int i = 0; i < n_lig; ++i) cnt += cross_within_scaled(lps + 3 * i, rp + 3 * j) ? 1 : 0;
     c_rl[j] = cnt;
+    lvl[j] = (G.prune && cnt == 0) ? 3 : 0;
   }
   __syncthreads();
   for (int j = tid; j < n_lig; j += 256) {
@@ -164,7 +238,8 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(GraphArgs G) {
     odeg[j] = od;
   }
   __syncthreads();
-  const int lig0 = b * n_lig, rec0 = (G.rec_node_base >= 0 ? G.rec_node_base : G.B * n_lig) + b * n_rec;
+  const int rec_base = G.rec_node_base >= 0 ? G.rec_node_base : G.B * n_lig;
+  const int lig0 = b * n_lig, rec0 = rec_base + b * n_rec;
   // degrees (scatter 'mean' divisor: all incoming groups together, tensor_layers.py:159)
   if (slice == 0) {
     for (int i = tid; i < n_lig; i += 256) G.deg[lig0 + i] = bdeg[i] + odeg[i] + c_lr[i];
@@ -178,11 +253,13 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(GraphArgs G) {
       lr_pre[i] = c; c += c_lr[i];
     }
   }
+  if (G.prune) propagate_levels(lvl, G);
   block_exclusive_scan(c_rl, n_rec, scan_tmp);   // exclusive prefix of the per-residue rec->lig counts (in place; ends with a barrier)
-  const int g1 = G.info[6], g2 = G.info[7], g3 = G.info[8];
+  const int g1 = G.info[I_GO + 1], g3 = G.info[I_GO + 3];
+  const int32_t* offs = G.offs + CNT_STRIDE * b;
   // ---- group 0: lig-lig, sorted by src: bonds of the atom (bond order) then radius edges (ascending dst)
   for (int j = tid; slice == 0 && j < n_lig; j += 256) {
-    int pos = G.offs[2 * b] + ll_pre[j];
+    int pos = offs[0] + ll_pre[j];
     for (int m = 0; m < G.M; ++m)
       if (G.bond_src[m] == j) {
         G.e_src[pos] = lig0 + j; G.e_dst[pos] = lig0 + G.bond_dst[m]; G.e_aux[pos] = m; ++pos;
@@ -194,7 +271,7 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(GraphArgs G) {
   }
   // ---- group 1: lig->rec, sorted by ligand atom then residue: one wave per ligand atom, ballot compaction
   for (int i = wave + 4 * slice; i < n_lig; i += 4 * FILL_SLICES) {
-    int pos = g1 + G.offs[2 * b + 1] + lr_pre[i];
+    int pos = g1 + offs[1] + lr_pre[i];
     for (int j0 = 0; j0 < n_rec; j0 += 64) {
       const int j = j0 + lane;
       const bool in = j < n_rec && cross_within_scaled(lps + 3 * i, rp + 3 * j);
@@ -208,16 +285,29 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(GraphArgs G) {
   }
   // ---- group 3: rec->lig (flipped cross edges), sorted by residue then ligand atom
   for (int j = tid + 256 * slice; j < n_rec; j += 256 * FILL_SLICES) {
-    int pos = g3 + G.offs[2 * b + 1] + c_rl[j];
+    int pos = g3 + offs[1] + c_rl[j];
     for (int i = 0; i < n_lig; ++i)
       if (cross_within_scaled(lps + 3 * i, rp + 3 * j)) {
         G.e_src[pos] = rec0 + j; G.e_dst[pos] = lig0 + i; G.e_aux[pos] = -1; ++pos;
       }
   }
-  // ---- group 2: static receptor edges of this sample
+  // ---- group 2: the static receptor edges of this sample in four segments [A | B | C | rest] by the level of the receiving
+  // residue; inside a segment by (sample, residue, static order), i.e. still sorted by edge_src.  Position of static edge k of
+  // residue j: segment start + edges of this level in the samples before + in the residues before + rank among j's edges.
+  __syncthreads();                                  // group 3 has consumed c_rl: reuse it for the per-level prefix
+  level_scan(lvl, G.rr_outdeg, n_rec, c_rl, lvl_tmp, lvl_tot);
   for (int k = tid + 256 * slice; k < G.E_rr; k += 256 * FILL_SLICES) {
-    const int pos = g2 + b * G.E_rr + k;
-    G.e_src[pos] = rec0 + G.rr_src[k]; G.e_dst[pos] = rec0 + G.rr_dst[k]; G.e_aux[pos] = k;
+    const int j = G.rr_src[k], l = lvl[j];
+    const int pos = G.info[I_SEG + l] + offs[2 + l] + c_rl[j] + (k - G.rr_start[j]);
+    G.e_src[pos] = rec0 + j; G.e_dst[pos] = rec0 + G.rr_dst[k]; G.e_aux[pos] = k;
+  }
+  // ---- the shared copy of the receptor edges (sample-0 numbering) behind the four groups: layer 0 evaluates the rec-rec
+  // messages once for the whole batch (see model.hip)
+  if (G.shared_rr && b == 0) {
+    const int g4 = G.info[I_SHARED];
+    for (int k = tid + 256 * slice; k < G.E_rr; k += 256 * FILL_SLICES) {
+      G.e_src[g4 + k] = rec_base + G.rr_src[k]; G.e_dst[g4 + k] = rec_base + G.rr_dst[k]; G.e_aux[g4 + k] = k;
+    }
   }
 }
 
@@ -229,12 +319,13 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(GraphArgs G) {
 
 __global__ __launch_bounds__(256) void edge_features_kernel(EdgeFeatArgs A) {
   const int blk = blockIdx.x;
-  const int bs1 = A.info[19], bs2 = A.info[20], bs3 = A.info[21], bs4 = A.info[22];
-  if (blk >= bs4) return;
-  const int g = (blk >= bs1) + (blk >= bs2) + (blk >= bs3);
-  const int bstart = g == 0 ? 0 : (g == 1 ? bs1 : (g == 2 ? bs2 : bs3));
-  const int e = A.info[5 + g] + 256 * (blk - bstart) + threadIdx.x;
-  if (e >= A.info[6 + g]) return;
+  const int bs1 = A.info[I_FB + 1], bs2 = A.info[I_FB + 2], bs3 = A.info[I_FB + 3], bs4 = A.info[I_FB + 4], bs5 = A.info[I_FB + 5];
+  if (blk >= bs5) return;
+  const int fg = (blk >= bs1) + (blk >= bs2) + (blk >= bs3) + (blk >= bs4);      // feature group: the four edge groups + the shared rec-rec copy
+  const int bstart = fg == 0 ? 0 : (fg == 1 ? bs1 : (fg == 2 ? bs2 : (fg == 3 ? bs3 : bs4)));
+  const int e = (fg < 4 ? A.info[I_GO + fg] : A.info[I_SHARED]) + 256 * (blk - bstart) + threadIdx.x;
+  if (e >= (fg < 4 ? A.info[I_GO + 1 + fg] : A.info[I_SHARED] + A.n_shared)) return;
+  const int g = fg == 4 ? 2 : fg;
   const int sn = A.e_src[e], dn = A.e_dst[e], aux = A.e_aux[e];
   const EdgeMlpDev& M = g == 0 ? A.lig : (g == 2 ? A.rec : A.cross);
   const float* sigb = g == 0 ? A.sp.lig_edge_sigb : (g == 2 ? A.sp.rec_edge_sigb : A.sp.cross_edge_sigb);
@@ -336,7 +427,7 @@ __global__ void node_embed_kernel(NodeEmbedArgs A) {
 }
 
 hipError_t launch_graph(const GraphArgs& G, int64_t edge_cap, hipStream_t s) {
-  const size_t lds = (size_t)(MAX_LIG * 3 + G.n_rec * 3) * 4 + (size_t)G.n_rec * 4;
+  const size_t lds = (size_t)(MAX_LIG * 3 + G.n_rec * 3) * 4 + (size_t)G.n_rec * 4 + (((size_t)G.n_rec + 15) & ~(size_t)15);   // + the level bytes
   hipLaunchKernelGGL(graph_count_kernel, dim3(G.B), dim3(256), lds, s, G);
   hipLaunchKernelGGL(graph_scan_kernel, dim3(1), dim3(64), 0, s, G, edge_cap);
   hipLaunchKernelGGL(graph_fill_kernel, dim3(G.B, FILL_SLICES), dim3(256), lds, s, G);
@@ -344,7 +435,7 @@ hipError_t launch_graph(const GraphArgs& G, int64_t edge_cap, hipStream_t s) {
 }
 
 hipError_t launch_edge_features(const EdgeFeatArgs& A, int64_t edge_cap, hipStream_t s) {
-  const unsigned blocks = (unsigned)((edge_cap + 255) / 256 + 4);
+  const unsigned blocks = (unsigned)((edge_cap + 255) / 256 + 5);
   hipLaunchKernelGGL(edge_features_kernel, dim3(blocks), dim3(256), 0, s, A);
   return hipGetLastError();
 }

@@ -67,6 +67,57 @@ __device__ void horn_rotation(const double* S, float* R) {
   R[6] = (float)(s2 * (x * z - y * w)); R[7] = (float)(s2 * (y * z + x * w)); R[8] = (float)(1 - s2 * (x * x + y * y));
 }
 
+// rigid_transform_Kabsch_3D_torch_batch (utils/geometry.py:126-156) for one point-set pair held in LDS: R, t with R a + t ~ b, proper
+// rotation also in the reflection case.  All threads of the block call it (barriers inside); cA, cB [3], S [9], Rk [9], tk [3] in LDS.
+__device__ void kabsch_block(const float* a, const float* bpts, int n, float* cA, float* cB, double* S, float* Rk, float* tk) {
+  const int tid = threadIdx.x;
+  if (tid < 3) {
+    float sa = 0.0f, sb = 0.0f;
+    for (int i = 0; i < n; ++i) { sa += a[3 * i + tid]; sb += bpts[3 * i + tid]; }
+    cA[tid] = sa / (float)n; cB[tid] = sb / (float)n;
+  }
+  __syncthreads();
+  if (tid < 9) {
+    const int r = tid / 3, c = tid % 3;
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += (double)(a[3 * i + r] - cA[r]) * (double)(bpts[3 * i + c] - cB[c]);
+    S[tid] = s;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    horn_rotation(S, Rk);
+    for (int k = 0; k < 3; ++k) tk[k] = -(Rk[3 * k] * cA[0] + Rk[3 * k + 1] * cA[1] + Rk[3 * k + 2] * cA[2]) + cB[k];
+  }
+  __syncthreads();
+}
+
+// test hooks (include/ddk_debug.h): the device functions above on caller-supplied inputs
+__global__ __launch_bounds__(256) void debug_kabsch_kernel(const float* A, const float* Bp, int n, float* R_out, float* t_out) {
+  __shared__ float a[MAX_LIG * 3], bb[MAX_LIG * 3], cA[3], cB[3], Rk[9], tk[3];
+  __shared__ double S[9];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < n * 3; i += 256) { a[i] = A[(size_t)b * n * 3 + i]; bb[i] = Bp[(size_t)b * n * 3 + i]; }
+  __syncthreads();
+  kabsch_block(a, bb, n, cA, cB, S, Rk, tk);
+  if (tid < 9) R_out[9 * b + tid] = Rk[tid];
+  if (tid < 3) t_out[3 * b + tid] = tk[tid];
+}
+
+__global__ void debug_axis_angle_kernel(const float* aa, int n, float* R_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) axis_angle_to_matrix_dev(aa[3 * i], aa[3 * i + 1], aa[3 * i + 2], R_out + 9 * i);
+}
+
+hipError_t launch_debug_kabsch(const float* A, const float* Bp, int B, int n, float* R_out, float* t_out, hipStream_t s) {
+  hipLaunchKernelGGL(debug_kabsch_kernel, dim3(B), dim3(256), 0, s, A, Bp, n, R_out, t_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_debug_axis_angle(const float* aa, int n, float* R_out, hipStream_t s) {
+  hipLaunchKernelGGL(debug_axis_angle_kernel, dim3((n + 63) / 64), dim3(64), 0, s, aa, n, R_out);
+  return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void se3_update_kernel(Se3Args A) {
   __shared__ float rig[MAX_LIG * 3], flx[MAX_LIG * 3];
   __shared__ float upd[6], ctr[3], Rm[9], Rt[9], piv[3], cA[3], cB[3], Rk[9], tk[3];
@@ -119,25 +170,7 @@ __global__ __launch_bounds__(256) void se3_update_kernel(Se3Args A) {
     }
     __syncthreads();
   }
-  // Kabsch: align flex (A) onto rigid (B)
-  if (tid < 3) {
-    float sa = 0.0f, sb = 0.0f;
-    for (int i = 0; i < n; ++i) { sa += flx[3 * i + tid]; sb += rig[3 * i + tid]; }
-    cA[tid] = sa / (float)n; cB[tid] = sb / (float)n;
-  }
-  __syncthreads();
-  if (tid < 9) {
-    const int a = tid / 3, c = tid % 3;
-    double s = 0.0;
-    for (int i = 0; i < n; ++i) s += (double)(flx[3 * i + a] - cA[a]) * (double)(rig[3 * i + c] - cB[c]);
-    S[tid] = s;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    horn_rotation(S, Rk);
-    for (int k = 0; k < 3; ++k) tk[k] = -(Rk[3 * k] * cA[0] + Rk[3 * k + 1] * cA[1] + Rk[3 * k + 2] * cA[2]) + cB[k];
-  }
-  __syncthreads();
+  kabsch_block(flx, rig, n, cA, cB, S, Rk, tk);
   if (tid < n) {
     const float x = flx[3 * tid], y = flx[3 * tid + 1], z = flx[3 * tid + 2];
     float* o = A.pos_out + ((size_t)b * n + tid) * 3;

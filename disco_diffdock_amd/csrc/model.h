@@ -11,6 +11,25 @@ constexpr int MAX_REC = 8192;  // residues per sample
 constexpr int LIG_CAP = 33;    // radius_graph(max_num_neighbors=32) -> radius(..., 33) including self
 constexpr int BOND_CAP = 32;   // radius(..., max_num_neighbors=32) of the bond-centre graph
 
+// Layout of the per-complex int32 `info` table written by graph_scan_kernel (device side; no launch depends on a host read-back).
+// Group 2 (rec-rec) of the merged edge list is stored in four segments ordered by the BACKWARD RECEPTIVE-FIELD LEVEL of the edge's
+// receiving residue (see graph_fill_kernel): [A | B | C | rest], so that every conv layer evaluates a PREFIX of the group.
+enum InfoSlot : int {
+  I_GO = 5,       // [5..9]   go[0..4]: offsets of the reference's four edge groups [ll | lr | rr | rl], go[4] = E
+  I_CNT = 10,     // [10..17] per-layer work-queue counters of the fused conv kernel
+  I_FB = 18,      // [18..23] edge-feature block prefix over 5 feature groups (the 4 groups + the shared rec-rec copy), 256 edges per block
+  I_E = 24,       // total edges of the reference graph (go[4])
+  I_OVF = 25,     // capacity overflow flag
+  I_SEG = 27,     // [27..30] first edge of the four level segments [A | B | C | rest] of group 2
+  I_SHARED = 26,  // first edge of the shared rec-rec copy (= go[4]; E_rr edges in sample-0 numbering, layer-0 de-duplication) or -1
+  I_TAB = 32,     // group tables: [32 + 8k + g] = gbeg, [36 + 8k + g] = gend of table k (N_TAB tables)
+  I_EXEC = 80,    // [80] = E, [81] = go[2] (edges of groups 0+1), [82 + k] = edges table k evaluates over all four groups
+  INFO_INTS = 128
+};
+// group tables: which rec-rec edges a layer evaluates
+enum GroupTable : int { TAB_ALL = 0, TAB_C = 1, TAB_B = 2, TAB_A = 3, TAB_SHARED = 4, N_TAB = 5 };
+constexpr int CNT_STRIDE = 6;   // counts / offs per sample: ll radius edges, lr edges, rec-rec edges of level A, B, C, (spare)
+
 // Everything that depends only on the diffusion time of a forward (computed on the HOST from t, which the
 // sampler knows without reading the device: utils/sampling.py:106-113, diffusion_utils.py:12-16,58-69).
 struct StepParams {
@@ -85,9 +104,12 @@ struct GraphArgs {
   int B, n_lig, n_rec, M, E_rr;
   float lig_r2;             // lig_max_radius^2
   float cross_cutoff;
-  int32_t* counts;          // [B, 2]: ll radius edges, lr edges
-  int32_t* offs;            // [B, 2]: exclusive prefix of counts
-  int32_t* info;            // tile_info (see graph_scan_kernel)
+  const int32_t* rr_start;  // [n_rec] exclusive prefix of rr_outdeg (first static edge of each residue)
+  int32_t* counts;          // [B, CNT_STRIDE]: ll radius edges, lr edges, rec-rec edges of level A / B / C
+  int32_t* offs;            // [B, CNT_STRIDE]: exclusive prefix of counts over the samples
+  int32_t* info;            // InfoSlot table
+  int prune = 0;            // 1: order group 2 by receptive-field level (0: every residue is level A -> the reference order)
+  int shared_rr = 0;        // 1: append the shared rec-rec copy (layer-0 de-duplication) behind the four groups
   int32_t* e_src;
   int32_t* e_dst;
   int32_t* e_aux;
@@ -112,6 +134,7 @@ struct EdgeFeatArgs {
   int n_lig_total;         // B*n_lig
   int rec_node_base = -1;  // -1: n_lig_total
   int n_rec;
+  int n_shared = 0;        // edges of the shared rec-rec copy (E_rr or 0)
   const float* lig_latent; // [B*n_lig, latent_dim] or null
   const float* rec_latent; // [B*n_rec, latent_dim] or null
   float unconditional;     // data[...].unconditional (same value on every node of a forward, sampling.py:114-115,121-122)
@@ -159,6 +182,8 @@ struct RandPosArgs {
   float* pos_out;
 };
 hipError_t launch_randomize(const RandPosArgs& A, hipStream_t s);
+hipError_t launch_debug_kabsch(const float* A, const float* Bp, int B, int n, float* R_out, float* t_out, hipStream_t s);
+hipError_t launch_debug_axis_angle(const float* aa, int n, float* R_out, hipStream_t s);
 hipError_t launch_pose_metrics(const float* pos, const float* ref, const uint8_t* mask, const float* rec_pos, int B, int n_lig, int n_rec,
                                float* out, hipStream_t s);
 
@@ -187,7 +212,7 @@ struct ddk_complex {
   float* bond_attr = nullptr;
   uint8_t* mask_rotate = nullptr;
   float *rec_pos = nullptr, *lig_node_static = nullptr, *rec_node_static = nullptr;
-  int32_t *rr_src = nullptr, *rr_dst = nullptr, *rr_outdeg = nullptr;
+  int32_t *rr_src = nullptr, *rr_dst = nullptr, *rr_outdeg = nullptr, *rr_start = nullptr;
   float *rr_pre1 = nullptr, *rr_sh = nullptr;
   // per-forward workspaces (sized for max_batch)
   int64_t edge_cap = 0;

@@ -269,11 +269,13 @@ static T* cx_upload(ddk_complex* cx, const T* src, size_t n) {
 }
 
 // a6-a8 + the merge of score_model.py:218-225: counts, offsets and the sorted edge list of B poses into the complex' workspace
-static hipError_t build_graph(ddk_ctx* ctx, ddk_complex* cx, int B, const float* lig_pos, float cross_cutoff, hipStream_t s) {
+static hipError_t build_graph(ddk_ctx* ctx, ddk_complex* cx, int B, const float* lig_pos, float cross_cutoff, bool prune, bool shared_rr,
+                              hipStream_t s) {
   const ddk_config& c = ctx->cfg;
   GraphArgs G;
   G.lig_pos = lig_pos; G.rec_pos = cx->rec_pos; G.bond_src = cx->bond_src; G.bond_dst = cx->bond_dst;
-  G.rr_src = cx->rr_src; G.rr_dst = cx->rr_dst; G.rr_outdeg = cx->rr_outdeg;
+  G.rr_src = cx->rr_src; G.rr_dst = cx->rr_dst; G.rr_outdeg = cx->rr_outdeg; G.rr_start = cx->rr_start;
+  G.prune = prune ? 1 : 0; G.shared_rr = shared_rr ? 1 : 0;
   G.B = B; G.n_lig = cx->n_lig; G.n_rec = cx->n_rec; G.M = cx->M; G.E_rr = cx->E_rr;
   G.lig_r2 = c.lig_max_radius * c.lig_max_radius; G.cross_cutoff = cross_cutoff;
   G.counts = cx->counts; G.offs = cx->offs; G.info = cx->info; G.e_src = cx->e_src; G.e_dst = cx->e_dst; G.e_aux = cx->e_aux;
@@ -289,17 +291,22 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
   const int64_t N = (int64_t)B * (n_lig + n_rec);
   hipError_t e;
 #define CK(x, what) do { e = (x); if (e != hipSuccess) return hip_fail(ctx, e, what); } while (0)
-  CK(build_graph(ctx, cx, B, lig_pos, sp.cross_cutoff, s), "graph build");
+  // layer 0: the receptor's node features and rec-rec edge features are the same for every sample of the batch
+  // (no latents) -> evaluate the rec-rec messages once, exact in real arithmetic
+  const bool dedup = (c.latent_dim == 0 && B > 1 && cx->E_rr > 0);
+  // backward receptive-field pruning of the rec-rec messages (k_graph.hip): off when the caller wants the receptor rows of the last layer
+  const bool prune = ctx->prune && !cx->keep_rec && cx->E_rr > 0;
+  CK(build_graph(ctx, cx, B, lig_pos, sp.cross_cutoff, prune, dedup, s), "graph build");
   EdgeFeatArgs F;
   F.lig_pos = lig_pos; F.rec_pos = cx->rec_pos; F.bond_attr = cx->bond_attr; F.rr_pre1 = cx->rr_pre1; F.rr_sh = cx->rr_sh;
   F.e_src = cx->e_src; F.e_dst = cx->e_dst; F.e_aux = cx->e_aux; F.info = cx->info; F.e_emb = cx->e_emb; F.e_sh = cx->e_sh;
   F.lig = M->dev.lig_edge; F.rec = M->dev.rec_edge; F.cross = M->dev.cross_edge; F.sp = sp;
-  F.n_lig_total = B * n_lig; F.n_rec = n_rec;
+  F.n_lig_total = B * n_lig; F.n_rec = n_rec; F.n_shared = dedup ? cx->E_rr : 0;
   F.latent_dim = c.latent_dim; F.lig_latent = cx->lig_latent; F.rec_latent = cx->rec_latent; F.unconditional = cx->unconditional;
   if (c.latent_dim > 0 && (!cx->lig_latent || !cx->rec_latent))
     return fail(ctx, DDK_ERR_STATE, "latent-conditioned model: call ddk_set_latents before the forward");
   // worst-case edge count of THIS batch size bounds the launch
-  const int64_t cap_b = (int64_t)B * ((int64_t)cx->M + (int64_t)n_lig * (LIG_CAP - 1) + 2LL * n_lig * n_rec + cx->E_rr);
+  const int64_t cap_b = (int64_t)B * ((int64_t)cx->M + (int64_t)n_lig * (LIG_CAP - 1) + 2LL * n_lig * n_rec + cx->E_rr) + cx->E_rr;
   CK(launch_edge_features(F, cap_b < cx->edge_cap ? cap_b : cx->edge_cap, s), "edge features");
   float* xin = cx->xa;
   float* xout = cx->xb;
@@ -315,37 +322,45 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
   }
   cx->sum_clean = false;
   bool rr0_dirty = false;
-  for (int l = 0; l < c.num_conv_layers; ++l) {
+  const int NL = c.num_conv_layers;
+  int32_t* prof_slot = nullptr;
+  if (ctx->prof && ctx->prof_slots + 1 <= ctx->prof_cap) prof_slot = ctx->prof_edges + (size_t)PROF_INTS * ctx->prof_slots;
+  for (int l = 0; l < NL; ++l) {
     const ConvLayerDev& L = ctx->conv[l];
     ConvLaunch a;
     a.x = xin; a.src = cx->e_src; a.dst = cx->e_dst; a.edge_attr = cx->e_emb; a.sh = cx->e_sh; a.sum = cx->sum;
-    a.tile_info = cx->info; a.counter = cx->info + 10 + (l % 8); a.gather = 1;
-    // layer 0: the receptor's node features and rec-rec edge features are the same for every sample of the batch
-    // (no latents) -> evaluate the rec-rec messages once, exact in real arithmetic
-    const bool dedup = (l == 0 && c.latent_dim == 0 && B > 1 && cx->E_rr > 0);
-    if (dedup) {
+    a.tile_info = cx->info; a.counter = cx->info + I_CNT + (l % 8); a.gather = 1;
+    // which rec-rec messages this layer evaluates: layer 0 the shared copy (de-duplication); layers L-2, L-3, L-4 only those received by
+    // the residues inside the backward receptive field of the heads (levels A, B, C of k_graph.hip); the last layer none (and no
+    // rec->lig... group 3 either): only ligand rows are read downstream unless the caller asked for the receptor rows
+    const bool lig_only = (l == NL - 1 && !cx->keep_rec);
+    const bool shared0 = dedup && l == 0;
+    int tab = TAB_ALL;
+    if (shared0) tab = TAB_SHARED;
+    else if (prune && l == NL - 2) tab = TAB_A;
+    else if (prune && l == NL - 3) tab = TAB_B;
+    else if (prune && l == NL - 4) tab = TAB_C;
+    a.gbeg = cx->info + I_TAB + 8 * tab; a.gend = a.gbeg + 4;
+    a.n_groups = 4; a.n_active = lig_only ? 2 : 4; a.n_slots = 1; a.slots = 0;
+    if (shared0) {
       rr0_dirty = true;
-      a.g2_limit = cx->E_rr; a.sum_g2 = cx->sum_rr0; a.g2_node_off = B * n_lig;
+      a.sum_g2 = cx->sum_rr0; a.g2_node_off = B * n_lig;
     }
-    // last layer: only ligand rows are read downstream (heads) unless the caller asked for the receptor rows
-    const bool lig_only = (l == c.num_conv_layers - 1 && !cx->keep_rec);
-    a.lig_side_only = lig_only ? 1 : 0;
-    if (l >= 8) CK(hipMemsetAsync(cx->info + 10 + (l % 8), 0, sizeof(int32_t), s), "counter reset");
+    if (l >= 8) CK(hipMemsetAsync(cx->info + I_CNT + (l % 8), 0, sizeof(int32_t), s), "counter reset");
     ddk_ctx::ProfRec pr;
-    const bool prof = ctx->prof && ctx->prof_slots + 1 < ctx->prof_cap;
-    if (prof) {
+    if (prof_slot) {
       CK(hipEventCreate(&pr.a), "event"); CK(hipEventCreate(&pr.b), "event");
-      pr.layer = l; pr.slot = ctx->prof_slots; pr.skipped = dedup ? (int64_t)(B - 1) * cx->E_rr : 0; pr.lig_only = lig_only;
+      pr.layer = l; pr.slot = ctx->prof_slots; pr.tab = tab; pr.lig_only = lig_only; pr.r01_skipped = shared0 ? (int64_t)(B - 1) * cx->E_rr : 0;
       CK(hipEventRecord(pr.a, s), "event record");
     }
     CK(launch_conv_fused(L, a, ctx->n_cu, s), "conv_fused");
-    if (prof) {
+    if (prof_slot) {
       CK(hipEventRecord(pr.b, s), "event record");
       ctx->prof_recs.push_back(pr);
     }
-    const bool clear_rr0 = rr0_dirty && !dedup;     // one launch after the layer whose finalize read the shared rows
+    const bool clear_rr0 = rr0_dirty && !shared0;     // one launch after the layer whose finalize read the shared rows
     CK(launch_node_finalize(cx->sum, cx->deg, xin, L.bn_mean, L.bn_scale, L.bn_bias, lig_only ? (int64_t)B * n_lig : N, L.dout, XW, xout, s,
-                            dedup ? cx->sum_rr0 : nullptr, (int64_t)B * n_lig, n_rec, 1, clear_rr0 ? cx->sum_rr0 : nullptr,
+                            shared0 ? cx->sum_rr0 : nullptr, (int64_t)B * n_lig, n_rec, 1, clear_rr0 ? cx->sum_rr0 : nullptr,
                             clear_rr0 ? (int64_t)n_rec * XW : 0), "node_finalize");
     if (clear_rr0) rr0_dirty = false;
     float* t = xin; xin = xout; xout = t;
@@ -354,10 +369,9 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
   cx->last_B = B;
   cx->last_full = cx->keep_rec;
   cx->sum_clean = !rr0_dirty;       // (a one-layer model leaves the shared rows to the memset of the next forward)
-  if (ctx->prof && ctx->prof_slots + 1 < ctx->prof_cap) {
-    CK(hipMemcpyAsync(ctx->prof_edges + ctx->prof_slots + 1, cx->info + 7, sizeof(int32_t), hipMemcpyDeviceToHost, s), "profile edge count");   // group_off[2] = edges of groups 0+1
-    CK(hipMemcpyAsync(ctx->prof_edges + ctx->prof_slots, cx->info + 23, sizeof(int32_t), hipMemcpyDeviceToHost, s), "profile edge count");
-    ctx->prof_slots += 2;
+  if (prof_slot) {    // E, edges of groups 0+1 and the edges each group table evaluates, of THIS forward (read at ddk_profile_read)
+    CK(hipMemcpyAsync(prof_slot, cx->info + I_EXEC, PROF_INTS * sizeof(int32_t), hipMemcpyDeviceToHost, s), "profile edge counts");
+    ctx->prof_slots += 1;
   }
   HeadArgs Hd;
   Hd.lig_pos = lig_pos; Hd.x = xin; Hd.md = M->dev; Hd.sp = sp; Hd.B = B; Hd.n_lig = n_lig; Hd.R = cx->R;
@@ -405,9 +419,9 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
   const int n_lig = d->n_lig, n_rec = d->n_rec, M = d->n_bond_edges, lm = c.lm_embedding_dim;
   {   // one chunk for everything this function allocates (sizes below mirror the uploads / workspaces; 256 B of slack per array)
     const size_t E0 = (size_t)d->n_rec_edges, Bm0 = (size_t)max_batch, R0 = (size_t)(d->n_rot > 0 ? d->n_rot : 1);
-    const size_t cap0 = Bm0 * ((size_t)M + (size_t)n_lig * (LIG_CAP - 1) + 2 * (size_t)n_lig * n_rec + E0) + 64, N0 = Bm0 * (size_t)(n_lig + n_rec);
+    const size_t cap0 = Bm0 * ((size_t)M + (size_t)n_lig * (LIG_CAP - 1) + 2 * (size_t)n_lig * n_rec + E0) + E0 + 64, N0 = Bm0 * (size_t)(n_lig + n_rec);
     size_t need = (size_t)M * 24 + R0 * 8 + R0 * n_lig + (size_t)n_rec * 12 + (size_t)(n_lig + n_rec) * NS * 4 + E0 * (8 + NS * 4 + 16) + (size_t)n_rec * 4;
-    need += cap0 * (12 + NS * 4 + 16) + N0 * 4 + Bm0 * 16 + 256 + 3 * N0 * XW * 4 + (size_t)n_rec * XW * 4 + Bm0 * n_lig * 12 + 2 * Bm0 * (6 + R0) * 4;
+    need += cap0 * (12 + NS * 4 + 16) + N0 * 4 + Bm0 * 2 * CNT_STRIDE * 4 + INFO_INTS * 4 + (size_t)n_rec * 4 + 3 * N0 * XW * 4 + (size_t)n_rec * XW * 4 + Bm0 * n_lig * 12 + 2 * Bm0 * (6 + R0) * 4;
     if (c.latent_dim > 0) need += N0 * c.latent_dim * 4;
     cx_reserve(cx, need + 64 * 256);
   }
@@ -502,11 +516,14 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
   cx->rr_src = cx_upload(cx, d->rec_edge_index, (size_t)E);
   cx->rr_dst = cx_upload(cx, d->rec_edge_index + E, (size_t)E);
   cx->rr_outdeg = cx_upload(cx, outdeg.data(), outdeg.size());
+  std::vector<int32_t> rstart(n_rec, 0);
+  for (int j = 1; j < n_rec; ++j) rstart[j] = rstart[j - 1] + outdeg[j - 1];
+  cx->rr_start = cx_upload(cx, rstart.data(), rstart.size());
   cx->rr_pre1 = cx_upload(cx, pre1.data(), pre1.size());
   cx->rr_sh = cx_upload(cx, sh.data(), sh.size());
   // ---- workspaces -------------------------------------------------------------------------------
   const int64_t Bm = max_batch;
-  cx->edge_cap = Bm * ((int64_t)M + (int64_t)n_lig * (LIG_CAP - 1) + 2LL * n_lig * n_rec + E) + 64;
+  cx->edge_cap = Bm * ((int64_t)M + (int64_t)n_lig * (LIG_CAP - 1) + 2LL * n_lig * n_rec + E) + E + 64;   // + the shared rec-rec copy
   if (cx->edge_cap >= ((int64_t)1 << 31)) return fail(ctx, DDK_ERR_INVALID, "edge capacity exceeds int32 (reduce max_batch)");
   const int64_t N = Bm * (n_lig + n_rec);
   cx->e_src = cx_upload<int32_t>(cx, nullptr, cx->edge_cap);
@@ -515,9 +532,9 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
   cx->e_emb = cx_upload<float>(cx, nullptr, cx->edge_cap * NS);
   cx->e_sh = cx_upload<float>(cx, nullptr, cx->edge_cap * 4);
   cx->deg = cx_upload<int32_t>(cx, nullptr, N);
-  cx->counts = cx_upload<int32_t>(cx, nullptr, Bm * 2);
-  cx->offs = cx_upload<int32_t>(cx, nullptr, Bm * 2);
-  cx->info = cx_upload<int32_t>(cx, nullptr, 64);
+  cx->counts = cx_upload<int32_t>(cx, nullptr, Bm * CNT_STRIDE);
+  cx->offs = cx_upload<int32_t>(cx, nullptr, Bm * CNT_STRIDE);
+  cx->info = cx_upload<int32_t>(cx, nullptr, INFO_INTS);
   cx->xa = cx_upload<float>(cx, nullptr, N * XW);
   cx->xb = cx_upload<float>(cx, nullptr, N * XW);
   cx->sum = cx_upload<float>(cx, nullptr, N * XW);
@@ -530,7 +547,7 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
     if (cx->zero_lat) hipMemset(cx->zero_lat, 0, (size_t)N * c.latent_dim * sizeof(float));
   }
   if (cx->oom || !cx->bond_src || !cx->rr_sh || !cx->scores) return fail(ctx, DDK_ERR_NOMEM, "device allocation failed in ddk_complex_create");
-  hipMemset(cx->info, 0, 64 * sizeof(int32_t));
+  hipMemset(cx->info, 0, INFO_INTS * sizeof(int32_t));
   return DDK_OK;
 }
 
@@ -563,10 +580,10 @@ int ddk_build_graph(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* lig_p
   StepParams sp;
   if ((rc = make_step_params(ctx, t_tr, t_tr, t_tr, sp))) return rc;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = build_graph(ctx, cx, B, lig_pos, sp.cross_cutoff, s);
+  hipError_t e = build_graph(ctx, cx, B, lig_pos, sp.cross_cutoff, /*prune=*/false, /*shared_rr=*/false, s);
   if (e == hipSuccess) e = hipMemcpyAsync(edge_src_out, cx->e_src, (size_t)need * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
   if (e == hipSuccess) e = hipMemcpyAsync(edge_dst_out, cx->e_dst, (size_t)need * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(group_offsets_out, cx->info + 5, 5 * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(group_offsets_out, cx->info + I_GO, 5 * sizeof(int32_t), hipMemcpyDeviceToDevice, s);
   if (e != hipSuccess) return hip_fail(ctx, e, "ddk_build_graph");
   return DDK_OK;
 }
@@ -656,15 +673,18 @@ int ddk_sample(ddk_ctx* ctx, ddk_complex* cx, int32_t B, int32_t steps, const fl
 
 int ddk_last_graph_stats(ddk_ctx* ctx, ddk_complex* cx, int64_t* out, void* stream) {
   if (!ctx || !cx || !out) return DDK_ERR_INVALID;
-  int32_t info[32];
+  int32_t info[INFO_INTS];
   hipError_t e = hipMemcpyAsync(info, cx->info, sizeof(info), hipMemcpyDeviceToHost, (hipStream_t)stream);
   if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(ctx, e, "graph stats readback");
-  for (int g = 0; g < 4; ++g) out[g] = info[6 + g] - info[5 + g];
-  out[4] = info[4];    // conv tiles
-  out[5] = info[23];   // total edges
-  out[6] = info[24];   // overflow flag
+  for (int g = 0; g < 4; ++g) out[g] = info[I_GO + 1 + g] - info[I_GO + g];
+  out[4] = info[I_SHARED] >= 0 ? cx->E_rr : 0;   // edges of the shared rec-rec copy (layer-0 de-duplication)
+  out[5] = info[I_E];      // total edges of the reference graph
+  out[6] = info[I_OVF];    // overflow flag
   out[7] = cx->edge_cap;
+  // rec-rec edges inside the backward receptive field of the heads: levels A, A+B, A+B+C (k_graph.hip); = E_rr * B when pruning is off
+  out[8] = info[I_SEG + 1] - info[I_SEG]; out[9] = info[I_SEG + 2] - info[I_SEG]; out[10] = info[I_SEG + 3] - info[I_SEG];
+  out[11] = 0;
   return DDK_OK;
 }
 
@@ -694,6 +714,12 @@ int ddk_set_keep_receptor_features(ddk_ctx* ctx, ddk_complex* cx, int32_t on) {
   return DDK_OK;
 }
 
+int ddk_set_receptive_field_pruning(ddk_ctx* ctx, int32_t on) {
+  if (!ctx) return DDK_ERR_INVALID;
+  ctx->prune = on != 0;
+  return DDK_OK;
+}
+
 int ddk_set_guidance(ddk_ctx* ctx, ddk_complex* cx, float weight, float cfg_start, float cfg_end) {
   if (!ctx || !cx) return DDK_ERR_INVALID;
   if (weight != 0.0f && ctx->cfg.latent_dim <= 0) return fail(ctx, DDK_ERR_INVALID, "classifier-free guidance needs a latent-conditioned model");
@@ -708,8 +734,8 @@ int ddk_profile_enable(ddk_ctx* ctx, int32_t on) {
   ctx->prof_recs.clear();
   ctx->prof_slots = 0;
   if (on && !ctx->prof_edges) {
-    ctx->prof_cap = 16384;
-    if (hipHostMalloc((void**)&ctx->prof_edges, ctx->prof_cap * sizeof(int32_t)) != hipSuccess)
+    ctx->prof_cap = 4096;      // forwards
+    if (hipHostMalloc((void**)&ctx->prof_edges, (size_t)ctx->prof_cap * PROF_INTS * sizeof(int32_t)) != hipSuccess)
       return fail(ctx, DDK_ERR_NOMEM, "hipHostMalloc failed");
   }
   ctx->prof = on != 0;
@@ -719,19 +745,39 @@ int ddk_profile_enable(ddk_ctx* ctx, int32_t on) {
 int ddk_profile_read(ddk_ctx* ctx, double* out, int32_t n) {
   if (!ctx || !out) return DDK_ERR_INVALID;
   const int L = ctx->cfg.num_conv_layers;
-  if (n < 3 * L) return fail(ctx, DDK_ERR_INVALID, "profile buffer too small");
-  for (int i = 0; i < 3 * L; ++i) out[i] = 0.0;
+  if (n < 5 * L) return fail(ctx, DDK_ERR_INVALID, "profile buffer too small");
+  for (int i = 0; i < 5 * L; ++i) out[i] = 0.0;
   hipError_t e = hipDeviceSynchronize();
   if (e != hipSuccess) return hip_fail(ctx, e, "profile sync");
   for (auto& r : ctx->prof_recs) {
     float ms = 0.f;
     e = hipEventElapsedTime(&ms, r.a, r.b);
     if (e != hipSuccess) return hip_fail(ctx, e, "hipEventElapsedTime");
-    out[3 * r.layer] += ms;
-    out[3 * r.layer + 1] += 1.0;
-    out[3 * r.layer + 2] += r.lig_only ? (double)ctx->prof_edges[r.slot + 1] : (double)ctx->prof_edges[r.slot] - (double)r.skipped;
+    const int32_t* pe = ctx->prof_edges + (size_t)PROF_INTS * r.slot;     // [0] = E, [1] = edges of groups 0+1, [2 + k] = edges of table k
+    const double E = pe[0], E01 = pe[1];
+    out[5 * r.layer] += ms;
+    out[5 * r.layer + 1] += 1.0;
+    out[5 * r.layer + 2] += r.lig_only ? E01 : (double)pe[2 + r.tab];            // edges the launch evaluated
+    out[5 * r.layer + 3] += r.lig_only ? E01 : E - (double)r.r01_skipped;          // without the receptive-field pruning (round-1 accounting)
+    out[5 * r.layer + 4] += E;                                                     // edges the reference evaluates in this layer
   }
   return DDK_OK;
+}
+
+// Test hooks: the device Kabsch / axis-angle routines of k_se3.hip on caller-supplied DEVICE arrays (A, B [nb, n, 3] -> R [nb,3,3], t [nb,3];
+// aa [n,3] -> R [n,3,3])
+int ddk_debug_kabsch(ddk_ctx* ctx, int32_t nb, int32_t n, const float* A, const float* B, float* R_out, float* t_out, void* stream) {
+  if (!ctx || ctx->host_only) return DDK_ERR_STATE;
+  if (nb < 1 || n < 1 || n > MAX_LIG || !A || !B || !R_out || !t_out) return fail(ctx, DDK_ERR_INVALID, "ddk_debug_kabsch: bad argument");
+  hipError_t e = launch_debug_kabsch(A, B, nb, n, R_out, t_out, (hipStream_t)stream);
+  return e == hipSuccess ? DDK_OK : hip_fail(ctx, e, "debug kabsch");
+}
+
+int ddk_debug_axis_angle(ddk_ctx* ctx, int32_t n, const float* aa, float* R_out, void* stream) {
+  if (!ctx || ctx->host_only) return DDK_ERR_STATE;
+  if (n < 1 || !aa || !R_out) return fail(ctx, DDK_ERR_INVALID, "ddk_debug_axis_angle: bad argument");
+  hipError_t e = launch_debug_axis_angle(aa, n, R_out, (hipStream_t)stream);
+  return e == hipSuccess ? DDK_OK : hip_fail(ctx, e, "debug axis angle");
 }
 
 // Test hook: copy raw device-side edge arrays of the last forward to host buffers (counts via ddk_last_graph_stats).

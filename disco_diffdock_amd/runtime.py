@@ -129,11 +129,16 @@ class Context:
         self._check(self.L.ddk_profile_enable(self.h, int(on)), 'ddk_profile_enable')
 
     def profile_read(self):
-        n = 3 * self.cfg.num_conv_layers
+        """per conv layer: kernel ms, launches, edges evaluated, edges without the receptive-field pruning, reference edges"""
+        n = 5 * self.cfg.num_conv_layers
         buf = (C.c_double * n)()
         self._check(self.L.ddk_profile_read(self.h, buf, n), 'ddk_profile_read')
-        a = np.array(list(buf)).reshape(-1, 3)
-        return [dict(ms=float(r[0]), launches=int(r[1]), edges=int(r[2])) for r in a]
+        a = np.array(list(buf)).reshape(-1, 5)
+        return [dict(ms=float(r[0]), launches=int(r[1]), edges=int(r[2]), edges_unpruned=int(r[3]), edges_reference=int(r[4])) for r in a]
+
+    def set_pruning(self, on=True):
+        """backward receptive-field pruning of the receptor-receptor messages (default on; exact)"""
+        self._check(self.L.ddk_set_receptive_field_pruning(self.h, int(bool(on))), 'ddk_set_receptive_field_pruning')
 
     # ---- operators ---------------------------------------------------------------------------
     def tp_forward(self, layer, x_dst, sh, w, dout):
@@ -341,12 +346,12 @@ class Complex:
         return torch.stack([src[:E], dst[:E]]), off
 
     def graph_stats(self):
-        out = (C.c_int64 * 8)()
+        out = (C.c_int64 * 12)()
         self.ctx._check(self.ctx.L.ddk_last_graph_stats(self.ctx.h, self.h, out, _stream()), 'ddk_last_graph_stats')
         v = list(out)
         if v[6]:
             raise RuntimeError('ddk: edge capacity overflow')
-        return dict(E_ll=v[0], E_lr=v[1], E_rr=v[2], E_rl=v[3], tiles=v[4], E=v[5], cap=v[7])
+        return dict(E_ll=v[0], E_lr=v[1], E_rr=v[2], E_rl=v[3], E_shared=v[4], E=v[5], cap=v[7], E_rr_live=(v[8], v[9], v[10]))
 
     def keep_receptor_features(self, on=True):
         """Evaluate the receptor rows of the last conv layer too (needed before ``node_features``' receptor output)."""

@@ -146,6 +146,14 @@ int ddk_set_guidance(ddk_ctx* ctx, ddk_complex* cx, float weight, float cfg_star
  *      the reference does.  tr/rot/tor are identical either way. */
 int ddk_set_keep_receptor_features(ddk_ctx* ctx, ddk_complex* cx, int32_t on);
 
+/* ---- Backward receptive-field pruning (default ON; exact in real arithmetic): because the heads read ligand rows only, conv
+ *      layer L-2 has to produce receptor rows only at the residues that carry a cross edge, layer L-3 only at those plus the
+ *      senders of their receptor-receptor messages, and so on (csrc/k_graph.hip).  The receptor-receptor messages outside that
+ *      set are not evaluated.  tr/rot/tor are unchanged (tests: test_pruned_layers_equal_full); 0 switches it off (every layer
+ *      evaluates every receptor-receptor message, as the reference does).  Forwards with ddk_set_keep_receptor_features(on)
+ *      never prune. */
+int ddk_set_receptive_field_pruning(ddk_ctx* ctx, int32_t on);
+
 /* ---- a5-a17: model.score_model(batch) -> (tr[B,3], rot[B,3], tor[B*R])  models/score_model.py:259-308
  *      for B copies of one complex at a common time (utils/sampling.py:113-117).
  *      lig_pos [B, n_lig, 3]; outputs tr [B,3], rot [B,3], tor [B*n_rot]. */
@@ -200,15 +208,20 @@ int ddk_build_graph(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* lig_p
                     int32_t* edge_dst_out, int64_t cap, int32_t* group_offsets_out, void* stream);
 
 /* ---- introspection for tests / benches ------------------------------------------------------ */
-/* Copies the last forward's per-stage edge counts into out[8] (HOST): E_ll, E_lr, E_rr, E_rl, tiles, ... */
+/* Copies the last forward's edge counts into out[12] (HOST, synchronises the stream): [0..3] = E_ll, E_lr, E_rr, E_rl of the reference
+ * graph, [4] = edges of the shared receptor-receptor copy (layer-0 de-duplication), [5] = E, [6] = capacity overflow flag,
+ * [7] = edge capacity, [8..10] = receptor-receptor edges inside the heads' backward receptive field one / two / three layers below
+ * the last conv layer (= E_rr when the pruning is off), [11] = 0. */
 int ddk_last_graph_stats(ddk_ctx* ctx, ddk_complex* cx, int64_t* out, void* stream);
 /* Node features after the conv stack of the last forward: lig [B*n_lig, 84], rec [B*n_rec, 84] (device ptrs, may be NULL).
  * rec_out != NULL requires ddk_set_keep_receptor_features(on) before that forward (DDK_ERR_STATE otherwise). */
 int ddk_last_node_features(ddk_ctx* ctx, ddk_complex* cx, int32_t B, float* lig_out, float* rec_out, void* stream);
 
 /* ---- measurement: HIP-event timing of every fused TP-conv launch on the stream it is launched on (bench.py's
- *      roofline leg).  ddk_profile_read synchronises, then fills per conv layer l: out[3l] = total kernel ms,
- *      out[3l+1] = launches, out[3l+2] = total edges processed; n = 3 * num_conv_layers doubles (HOST). */
+ *      roofline leg).  ddk_profile_read synchronises, then fills per conv layer l (n >= 5 * num_conv_layers doubles, HOST):
+ *      out[5l] = total kernel ms, out[5l+1] = launches, out[5l+2] = edges the launches evaluated, out[5l+3] = edges they would
+ *      have evaluated without the receptive-field pruning (layer-0 de-duplication and the last layer's ligand-only evaluation
+ *      still applied: the round-1 accounting), out[5l+4] = edges the reference evaluates in that layer (all of E every layer). */
 int ddk_profile_enable(ddk_ctx* ctx, int32_t on);
 int ddk_profile_read(ddk_ctx* ctx, double* out, int32_t n);
 

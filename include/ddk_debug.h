@@ -28,6 +28,12 @@ int ddk_debug_conf_nodes(ddk_ctx* ctx, ddk_complex* cx, float* x, int32_t* deg, 
 int ddk_debug_conf_edges(ddk_ctx* ctx, ddk_complex* cx, int64_t first, int64_t n, int32_t* src, int32_t* dst, float* emb, float* sh,
                          int32_t* gt);
 
+/* The device routines of csrc/k_se3.hip on caller-supplied DEVICE arrays (enqueue on `stream`, no synchronisation):
+ *   kabsch:     A, B [nb, n, 3] -> R [nb, 3, 3], t [nb, 3] with R a + t ~ b   (utils/geometry.py:126-156, reflection case included)
+ *   axis_angle: aa [n, 3] -> R [n, 3, 3]                                     (utils/geometry.py:71-85, small-angle branch included) */
+int ddk_debug_kabsch(ddk_ctx* ctx, int32_t nb, int32_t n, const float* A, const float* B, float* R_out, float* t_out, void* stream);
+int ddk_debug_axis_angle(ddk_ctx* ctx, int32_t n, const float* aa, float* R_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

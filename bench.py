@@ -1,26 +1,40 @@
 #!/usr/bin/env python
 """bench.py - headline benchmark of the ddk hot path (BASELINE.json metric):
 
-    complexes/sec, 20-step 40-sample reverse-diffusion inference of the DiffDock-S score model
+    complexes/sec, 20-step 40-sample reverse-diffusion inference
 
-One "step" = the complete hot path for ONE complex: 40 samples x 20 reverse steps (score-model forward with the
-fused TP-conv kernels + SE(3)/torsion update), inputs already resident in HBM (complex uploaded, start poses on the
-device) when the timed region starts.  N = 1 workload = BASELINE.json configs[1]: 8 synthetic complexes
-(~30 ligand atoms / ~300 C-alpha), samples_per_complex = 40, 20 steps; the K timed steps cycle through them.
-N > 1: one process per GPU (torch.distributed, backend nccl == RCCL), every rank runs K steps on its own shard of
-complexes (weak scaling), no collective on the data path, one final pose gather.
+``value`` uses the REFERENCE'S OWN BRACKET (evaluate.py:259,293): the wall time around ``sampling(data_list, model, ...)`` on host
+``data_list``s of 40 graph copies with host start poses, a NEW complex every call - collation, ``ddk_complex_create`` (static
+precompute + H2D), the pose upload, the device noise draws, the 20-step loop and the pose write-back are all inside; K calls
+back to back, one device synchronisation at the end, value = K / wall (x world).  One "step" = one complex.
 
-Prints ONE JSON line on rank 0, with two extra objects:
-  roofline      fused TP-conv kernel: algorithmic FLOPs of the launches in the timed region / their HIP-event time
-                vs the fp32 MFMA peak (the kernel is MFMA-bound), plus the algorithmic HBM bytes rate
-  cpu_baseline  the CPU oracle (PyTorch-CPU restatement of the reference, oracle/) timed on this box's host cores
-                on a bounded sample of the same workload
+    python bench.py --gpus N --steps K --warmup W [--config 2|3|4|5]
+
+configs (BASELINE.json ``configs``; the driver's N = 1 line is config 2):
+  2  DiffDock-S score model, 8 synthetic complexes (~30 ligand atoms / 300 C-alpha) per GPU, 40 samples, 20 steps
+  3  DisCo-DiffDock-S score model (latent_dim = 2) + AR latent model
+  4  config 3 + all-atom confidence model on the final poses, confidences gathered with the poses
+  5  large-pocket stress: 2000 C-alpha; the 40 samples of every complex are sharded over the ranks (N = 1: all 40 on one GPU)
+N > 1: one process per GPU (torch.distributed, backend nccl == RCCL); configs 2-4 shard COMPLEXES (weak scaling: K complexes per
+rank), config 5 shards SAMPLES (strong scaling); no collective on the data path, one final all_gather of the poses.
+
+Prints ONE JSON line on rank 0, with
+  roofline      fused TP-conv kernel, HIP events around every launch of the timed region: algorithmic FLOPs / event time vs the
+                fp32 MFMA peak; ``frac`` counts the rec-rec messages removed by the receptive-field pruning as work done (the
+                reference evaluates them), ``frac_executed`` counts only what the launches evaluated
+  extra         device_loop: the same workload with complexes and noise resident in HBM (round 1's bracket), for comparison
+  cpu_baseline  the CPU oracle (oracle/: PyTorch-CPU restatement of the reference) on this box's host cores, bounded sample;
+                its scores are asserted equal to the GPU's on the same inputs
 """
 import argparse
+import copy
 import json
 import os
 import sys
+import tempfile
 import time
+from argparse import Namespace
+from functools import partial
 
 import numpy as np
 import torch
@@ -28,29 +42,54 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-SAMPLES, STEPS, N_COMPLEXES, N_RES = 40, 20, 8, 300
+SAMPLES, STEPS, N_COMPLEXES = 40, 20, 8
 README_S = dict(temp_sampling=[1.886430780895051, 5.659562317960644, 2.8888668488630156],
                 temp_psi=[0.07085125444659945, 2.686505606141324, 4.089493860493927],
                 temp_sigma_data=[0.3617563913086843, 0.7437588205919711, 0.08897393057297842])
+README_DISCO = dict(temp_sampling=[1.546842681537956, 4.005218254154881, 3.6499018519649384],
+                    temp_psi=[1.2685697872473618, 1.2760150490206228, 2.0625243924678136],
+                    temp_sigma_data=[0.8456140350087653, 0.453446580767075, 0.3292199987743284])
 W_LAYER = [720, 936, 1152, 1872, 1872]
 TP_FLOP = [2016, 2736, 3456, 5472, 5472]
 FUSED_BYTES = [408, 480, 552, 648, 648]                        # fused boundary, bytes per edge
 PEAK_F32_MFMA_TFLOPS = 157.3                                   # MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
+ARGS_S = Namespace(ns=24, nv=6, num_conv_layers=5, sigma_embed_dim=32, distance_embed_dim=32, cross_distance_embed_dim=32,
+                   max_radius=5.0, cross_max_distance=80, dynamic_max_cross=True, embedding_scale=1000, embedding_type='sinusoidal',
+                   scale_by_sigma=True, no_torsion=False, no_batch_norm=False, dropout=0.1, sh_lmax=1, use_second_order_repr=False,
+                   use_old_atom_encoder=False, esm_embeddings_path='data/esm2_3billion_embeddings.pt', latent_dim=0, latent_vocab=64,
+                   latent_cross_attention=False, tr_sigma_min=0.1, tr_sigma_max=19.0, rot_sigma_min=0.03, rot_sigma_max=1.55,
+                   tor_sigma_min=0.03, tor_sigma_max=3.14)
+ARGS_DISCO = Namespace(**dict(vars(ARGS_S), latent_dim=2, latent_vocab=1, latent_droprate=0.1))
+ARGS_AR = Namespace(use_pretrained_score=True, ns=16, latent_no_batchnorm=False, latent_dropout=0.0, latent_hidden_dim=128,
+                    esm_embeddings_path='x', no_randomness=False)
+ARGS_CONF = Namespace(all_atoms=True, ns=24, nv=6, num_conv_layers=5, sigma_embed_dim=32, distance_embed_dim=32, cross_distance_embed_dim=32,
+                      max_radius=5.0, cross_max_distance=80, dynamic_max_cross=True, embedding_type='sinusoidal', embedding_scale=10000,
+                      scale_by_sigma=True, no_torsion=False, no_batch_norm=False, dropout=0.1, use_second_order_repr=False,
+                      esm_embeddings_path='data/esm2_3billion_embeddings.pt', rmsd_classification_cutoff=[2.0], confidence_no_batchnorm=False,
+                      tr_sigma_min=0.1, tr_sigma_max=34.0, rot_sigma_min=0.03, rot_sigma_max=1.55, tor_sigma_min=0.0314, tor_sigma_max=3.14)
+
+CONFIG_TEXT = {
+    2: 'DiffDock-S score model (random-init weights, reference state_dict layout), 8 synthetic complexes per GPU (20-40 ligand atoms / 300 '
+       'C-alpha, 24-NN receptor graph), samples_per_complex=40, inference_steps=20, README low-temperature sampling, no_final_step_noise',
+    3: 'DisCo-DiffDock-S score model (latent_dim=2, latent_vocab=1) + AR latent model (PretrainedScoreEncoder, softmax temperature e^-1.5), '
+       '8 synthetic complexes per GPU (300 C-alpha), samples_per_complex=40, inference_steps=20, README DisCo temperatures',
+    4: 'config 3 + all-atom confidence model (paper_confidence_model layout, ~2400 receptor atoms) on the final poses; confidences gathered '
+       'with the poses',
+    5: 'large-pocket stress: DiffDock-S score model, synthetic complexes with 2000 C-alpha (24-NN within 15 A), samples_per_complex=40 '
+       'sharded over the ranks, inference_steps=20',
+}
+
 
 def pmc_traffic():
     """HBM bytes per fused-conv launch from the committed PMC passes of this same command (None if absent)."""
-    try:
-        return json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))['traffic_bytes_per_launch']
-    except Exception:
-        return None
-
-
-def model_args():
-    from argparse import Namespace
-    return Namespace(tr_sigma_min=0.1, tr_sigma_max=19.0, rot_sigma_min=0.03, rot_sigma_max=1.55, tor_sigma_min=0.03,
-                     tor_sigma_max=3.14, no_torsion=False)
+    for name in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+        try:
+            return json.load(open(os.path.join(ROOT, 'profiles', name)))['traffic_bytes_per_launch'], name
+        except Exception:
+            continue
+    return None, None
 
 
 def start_poses(c, rng, samples, tr_sigma_max=19.0):
@@ -66,43 +105,54 @@ def start_poses(c, rng, samples, tr_sigma_max=19.0):
     return np.stack(out).astype(np.float32)
 
 
-def cpu_baseline(c, P, coeffs, seconds_budget=30.0):
-    """Time the CPU oracle on a bounded sample: `b` samples x 1 reverse step of one complex, extrapolated."""
+def cpu_baseline(c, P, coeffs, gpu_scores, n_res, seconds_budget=40.0):
+    """The CPU oracle on a bounded sample: b samples x 1 reverse step of one complex at t in {1.0, 0.5, 0.05} (the cross graph shrinks
+    with t), >= 3 warm runs each; the mean of the per-t medians is extrapolated to 20 steps x 40 samples.  The oracle's scores are
+    compared with the GPU's on the same inputs (the oracle is the checker here, never the path)."""
     from oracle import score_model_ref as smr, sampler_ref as spr, graph_lite
     cfg = smr.ScoreModelConfig(latent_vocab=64)
     d = os.path.join(ROOT, 'disco_diffdock_amd', 'data')
     tables = (np.load(os.path.join(d, 'so3_exp_score_norms.npy')), np.load(os.path.join(d, 'torus_score_norm_seed0.npy')))
     b = 2
-    rng = np.random.default_rng(0)
-    pos = start_poses(c, rng, b)
+    pos = start_poses(c, np.random.default_rng(0), b, tr_sigma_max=6.0)
 
     def graph():
         g = graph_lite.make_complex(c['lig_x'], c['lig_pos'], c['bond_index'], c['bond_attr'], c['edge_mask'], c['mask_rotate'],
                                     c['rec_x'], c['rec_pos'], c['rec_edge_index'])
         g['ligand'].mask_rotate = [g['ligand'].mask_rotate]
         return g
-    times = []
     t_arr, sc, nc = coeffs
-    for rep in range(3):
-        dl = [graph() for _ in range(b)]
-        for g, p in zip(dl, pos):
-            g['ligand'].pos = torch.from_numpy(p)
-        batch = graph_lite.collate(dl)
-        t0 = time.perf_counter()
-        with torch.no_grad():
-            spr.set_time(batch, 1.0, 1.0, 1.0, b)
-            tr, rot, tor = smr.score_model_forward(P, cfg, batch, tables[0], tables[1])
-            spr.modify_conformer_batch(batch['ligand'].pos, batch, sc[0, 0] * tr, sc[0, 1] * rot, sc[0, 2] * tor,
-                                       torch.from_numpy(c['mask_rotate']))
-        times.append(time.perf_counter() - t0)
-        if sum(times) > seconds_budget:
-            break
-    t_step = float(np.median(times[1:] if len(times) > 1 else times))
+    per_t, worst, t_used, t_start = {}, 0.0, [], time.perf_counter()
+    for t in (1.0, 0.5, 0.05):
+        times = []
+        for rep in range(4):           # 1 cold + 3 warm
+            dl = [graph() for _ in range(b)]
+            for g, p in zip(dl, pos):
+                g['ligand'].pos = torch.from_numpy(p)
+            batch = graph_lite.collate(dl)
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                spr.set_time(batch, t, t, t, b)
+                tr, rot, tor = smr.score_model_forward(P, cfg, batch, tables[0], tables[1])
+                spr.modify_conformer_batch(batch['ligand'].pos, batch, sc[0, 0] * tr, sc[0, 1] * rot, sc[0, 2] * tor,
+                                           torch.from_numpy(np.asarray(c['mask_rotate'])))
+            times.append(time.perf_counter() - t0)
+            if rep >= 1 and time.perf_counter() - t_start > seconds_budget and len(times) >= 2:
+                break
+        per_t[t] = float(np.median(times[1:]))
+        t_used.append(len(times) - 1)
+        g_tr, g_rot, g_tor = gpu_scores(pos, t)
+        for a, r in ((g_tr, tr), (g_rot, rot), (g_tor, tor)):
+            if r.numel():
+                worst = max(worst, float((a.cpu() - r).abs().max() / r.abs().max()))
+    assert worst < 1e-4, f'GPU scores differ from the CPU oracle on the cpu_baseline sample: {worst:.2e}'
+    t_step = float(np.mean(list(per_t.values())))
     per_complex = t_step * STEPS * (SAMPLES / b)
     return dict(value=1.0 / per_complex, unit='complexes/s', cores=torch.get_num_threads(), kind='port',
-                sample=f'oracle (PyTorch-CPU restatement, materialised [E,W] weights): {b} samples x 1 reverse step at t=1 of one '
-                       f'{N_RES}-residue complex, median of {max(len(times) - 1, 1)} warm runs = {t_step:.2f} s, extrapolated x{STEPS} steps x{SAMPLES // b} '
-                       f'(batch {SAMPLES})')
+                gpu_vs_oracle_rel_err=worst,
+                sample=f'oracle (PyTorch-CPU restatement, materialised [E,W] weights): {b} samples x 1 reverse step of one {n_res}-residue complex at '
+                       f't = 1.0 / 0.5 / 0.05, median of {min(t_used)} warm runs each = ' + ' / '.join(f'{per_t[t]:.2f}' for t in per_t) +
+                       f' s, mean {t_step:.2f} s extrapolated x{STEPS} steps x{SAMPLES // b} (batch {SAMPLES}); oracle scores == GPU scores to {worst:.1e}')
 
 
 def main():
@@ -110,8 +160,10 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--config', type=int, default=2, choices=[2, 3, 4, 5])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-alt', action='store_true', help='skip the opt-in 3 x f16 measurement')
+    ap.add_argument('--no-device-loop', action='store_true', help='skip the resident-loop comparison figure')
     a = ap.parse_args()
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
@@ -122,82 +174,167 @@ def main():
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
 
-    from functools import partial
-    from disco_diffdock_amd import build, synthetic
-    from disco_diffdock_amd.runtime import Context, Complex
-    from disco_diffdock_amd.sampling import step_coefficients
+    from disco_diffdock_amd import build, synthetic, graph_cache, score_model as sm_mod
+    from disco_diffdock_amd.runtime import Complex
+    from disco_diffdock_amd.data import from_arrays
+    from disco_diffdock_amd.model_utils import get_model, get_ar_model
+    from disco_diffdock_amd.sampling import sampling, step_coefficients, draw_noise
     from disco_diffdock_amd.diffusion_utils import t_to_sigma, get_t_schedule
-    from disco_diffdock_amd.distributed import shard_indices, gather_poses
+    from disco_diffdock_amd.distributed import shard_indices, shard_samples, gather_poses, gather_samples, gather_confidences
     if rank == 0:
         build.build(verbose=False)       # no-op when the shipped libddk.so is current; never build concurrently
     if world > 1:
         dist.barrier()
 
-    # ---- workload: this rank's shard of the (world * 8) synthetic complexes ---------------------------------
-    n_total = N_COMPLEXES * world
-    mine = [rank * N_COMPLEXES + i for i in range(N_COMPLEXES)] if world == 1 else \
-        shard_indices([1.0] * n_total, rank, world)
-    complexes = {i: synthetic.make_complex(i, n_res=N_RES) for i in mine}
-    P = synthetic.random_score_model_state_dict(seed=0)
-    margs = model_args()
+    cfg_id = a.config
+    disco, with_conf, big = cfg_id in (3, 4), cfg_id == 4, cfg_id == 5
+    n_res = 2000 if big else 300
+    margs = ARGS_DISCO if disco else ARGS_S
+    temps = README_DISCO if disco else README_S
+
+    # ---- workload: this rank's complexes, written to and read back from the flat graph cache (the format a GPU box receives real
+    #      PDBBind graphs in, disco_diffdock_amd/graph_cache.py) ---------------------------------------------------------------
+    n_cx = 4 if big else N_COMPLEXES
+    if big:                                  # samples sharded: every rank works on the same complexes
+        mine = list(range(n_cx))
+        lo, hi = shard_samples(SAMPLES, rank, world)
+    else:
+        n_total = n_cx * world
+        mine = [rank * n_cx + i for i in range(n_cx)] if world == 1 else shard_indices([1.0] * n_total, rank, world)
+        lo, hi = 0, SAMPLES
+    b_local = hi - lo
+    made = []
+    for i in mine:
+        c = synthetic.make_complex(i, n_res=n_res)
+        if with_conf:
+            synthetic.add_receptor_atoms(c, np.random.default_rng(i))
+        made.append(c)
+    cache_path = os.path.join(tempfile.gettempdir(), f'ddk_bench_cfg{cfg_id}_rank{rank}.ddkg')
+    graph_cache.save_complexes(cache_path, made)
+    complexes = dict(zip(mine, graph_cache.load_complexes(cache_path)))
+
+    # ---- models through the reference's call surface ----------------------------------------------------------------------------
+    tsig = partial(t_to_sigma, args=margs)
+    model = get_model(margs, dev, tsig, no_parallel=True)
+    score_model = getattr(model, 'score_model', model)
+    P = synthetic.random_score_model_state_dict(seed=0, latent_dim=margs.latent_dim, latent_droprate=getattr(margs, 'latent_droprate', 0.0))
+    score_model.load_state_dict(P, strict=True)
+    extra = {}
+    if disco:
+        ar = get_ar_model(ARGS_AR, margs, dev, training=False)
+        ar.load_state_dict(synthetic.random_ar_state_dict(seed=14))
+        ar.eval()
+        extra.update(ar_model=ar, ar_args=ARGS_AR, softmax_latent_temperature=float(np.exp(-1.5)))
+    else:
+        extra.update(use_latent=False)
+    if with_conf:
+        cm = get_model(ARGS_CONF, dev, partial(t_to_sigma, args=ARGS_CONF), no_parallel=True, confidence_mode=True)
+        cm.load_state_dict(synthetic.random_confidence_state_dict(seed=1), strict=True)
+        cm.eval()
+        extra.update(confidence_model=cm, confidence_model_args=ARGS_CONF)
     sched = get_t_schedule(STEPS)
-    coeffs = step_coefficients(STEPS, sched, sched, sched, partial(t_to_sigma, args=margs), margs, False, False, True,
-                               README_S['temp_sampling'], README_S['temp_psi'], README_S['temp_sigma_data'])
+    coeffs = step_coefficients(STEPS, sched, sched, sched, tsig, margs, False, False, True, temps['temp_sampling'], temps['temp_psi'],
+                               temps['temp_sigma_data'])
     t_arr, sc, nc = coeffs
     order = [mine[k % len(mine)] for k in range(a.warmup + a.steps)]
+    ctx = score_model.ctx
 
-    def measure(**ctx_kw):
-        """W warmup + K timed complexes on a fresh context; returns (seconds, per-layer conv profile, final poses, n_lig per complex)."""
-        ctx = Context(device=local, **ctx_kw)
-        ctx.load_state_dict(P)
-        cxs, poses0, noises = {}, {}, {}
-        gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-        for i in mine:
-            c = complexes[i]
-            cxs[i] = Complex(ctx, c, SAMPLES)
-            poses0[i] = torch.from_numpy(start_poses(c, np.random.default_rng(i), SAMPLES)).to(dev)
-            noises[i] = torch.randn((STEPS, SAMPLES, 6 + cxs[i].R), device=dev, generator=gen)
+    # host data_lists of every call, prepared BEFORE the clock starts like evaluate.py:232-233 (deepcopy + randomize_position)
+    poses_all = {i: start_poses(complexes[i], np.random.default_rng(i), SAMPLES) for i in mine}
+    graphs0 = {}
+    for i in mine:
+        c = complexes[i]
+        score_only = {k: v for k, v in c.items() if not k.startswith('atom_')}
+        graphs0[i] = (from_arrays(score_only), from_arrays(c) if with_conf else None)
 
-        def run_one(i):
-            pos = poses0[i].clone()
-            cxs[i].sample(pos, t_arr, sc, nc, noises[i])
-            return pos
+    def data_lists(i):
+        g0, gc = graphs0[i]
+        dl = [copy.copy(g0) for _ in range(b_local)]
+        for d, p in zip(dl, poses_all[i][lo:hi]):
+            d['ligand'].pos = torch.from_numpy(p)
+            if disco:
+                d['ligand'].ar_pos = torch.from_numpy(p).clone()
+        cdl = [copy.copy(gc) for _ in range(b_local)] if with_conf else None
+        return dl, cdl
+    calls = [data_lists(i) for i in order]
 
-        for k in range(a.warmup):
-            run_one(order[k])
-        torch.cuda.synchronize()
-        ctx.profile_enable(True)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        final = {}
-        for k in range(a.warmup, a.warmup + a.steps):
-            final[order[k]] = run_one(order[k])
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        prof = ctx.profile_read()
-        ctx.profile_enable(False)
-        return elapsed, prof, final, {i: cxs[i].n_lig for i in mine}, int(ctx.cfg.conv_f16x3)
+    def one_call(k):
+        dl, cdl = calls[k]
+        kw = dict(extra)
+        if with_conf:
+            kw['confidence_data_list'] = cdl
+        out, conf = sampling(dl, model, STEPS, sched, sched, sched, dev, tsig, margs, batch_size=b_local, no_final_step_noise=True, **temps, **kw)
+        return out, conf
 
-    elapsed, prof, final, n_ligs, main_f16x3 = measure()
+    for k in range(a.warmup):
+        one_call(k)
+    torch.cuda.synchronize()
+    torch.cuda.manual_seed(4321 + rank)      # the device generator sampling() draws its noise from (the resident-loop figure below replays it)
+    sm_mod._complex_cache.clear()            # a NEW complex every timed call: no Complex of the warm-up survives
+    ctx.profile_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    final, confs = {}, {}
+    for k in range(a.warmup, a.warmup + a.steps):
+        if (k - a.warmup) % len(mine) == 0 and k > a.warmup:
+            sm_mod._complex_cache.clear()    # K > #complexes: the second pass over the shard must not hit the cache either
+        out, conf = one_call(k)
+        final[order[k]] = torch.stack([d['ligand'].pos for d in out])
+        if with_conf:
+            confs[order[k]] = conf
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        # the one exchange of the path: final poses of every complex to every rank (RCCL over xGMI)
+    # ---- the one exchange of the path: final poses (and confidences) of every complex to every rank (RCCL over xGMI) ----------
+    if big:
+        gathered = {i: gather_samples(p, SAMPLES, rank, world, dev) for i, p in final.items()}
+        assert all(g.shape[0] == SAMPLES for g in gathered.values())
+        n_done = a.steps                                    # the ranks worked on the SAME K complexes
+    else:
+        n_total = n_cx * world
         nl = torch.zeros(n_total, dtype=torch.int64, device=dev)
         for i in mine:
-            nl[i] = n_ligs[i]
-        dist.all_reduce(nl)
+            nl[i] = complexes[i]['lig_pos'].shape[0]
+        if world > 1:
+            dist.all_reduce(nl)
         if len(final) == len(mine):
             gathered = gather_poses(final, [int(v) for v in nl.tolist()], SAMPLES, dev)
             assert len(gathered) == n_total
+            if with_conf:
+                assert len(gather_confidences(confs, n_total, dev)) == n_total
+        n_done = world * a.steps
     for p in final.values():
         assert bool(torch.isfinite(p).all()), 'non-finite pose'
+
+    # ---- comparison figure: the loop alone on resident complexes with pre-drawn noise (round 1's bracket) ----------------------
+    device_loop = None
+    if not a.no_device_loop and not disco:
+        cxs = {i: Complex(ctx, complexes[i], b_local) for i in mine}
+        p0 = {i: torch.from_numpy(poses_all[i][lo:hi]).to(dev) for i in mine}
+        torch.cuda.manual_seed(4321 + rank)      # the same draws, in the same order, as the timed sampling() calls above: identical work
+        nz = {k: draw_noise(STEPS, b_local, cxs[order[k]].R, cxs[order[k]].R, nc, dev) for k in range(a.warmup, a.warmup + a.steps)}
+        for k in range(a.warmup):
+            cxs[order[k]].sample(p0[order[k]].clone(), t_arr, sc, nc, None)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(a.warmup, a.warmup + a.steps):
+            cxs[order[k]].sample(p0[order[k]].clone(), t_arr, sc, nc, nz[k])
+        torch.cuda.synchronize()
+        e1 = time.perf_counter() - t1
+        device_loop = {'value': (1 if big else world) * a.steps / e1, 'unit': 'complexes/s', 'ms_per_step': 1e3 * e1 / a.steps,
+                       'note': 'complexes, start poses and noise resident in HBM before the clock starts (this rank; round-1 bracket)'}
+        del cxs
 
     if rank == 0:
         conv_ms = sum(p['ms'] for p in prof)
@@ -205,28 +342,34 @@ def main():
         flops_exec, flops, flops_full = fl('edges'), fl('edges_unpruned'), fl('edges_reference')
         byts = sum(p['edges'] * FUSED_BYTES[l] for l, p in enumerate(prof))
         launches = sum(p['launches'] for p in prof)
-        achieved = flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        tf = lambda f: f / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        traffic, traffic_file = pmc_traffic()
         out = {
             'metric': 'complexes/sec, 20-step 40-sample inference',
-            'value': world * a.steps / elapsed, 'unit': 'complexes/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
-            'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if not main_f16x3 else 'f32 (radial-MLP GEMMs as error-compensated 3 x f16 MFMA, f32 accumulation)', 'data': 'synthetic',
-            'config': {'workload': 'DiffDock-S score model (random-init weights, reference state_dict layout), 8 synthetic complexes per GPU '
-                                   '(20-40 ligand atoms / 300 C-alpha, 24-NN receptor graph), samples_per_complex=40, inference_steps=20, '
-                                   'README low-temperature sampling, no_final_step_noise; 1 step = 1 complex',
-                       'samples_per_complex': SAMPLES, 'inference_steps': STEPS, 'complexes_per_gpu': N_COMPLEXES,
-                       'parallelism': f'complexes sharded over {world} process(es), one per GPU, final RCCL pose gather'},
-            'roofline': {'bound': 'mfma', 'kernel': 'ddk::conv_fused_kernel<true, 0>', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS,
-                         'achieved_executed': flops_exec / (conv_ms * 1e-3) / 1e12, 'frac_executed': flops_exec / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                         'achieved_full_reference': flops_full / (conv_ms * 1e-3) / 1e12,
+            'value': n_done / elapsed, 'unit': 'complexes/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True, 'scaling': 'strong' if big else 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'BASELINE config {cfg_id}: ' + CONFIG_TEXT[cfg_id] + '; 1 step = 1 complex',
+                       'bracket': 'wall time around sampling(data_list, model, ...) on host data_lists, a new complex every call (evaluate.py:259,293): '
+                                  'collation, ddk_complex_create, H2D, noise draws, the 20-step loop, pose write-back; K calls + one final synchronisation',
+                       'samples_per_complex': SAMPLES, 'inference_steps': STEPS, 'complexes_per_gpu': n_cx,
+                       'parallelism': (f'the {SAMPLES} samples of every complex sharded over {world} process(es) ({b_local} per GPU), final all_gather'
+                                       if big else f'complexes sharded over {world} process(es), one per GPU, final RCCL all_gather of the poses')},
+            'roofline': {'bound': 'mfma', 'kernel': 'ddk::conv_fused_kernel<true, 0>', 'achieved': tf(flops), 'peak': PEAK_F32_MFMA_TFLOPS,
+                         'unit': 'TFLOP/s', 'frac': tf(flops) / PEAK_F32_MFMA_TFLOPS,
+                         'accounting': 'achieved / frac: algorithmic FLOPs of the edges the launches evaluated PLUS the receptor-receptor messages the '
+                                       'backward receptive-field pruning proved dead (round-1 accounting: layer-0 de-duplication and the last '
+                                       "layer's ligand-only evaluation are not counted as work); achieved_executed: only the edges the launches "
+                                       'evaluated; achieved_full_reference: every edge of the reference graph in every layer',
+                         'achieved_executed': tf(flops_exec), 'frac_executed': tf(flops_exec) / PEAK_F32_MFMA_TFLOPS,
+                         'achieved_full_reference': tf(flops_full),
                          'edges_executed_over_unpruned': sum(p['edges'] for p in prof) / max(sum(p['edges_unpruned'] for p in prof), 1),
-                         'traffic': pmc_traffic(),
-                         'traffic_source': 'profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over this '
-                                           'command, bytes per conv_fused launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 FETCH correction)',
+                         'traffic': traffic,
+                         'traffic_source': f'profiles/{traffic_file}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over this command, '
+                                           'bytes per conv_fused launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 FETCH correction)' if traffic_file else None,
                          'algorithmic_bytes_per_launch': byts / max(launches, 1),
                          'launches': launches, 'avg_launch_ms': conv_ms / max(launches, 1),
-                         'flop_per_launch': flops / max(launches, 1),
+                         'flop_per_launch': flops / max(launches, 1), 'flop_per_launch_executed': flops_exec / max(launches, 1),
                          'algorithmic_hbm_GBps': byts / (conv_ms * 1e-3) / 1e9 if conv_ms > 0 else 0.0,
                          'algorithmic_hbm_frac_of_peak': (byts / (conv_ms * 1e-3) / 1e9) / PEAK_HBM_GBS if conv_ms > 0 else 0.0,
                          'conv_share_of_wall': conv_ms * 1e-3 / elapsed,
@@ -235,22 +378,38 @@ def main():
                                         'TFLOPs_executed': p['edges'] * (2 * 72 * (72 + W_LAYER[l]) + TP_FLOP[l]) / max(p['ms'], 1e-9) / 1e9,
                                         'edges_executed_frac': p['edges'] / max(p['edges_unpruned'], 1)}
                                        for l, p in enumerate(prof)]},
+            'extra': {'device_loop': device_loop},
         }
-        if world == 1 and not a.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(complexes[mine[0]], P, coeffs)
+        if world == 1 and not a.no_cpu_baseline and not disco:
+            c0 = complexes[mine[0]]
+            cx0 = Complex(ctx, c0, 2)
+
+            def gpu_scores(pos, t):
+                return cx0.score_forward(torch.from_numpy(pos).to(dev), t, t, t)
+            out['cpu_baseline'] = cpu_baseline(c0, P, coeffs, gpu_scores, n_res)
         else:
             out['cpu_baseline'] = None
-        if world == 1 and not main_f16x3 and not a.no_alt:
-            # opt-in mode ddk_config.conv_f16x3 (NOT the headline): the same workload with the radial-MLP GEMMs as an error-compensated
-            # 3 x f16 product on the f16 matrix pipe (fp32-level accuracy, every parity test passes unchanged)
-            e2, prof2, final2, _, _ = measure(conv_f16x3=1)
-            ms2 = sum(p['ms'] for p in prof2)
-            fl2 = sum(p['edges_unpruned'] * (2 * 72 * (72 + W_LAYER[l]) + TP_FLOP[l]) for l, p in enumerate(prof2))
-            dev_max = max(float((final2[i] - final[i]).abs().max()) for i in final)
-            out['alt_precision'] = {'mode': 'conv_f16x3 (error-compensated 3 x f16 MFMA, f32 accumulation; opt-in, ddk_config.conv_f16x3 = 1)',
-                                    'value': a.steps / e2, 'unit': 'complexes/s', 'ms_per_step': 1e3 * e2 / a.steps,
-                                    'conv_fp32_equivalent_TFLOPs': fl2 / (ms2 * 1e-3) / 1e12 if ms2 > 0 else 0.0,
-                                    'max_abs_pose_deviation_from_fp32_run_A': dev_max}
+        if world == 1 and cfg_id == 2 and not a.no_alt:
+            # opt-in mode ddk_config.conv_f16x3 (NOT the headline; VERDICT r01: alt_precision): resident loop with the radial-MLP GEMMs as an
+            # error-compensated 3 x f16 product on the f16 matrix pipe
+            from disco_diffdock_amd.runtime import Context
+            ctx2 = Context(device=local, conv_f16x3=1)
+            ctx2.load_state_dict(P)
+            cxs = {i: Complex(ctx2, complexes[i], SAMPLES) for i in mine}
+            gen = torch.Generator(device=dev).manual_seed(1234)
+            p0 = {i: torch.from_numpy(poses_all[i]).to(dev) for i in mine}
+            nz = {i: torch.randn((STEPS, SAMPLES, 6 + cxs[i].R), device=dev, generator=gen) for i in mine}
+            for k in range(a.warmup):
+                cxs[order[k]].sample(p0[order[k]].clone(), t_arr, sc, nc, nz[order[k]])
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for k in range(a.warmup, a.warmup + a.steps):
+                cxs[order[k]].sample(p0[order[k]].clone(), t_arr, sc, nc, nz[order[k]])
+            torch.cuda.synchronize()
+            e2 = time.perf_counter() - t2
+            out['alt_precision'] = {'mode': 'conv_f16x3 (error-compensated 3 x f16 MFMA, f32 accumulation; opt-in, ddk_config.conv_f16x3 = 1), '
+                                            'resident-loop bracket (compare with extra.device_loop)',
+                                    'value': a.steps / e2, 'unit': 'complexes/s', 'ms_per_step': 1e3 * e2 / a.steps}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -81,7 +81,9 @@ class ConfidenceModel(nn.Module):
             _conf_cache[key] = cx
         return cx, B
 
-    def forward(self, data):
+    def forward(self, data, check=True):
+        """``check=False``: no host synchronisation here; the caller runs ``self.last_complex.confidence_counts()`` later (sampling()
+        does it once per call, behind its own read-back)."""
         if not self._loaded:
             raise RuntimeError('ddk confidence model: load_state_dict() first')
         pos = data['ligand'].pos
@@ -92,5 +94,5 @@ class ConfidenceModel(nn.Module):
             raise RuntimeError('ddk confidence model: implemented for complex_t = 0 (utils/sampling.py:236)')
         cx, B = self.complex_for(data)
         self.last_complex = cx
-        out = cx.confidence_forward(pos.reshape(B, -1, 3))
+        out = cx.confidence_forward(pos.reshape(B, -1, 3), check=check)
         return out.squeeze(dim=-1)

@@ -61,6 +61,8 @@ struct ConfComplex {
   int64_t cap4 = 0, cap_la = 0, cap_total = 0, off_la = 0, off_al = 0, off_aa = 0, off_ar = 0, off_ra = 0;
   int32_t *e_src = nullptr, *e_dst = nullptr, *e_aux = nullptr;
   float *e_emb = nullptr, *e_sh = nullptr;
+  int32_t *st_a = nullptr, *st_b = nullptr;      // one copy of the static sets: aa (atom, atom) then ar (atom, residue) local endpoints
+  float *st_emb = nullptr, *st_sh = nullptr;
   int32_t* gtab = nullptr;     // [0..8] gbeg, [9..17] gend, [18] la counter, [19] overflow flag
   int32_t* deg_scratch = nullptr;
   float *xa = nullptr, *xb = nullptr, *sum3 = nullptr;
@@ -407,6 +409,44 @@ __global__ __launch_bounds__(64) void conf_head_kernel(HeadCArgs A) {
   }
 }
 
+// per-sample replicas of the static edge sets: aa (src = atom a, dst = atom b), ar (src = atom, dst = its residue) and ra (the flip with
+// the same features), node ids offset by the sample
+__global__ void conf_static_replicate_kernel(const int32_t* a1, const int32_t* b1, const float* emb1, const float* sh1, int E_aa, int n_atom, int n_rec,
+                                             int Bm, int64_t atom_base, int64_t rec_base, int64_t off_aa, int64_t off_ar, int64_t off_ra,
+                                             int32_t* e_src, int32_t* e_dst, float* e_emb, float* e_sh) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n_aa = (int64_t)Bm * E_aa;
+  if (i >= n_aa + (int64_t)Bm * n_atom) return;
+  int64_t p, p2 = -1;
+  int k, sn, dn;
+  if (i < n_aa) {
+    const int b = (int)(i / E_aa);
+    k = (int)(i - (int64_t)b * E_aa);
+    p = off_aa + i;
+    sn = (int)(atom_base + (int64_t)b * n_atom + a1[k]); dn = (int)(atom_base + (int64_t)b * n_atom + b1[k]);
+  } else {
+    const int64_t j = i - n_aa;
+    const int b = (int)(j / n_atom), a = (int)(j - (int64_t)b * n_atom);
+    k = E_aa + a;
+    p = off_ar + j; p2 = off_ra + j;
+    sn = (int)(atom_base + (int64_t)b * n_atom + a); dn = (int)(rec_base + (int64_t)b * n_rec + b1[k]);
+  }
+  e_src[p] = sn; e_dst[p] = dn;
+  const float4* es = reinterpret_cast<const float4*>(emb1 + (size_t)k * NS);
+  float4* ed = reinterpret_cast<float4*>(e_emb + (size_t)p * NS);
+#pragma unroll
+  for (int q = 0; q < NS / 4; ++q) ed[q] = es[q];
+  const float4 shv = *reinterpret_cast<const float4*>(sh1 + (size_t)k * 4);
+  *reinterpret_cast<float4*>(e_sh + (size_t)p * 4) = shv;
+  if (p2 >= 0) {
+    e_src[p2] = dn; e_dst[p2] = sn;
+    float4* ed2 = reinterpret_cast<float4*>(e_emb + (size_t)p2 * NS);
+#pragma unroll
+    for (int q = 0; q < NS / 4; ++q) ed2[q] = es[q];
+    *reinterpret_cast<float4*>(e_sh + (size_t)p2 * 4) = shv;
+  }
+}
+
 void conf_complex_free(ddk_complex* cx) {
   if (cx && cx->conf) { delete cx->conf; cx->conf = nullptr; }   // device arrays live in cx->allocs
 }
@@ -415,7 +455,7 @@ template <typename T>
 static T* cxu(ddk_complex* cx, const T* src, size_t n) {
   T* p = (T*)cx_alloc(cx, n * sizeof(T));
   if (!p) return nullptr;
-  if (n && src && hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  if (n && src && !cx_put(cx, p, src, n * sizeof(T))) return nullptr;
   return p;
 }
 
@@ -439,6 +479,12 @@ int ddk_complex_set_atoms(ddk_ctx* ctx, ddk_complex* cx, const ddk_atoms_desc* d
   cx->conf = K;
   K->n_atom = n_atom; K->E_aa = E_aa;
   const int64_t Bm = cx->max_batch;
+  {   // staged, asynchronous upload of everything below (model.h: cx_put / cx_stage_flush)
+    const size_t n_st = (size_t)E_aa + (size_t)n_atom;
+    int rc0 = cx_stage_begin(ctx, cx, (size_t)(n_lig + n_atom + n_rec) * NS * 4 + (size_t)n_atom * 12 + (size_t)cx->E_rr * NS * 4 +
+                                          n_st * (8 + NS * 4 + 16) + 16 * 256);
+    if (rc0) return rc0;
+  }
   // ---- node embeddings (OldAtomEncoder at t = 0) --------------------------------------------------
   std::vector<float> lx((size_t)n_lig * NS), ax((size_t)n_atom * NS), rx((size_t)n_rec * NS);
   for (int i = 0; i < n_lig; ++i)
@@ -489,12 +535,9 @@ int ddk_complex_set_atoms(ddk_ctx* ctx, ddk_complex* cx, const ddk_atoms_desc* d
   K->atom_pos = cxu(cx, d->atom_pos, (size_t)n_atom * 3);
   // ---- receptor-edge first layer with THIS model's rec_edge_embedding (the shared edge-feature kernel reads cx->rr_pre1) ----
   {
-    std::vector<int32_t> ei((size_t)2 * cx->E_rr);
-    if (hipMemcpy(ei.data(), cx->rr_src, (size_t)cx->E_rr * 4, hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(ei.data() + cx->E_rr, cx->rr_dst, (size_t)cx->E_rr * 4, hipMemcpyDeviceToHost) != hipSuccess)
-      return fail(ctx, DDK_ERR_HIP, "receptor edge read-back failed");
-    std::vector<float> rp((size_t)n_rec * 3), pre1((size_t)cx->E_rr * NS);
-    if (hipMemcpy(rp.data(), cx->rec_pos, rp.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(ctx, DDK_ERR_HIP, "rec_pos read-back failed");
+    const std::vector<int32_t>& ei = cx->h_rr;          // host copies kept by ddk_complex_create (no read-back: the upload may be in flight)
+    const std::vector<float>& rp = cx->h_rec_pos;
+    std::vector<float> pre1((size_t)cx->E_rr * NS);
     for (int k = 0; k < cx->E_rr; ++k) {
       const int a = ei[k], b = ei[cx->E_rr + k];
       const float vx = rp[3 * b] - rp[3 * a], vy = rp[3 * b + 1] - rp[3 * a + 1], vz = rp[3 * b + 2] - rp[3 * a + 2];
@@ -507,7 +550,7 @@ int ddk_complex_set_atoms(ddk_ctx* ctx, ddk_complex* cx, const ddk_atoms_desc* d
         pre1[(size_t)k * NS + o] = a2;
       }
     }
-    if (hipMemcpy(cx->rr_pre1, pre1.data(), pre1.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(ctx, DDK_ERR_HIP, "rr_pre1 upload failed");
+    if (!cx_put(cx, cx->rr_pre1, pre1.data(), pre1.size() * 4)) return fail(ctx, DDK_ERR_HIP, "rr_pre1 upload failed");
     // static sets need rec_pos on the host below
     // ---- edge arrays: [4-group region of the shared graph kernel | la | al | aa | ar | ra] -------------
     K->cap4 = cx->edge_cap;
@@ -519,15 +562,16 @@ int ddk_complex_set_atoms(ddk_ctx* ctx, ddk_complex* cx, const ddk_atoms_desc* d
     K->e_aux = cxu<int32_t>(cx, nullptr, K->cap4);
     K->e_emb = cxu<float>(cx, nullptr, K->cap_total * NS); K->e_sh = cxu<float>(cx, nullptr, K->cap_total * 4);
     if (!K->e_src || !K->e_dst || !K->e_aux || !K->e_emb || !K->e_sh) return fail(ctx, DDK_ERR_NOMEM, "device allocation failed (confidence edge arrays)");
-    // static sets (atom-atom; atom->residue and its flip), replicated for Bm samples
-    const int64_t atom_base = Bm * n_lig, rec_base = Bm * ((int64_t)n_lig + n_atom);
-    const int64_t n_static = Bm * ((int64_t)E_aa + 2 * n_atom);
-    std::vector<int32_t> ssrc((size_t)n_static), sdst((size_t)n_static);
-    std::vector<float> semb((size_t)n_static * NS), ssh((size_t)n_static * 4);
-    std::vector<float> emb1((size_t)(E_aa + n_atom) * NS), sh1((size_t)(E_aa + n_atom) * 4);
+    // static sets (atom-atom; atom->residue and its flip)
+    // ONE copy of the static sets goes up (E_aa + n_atom edges: local endpoints, embedding, SH); a kernel writes the Bm per-sample
+    // replicas with their node-id offsets (the host used to assemble and upload all Bm copies: ~115 MB for 2400 atoms x 40 samples)
+    const int n1 = E_aa + n_atom;
+    std::vector<int32_t> a1((size_t)n1), b1((size_t)n1);
+    std::vector<float> emb1((size_t)n1 * NS), sh1((size_t)n1 * 4);
     for (int k = 0; k < E_aa; ++k) {
       const int a = d->atom_edge_index[k], b = d->atom_edge_index[E_aa + k];
       if (a < 0 || a >= n_atom || b < 0 || b >= n_atom) return fail(ctx, DDK_ERR_INVALID, "atom edge index out of range");
+      a1[k] = a; b1[k] = b;
       host_edge(M->h_atom, d->atom_pos[3 * b] - d->atom_pos[3 * a], d->atom_pos[3 * b + 1] - d->atom_pos[3 * a + 1],
                 d->atom_pos[3 * b + 2] - d->atom_pos[3 * a + 2], emb1.data() + (size_t)k * NS, sh1.data() + (size_t)k * 4);
     }
@@ -535,29 +579,16 @@ int ddk_complex_set_atoms(ddk_ctx* ctx, ddk_complex* cx, const ddk_atoms_desc* d
       if (d->atom_rec_index[i] != i) return fail(ctx, DDK_ERR_INVALID, "atom_rec_index row 0 must be arange(n_atom) (process_mols.py:472)");
       const int r = d->atom_rec_index[n_atom + i];
       if (r < 0 || r >= n_rec) return fail(ctx, DDK_ERR_INVALID, "atom residue index out of range");
+      a1[E_aa + i] = i; b1[E_aa + i] = r;
       host_edge(M->h_ar, rp[3 * r] - d->atom_pos[3 * i], rp[3 * r + 1] - d->atom_pos[3 * i + 1], rp[3 * r + 2] - d->atom_pos[3 * i + 2],
                 emb1.data() + (size_t)(E_aa + i) * NS, sh1.data() + (size_t)(E_aa + i) * 4);
     }
-    for (int64_t b = 0; b < Bm; ++b) {
-      for (int k = 0; k < E_aa; ++k) {          // aa: src = row 0, dst = row 1
-        const int64_t p = b * E_aa + k;
-        ssrc[p] = (int32_t)(atom_base + b * n_atom + d->atom_edge_index[k]);
-        sdst[p] = (int32_t)(atom_base + b * n_atom + d->atom_edge_index[E_aa + k]);
-        memcpy(&semb[p * NS], &emb1[(size_t)k * NS], NS * 4); memcpy(&ssh[p * 4], &sh1[(size_t)k * 4], 16);
-      }
-      for (int i = 0; i < n_atom; ++i) {        // ar: src atom, dst residue ; ra: the flip with the same features
-        const int64_t p1 = Bm * E_aa + b * n_atom + i, p2 = Bm * ((int64_t)E_aa + n_atom) + b * n_atom + i;
-        const int32_t an = (int32_t)(atom_base + b * n_atom + i), rn = (int32_t)(rec_base + b * n_rec + d->atom_rec_index[n_atom + i]);
-        ssrc[p1] = an; sdst[p1] = rn; ssrc[p2] = rn; sdst[p2] = an;
-        memcpy(&semb[p1 * NS], &emb1[(size_t)(E_aa + i) * NS], NS * 4); memcpy(&ssh[p1 * 4], &sh1[(size_t)(E_aa + i) * 4], 16);
-        memcpy(&semb[p2 * NS], &emb1[(size_t)(E_aa + i) * NS], NS * 4); memcpy(&ssh[p2 * 4], &sh1[(size_t)(E_aa + i) * 4], 16);
-      }
-    }
-    if (hipMemcpy(K->e_src + K->off_aa, ssrc.data(), ssrc.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(K->e_dst + K->off_aa, sdst.data(), sdst.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(K->e_emb + K->off_aa * NS, semb.data(), semb.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(K->e_sh + K->off_aa * 4, ssh.data(), ssh.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
-      return fail(ctx, DDK_ERR_HIP, "static edge upload failed");
+    int32_t* d_a1 = cxu(cx, a1.data(), a1.size());
+    int32_t* d_b1 = cxu(cx, b1.data(), b1.size());
+    float* d_emb1 = cxu(cx, emb1.data(), emb1.size());
+    float* d_sh1 = cxu(cx, sh1.data(), sh1.size());
+    if (!d_a1 || !d_b1 || !d_emb1 || !d_sh1) return fail(ctx, DDK_ERR_NOMEM, "device allocation failed (confidence static sets)");
+    K->st_a = d_a1; K->st_b = d_b1; K->st_emb = d_emb1; K->st_sh = d_sh1;
   }
   K->n_nodes = Bm * ((int64_t)n_lig + n_atom + n_rec);
   K->gtab = cxu<int32_t>(cx, nullptr, 32);
@@ -567,6 +598,17 @@ int ddk_complex_set_atoms(ddk_ctx* ctx, ddk_complex* cx, const ddk_atoms_desc* d
   K->deg3 = cxu<int32_t>(cx, nullptr, K->n_nodes * 3);
   if (!K->lig_x0 || !K->atom_x0 || !K->rec_x0 || !K->atom_pos || !K->gtab || !K->deg_scratch || !K->xa || !K->xb || !K->sum3 || !K->deg3)
     return fail(ctx, DDK_ERR_NOMEM, "device allocation failed in ddk_complex_set_atoms");
+  int rcf = cx_stage_flush(ctx, cx);
+  if (rcf) return rcf;
+  {   // replicate the static sets for the Bm samples on the device, behind the upload on the upload stream
+    const int64_t atom_base = Bm * n_lig, rec_base = Bm * ((int64_t)n_lig + n_atom);
+    const int64_t tot = Bm * ((int64_t)E_aa + n_atom);
+    hipLaunchKernelGGL(conf_static_replicate_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->up_stream, K->st_a, K->st_b, K->st_emb,
+                       K->st_sh, E_aa, n_atom, n_rec, (int)Bm, atom_base, rec_base, K->off_aa, K->off_ar, K->off_ra, K->e_src, K->e_dst, K->e_emb, K->e_sh);
+    if (hipGetLastError() != hipSuccess) return fail(ctx, DDK_ERR_HIP, "static set replication launch failed");
+    hipError_t e = hipEventRecord(cx->ready, ctx->up_stream);
+    if (e != hipSuccess) return hip_fail(ctx, e, "event record");
+  }
   return DDK_OK;
 }
 
@@ -580,6 +622,7 @@ int ddk_confidence_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float
   const ddk_config& c = ctx->cfg;
   ConfComplex* K = cx->conf;
   hipStream_t s = (hipStream_t)stream;
+  { hipError_t we = cx_wait_ready(cx, s); if (we != hipSuccess) return hip_fail(ctx, we, "wait for the complex upload"); }
   const int n_lig = cx->n_lig, n_rec = cx->n_rec, n_atom = K->n_atom;
   const int64_t Bm = cx->max_batch;
   const int64_t atom_base = Bm * n_lig, rec_base = Bm * ((int64_t)n_lig + n_atom);

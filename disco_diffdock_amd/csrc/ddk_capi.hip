@@ -447,6 +447,8 @@ int ddk_create(const ddk_config* cfg, ddk_ctx** out) {
   e = hipGetDeviceProperties(&prop, cfg->device);
   if (e != hipSuccess) return hip_fail(ctx, e, "hipGetDeviceProperties");
   ctx->n_cu = prop.multiProcessorCount;
+  e = hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking);
+  if (e != hipSuccess) return hip_fail(ctx, e, "hipStreamCreate (upload stream)");
   e = conv_prepare_device();
   if (e != hipSuccess) return hip_fail(ctx, e, "hipFuncSetAttribute(dynamic LDS)");
   ctx->ws.tile_info = (int32_t*)dev_alloc(ctx, 64 * sizeof(int32_t));
@@ -462,6 +464,9 @@ void ddk_destroy(ddk_ctx* ctx) {
     conf_model_destroy(ctx);
     for (auto& r : ctx->prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     if (ctx->prof_edges) hipHostFree(ctx->prof_edges);
+    for (auto& c : ctx->chunk_pool) { if (c.free_after) hipEventDestroy(c.free_after); hipFree(c.p); }
+    for (auto& b : ctx->stage_pool) { if (b.done) hipEventDestroy(b.done); hipHostFree(b.p); }
+    if (ctx->up_stream) hipStreamDestroy(ctx->up_stream);
     for (void* p : ctx->dev_allocs) hipFree(p);
     if (ctx->ws.xpad) hipFree(ctx->ws.xpad);
     if (ctx->ws.sum) hipFree(ctx->ws.sum);

@@ -146,6 +146,14 @@ struct ddk_ctx {
   // packed small weights for the non-conv kernels live in model.hip (opaque here)
   void* model = nullptr;
   void* conf_model = nullptr;   // conf.hip
+  // asynchronous complex upload (model.hip): a non-blocking upload stream, pinned staging buffers and a pool of device chunks, so
+  // that ddk_complex_create / ddk_complex_destroy never synchronise with a sampling loop in flight on the compute stream
+  hipStream_t up_stream = nullptr;
+  struct StageBuf { char* p = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool in_flight = false; };
+  std::vector<StageBuf> stage_pool;
+  struct PoolChunk { void* p = nullptr; size_t cap = 0; hipEvent_t free_after = nullptr; };   // free_after: last use by the previous owner
+  std::vector<PoolChunk> chunk_pool;
+  size_t chunk_pool_bytes = 0;
   // profiling (ddk_profile_enable / ddk_profile_read)
   bool prof = false;
   bool prune = true;                // backward receptive-field pruning of the rec-rec messages (ddk_set_receptive_field_pruning)

@@ -73,6 +73,29 @@ struct ModelDev {
   const float *tf_w0, *tf_w3;                    // [NS][2NS], [NS]
 };
 
+// AR latent model predictors (k_ar.hip); BatchNorm1d (eval) folded into the Linear in front of it
+constexpr int AR_H = 128;        // latent_hidden_dim the kernel is compiled for (smaller values run zero padded)
+constexpr int AR_NS_MAX = 24;    // ns of the AR yml (scalar channels taken from each end of the node row)
+struct ArMlpDev { const float *w0, *b0, *w4, *b4, *w8; float b8; };
+struct ArArgs {
+  const float* x;          // [N, XW] node features after the conv stack (ligand nodes first), receptor rows of the last layer included
+  ArMlpDev s, r;           // latent_s_predictor (ligand atoms), latent_r_predictor (residues)
+  int ar_ns, H;
+  int n_lig_total, n_rec_total, n_lig, n_rec;
+  float* logits;           // [B, n_lig + n_rec]
+};
+struct ArDecodeArgs {
+  const float* logits;     // [B, n_lig + n_rec]
+  const float* uniforms;   // [B] in [0, 1) (unused for temperature >= 100)
+  float temperature;
+  int n_lig, n_rec, idx, latent_dim;
+  float* lig_latent;       // [B * n_lig, latent_dim]
+  float* rec_latent;       // [B * n_rec, latent_dim]
+  int32_t* choices;        // [B, latent_dim] or null
+};
+hipError_t launch_ar_logits(const ArArgs& A, hipStream_t s);
+hipError_t launch_ar_decode(const ArDecodeArgs& A, int B, hipStream_t s);
+
 struct ModelHost {   // host copies needed per forward / per complex
   std::vector<float> lig_tables;        // concatenated embedding tables [sum(dims)][NS]
   std::vector<int> lig_table_off;       // row offset of each categorical feature
@@ -89,6 +112,9 @@ struct ModelHost {   // host copies needed per forward / per complex
 struct Model {
   ModelDev dev;
   ModelHost host;
+  bool has_ar = false;     // latent_{s,r}_predictor.* tensors were loaded into this context (the AR checkpoint's score-model copy)
+  ArMlpDev ar_s, ar_r;
+  int ar_ns = 0, ar_H = 0;
 };
 
 
@@ -229,25 +255,43 @@ struct ddk_complex {
   bool sum_clean = false;             // the accumulators are all zero (the last forward completed; node_finalize clears behind itself)
   bool keep_rec = false, last_full = false;   // last conv layer: all groups (true) or ligand-side groups only
   ddk::ConfComplex* conf = nullptr;   // all-atom level (ddk_complex_set_atoms), owned
-  std::vector<void*> allocs;          // arena chunks (hipFree'd by ddk_complex_destroy)
+  ddk_ctx* owner = nullptr;
+  struct Chunk { void* p; size_t cap; };
+  std::vector<Chunk> allocs;          // arena chunks (returned to the context's pool by ddk_complex_destroy)
   char* chunk = nullptr;              // current chunk: bump allocation, 256-B aligned
   size_t chunk_cap = 0, chunk_off = 0, reserve_hint = 0;
   bool oom = false;                   // a chunk allocation failed (checked once at the end of the creating call)
+  // staged upload: host arrays are copied into a pinned buffer and leave for the device on the context's upload stream
+  int stage_idx = -1;                 // index into owner->stage_pool while a staging session is open
+  size_t stage_off = 0;
+  struct CopyRec { void* dst; size_t off, bytes; };
+  std::vector<CopyRec> pending;
+  hipEvent_t ready = nullptr;         // recorded on the upload stream behind the last staged copy
+  bool ready_pending = false;         // compute streams still have to wait for `ready`
+  hipStream_t last_stream = nullptr;  // stream of the last launch that used this complex (ordering of the chunks' reuse)
+  bool used = false;
+  std::vector<int32_t> h_rr;          // host copies the confidence level needs again (ddk_complex_set_atoms)
+  std::vector<float> h_rec_pos;
 };
 
 namespace ddk {
 // Device memory of a complex comes from a few large chunks instead of one hipMalloc per array (34 + of them per complex, each a
-// driver call; and every hipFree synchronises the device, which stalls a caller that drops complexes while the GPU is busy).
+// driver call), and the chunks come from / return to a pool of the context: hipFree synchronises the device, which would stall
+// a caller that drops complexes while the GPU is busy.
+void* cx_new_chunk(ddk_complex* cx, size_t cap);                       // model.hip: pool or hipMalloc
+int cx_stage_begin(ddk_ctx* ctx, ddk_complex* cx, size_t bytes);        // open a staging session with room for `bytes`
+bool cx_put(ddk_complex* cx, void* dst, const void* src, size_t bytes); // host -> staging (or a synchronous copy without a session)
+int cx_stage_flush(ddk_ctx* ctx, ddk_complex* cx);                      // enqueue the staged copies, record cx->ready
+hipError_t cx_wait_ready(ddk_complex* cx, hipStream_t s);               // first thing every launch entry point does with a complex
 inline void cx_reserve(ddk_complex* cx, size_t bytes) { cx->reserve_hint = bytes; }
 inline void* cx_alloc(ddk_complex* cx, size_t bytes) {
   const size_t need = ((bytes ? bytes : 4) + 255) & ~(size_t)255;
   if (!cx->chunk || cx->chunk_off + need > cx->chunk_cap) {
     size_t cap = need > cx->reserve_hint ? need : cx->reserve_hint;
     if (cap < ((size_t)1 << 20)) cap = (size_t)1 << 20;
-    void* p = nullptr;
-    if (hipMalloc(&p, cap) != hipSuccess) { cx->oom = true; return nullptr; }
-    cx->allocs.push_back(p);
-    cx->chunk = (char*)p; cx->chunk_cap = cap; cx->chunk_off = 0; cx->reserve_hint = 0;
+    void* p = cx_new_chunk(cx, cap);
+    if (!p) { cx->oom = true; return nullptr; }
+    cx->chunk = (char*)p; cx->chunk_off = 0; cx->reserve_hint = 0;
   }
   void* r = cx->chunk + cx->chunk_off;
   cx->chunk_off += need;

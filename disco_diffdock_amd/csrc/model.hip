@@ -179,6 +179,47 @@ int model_finalize(ddk_ctx* ctx) {
 #undef GET
   for (int l = 0; l < c.num_conv_layers; ++l)
     if (!ctx->conv[l].has_weights) return fail(ctx, DDK_ERR_INVALID, "score model checkpoint lacks conv_layers." + std::to_string(l));
+  // ---- AR latent model predictors (models/pretrained_score_encoder.py:24-45), present when this context holds the AR checkpoint's
+  //      own copy of the score model: Linear - BatchNorm1d - ReLU - Linear - BatchNorm1d - ReLU - Linear, BatchNorm (eval) folded ----
+  if (ctx->weights.find("latent_s_predictor.0.weight") != ctx->weights.end()) {
+    auto w0it = ctx->weights.find("latent_s_predictor.0.weight");
+    if (w0it->second.shape.size() != 2) return fail(ctx, DDK_ERR_INVALID, "latent_s_predictor.0.weight must be 2-d");
+    const int Hd = (int)w0it->second.shape[0], nin = (int)w0it->second.shape[1];
+    if (Hd < 1 || Hd > AR_H || nin < 2 || nin % 2 || nin / 2 > AR_NS_MAX || nin > XW)
+      return fail(ctx, DDK_ERR_INVALID, "AR predictor: hidden width must be <= 128 and the input 2*ns with ns <= 24 (num_conv_layers >= 3 layout)");
+    auto pack = [&](const char* pre, ArMlpDev& D) -> bool {
+      const std::string p(pre);
+      const HostTensor* w0 = getw(ctx, p + ".0.weight", {Hd, nin});
+      const HostTensor* b0 = getw(ctx, p + ".0.bias", {Hd});
+      const HostTensor* w4 = getw(ctx, p + ".4.weight", {Hd, Hd});
+      const HostTensor* b4 = getw(ctx, p + ".4.bias", {Hd});
+      const HostTensor* w8 = getw(ctx, p + ".8.weight", {1, Hd});
+      const HostTensor* b8 = getw(ctx, p + ".8.bias", {1});
+      if (!w0 || !b0 || !w4 || !b4 || !w8 || !b8)
+        return false;     // (latent_dim of the predictors is 1: model_utils.py:133-139 builds PretrainedScoreEncoder(latent_dim=1))
+      std::vector<float> W0 = w0->data, B0 = b0->data, W4 = w4->data, B4 = b4->data;
+      auto fold = [&](const char* idx, std::vector<float>& W, std::vector<float>& Bv, int in) -> bool {
+        if (ctx->weights.find(p + "." + idx + ".running_var") == ctx->weights.end()) return true;    // latent_no_batchnorm
+        const HostTensor* g = getw(ctx, p + "." + idx + ".weight", {Hd});
+        const HostTensor* be = getw(ctx, p + "." + idx + ".bias", {Hd});
+        const HostTensor* rm = getw(ctx, p + "." + idx + ".running_mean", {Hd});
+        const HostTensor* rv = getw(ctx, p + "." + idx + ".running_var", {Hd});
+        if (!g || !be || !rm || !rv) return false;
+        for (int j = 0; j < Hd; ++j) {
+          const float sc = g->data[j] / sqrtf(rv->data[j] + 1e-5f);      // nn.BatchNorm1d default eps
+          for (int k = 0; k < in; ++k) W[(size_t)j * in + k] *= sc;
+          Bv[j] = (Bv[j] - rm->data[j]) * sc + be->data[j];
+        }
+        return true;
+      };
+      if (!fold("1", W0, B0, nin) || !fold("5", W4, B4, Hd)) return false;
+      D.w0 = dev_upload(ctx, W0); D.b0 = dev_upload(ctx, B0); D.w4 = dev_upload(ctx, W4); D.b4 = dev_upload(ctx, B4);
+      D.w8 = dev_upload(ctx, w8->data); D.b8 = b8->data[0];
+      return D.w0 && D.b0 && D.w4 && D.b4 && D.w8;
+    };
+    if (!pack("latent_s_predictor", M->ar_s) || !pack("latent_r_predictor", M->ar_r)) return DDK_ERR_INVALID;
+    M->has_ar = true; M->ar_ns = nin / 2; M->ar_H = Hd;
+  }
   H.ready = true;
   return DDK_OK;
 }
@@ -260,11 +301,107 @@ static void host_parallel_for(int n, F&& body) {
   for (auto& x : th) x.join();
 }
 
+// ---- asynchronous upload machinery (see ddk_ctx / ddk_complex) -----------------------------------------------------------------
+constexpr size_t CHUNK_POOL_MAX_BYTES = (size_t)24 << 30;   // device memory parked in the pool (288 GB of HBM per GPU)
+
+void* cx_new_chunk(ddk_complex* cx, size_t cap) {
+  ddk_ctx* ctx = cx->owner;
+  int best = -1;
+  for (int i = 0; i < (int)ctx->chunk_pool.size(); ++i) {
+    const auto& c = ctx->chunk_pool[i];
+    if (c.cap >= cap && c.cap <= 4 * cap + ((size_t)64 << 20) && (best < 0 || c.cap < ctx->chunk_pool[best].cap)) best = i;
+  }
+  void* p = nullptr;
+  if (best >= 0) {
+    ddk_ctx::PoolChunk c = ctx->chunk_pool[best];
+    ctx->chunk_pool.erase(ctx->chunk_pool.begin() + best);
+    ctx->chunk_pool_bytes -= c.cap;
+    if (c.free_after) {        // the previous owner's last launch must have finished before anything of the new owner lands here
+      hipStreamWaitEvent(ctx->up_stream, c.free_after, 0);
+      hipEventDestroy(c.free_after);
+    }
+    p = c.p; cap = c.cap;
+  } else if (hipMalloc(&p, cap) != hipSuccess) {
+    return nullptr;
+  }
+  cx->allocs.push_back({p, cap});
+  cx->chunk_cap = cap;
+  return p;
+}
+
+int cx_stage_begin(ddk_ctx* ctx, ddk_complex* cx, size_t bytes) {
+  bytes = (bytes + 4095) & ~(size_t)4095;
+  int idx = -1;
+  for (int i = 0; i < (int)ctx->stage_pool.size(); ++i) {
+    auto& b = ctx->stage_pool[i];
+    if (b.in_flight && hipEventQuery(b.done) == hipSuccess) b.in_flight = false;
+    if (!b.in_flight && b.cap >= bytes && (idx < 0 || b.cap < ctx->stage_pool[idx].cap)) idx = i;
+  }
+  if (idx < 0) {
+    ddk_ctx::StageBuf b;
+    b.cap = bytes < ((size_t)4 << 20) ? ((size_t)4 << 20) : bytes;
+    if (hipHostMalloc((void**)&b.p, b.cap) != hipSuccess) return fail(ctx, DDK_ERR_NOMEM, "hipHostMalloc failed (staging buffer)");
+    if (hipEventCreateWithFlags(&b.done, hipEventDisableTiming) != hipSuccess) return fail(ctx, DDK_ERR_HIP, "event create failed");
+    ctx->stage_pool.push_back(b);
+    idx = (int)ctx->stage_pool.size() - 1;
+  }
+  ctx->stage_pool[idx].in_flight = true;       // reserved for this session (released by the event of cx_stage_flush)
+  cx->stage_idx = idx; cx->stage_off = 0; cx->pending.clear();
+  return DDK_OK;
+}
+
+bool cx_put(ddk_complex* cx, void* dst, const void* src, size_t bytes) {
+  if (!dst || !bytes) return dst != nullptr;
+  ddk_ctx* ctx = cx->owner;
+  if (cx->stage_idx >= 0) {
+    auto& b = ctx->stage_pool[cx->stage_idx];
+    const size_t off = (cx->stage_off + 255) & ~(size_t)255;
+    if (off + bytes <= b.cap) {
+      memcpy(b.p + off, src, bytes);
+      cx->stage_off = off + bytes;
+      if (!cx->pending.empty()) {      // bump allocation on both sides: neighbours stay neighbours -> one DMA for a run of arrays
+        auto& l = cx->pending.back();
+        const size_t gap = off - l.off;
+        if ((char*)l.dst + gap == (char*)dst && gap >= l.bytes && gap - l.bytes < 256) { l.bytes = gap + bytes; return true; }
+      }
+      cx->pending.push_back({dst, off, bytes});
+      return true;
+    }
+  }
+  // no session / staging buffer full: ordered behind the staged copies on the upload stream, synchronous for the caller's memory
+  if (hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->up_stream) != hipSuccess) return false;
+  return hipStreamSynchronize(ctx->up_stream) == hipSuccess;
+}
+
+int cx_stage_flush(ddk_ctx* ctx, ddk_complex* cx) {
+  hipError_t e = hipSuccess;
+  if (cx->stage_idx >= 0) {
+    auto& b = ctx->stage_pool[cx->stage_idx];
+    for (const auto& r : cx->pending)
+      if (e == hipSuccess) e = hipMemcpyAsync(r.dst, b.p + r.off, r.bytes, hipMemcpyHostToDevice, ctx->up_stream);
+    if (e == hipSuccess) e = hipEventRecord(b.done, ctx->up_stream);
+    cx->pending.clear();
+    cx->stage_idx = -1;
+  }
+  if (e == hipSuccess && !cx->ready) e = hipEventCreateWithFlags(&cx->ready, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventRecord(cx->ready, ctx->up_stream);
+  if (e != hipSuccess) return hip_fail(ctx, e, "complex upload");
+  cx->ready_pending = true;
+  return DDK_OK;
+}
+
+hipError_t cx_wait_ready(ddk_complex* cx, hipStream_t s) {
+  cx->last_stream = s; cx->used = true;
+  if (!cx->ready_pending) return hipSuccess;
+  if (hipEventQuery(cx->ready) == hipSuccess) { cx->ready_pending = false; return hipSuccess; }
+  return hipStreamWaitEvent(s, cx->ready, 0);
+}
+
 template <typename T>
 static T* cx_upload(ddk_complex* cx, const T* src, size_t n) {
   T* p = (T*)cx_alloc(cx, n * sizeof(T));
   if (!p) return nullptr;
-  if (n && src && hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  if (n && src && !cx_put(cx, p, src, n * sizeof(T))) return nullptr;
   return p;
 }
 
@@ -413,6 +550,7 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
   if (max_batch < 1) return fail(ctx, DDK_ERR_INVALID, "max_batch < 1");
   hipSetDevice(c.device);
   ddk_complex* cx = new ddk_complex();
+  cx->owner = ctx;
   *out = cx;
   cx->n_lig = d->n_lig; cx->n_rec = d->n_rec; cx->M = d->n_bond_edges; cx->R = d->n_rot; cx->E_rr = d->n_rec_edges;
   cx->max_batch = max_batch;
@@ -424,6 +562,11 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
     need += cap0 * (12 + NS * 4 + 16) + N0 * 4 + Bm0 * 2 * CNT_STRIDE * 4 + INFO_INTS * 4 + (size_t)n_rec * 4 + 3 * N0 * XW * 4 + (size_t)n_rec * XW * 4 + Bm0 * n_lig * 12 + 2 * Bm0 * (6 + R0) * 4;
     if (c.latent_dim > 0) need += N0 * c.latent_dim * 4;
     cx_reserve(cx, need + 64 * 256);
+    // everything uploaded below (topology, static embeddings, receptor-edge geometry) goes through one pinned staging buffer
+    const size_t staged = (size_t)M * 24 + R0 * 8 + R0 * n_lig + (size_t)n_rec * 12 + (size_t)(n_lig + n_rec) * NS * 4 + E0 * (8 + NS * 4 + 16) +
+                          (size_t)n_rec * 8 + 24 * 256;
+    int rc0 = cx_stage_begin(ctx, cx, staged);
+    if (rc0) return rc0;
   }
   // ---- topology ------------------------------------------------------------------------------
   std::vector<int32_t> ru, rv;
@@ -513,6 +656,8 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
       pre1[(size_t)k * NS + o] = a2;
     }
   });
+  cx->h_rr.assign(d->rec_edge_index, d->rec_edge_index + 2 * (size_t)E);
+  cx->h_rec_pos.assign(d->rec_pos, d->rec_pos + 3 * (size_t)n_rec);
   cx->rr_src = cx_upload(cx, d->rec_edge_index, (size_t)E);
   cx->rr_dst = cx_upload(cx, d->rec_edge_index + E, (size_t)E);
   cx->rr_outdeg = cx_upload(cx, outdeg.data(), outdeg.size());
@@ -544,18 +689,36 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
   cx->scores2 = cx_upload<float>(cx, nullptr, Bm * (6 + (d->n_rot > 0 ? d->n_rot : 1)));
   if (c.latent_dim > 0) {
     cx->zero_lat = cx_upload<float>(cx, nullptr, N * c.latent_dim);
-    if (cx->zero_lat) hipMemset(cx->zero_lat, 0, (size_t)N * c.latent_dim * sizeof(float));
+    if (cx->zero_lat) hipMemsetAsync(cx->zero_lat, 0, (size_t)N * c.latent_dim * sizeof(float), ctx->up_stream);
   }
   if (cx->oom || !cx->bond_src || !cx->rr_sh || !cx->scores) return fail(ctx, DDK_ERR_NOMEM, "device allocation failed in ddk_complex_create");
-  hipMemset(cx->info, 0, INFO_INTS * sizeof(int32_t));
-  return DDK_OK;
+  hipMemsetAsync(cx->info, 0, INFO_INTS * sizeof(int32_t), ctx->up_stream);
+  return cx_stage_flush(ctx, cx);   // the copies are in flight on the upload stream; every launch entry point waits for cx->ready
 }
 
 void ddk_complex_destroy(ddk_ctx* ctx, ddk_complex* cx) {
   if (!cx) return;
-  if (ctx) hipSetDevice(ctx->cfg.device);
-  for (void* p : cx->allocs)
-    if (p) hipFree(p);
+  if (!ctx) ctx = cx->owner;
+  hipSetDevice(ctx->cfg.device);
+  if (cx->stage_idx >= 0) { ctx->stage_pool[cx->stage_idx].in_flight = false; cx->stage_idx = -1; }   // a create that failed half way
+  // the chunks go back to the context's pool (hipFree would synchronise the device); whoever takes one waits for this complex' last launch
+  for (auto& a : cx->allocs) {
+    if (!a.p) continue;
+    ddk_ctx::PoolChunk c;
+    c.p = a.p; c.cap = a.cap;
+    bool ok = hipEventCreateWithFlags(&c.free_after, hipEventDisableTiming) == hipSuccess;
+    // (a complex that was never launched: its copies may still be in flight on the upload stream; otherwise the launch stream, which
+    // waited for them in cx_wait_ready)
+    if (ok) ok = hipEventRecord(c.free_after, cx->used ? cx->last_stream : ctx->up_stream) == hipSuccess;
+    if (!ok || ctx->chunk_pool_bytes + c.cap > CHUNK_POOL_MAX_BYTES || ctx->chunk_pool.size() >= 64) {
+      if (c.free_after) hipEventDestroy(c.free_after);
+      hipFree(a.p);
+      continue;
+    }
+    ctx->chunk_pool.push_back(c);
+    ctx->chunk_pool_bytes += c.cap;
+  }
+  if (cx->ready) hipEventDestroy(cx->ready);
   conf_complex_free(cx);
   delete cx;
 }
@@ -564,6 +727,7 @@ int ddk_score_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* lig
                       float* tr_out, float* rot_out, float* tor_out, void* stream) {
   int rc = check_model(ctx, cx, B);
   if (rc) return rc;
+  { hipError_t we = cx_wait_ready(cx, (hipStream_t)stream); if (we != hipSuccess) return hip_fail(ctx, we, "wait for the complex upload"); }
   StepParams sp;
   if ((rc = make_step_params(ctx, t_tr, t_rot, t_tor, sp))) return rc;
   return score_forward_impl(ctx, cx, B, lig_pos, sp, tr_out, rot_out, tor_out, (hipStream_t)stream);
@@ -573,6 +737,7 @@ int ddk_build_graph(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* lig_p
                     int32_t* edge_dst_out, int64_t cap, int32_t* group_offsets_out, void* stream) {
   int rc = check_model(ctx, cx, B);
   if (rc) return rc;
+  { hipError_t we = cx_wait_ready(cx, (hipStream_t)stream); if (we != hipSuccess) return hip_fail(ctx, we, "wait for the complex upload"); }
   if (!lig_pos || !edge_src_out || !edge_dst_out || !group_offsets_out) return fail(ctx, DDK_ERR_INVALID, "ddk_build_graph: null argument");
   const int64_t cap_b = (int64_t)B * ((int64_t)cx->M + (int64_t)cx->n_lig * (LIG_CAP - 1) + 2LL * cx->n_lig * cx->n_rec + cx->E_rr);
   const int64_t need = cap_b < cx->edge_cap ? cap_b : cx->edge_cap;
@@ -593,6 +758,7 @@ int ddk_se3_update(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* pos, c
   if (!ctx) return DDK_ERR_INVALID;
   if (ctx->host_only) return fail(ctx, DDK_ERR_STATE, "host-only context (device < 0) cannot launch kernels");
   if (!cx || B < 1) return fail(ctx, DDK_ERR_INVALID, "bad complex / batch");
+  { hipError_t we = cx_wait_ready(cx, (hipStream_t)stream); if (we != hipSuccess) return hip_fail(ctx, we, "wait for the complex upload"); }
   Se3Args A;
   A.pos = pos; A.tr = tr; A.rot = rot; A.tor = tor; A.noise = nullptr;
   for (int k = 0; k < 3; ++k) { A.sc[k] = 1.0f; A.nc[k] = 0.0f; }
@@ -608,6 +774,7 @@ int ddk_randomize_position(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float
   if (!ctx) return DDK_ERR_INVALID;
   if (ctx->host_only) return fail(ctx, DDK_ERR_STATE, "host-only context (device < 0) cannot launch kernels");
   if (!cx || B < 1 || !pos0 || !rot || !pos_out) return fail(ctx, DDK_ERR_INVALID, "ddk_randomize_position: bad complex / batch / null argument");
+  { hipError_t we = cx_wait_ready(cx, (hipStream_t)stream); if (we != hipSuccess) return hip_fail(ctx, we, "wait for the complex upload"); }
   RandPosArgs A;
   A.pos0 = pos0; A.tor = tor; A.rot = rot; A.tr = tr;
   A.rot_u = cx->rot_u; A.rot_v = cx->rot_v; A.mask_rotate = cx->mask_rotate; A.B = B; A.n_lig = cx->n_lig; A.R = cx->R;
@@ -622,6 +789,7 @@ int ddk_pose_metrics(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* pos,
   if (!ctx) return DDK_ERR_INVALID;
   if (ctx->host_only) return fail(ctx, DDK_ERR_STATE, "host-only context (device < 0) cannot launch kernels");
   if (!cx || B < 1 || !pos || !ref_pos || !out) return fail(ctx, DDK_ERR_INVALID, "ddk_pose_metrics: bad complex / batch / null argument");
+  { hipError_t we = cx_wait_ready(cx, (hipStream_t)stream); if (we != hipSuccess) return hip_fail(ctx, we, "wait for the complex upload"); }
   hipError_t e = launch_pose_metrics(pos, ref_pos, atom_mask, cx->rec_pos, B, cx->n_lig, cx->n_rec, out, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(ctx, e, "pose_metrics launch");
   return DDK_OK;
@@ -631,6 +799,7 @@ int ddk_sample(ddk_ctx* ctx, ddk_complex* cx, int32_t B, int32_t steps, const fl
                const float* noise_coeff, const float* noise, float* pos, void* stream) {
   int rc = check_model(ctx, cx, B);
   if (rc) return rc;
+  { hipError_t we = cx_wait_ready(cx, (hipStream_t)stream); if (we != hipSuccess) return hip_fail(ctx, we, "wait for the complex upload"); }
   if (steps < 1 || !t || !score_coeff || !noise_coeff || !pos) return fail(ctx, DDK_ERR_INVALID, "ddk_sample: null argument");
   hipStream_t s = (hipStream_t)stream;
   const int R = cx->R;
@@ -712,6 +881,37 @@ int ddk_set_keep_receptor_features(ddk_ctx* ctx, ddk_complex* cx, int32_t on) {
   if (!ctx || !cx) return DDK_ERR_INVALID;
   cx->keep_rec = on != 0;
   return DDK_OK;
+}
+
+int ddk_ar_logits(ddk_ctx* ctx, ddk_complex* cx, int32_t B, float* logits_out, void* stream) {
+  int rc = check_model(ctx, cx, B);
+  if (rc) return rc;
+  Model* M = (Model*)ctx->model;
+  if (!M->has_ar) return fail(ctx, DDK_ERR_STATE, "no AR predictor weights in this context (latent_s_predictor.* / latent_r_predictor.*)");
+  if (!logits_out) return fail(ctx, DDK_ERR_INVALID, "ddk_ar_logits: null argument");
+  if (!cx->x_last || cx->last_B != B || !cx->last_full)
+    return fail(ctx, DDK_ERR_STATE, "ddk_ar_logits needs a forward of this batch size with ddk_set_keep_receptor_features(on) first");
+  { hipError_t we = cx_wait_ready(cx, (hipStream_t)stream); if (we != hipSuccess) return hip_fail(ctx, we, "wait for the complex upload"); }
+  ArArgs A;
+  A.x = cx->x_last; A.s = M->ar_s; A.r = M->ar_r; A.ar_ns = M->ar_ns; A.H = M->ar_H;
+  A.n_lig_total = B * cx->n_lig; A.n_rec_total = B * cx->n_rec; A.n_lig = cx->n_lig; A.n_rec = cx->n_rec; A.logits = logits_out;
+  hipError_t e = launch_ar_logits(A, (hipStream_t)stream);
+  return e == hipSuccess ? DDK_OK : hip_fail(ctx, e, "ar_logits launch");
+}
+
+int ddk_ar_decode(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* logits, float temperature, const float* uniforms,
+                  int32_t decoding_idx, int32_t latent_dim, float* lig_latent, float* rec_latent, int32_t* choices, void* stream) {
+  if (!ctx) return DDK_ERR_INVALID;
+  if (ctx->host_only) return fail(ctx, DDK_ERR_STATE, "host-only context (device < 0) cannot launch kernels");
+  if (!cx || B < 1 || !logits || !lig_latent || !rec_latent || latent_dim < 1 || decoding_idx < 0 || decoding_idx >= latent_dim)
+    return fail(ctx, DDK_ERR_INVALID, "ddk_ar_decode: bad argument");
+  if (temperature < 100.0f && !uniforms) return fail(ctx, DDK_ERR_INVALID, "ddk_ar_decode: uniforms are required below temperature 100");
+  { hipError_t we = cx_wait_ready(cx, (hipStream_t)stream); if (we != hipSuccess) return hip_fail(ctx, we, "wait for the complex upload"); }
+  ArDecodeArgs A;
+  A.logits = logits; A.uniforms = uniforms; A.temperature = temperature; A.n_lig = cx->n_lig; A.n_rec = cx->n_rec; A.idx = decoding_idx;
+  A.latent_dim = latent_dim; A.lig_latent = lig_latent; A.rec_latent = rec_latent; A.choices = choices;
+  hipError_t e = launch_ar_decode(A, B, (hipStream_t)stream);
+  return e == hipSuccess ? DDK_OK : hip_fail(ctx, e, "ar_decode launch");
 }
 
 int ddk_set_receptive_field_pruning(ddk_ctx* ctx, int32_t on) {

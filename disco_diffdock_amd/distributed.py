@@ -1,5 +1,5 @@
 """Multi-GPU layout of the hot path: complexes are independent units -> shard them across ranks
-(one process per GPU) with NO collective on the data path; one final gather of the poses over RCCL
+(one process per GPU) with NO collective on the data path; one final all_gather of the poses over RCCL
 (backend 'nccl' on ROCm) / gloo on CPU tests."""
 import torch
 import torch.distributed as dist
@@ -19,46 +19,72 @@ def shard_indices(costs, rank, world):
     return sorted(mine)
 
 
+def _multi():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def _all_gather_rows(rows, idx, device):
+    """rows [k, ...] with global row ids idx [k] held by this rank -> (rows, ids) of every rank.  One all_gather of a buffer padded
+    to the largest per-rank count (+ one of the ids): each byte crosses each link once, half the traffic of the all_reduce of a
+    zero-padded full-size buffer this replaced."""
+    k = torch.tensor([rows.shape[0]], dtype=torch.int64, device=device)
+    ks = [torch.zeros_like(k) for _ in range(dist.get_world_size())]
+    dist.all_gather(ks, k)
+    kmax = max(int(v.item()) for v in ks)
+    buf = torch.zeros((kmax,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=device)
+    ids = torch.full((kmax,), -1, dtype=torch.int64, device=device)
+    buf[:rows.shape[0]] = rows
+    ids[:rows.shape[0]] = idx
+    bufs = [torch.zeros_like(buf) for _ in ks]
+    idss = [torch.zeros_like(ids) for _ in ks]
+    dist.all_gather(bufs, buf)
+    dist.all_gather(idss, ids)
+    return torch.cat(bufs), torch.cat(idss)
+
+
 def gather_poses(poses, n_lig, samples, device):
-    """poses: {complex index: tensor [samples, n_lig_i, 3]} held by this rank -> on every rank the full
-    {index: tensor}.  One padded all_gather ([n_complexes, samples, max n_lig, 3] fp32, a few MB)."""
+    """poses: {complex index: tensor [samples, n_lig_i, 3]} held by this rank -> on every rank the full {index: tensor}.
+    The ONE exchange of the path: an all_gather of the ranks' padded pose blocks ([k_rank, samples, max n_lig, 3] fp32, a few MB)."""
     n = len(n_lig)
     nmax = max(n_lig)
-    buf = torch.zeros((n, samples, nmax, 3), dtype=torch.float32, device=device)
-    own = torch.zeros(n, dtype=torch.float32, device=device)
-    for i, p in poses.items():
-        buf[i, :, :n_lig[i]] = p.to(device)
-        own[i] = 1.0
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)      # every slot is written by exactly one rank
-        dist.all_reduce(own, op=dist.ReduceOp.SUM)
-    assert bool((own == 1).all()), 'every complex must be owned by exactly one rank'
-    return {i: buf[i, :, :n_lig[i]].clone() for i in range(n)}
+    own = sorted(poses)
+    rows = torch.zeros((len(own), samples, nmax, 3), dtype=torch.float32, device=device)
+    for r, i in enumerate(own):
+        rows[r, :, :n_lig[i]] = poses[i].to(device)
+    ids = torch.tensor(own, dtype=torch.int64, device=device)
+    if _multi():
+        rows, ids = _all_gather_rows(rows, ids, device)
+    out = {}
+    for r, i in enumerate(ids.tolist()):
+        if i >= 0:
+            assert i not in out, 'every complex must be owned by exactly one rank'
+            out[i] = rows[r, :, :n_lig[i]].clone()
+    assert len(out) == n, 'every complex must be owned by exactly one rank'
+    return out
 
 
 def gather_confidences(conf, n_complexes, device):
     """conf: {complex index: tensor [samples] or [samples, k]} (the confidence model's output for this rank's complexes,
-    evaluate.py:317-325 ranks poses by it) -> on every rank the full {index: tensor}; rides with the pose gather (disjoint slots)."""
+    evaluate.py:317-325 ranks poses by it) -> on every rank the full {index: tensor}; same all_gather as the poses."""
     shape = None
     for v in conf.values():
         shape = tuple(v.shape)
     meta = torch.zeros(3, dtype=torch.int64, device=device)       # a rank without complexes learns the shape from the others
     if shape is not None:
         meta[0], meta[1], meta[2] = len(shape), shape[0], (shape[1] if len(shape) > 1 else 1)
-    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-    if multi:
+    if _multi():
         dist.all_reduce(meta, op=dist.ReduceOp.MAX)
     nd, S, k = [int(v) for v in meta.tolist()]
-    buf = torch.zeros((n_complexes, S, k), dtype=torch.float32, device=device)
-    own = torch.zeros(n_complexes, dtype=torch.float32, device=device)
-    for i, v in conf.items():
-        buf[i] = v.to(device).float().reshape(S, k)
-        own[i] = 1.0
-    if multi:
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-        dist.all_reduce(own, op=dist.ReduceOp.SUM)
-    assert bool((own == 1).all()), 'every complex must be owned by exactly one rank'
-    return {i: (buf[i, :, 0] if nd == 1 else buf[i]).clone() for i in range(n_complexes)}
+    own = sorted(conf)
+    rows = torch.zeros((len(own), S, k), dtype=torch.float32, device=device)
+    for r, i in enumerate(own):
+        rows[r] = conf[i].to(device).float().reshape(S, k)
+    ids = torch.tensor(own, dtype=torch.int64, device=device)
+    if _multi():
+        rows, ids = _all_gather_rows(rows, ids, device)
+    out = {i: (rows[r, :, 0] if nd == 1 else rows[r]).clone() for r, i in enumerate(ids.tolist()) if i >= 0}
+    assert len(out) == n_complexes, 'every complex must be owned by exactly one rank'
+    return out
 
 
 def shard_samples(n_samples, rank, world):
@@ -70,10 +96,17 @@ def shard_samples(n_samples, rank, world):
 
 
 def gather_samples(pos, n_samples, rank, world, device):
-    """pos: this rank's [hi-lo, n_lig, 3] slice -> on every rank the full [n_samples, n_lig, 3] (disjoint slots, one all_reduce)."""
+    """pos: this rank's [hi-lo, n_lig, 3] slice -> on every rank the full [n_samples, n_lig, 3] (one all_gather of equally padded slices)."""
     lo, hi = shard_samples(n_samples, rank, world)
-    buf = torch.zeros((n_samples,) + tuple(pos.shape[1:]), dtype=torch.float32, device=device)
-    buf[lo:hi] = pos.to(device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-    return buf
+    if not _multi():
+        return pos.to(device).float()
+    per = (n_samples + world - 1) // world
+    buf = torch.zeros((per,) + tuple(pos.shape[1:]), dtype=torch.float32, device=device)
+    buf[:hi - lo] = pos.to(device)
+    bufs = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(bufs, buf)
+    out = []
+    for r in range(world):
+        l, h = shard_samples(n_samples, r, world)
+        out.append(bufs[r][:h - l])
+    return torch.cat(out)

@@ -1,49 +1,62 @@
 """Host mirror of the reference's AR latent model at inference:
 ``PretrainedScoreEncoder`` (models/pretrained_score_encoder.py:9-89) and ``GenericEncoder.encode_ar``
-(models/model_classes.py:9-49), latent_vocab == 1.  The expensive part - ``score_model.embed()`` at t = 1 with
-unconditional = 1 and the partially decoded input latents - runs in libddk.so (the AR checkpoint carries its own copy
-of the score model, loaded into its own ddk context); the two 32->128->128->1 predictor MLPs with BatchNorm1d(eval) are
-plain dense layers on the [N, 32] scalar channels (torch, rocBLAS)."""
-import copy
-
+(models/model_classes.py:9-49), latent_vocab == 1.  Everything runs in libddk.so: ``score_model.embed()`` at t = 1 with
+unconditional = 1 and the partially decoded input latents is the ordinary score-model forward of the AR checkpoint's own
+score-model copy (its own ddk context), the two predictor MLPs with BatchNorm1d(eval) are ``ddk_ar_logits`` and the per-graph
+pick + one-hot write is ``ddk_ar_decode`` (csrc/k_ar.hip).  ``encode_ar`` never reads the device back."""
 import torch
 from torch import nn
 
-from .diffusion_utils import set_time
+from .score_model import complex_for_batch
 
 
 class GenericEncoder(nn.Module):
-    def encode_ar(self, data, sampling_temperature=1.0, choice_fn=None):
-        """assumes graphs of the same complex as input (model_classes.py:10).  ``choice_fn(idx, logits)`` (extra, optional)
-        replaces the multinomial draw - used by the parity tests."""
+    def encode_ar(self, data, sampling_temperature=1.0, choice_fn=None, uniforms=None):
+        """assumes graphs of the same complex as input (model_classes.py:10).  Returns the one-hot latents
+        ``(latent_l [B*n_lig, D], latent_r [B*n_rec, D])`` on the device; ``self.last_choices`` [B, D] (int32, device) holds the
+        picked node of every graph (ligand atoms first).
+        Extras for the parity tests: ``uniforms`` [D, B] replaces the device draws of the inverse-CDF pick;
+        ``choice_fn(idx, logits)`` replaces the pick altogether (host round trip)."""
         if self.latent_vocab != 1:
             raise RuntimeError('ddk: AR decoding is implemented for latent_vocab == 1')
-        B = data.num_graphs
-        dev = data['ligand'].pos.device
-        len_lig, len_rec = len(data['ligand'].pos) // B, len(data['receptor'].pos) // B
-        latent_l = torch.zeros(len(data['ligand'].pos), self.input_latent_dim, device=dev)
-        latent_r = torch.zeros(len(data['receptor'].pos), self.input_latent_dim, device=dev)
-        for decoding_idx in range(self.input_latent_dim):
-            data['ligand'].input_latent, data['receptor'].input_latent = latent_l, latent_r
-            data.decoding_idx = torch.zeros(B, device=dev).long() + decoding_idx
-            lat = self.logits(data)[:, 0, :] * sampling_temperature
-            assert lat.shape == (B, len_lig + len_rec)
-            if sampling_temperature >= 100:
-                lat_choice = torch.argmax(lat, 1, keepdim=True)
-            elif choice_fn is not None:
-                lat_choice = choice_fn(decoding_idx, lat)
-            else:
-                p = torch.exp(lat)
-                if torch.any(torch.isnan(p)) or torch.any(torch.isinf(p)):
-                    print("Warning: NaNs or INF in AR setting them to 0")
-                    p = torch.nan_to_num(p)
-                lat_choice = torch.multinomial(p, 1)
-            rows = torch.arange(B, device=dev)
-            c = lat_choice[:, 0]
-            in_lig = c < len_lig
-            latent_l[(rows * len_lig + c)[in_lig], decoding_idx] = 1
-            latent_r[(rows * len_rec + c - len_lig)[~in_lig], decoding_idx] = 1
+        sm = self.pretrained_score_model
+        pos = data['ligand'].pos
+        if not pos.is_cuda:
+            raise RuntimeError('ddk AR model runs on the GPU only (no CPU fallback)')
+        dev = pos.device
+        cx, B = complex_for_batch(data, dev, ctx=sm.ctx)
+        D = self.input_latent_dim
+        latent_l = torch.zeros(B * cx.n_lig, D, device=dev)
+        latent_r = torch.zeros(B * cx.n_rec, D, device=dev)
+        choices = torch.full((B, D), -1, dtype=torch.int32, device=dev)
+        T = float(sampling_temperature)
+        p3 = pos.reshape(B, -1, 3)
+        cx.keep_receptor_features(True)        # embed(): the predictors read the receptor rows of the last conv layer too
+        try:
+            for idx in range(D):
+                logits = self._logits(cx, p3, latent_l, latent_r)
+                if choice_fn is not None:
+                    c = choice_fn(idx, logits * T)[:, 0].to(dev)
+                    rows = torch.arange(B, device=dev)
+                    in_lig = c < cx.n_lig
+                    latent_l[(rows * cx.n_lig + c)[in_lig], idx] = 1
+                    latent_r[(rows * cx.n_rec + c - cx.n_lig)[~in_lig], idx] = 1
+                    choices[:, idx] = c.int()
+                    continue
+                u = None
+                if T < 100:
+                    u = uniforms[idx].to(dev).float().contiguous() if uniforms is not None else torch.rand(B, device=dev)
+                cx.ar_decode(logits, T, u, idx, latent_l, latent_r, choices)
+        finally:
+            cx.keep_receptor_features(False)
+        self.last_choices = choices
         return latent_l, latent_r
+
+    def _logits(self, cx, pos, latent_l, latent_r):
+        """one embed() pass + the predictors: [B, n_lig + n_rec]"""
+        cx.set_latents(latent_l, latent_r, 1.0)            # unconditional = 1 (pretrained_score_encoder.py:62-64)
+        cx.score_forward(pos, 1.0, 1.0, 1.0)               # set_time(data, 1, 1, 1, ...) (:59-61)
+        return cx.ar_logits(pos.shape[0])
 
 
 class PretrainedScoreEncoder(GenericEncoder):
@@ -51,61 +64,60 @@ class PretrainedScoreEncoder(GenericEncoder):
                  latent_hidden_dim=128, input_latent_dim=0, apply_gumbel_softmax=True):
         super().__init__()
         assert input_latent_dim > 0
+        if latent_dim != 1:
+            raise RuntimeError('ddk: the AR predictors emit one logit per node (latent_dim = 1, utils/model_utils.py:133-139)')
+        if pretrained_score_model.cfg['num_conv_layers'] < 3:
+            raise RuntimeError('ddk: AR predictors need the full irreps (num_conv_layers >= 3: inputs [x[:, :ns] | x[:, -ns:]])')
         self.ns, self.latent_dim, self.latent_vocab = ns, latent_dim, latent_vocab
         self.latent_temperature = 1.0
         self.input_latent_dim = input_latent_dim
         self.apply_gumbel_softmax = apply_gumbel_softmax
         self.pretrained_score_model = pretrained_score_model      # ddk-backed TensorProductScoreModel
-        n_in = 2 * ns if pretrained_score_model.cfg['num_conv_layers'] >= 3 else ns
+        self.hidden, self.no_bn = latent_hidden_dim, bool(latent_no_batchnorm)
+        self.last_choices = None
 
-        def predictor():
-            bn = (lambda: nn.Identity()) if latent_no_batchnorm else (lambda: nn.BatchNorm1d(latent_hidden_dim))
-            return nn.Sequential(nn.Linear(n_in, latent_hidden_dim), bn(), nn.ReLU(), nn.Dropout(latent_dropout),
-                                 nn.Linear(latent_hidden_dim, latent_hidden_dim), bn(), nn.ReLU(), nn.Dropout(latent_dropout),
-                                 nn.Linear(latent_hidden_dim, latent_dim))
-        self.latent_s_predictor = predictor()
-        self.latent_r_predictor = predictor()
+    def predictor_spec(self):
+        """name -> shape of the predictor part of the AR checkpoint (models/pretrained_score_encoder.py:24-45)."""
+        H, n_in, spec = self.hidden, 2 * self.ns, {}
+        for name in ('latent_s_predictor', 'latent_r_predictor'):
+            for i, shape in ((0, (H, n_in)), (4, (H, H)), (8, (self.latent_dim, H))):
+                spec[f'{name}.{i}.weight'], spec[f'{name}.{i}.bias'] = shape, (shape[0],)
+            if not self.no_bn:
+                for i in (1, 5):
+                    for k in ('weight', 'bias', 'running_mean', 'running_var'):
+                        spec[f'{name}.{i}.{k}'] = (H,)
+                    spec[f'{name}.{i}.num_batches_tracked'] = ()
+        return spec
 
     def load_state_dict(self, state_dict, strict=True):
         pre = 'pretrained_score_model.'
-        self.pretrained_score_model.load_state_dict({k[len(pre):]: v for k, v in state_dict.items() if k.startswith(pre)}, strict=strict)
         own = {k: v for k, v in state_dict.items() if not k.startswith(pre)}
-        missing, unexpected = [], []
-        sd = nn.Module.state_dict(self)
-        for k in sd:
-            if k not in own:
-                missing.append(k)
-        for k in own:
-            if k not in sd:
-                unexpected.append(k)
-        if strict and (missing or unexpected):
-            raise RuntimeError(f'AR state_dict mismatch: missing {missing}, unexpected {unexpected}')
-        with torch.no_grad():
-            for k, v in own.items():
-                if k in sd:
-                    sd[k].copy_(v)
-        return self
+        spec = self.predictor_spec()
+        missing = [k for k in spec if k not in own and not k.endswith('num_batches_tracked')]
+        unexpected = [k for k in own if k not in spec]
+        bad = [k for k in spec if k in own and tuple(own[k].shape) != tuple(spec[k])]
+        if missing or bad or (strict and unexpected):
+            raise RuntimeError(f'AR state_dict mismatch: missing {missing}, unexpected {unexpected}, mis-shaped {bad}')
+        # the predictors live in the SAME ddk context as the AR checkpoint's score-model copy (ddk_finalize_weights folds the BatchNorms)
+        self.pretrained_score_model.load_state_dict({k[len(pre):]: v for k, v in state_dict.items() if k.startswith(pre)}, strict=strict,
+                                                    extra={k: v for k, v in own.items() if k in spec})
+        return torch.nn.modules.module._IncompatibleKeys([], unexpected)
 
     def logits(self, data):
-        """[B, latent_dim, n_lig + n_rec] logits of PretrainedScoreEncoder.forward with apply_gumbel_softmax=False."""
+        """[B, latent_dim, n_lig + n_rec] logits of PretrainedScoreEncoder.forward with apply_gumbel_softmax=False, for the input
+        latents ``data[...].input_latent`` (the batch is left untouched)."""
         if self.training:
             raise RuntimeError('ddk: inference (eval mode) only')
-        data = copy.copy(data)          # shallow: the forward only rebinds attributes (reference deep-copies, model_classes.py:34)
-        lig, rec = data['ligand'], data['receptor']
-        dev = lig.pos.device
-        lig.latent_h, rec.latent_h = lig.input_latent, rec.input_latent
-        B = data.num_graphs
-        set_time(data, 1, 1, 1, B, False, dev)
-        lig.unconditional = torch.ones((len(lig.pos), 1), device=dev)
-        rec.unconditional = torch.ones((len(rec.pos), 1), device=dev)
-        lig_h, rec_h = self.pretrained_score_model.embed(data)[:2]
-        ns = self.ns
-        deep = self.pretrained_score_model.cfg['num_conv_layers'] >= 3
-        sl = torch.cat([lig_h[:, :ns], lig_h[:, -ns:]], 1) if deep else lig_h[:, :ns]
-        sr = torch.cat([rec_h[:, :ns], rec_h[:, -ns:]], 1) if deep else rec_h[:, :ns]
-        sl, sr = self.latent_s_predictor(sl), self.latent_r_predictor(sr)
-        n_l, n_r = sl.shape[0] // B, sr.shape[0] // B
-        return torch.cat([sl.reshape(B, n_l, -1), sr.reshape(B, n_r, -1)], 1).transpose(1, 2)
+        pos = data['ligand'].pos
+        if not pos.is_cuda:
+            raise RuntimeError('ddk AR model runs on the GPU only (no CPU fallback)')
+        cx, B = complex_for_batch(data, pos.device, ctx=self.pretrained_score_model.ctx)
+        cx.keep_receptor_features(True)
+        try:
+            lg = self._logits(cx, pos.reshape(B, -1, 3), data['ligand'].input_latent.to(pos.device), data['receptor'].input_latent.to(pos.device))
+        finally:
+            cx.keep_receptor_features(False)
+        return lg[:, None, :]
 
     def forward(self, data):
         raise RuntimeError('ddk: use encode_ar() / logits(); the Gumbel-softmax training path is outside the hot path')

@@ -45,6 +45,29 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_side_streams = {}
+
+
+def h2d_async(t, device):
+    """Host tensor -> device WITHOUT waiting for the work already queued on the current stream: the copy runs from pinned memory on
+    a side stream and the current stream waits for it (a plain ``t.to(device)`` of pageable memory blocks the host until the copy
+    has run, i.e. until the sampling loop of the previous complex has drained).  Device tensors pass through."""
+    device = torch.device(device)
+    if t.is_cuda:
+        return t if t.device == device else t.to(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    side = _side_streams.get(idx)
+    if side is None:
+        side = _side_streams[idx] = torch.cuda.Stream(device=idx)
+    pinned = t.contiguous().pin_memory()
+    cur = torch.cuda.current_stream(idx)
+    with torch.cuda.stream(side):
+        d = pinned.to(device, non_blocking=True)
+    cur.wait_stream(side)
+    d.record_stream(cur)
+    return d
+
+
 def _need_cuda(t):
     if not t.is_cuda:
         raise RuntimeError('ddk: device tensors only (no CPU path exists); got a tensor on ' + str(t.device))
@@ -234,6 +257,22 @@ class Complex:
                    'ddk_se3_update')
         return out
 
+    # ---- AR latent model (ddk_ar_logits / ddk_ar_decode) --------------------------------------------------------------------
+    def ar_logits(self, B):
+        """predictor logits [B, n_lig + n_rec] on the node features of the last forward (keep_receptor_features(True) before it)"""
+        dev = torch.device('cuda', self.ctx.device)
+        out = torch.empty((B, self.n_lig + self.n_rec), dtype=torch.float32, device=dev)
+        self.ctx._check(self.ctx.L.ddk_ar_logits(self.ctx.h, self.h, B, _ptr(out), _stream()), 'ddk_ar_logits')
+        return out
+
+    def ar_decode(self, logits, temperature, uniforms, idx, latent_l, latent_r, choices=None):
+        """in place: one-hot of the picked node of every graph into column idx of latent_l / latent_r ([B*n, D], contiguous fp32)"""
+        B, D = logits.shape[0], latent_l.shape[1]
+        assert logits.is_contiguous() and latent_l.is_contiguous() and latent_r.is_contiguous() and latent_l.dtype == torch.float32
+        assert choices is None or (choices.dtype == torch.int32 and choices.is_contiguous() and tuple(choices.shape) == (B, D))
+        self.ctx._check(self.ctx.L.ddk_ar_decode(self.ctx.h, self.h, B, _ptr(logits), float(temperature), _ptr(uniforms), int(idx), D,
+                                                 _ptr(latent_l), _ptr(latent_r), _ptr(choices), _stream()), 'ddk_ar_decode')
+
     def set_atoms(self, atom_x, atom_pos, atom_edge_index, atom_rec_index, lig_x=None, rec_x=None):
         """Receptor-atom level of the confidence model's graph (data['atom'] of datasets_utils/process_mols.py:474-477)."""
         f = lambda a, dt: np.ascontiguousarray(a.detach().cpu().numpy() if torch.is_tensor(a) else a, dtype=dt)
@@ -247,13 +286,15 @@ class Complex:
         self.ctx._check(self.ctx.L.ddk_complex_set_atoms(self.ctx.h, self.h, C.byref(d), lig_x.ctypes.data_as(C.c_void_p),
                                                          rec_x.ctypes.data_as(C.c_void_p), rec_x.shape[1]), 'ddk_complex_set_atoms')
 
-    def confidence_forward(self, pos):
-        """confidence_model(batch) for B poses of this complex -> [B, num_confidence_outputs] (device)."""
+    def confidence_forward(self, pos, check=True):
+        """confidence_model(batch) for B poses of this complex -> [B, num_confidence_outputs] (device).  check=False skips the host
+        read-back of the edge-capacity flag (the caller runs ``confidence_counts()`` at its own synchronisation point)."""
         pos = pos.contiguous().float().reshape(-1, self.n_lig, 3)
         B = pos.shape[0]
         out = torch.empty((B, int(self.ctx.cfg.num_confidence_outputs)), dtype=torch.float32, device=pos.device)
         self.ctx._check(self.ctx.L.ddk_confidence_forward(self.ctx.h, self.h, B, _ptr(pos), _ptr(out), _stream()), 'ddk_confidence_forward')
-        self.confidence_counts()      # one host sync per confidence batch: fails loudly if the ligand-atom edge capacity overflowed
+        if check:
+            self.confidence_counts()      # one host sync per confidence batch: fails loudly if the ligand-atom edge capacity overflowed
         return out
 
     def confidence_counts(self):

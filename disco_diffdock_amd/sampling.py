@@ -9,6 +9,7 @@ import torch
 
 from .data import DataLoader
 from .diffusion_utils import set_time
+from .runtime import h2d_async
 from .score_model import complex_for_batch
 
 
@@ -78,6 +79,20 @@ def randomize_position_device(data_list, no_torsion, no_random, tr_sigma_max, de
     return pos
 
 
+def draw_noise(inference_steps, b, R_total, R, nc, device):
+    """N(0,1) draws of one batch from the device generator in the reference's order (tr, rot, tor per step, utils/sampling.py:146-164);
+    steps whose noise coefficients are all zero (no_final_step_noise) draw nothing, like the reference.  -> [steps, b, 6 + R_total]"""
+    z = torch.zeros((inference_steps, b, 6 + R_total), device=device)
+    for t_idx in range(inference_steps):
+        if not nc[t_idx].any():
+            continue
+        z[t_idx, :, 0:3] = torch.normal(mean=0, std=1, size=(b, 3), device=device)
+        z[t_idx, :, 3:6] = torch.normal(mean=0, std=1, size=(b, 3), device=device)
+        if R:
+            z[t_idx, :, 6:] = torch.normal(mean=0, std=1, size=(b * R,), device=device).reshape(b, R)
+    return z
+
+
 def step_coefficients(inference_steps, tr_schedule, rot_schedule, tor_schedule, t_to_sigma, model_args, ode, no_random,
                       no_final_step_noise, temp_sampling, temp_psi, temp_sigma_data):
     """Host scalars of every reverse step, formed with the reference's expressions and dtypes
@@ -137,6 +152,7 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
             raise RuntimeError('ddk: the confidence model needs confidence_data_list (all-atom graphs; the score graphs carry no atoms)')
         confidence_loader = iter(DataLoader(confidence_data_list, batch_size=batch_size))
         confidence = []
+    conf_checks = []
     latent_model = use_latent and getattr(model_args, 'latent_dim', 0) > 0
     if classifier_free_guidance_weight != 0.0 and not latent_model:
         raise RuntimeError('ddk: classifier-free guidance needs the latent-conditioned model (sampling.py:119-135)')
@@ -160,9 +176,9 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
             latent_h = None
             if latent_model:   # utils/sampling.py:69-103: AR decoding on the ar_pos pose, then the latents condition every step
                 lig_st = batch['ligand']      # only the poses go to the device: the encoder's score-model copy takes everything else
-                lig_st.pos = lig_st.pos.to(device)      # from the cached ddk_complex (a batch.to(device) moved 61 MB of ESM features)
+                lig_st.pos = h2d_async(lig_st.pos, device)      # from the cached ddk_complex (a batch.to(device) moved 61 MB of ESM features)
                 if 'ar_pos' in lig_st:
-                    lig_st.ar_pos = lig_st.ar_pos.to(device)
+                    lig_st.ar_pos = h2d_async(lig_st.ar_pos, device)
                 temp_lig_pos = batch['ligand'].pos
                 if 'ar_pos' in batch['ligand']:
                     batch['ligand'].pos = batch['ligand'].ar_pos
@@ -170,56 +186,57 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
                 batch['ligand'].pos = temp_lig_pos
                 batch['ligand'].latent_h, batch['receptor'].latent_h = latent_h
                 cx.set_latents(latent_h[0], latent_h[1], 0.0)
-                lat_cpu = (latent_h[0].cpu(), latent_h[1].cpu())     # for the bookkeeping below, fetched before the sampler is enqueued
+                choices = ar_model.last_choices          # [b, latent_dim] picked nodes (device): read back ONCE, after the sampler is enqueued
                 cx.set_guidance(classifier_free_guidance_weight, cfg_start, cfg_end)
             elif score_model.cfg['latent_dim'] > 0:
                 raise RuntimeError('ddk: a latent-conditioned score model was given but use_latent / model_args.latent_dim disable the latents')
-            pos = batch['ligand'].pos.to(device).float().reshape(b, -1, 3).contiguous()
+            pos = h2d_async(batch['ligand'].pos.float(), device).reshape(b, -1, 3).contiguous()
+            if pos.data_ptr() == batch['ligand'].pos.data_ptr():
+                pos = pos.clone()       # ddk_sample updates in place; the caller's start poses stay intact (the reference rebinds, never mutates)
             R = cx.R if not model_args.no_torsion else 0
             if noise is not None:
                 z = noise[batch_id].to(device)
             elif no_random or ode:
                 z = None
             else:
-                z = torch.zeros((inference_steps, b, 6 + cx.R), device=device)
-                for t_idx in range(inference_steps):   # draw order of the reference: tr, rot, tor per step
-                    if not nc[t_idx].any():            # no_final_step_noise: the reference draws nothing there (sampling.py:146-164)
-                        continue
-                    z[t_idx, :, 0:3] = torch.normal(mean=0, std=1, size=(b, 3), device=device)
-                    z[t_idx, :, 3:6] = torch.normal(mean=0, std=1, size=(b, 3), device=device)
-                    if R:
-                        z[t_idx, :, 6:] = torch.normal(mean=0, std=1, size=(b * R,), device=device).reshape(b, R)
+                z = draw_noise(inference_steps, b, cx.R, R, nc, device)
             cx.sample(pos, t_arr, sc, nc, z)
             if confidence_model is not None:   # utils/sampling.py:230-243: final poses into the all-atom graphs, t = 0
                 cbatch = next(confidence_loader)
                 cbatch['ligand'].pos = pos.reshape(-1, 3)
                 set_time(cbatch, 0, 0, 0, b, confidence_model_args.all_atoms if confidence_model_args is not None else True, device)
-                out = confidence_model(cbatch)
+                from .confidence import ConfidenceModel
+                if isinstance(confidence_model, ConfidenceModel):
+                    out = confidence_model(cbatch, check=False)       # the capacity flag is read once per call, below
+                    conf_checks.append(confidence_model.last_complex)
+                else:
+                    out = confidence_model(cbatch)
                 confidence.append(out[0] if type(out) is tuple else out)
             len_lig = pos.shape[1]
             flat = pos.reshape(-1, 3)
-            len_rec = batch['receptor'].num_nodes // b
-            flat_cpu = None
+            if latent_model:   # latent bookkeeping of utils/sampling.py:205-221 from ONE read-back behind the sampler (the reference syncs 6x per pose)
+                ch = choices.cpu().tolist()
+                lig_latent = any(c < len_lig for row in ch for c in row)
+                flat_cpu = flat.detach().cpu() if lig_latent else None
             for i in range(b):
                 d_i = data_list[batch_id * batch_size + i]
                 d_i['ligand'].pos = flat[i * len_lig:len_lig * (i + 1)]
-                if latent_model:   # latent bookkeeping of utils/sampling.py:205-221 (on host copies: one read-back, not 6 syncs per pose)
-                    lig_lat, rec_lat = lat_cpu[0][i * len_lig:len_lig * (i + 1)], lat_cpu[1][i * len_rec:len_rec * (i + 1)]
+                if latent_model:
                     lat_str, lat_pos = "", []
+                    center = d_i.original_center.detach().cpu()
                     for j in range(model_args.latent_dim):
-                        assert torch.sum(lig_lat[:, j]) + torch.sum(rec_lat[:, j]) == 1
-                        if torch.sum(lig_lat[:, j]) == 1:
-                            idx = int(torch.argmax(lig_lat[:, j]))
+                        idx = ch[i][j]
+                        if idx < len_lig:
                             lat_str += 'L' + str(idx)
-                            if flat_cpu is None:
-                                flat_cpu = flat.detach().cpu()
-                            lat_pos.append(flat_cpu[i * len_lig + idx:i * len_lig + idx + 1] + d_i.original_center.detach().cpu())
+                            lat_pos.append(flat_cpu[i * len_lig + idx:i * len_lig + idx + 1] + center)
                         else:
-                            idx = int(torch.argmax(rec_lat[:, j]))
+                            idx -= len_lig
                             lat_str += 'R' + str(idx)
-                            lat_pos.append(d_i['receptor'].pos[idx:idx + 1].detach().cpu() + d_i.original_center.detach().cpu())
+                            lat_pos.append(d_i['receptor'].pos[idx:idx + 1].detach().cpu() + center)
                     d_i.latent_str = lat_str
                     d_i.latent_pos = torch.cat(lat_pos, dim=0)
     if confidence_model is not None:          # utils/sampling.py:245-247
         confidence = torch.nan_to_num(torch.cat(confidence, dim=0), nan=-1000)
+        for ccx in conf_checks:               # fails loudly if a ligand-atom edge capacity overflowed (one read-back, at the end of the call)
+            ccx.confidence_counts()
     return data_list, confidence

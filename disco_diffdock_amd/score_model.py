@@ -125,17 +125,8 @@ class TensorProductScoreModel(nn.Module):
         from .synthetic import score_model_state_dict_spec
         c = self.cfg
         ns, sig, dist, lm = c['ns'], c['sigma_embed_dim'], c['distance_embed_dim'], c['lm_embedding_dim']
-        spec = dict(score_model_state_dict_spec(ns=ns, nv=c['nv'], num_conv_layers=c['num_conv_layers'], sigma=sig, dist=dist, lm=lm))
-        ld = c['latent_dim']
-        if ld > 0:      # DisCo: +latent_dim node columns, +2*latent_dim edge columns, unconditional embeddings (score_model.py:46-62)
-            spec['lig_node_embedding.additional_features_embedder.weight'] = (ns, ns + sig + ld)
-            spec['rec_node_embedding.additional_features_embedder.weight'] = (ns, ns + sig + lm + ld)
-            spec['lig_edge_embedding.0.weight'] = (ns, 4 + sig + dist + 2 * ld)
-            spec['rec_edge_embedding.0.weight'] = (ns, sig + dist + 2 * ld)
-            spec['cross_edge_embedding.0.weight'] = (ns, sig + c['cross_distance_embed_dim'] + 2 * ld)
-            if c['latent_droprate'] > 0:
-                for k in ('lig_node', 'rec_node', 'lig_edge', 'rec_edge', 'cross_edge'):
-                    spec[f'{k}_unconditional_embedding'] = (1, ns)
+        spec = dict(score_model_state_dict_spec(ns=ns, nv=c['nv'], num_conv_layers=c['num_conv_layers'], sigma=sig, dist=dist, lm=lm,
+                                                latent_dim=c['latent_dim'], latent_droprate=c['latent_droprate']))
         if not c['batch_norm']:
             spec = {k: v for k, v in spec.items() if '.batch_norm.' not in k}
         if c['no_torsion']:
@@ -143,9 +134,10 @@ class TensorProductScoreModel(nn.Module):
         return spec
 
     # the parameters live in the ddk context (packed for the kernels), not in nn.Parameters
-    def load_state_dict(self, state_dict, strict=True):
+    def load_state_dict(self, state_dict, strict=True, extra=None):
         """``nn.Module.load_state_dict`` semantics on the reference key set: with ``strict`` a missing, unexpected or mis-shaped
-        key raises; e3nn's internal ``*.tp.*`` buffers of real checkpoints are ignored."""
+        key raises; e3nn's internal ``*.tp.*`` buffers of real checkpoints are ignored.  ``extra``: further tensors
+        for the same ddk context (the AR model's predictor weights, already validated by the caller)."""
         spec = self.expected_state_dict_spec()
         have = {k: v for k, v in state_dict.items() if '.tp.' not in k}
         missing = [k for k in spec if k not in have]
@@ -158,6 +150,8 @@ class TensorProductScoreModel(nn.Module):
             raise RuntimeError(f'ddk score model: error(s) in loading state_dict: missing keys {missing}, unexpected keys {unexpected}')
         if missing:      # non-strict: nothing on the device can run with a partial checkpoint
             raise RuntimeError(f'ddk score model: the device path needs the complete checkpoint; missing {missing}')
+        if extra:
+            self.ctx.load_state_dict(extra, finalize=False)
         self.ctx.load_state_dict({k: have[k] for k in spec})
         self._loaded = True
         return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)

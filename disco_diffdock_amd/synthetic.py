@@ -272,9 +272,12 @@ def make_complex(seed, n_res=300, n_lig=None, cutoff=15.0, max_neighbor=24, esm_
     return out
 
 
-def score_model_state_dict_spec(ns=24, nv=6, num_conv_layers=5, sigma=32, dist=32, lm=1280):
-    """name -> shape of the DiffDock-S ``score_model.state_dict()`` (171 tensors / 2 107 134 elements)."""
+def score_model_state_dict_spec(ns=24, nv=6, num_conv_layers=5, sigma=32, dist=32, lm=1280, latent_dim=0, latent_droprate=0.0):
+    """name -> shape of the DiffDock-S ``score_model.state_dict()`` (171 tensors / 2 107 134 elements); with
+    latent_dim = 2, latent_droprate > 0 the DisCo-DiffDock-S layout (176 tensors / 2 107 638 elements: + latent_dim node columns,
+    + 2 latent_dim edge columns, five unconditional embeddings; models/score_model.py:46-62)."""
     spec = {}
+    ld = latent_dim
 
     def lin(name, o, i, bias=True):
         spec[f'{name}.weight'] = (o, i)
@@ -283,14 +286,14 @@ def score_model_state_dict_spec(ns=24, nv=6, num_conv_layers=5, sigma=32, dist=3
 
     for i, d in enumerate(LIG_FEATURE_DIMS):
         spec[f'lig_node_embedding.atom_embedding_list.{i}.weight'] = (d, ns)
-    lin('lig_node_embedding.additional_features_embedder', ns, ns + sigma)
-    lin('lig_edge_embedding.0', ns, 4 + sigma + dist)
+    lin('lig_node_embedding.additional_features_embedder', ns, ns + sigma + ld)
+    lin('lig_edge_embedding.0', ns, 4 + sigma + dist + 2 * ld)
     lin('lig_edge_embedding.3', ns, ns)
     spec['rec_node_embedding.atom_embedding_list.0.weight'] = (REC_RESIDUE_FEATURE_DIMS[0], ns)
-    lin('rec_node_embedding.additional_features_embedder', ns, ns + sigma + lm)
-    lin('rec_edge_embedding.0', ns, sigma + dist)
+    lin('rec_node_embedding.additional_features_embedder', ns, ns + sigma + lm + ld)
+    lin('rec_edge_embedding.0', ns, sigma + dist + 2 * ld)
     lin('rec_edge_embedding.3', ns, ns)
-    lin('cross_edge_embedding.0', ns, sigma + dist)
+    lin('cross_edge_embedding.0', ns, sigma + dist + 2 * ld)
     lin('cross_edge_embedding.3', ns, ns)
     for k in ('lig', 'rec', 'cross', 'center'):
         spec[f'{k}_distance_expansion.offset'] = (dist,)
@@ -323,20 +326,26 @@ def score_model_state_dict_spec(ns=24, nv=6, num_conv_layers=5, sigma=32, dist=3
                  'tor_bond_conv.batch_norm.running_mean': (ns,), 'tor_bond_conv.batch_norm.running_var': (2 * ns,)})
     lin('tor_final_layer.0', ns, 2 * ns, bias=False)
     lin('tor_final_layer.3', 1, ns, bias=False)
+    if ld > 0 and latent_droprate > 0:
+        for k in ('lig_node', 'rec_node', 'lig_edge', 'rec_edge', 'cross_edge'):
+            spec[f'{k}_unconditional_embedding'] = (1, ns)
     return spec
 
 
-def random_score_model_state_dict(seed=0):
-    """Random-init DiffDock-S weights (PyTorch-default style, randomised BatchNorm statistics) - no checkpoints exist offline."""
+def random_score_model_state_dict(seed=0, latent_dim=0, latent_droprate=0.0):
+    """Random-init DiffDock-S (or, with latent_dim = 2 / latent_droprate = 0.1, DisCo-DiffDock-S) weights (PyTorch-default style,
+    randomised BatchNorm statistics) - no checkpoints exist offline."""
     import math
     import torch
     g = torch.Generator().manual_seed(seed)
     stops = {'lig': 5.0, 'rec': 30.0, 'cross': 80.0, 'center': 30.0}
-    spec = score_model_state_dict_spec()
+    spec = score_model_state_dict_spec(latent_dim=latent_dim, latent_droprate=latent_droprate)
     P = {}
     for name, shape in spec.items():
         if name.endswith('distance_expansion.offset'):
             P[name] = torch.linspace(0.0, stops[name.split('_')[0]], shape[0])
+        elif name.endswith('unconditional_embedding'):
+            P[name] = torch.randn(shape, generator=g) * 0.1
         elif 'atom_embedding_list' in name:
             P[name] = (torch.rand(shape, generator=g) * 2 - 1) * math.sqrt(6.0 / (shape[0] + shape[1]))
         elif '.batch_norm.' in name:
@@ -344,6 +353,27 @@ def random_score_model_state_dict(seed=0):
         else:
             fan_in = shape[1] if name.endswith('weight') else spec[name[:-4] + 'weight'][1]
             P[name] = (torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(fan_in)
+    return P
+
+
+def random_ar_state_dict(seed=0, ar_ns=16, hidden=128, latent_dim=2, latent_droprate=0.1):
+    """Random-init checkpoint of the AR latent model (workdir/disco_diffdockS_ar_model layout): ``pretrained_score_model.*`` (its own
+    copy of the DisCo score model) + the two predictor MLPs 2*ar_ns -> hidden -> hidden -> 1 with BatchNorm1d
+    (models/pretrained_score_encoder.py:24-45)."""
+    import math
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    P = {'pretrained_score_model.' + k: v for k, v in random_score_model_state_dict(seed + 1, latent_dim, latent_droprate).items()}
+    for name in ('latent_s_predictor', 'latent_r_predictor'):
+        for i, (o, n_in) in ((0, (hidden, 2 * ar_ns)), (4, (hidden, hidden)), (8, (1, hidden))):
+            P[f'{name}.{i}.weight'] = (torch.rand(o, n_in, generator=g) * 2 - 1) / math.sqrt(n_in)
+            P[f'{name}.{i}.bias'] = (torch.rand(o, generator=g) * 2 - 1) / math.sqrt(n_in)
+        for i in (1, 5):
+            P[f'{name}.{i}.weight'] = torch.rand(hidden, generator=g) + 0.5
+            P[f'{name}.{i}.bias'] = torch.randn(hidden, generator=g) * 0.1
+            P[f'{name}.{i}.running_mean'] = torch.randn(hidden, generator=g) * 0.1
+            P[f'{name}.{i}.running_var'] = torch.rand(hidden, generator=g) + 0.5
+            P[f'{name}.{i}.num_batches_tracked'] = torch.tensor(7)
     return P
 
 

@@ -134,6 +134,22 @@ int ddk_confidence_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float
  *      Applies to the subsequent ddk_score_forward / ddk_sample calls on this complex; NULL, NULL clears. */
 int ddk_set_latents(ddk_ctx* ctx, ddk_complex* cx, const float* lig_latent, const float* rec_latent, float unconditional);
 
+/* ---- a22: the AR latent model (config 3).  A context that was given the AR checkpoint (its own score-model copy under the plain
+ *      key names + latent_s_predictor.* / latent_r_predictor.*) evaluates, after a forward at t = 1 with unconditional = 1, the
+ *      partially decoded latents bound by ddk_set_latents and ddk_set_keep_receptor_features(on)  (= score_model.embed(),
+ *      models/pretrained_score_encoder.py:58-75):
+ *      ddk_ar_logits: the two predictor MLPs (Linear-BatchNorm1d-ReLU-Linear-BatchNorm1d-ReLU-Linear, :24-45) on the scalar
+ *        channels [x[:, :ns] | x[:, -ns:]] of every node -> logits [B, n_lig + n_rec] (ligand atoms first, :84-88), DEVICE;
+ *      ddk_ar_decode: GenericEncoder.encode_ar's pick for latent dimension decoding_idx (models/model_classes.py:21-47):
+ *        logits * temperature; temperature >= 100: argmax; else index i with probability exp(.)_i / sum (NaN -> 0, inf -> FLT_MAX
+ *        like torch.nan_to_num), drawn by inverse CDF from the caller's uniforms [B] in [0,1) (DEVICE; the reference calls
+ *        torch.multinomial: same distribution, the draws stay with the caller); sets lig_latent[b*n_lig + c, decoding_idx] = 1 or
+ *        rec_latent[b*n_rec + c - n_lig, decoding_idx] = 1 ([B*n, latent_dim] DEVICE arrays the caller zeroed) and, when not NULL,
+ *        choices[b, decoding_idx] = c ([B, latent_dim] int32 DEVICE). */
+int ddk_ar_logits(ddk_ctx* ctx, ddk_complex* cx, int32_t B, float* logits_out, void* stream);
+int ddk_ar_decode(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* logits, float temperature, const float* uniforms,
+                  int32_t decoding_idx, int32_t latent_dim, float* lig_latent, float* rec_latent, int32_t* choices, void* stream);
+
 /* ---- classifier-free guidance of the sampler (utils/sampling.py:119-135): while cfg_end <= t_tr <= cfg_start every step of
  *      ddk_sample runs a second forward with unconditional = 1 and zeroed latents and uses
  *      score + weight * (score - score_unconditional).  weight = 0 (default) disables it. */

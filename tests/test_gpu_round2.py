@@ -182,3 +182,55 @@ def test_device_kabsch_and_axis_angle_goldens(dev, golden):
     Ra = torch.empty((aa.shape[0], 3, 3), device=dev)
     ctx._check(ctx.L.ddk_debug_axis_angle(ctx.h, aa.shape[0], C.c_void_p(aa.data_ptr()), C.c_void_p(Ra.data_ptr()), st), 'ddk_debug_axis_angle')
     assert np.abs(Ra.cpu().numpy() - za['R']).max() < 2e-6
+
+
+def test_ar_multinomial_decode_vs_oracle(dev):
+    """a22 on the device: encode_ar below temperature 100 - ddk_ar_logits + ddk_ar_decode's inverse-CDF pick on injected
+    uniforms against oracle.ar_ref.encode_ar with the same pick rule as choice_fn; the second latent dimension sees the first one's
+    one-hot through the embed() pass, so equal latents pin the whole AR loop.  No host read-back inside encode_ar."""
+    from argparse import Namespace
+    from disco_diffdock_amd import synthetic
+    from disco_diffdock_amd.model_utils import get_ar_model
+    from disco_diffdock_amd.data import from_arrays, collate
+    from oracle import ar_ref, graph_lite
+    score_args = Namespace(ns=24, nv=6, num_conv_layers=5, sigma_embed_dim=32, distance_embed_dim=32, cross_distance_embed_dim=32,
+                           max_radius=5.0, cross_max_distance=80, dynamic_max_cross=True, embedding_scale=1000, embedding_type='sinusoidal',
+                           scale_by_sigma=True, no_torsion=False, no_batch_norm=False, dropout=0.1, sh_lmax=1, use_second_order_repr=False,
+                           use_old_atom_encoder=False, esm_embeddings_path='x', latent_dim=2, latent_vocab=1, latent_droprate=0.1,
+                           latent_cross_attention=False, tr_sigma_min=0.1, tr_sigma_max=19.0, rot_sigma_min=0.03, rot_sigma_max=1.55,
+                           tor_sigma_min=0.03, tor_sigma_max=3.14)
+    ar_args = Namespace(use_pretrained_score=True, ns=16, latent_no_batchnorm=False, latent_dropout=0.0, latent_hidden_dim=128,
+                        esm_embeddings_path='x', no_randomness=False)
+    cfg = smr.ScoreModelConfig(latent_dim=2, latent_vocab=1, latent_droprate=0.1)
+    P_ar = ar_ref.random_ar_state_dict(cfg, ar_ns=16, hidden=128, seed=21)
+    ar = get_ar_model(ar_args, score_args, dev, training=False)
+    ar.load_state_dict(P_ar, strict=True)
+    ar.eval()
+    c = synthetic.make_complex(17, n_res=45, n_lig=19)
+    B, Tmp = 5, 6.0                      # (a temperature that spreads the picks: random-init logits are close to each other)
+    rng = np.random.default_rng(4)
+    pos = _poses(c, B, rng, spread=3.0)
+    u = torch.rand(2, B, generator=torch.Generator().manual_seed(9))
+
+    def inverse_cdf(idx, lat):           # the pick rule of ddk_ar_decode (include/ddk.h), restated on the oracle's logits
+        p = torch.nan_to_num(torch.exp(lat.float())).double()
+        cum = torch.cumsum(p, 1)
+        target = u[idx].double()[:, None] * cum[:, -1:]
+        return (cum > target).int().argmax(1, keepdim=True)
+
+    ob = graph_lite.collate([to_graph(c) for _ in range(B)])
+    ob['ligand'].pos = T(pos.reshape(-1, 3))
+    want_l, want_r = ar_ref.encode_ar(P_ar, cfg, 16, ob, sampling_temperature=Tmp, choice_fn=inverse_cdf)
+    b = collate([from_arrays(c) for _ in range(B)])
+    b['ligand'].pos = T(pos.reshape(-1, 3)).to(dev)
+    with torch.no_grad():
+        got_l, got_r = ar.encode_ar(b, Tmp, uniforms=u)
+    assert got_l.is_cuda and ar.last_choices.is_cuda
+    assert torch.equal(got_l.cpu(), want_l) and torch.equal(got_r.cpu(), want_r)
+    ch = ar.last_choices.cpu()
+    assert len(set(ch[:, 0].tolist())) > 1                      # the draws really spread over nodes
+    n_l = len(c['lig_pos'])
+    for i in range(B):
+        for j in range(2):
+            k = int(ch[i, j])
+            assert (got_l[i * n_l + k, j] if k < n_l else got_r[i * len(c['rec_pos']) + k - n_l, j]) == 1

@@ -75,7 +75,7 @@ def lib():
     L.ddk_randomize_position.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp]
     L.ddk_complex_set_atoms.argtypes = [vp, vp, vp, vp, vp, i32]
     L.ddk_confidence_forward.argtypes = [vp, vp, i32, vp, vp, vp]
-    L.ddk_pose_metrics.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp]
+    L.ddk_pose_metrics.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp]
     L.ddk_sample.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]
     L.ddk_last_graph_stats.argtypes = [vp, vp, vp, vp]
     L.ddk_build_graph.argtypes = [vp, vp, C.c_int32, vp, C.c_float, vp, vp, C.c_int64, vp, vp]

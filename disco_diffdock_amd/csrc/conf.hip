@@ -634,7 +634,7 @@ int ddk_confidence_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float
   G.rr_src = cx->rr_src; G.rr_dst = cx->rr_dst; G.rr_outdeg = cx->rr_outdeg; G.rr_start = cx->rr_start;
   G.B = B; G.n_lig = n_lig; G.n_rec = n_rec; G.M = cx->M; G.E_rr = cx->E_rr;
   G.lig_r2 = c.lig_max_radius * c.lig_max_radius; G.cross_cutoff = M->sp.cross_cutoff;
-  G.counts = cx->counts; G.offs = cx->offs; G.info = cx->info; G.e_src = K->e_src; G.e_dst = K->e_dst; G.e_aux = K->e_aux;
+  G.counts = cx->counts; G.offs = cx->offs; G.info = cx->info; G.levels = cx->levels; G.e_src = K->e_src; G.e_dst = K->e_dst; G.e_aux = K->e_aux;
   G.deg = K->deg_scratch; G.rec_node_base = (int)rec_base;
   CK(launch_graph(G, K->cap4, s), "graph");
   EdgeFeatArgs EF;

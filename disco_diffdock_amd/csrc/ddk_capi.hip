@@ -305,6 +305,25 @@ static int build_conv_layer(ddk_ctx* ctx, int mode, int l, ConvLayerDev& L) {
         }
     }
   }
+  // node terms of GEMM1 (score model): see ConvLayerDev::wn
+  if (mode == 0) {
+    L.h_wn.assign((size_t)2 * 4 * NE * NS, 0.f);
+    L.h_bnp.assign((size_t)2 * 4 * NE, 0.f);
+    const int recv_g[2][2] = {{0, 1}, {2, 3}}, send_g[2][2] = {{0, 3}, {1, 2}};     // [node type][slot]: ligand atom / residue
+    for (int type = 0; type < 2; ++type)
+      for (int slot = 0; slot < 4; ++slot) {
+        const int g = slot < 2 ? recv_g[type][slot] : send_g[type][slot - 2];
+        const HostTensor* W1 = find_w(ctx, fc_name(g) + ".0.weight", {ne, ne});
+        const HostTensor* B1 = find_w(ctx, fc_name(g) + ".0.bias", {ne});
+        if (!W1 || !B1) return DDK_ERR_INVALID;
+        const int col0 = slot < 2 ? NS : 2 * NS;       // x[edge_src][:ns] columns (receiver) / x[edge_dst][:ns] columns (sender)
+        for (int o = 0; o < ne; ++o) {
+          const size_t row = ((size_t)(type * 4 + slot) * NE + pre_pos(o));
+          for (int k = 0; k < NS; ++k) L.h_wn[row * NS + k] = W1->data[(size_t)o * ne + col0 + k];
+          L.h_bnp[row] = slot < 2 ? B1->data[o] : 0.f;       // the bias rides with the receiver's term
+        }
+      }
+  }
   // BatchNorm (e3nn, eval): per multiplicity channel; one per layer (mode 0) or one per conv (mode 1)
   const int n_bn = mode == 0 ? 1 : NG;
   L.h_bn_mean.assign((size_t)n_bn * XW, 0.f);
@@ -337,6 +356,7 @@ static int build_conv_layer(ddk_ctx* ctx, int mode, int l, ConvLayerDev& L) {
     float* db1 = dev_upload(ctx, b1all);
     float* d2 = dev_upload(ctx, w2rec);
     L.tiles = (TileDesc*)dev_alloc(ctx, tiles.size() * sizeof(TileDesc));
+    if (mode == 0) { L.wn = dev_upload(ctx, L.h_wn); L.bnp = dev_upload(ctx, L.h_bnp); if (!L.wn || !L.bnp) return fail(ctx, DDK_ERR_NOMEM, "device allocation failed while packing conv weights"); }
     L.bn_mean = dev_upload(ctx, L.h_bn_mean);
     L.bn_scale = dev_upload(ctx, L.h_bn_scale);
     L.bn_bias = dev_upload(ctx, L.h_bn_bias);
@@ -601,6 +621,8 @@ int64_t ddk_debug_export(ddk_ctx* ctx, const char* what, void* buf, int64_t cap_
     else if (it == "b1p") { src = L.h_b1p[g].data(); n = L.h_b1p[g].size(); }
     else if (it == "w2p") { src = L.h_w2p[g].data(); n = L.h_w2p[g].size(); }
     else if (it == "b2p") { src = L.h_b2p[g].data(); n = L.h_b2p[g].size(); }
+    else if (it == "wn") { src = L.h_wn.data(); n = L.h_wn.size(); }
+    else if (it == "bnp") { src = L.h_bnp.data(); n = L.h_bnp.size(); }
     else if (it == "tiles") { src = L.h_tiles.data(); n = L.h_tiles.size() * (sizeof(TileDesc) / 4); }
     else if (it == "bn_mean") { src = L.h_bn_mean.data(); n = L.h_bn_mean.size(); }
     else if (it == "bn_scale") { src = L.h_bn_scale.data(); n = L.h_bn_scale.size(); }

@@ -102,6 +102,14 @@ struct ConvLayerDev {          // device copies for one TensorProductConvLayer w
   float w1s[4] = {1, 1, 1, 1}, w2s[4] = {1, 1, 1, 1};   // 3 x f16 mode: power-of-two range scale of the packed W1 / (W2, b2) of each group
   int n_cols = 0;              // flush columns (8 output channels each); col_start[c] = first tile of column c, col_start[n_cols] = n_tiles
   int col_start[17] = {};
+  // GEMM1 split: W1 [edge_emb | x_src[:ns] | x_dst[:ns]] = W1a edge_emb + (W1b x[src][:ns] + b1) + W1c x[dst][:ns]; the
+  // two node terms are formed once per NODE and layer (node_pre / node_finalize_pre kernels) instead of once per edge.  A node has four
+  // roles: ligand atoms  receive in groups 0,1 (slots 0,1) and send in groups 0,3 (slots 2,3); residues receive in 2,3 and send in 1,2.
+  // wn [2 node types][4 slots][72 pos][ns], bn [2][4][72]; pos = position of the hidden unit in GEMM1's accumulator layout
+  // (lane half hh, tile T, register r): hh*36 + T*16 + r  (pre_pos below)
+  float* wn = nullptr;
+  float* bnp = nullptr;
+  std::vector<float> h_wn, h_bnp;
   float* bn_mean = nullptr;    // [XW]  running_mean on 0e channels, 0 elsewhere
   float* bn_scale = nullptr;   // [XW]  weight/sqrt(var+eps)   (1 when batch_norm is off)
   float* bn_bias = nullptr;    // [XW]  bias on 0e channels, 0 elsewhere
@@ -114,6 +122,13 @@ struct ConvLayerDev {          // device copies for one TensorProductConvLayer w
   int n_in[4] = {}, n_out[4] = {}, blk_off[4] = {};
   int in_mul[4] = {}, out_mul[4] = {};   // 0e,1o,1e,0o multiplicities of the layer's in/out irreps
 };
+
+constexpr int PRE_W = 4 * NE;   // floats of node pre-activations per node: 4 roles x 72 hidden units
+// position of hidden unit o (0..71) inside a role's 72 floats: the order in which lane half hh reads its GEMM1 accumulator init
+static inline int pre_pos(int o) {
+  const int r32 = o < 64 ? o % 32 : o - 64, hh = (r32 >> 2) & 1;
+  return o < 64 ? hh * 36 + (o / 32) * 16 + (r32 & 3) + 4 * (r32 >> 3) : hh * 36 + 32 + (r32 & 3);
+}
 
 struct HostTensor {
   std::vector<int64_t> shape;
@@ -180,6 +195,7 @@ struct ConvLaunch {
   float* sum;                // [N_out, XW] fp32 accumulators (zeroed by the caller)
   const int32_t* tile_info;  // device: tile_start[5], group_off[5]
   int32_t* counter;          // device tile counter (zeroed by the caller)
+  const float* pre = nullptr;   // [N, PRE_W] node terms of GEMM1 (gather mode, score model) or null: GEMM1 over all 72 inputs
   int gather;                // 1: edge_attr is edge_emb[E,24] and x[src][:24], x[dst][:24] are gathered
   // layer-0 receptor-receptor de-duplication (all samples of a batch share the receptor and, before the first conv,
   // its node/edge features): group 2 of the launch's group table is the shared copy of the receptor edges (sample-0 numbering,
@@ -203,6 +219,13 @@ hipError_t launch_conv_setup(int32_t* tile_info, const int64_t* group_offsets_ho
 hipError_t launch_conv_one_group(int32_t* gt, int n_groups, int k, int64_t E, hipStream_t s);
 hipError_t launch_pad_rows(const float* x, int64_t n, int din, float* xpad, hipStream_t s);
 hipError_t launch_count_deg(const int32_t* src, int64_t E, int32_t* deg, hipStream_t s);
+// node_finalize of layer l fused with the node terms of layer l+1's GEMM1 (x_in == null, sum == null: the node terms of `x_out` alone)
+struct NodePreArgs {
+  float* sum; const int32_t* deg; const float* x_in; const float* bn_mean; const float* bn_scale; const float* bn_bias;
+  int dout; float* x_out; const float* sum_rr0; int n_lig_total, n_rec_total, n_rec; float* zero_extra; int64_t n_extra;
+  const float* wn; const float* bnp; float* pre;
+};
+hipError_t launch_node_finalize_pre(const NodePreArgs& a, bool finalize, hipStream_t s);
 hipError_t launch_node_finalize(float* sum, const int32_t* deg, const float* x_in /*[N,XW] or null*/,
                                 const float* bn_mean, const float* bn_scale, const float* bn_bias, int64_t n, int dout,
                                 int out_stride, float* out, hipStream_t s, const float* sum_rr0 = nullptr,

@@ -75,8 +75,11 @@ __device__ __forceinline__ void lds_frags(float4 (&a)[9], f32x16& B, const float
   }
 }
 
-template <bool GATHER, int MODE>
+// SPLIT (score model, gather mode): the x[src][:ns] / x[dst][:ns] columns of GEMM1 are per-NODE terms computed once per layer
+// (node_finalize_pre_kernel below); GEMM1 here contracts the 24 edge-embedding inputs only and starts from their sum (K 72 -> 24)
+template <bool GATHER, int MODE, bool SPLIT>
 __global__ __launch_bounds__(64 * ConvTraits<MODE>::WAVES) void conv_fused_kernel(ConvKArgs A) {
+  static_assert(!SPLIT || (GATHER && MODE == 0), "the GEMM1 split exists for the score model's gather path");
   constexpr int WAVES = ConvTraits<MODE>::WAVES, FS = ConvTraits<MODE>::FS, BLOCK_EDGES = 32 * WAVES;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -173,6 +176,52 @@ __global__ __launch_bounds__(64 * ConvTraits<MODE>::WAVES) void conv_fused_kerne
     }
 
     // ---- GEMM1: h = relu(W1 [edge_emb | x_src[:ns] | x_dst[:ns]] + b1), K order kappa(s,hh) = 24*(s/12)+12*hh+s%12 ----
+    float h[36];
+    if constexpr (SPLIT) {
+      // W1a edge_emb (12 MFMAs per 32-row tile) on top of the per-node terms (W1b x[src][:ns] + b1) + W1c x[dst][:ns], which arrive in
+      // the accumulator's own register order: role slot of the receiving node = g & 1, of the sending node = 2 + (g >> 1)
+      float bin[12];
+      {
+        const float* pe = A.edge_attr + (size_t)e * NS + 12 * hh;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const float4 a = ld4(pe + 4 * j);
+          bin[4 * j + 0] = a.x; bin[4 * j + 1] = a.y; bin[4 * j + 2] = a.z; bin[4 * j + 3] = a.w;
+        }
+      }
+      const float* ps = A.pre + ((size_t)sn * 4 + (g & 1)) * NE + 36 * hh;
+      const float* pd = A.pre + ((size_t)dn * 4 + 2 + (g >> 1)) * NE + 36 * hh;
+      const float* w1 = A.w1p + (size_t)g * (3 * 9 * 64 * 4);
+#pragma unroll
+      for (int T = 0; T < 3; ++T) {
+        f32x16 acc;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (T < 2 || j == 0) {
+            const float4 u = ld4(ps + 16 * T + 4 * j), w = ld4(pd + 16 * T + 4 * j);
+            acc[4 * j + 0] = u.x + w.x; acc[4 * j + 1] = u.y + w.y; acc[4 * j + 2] = u.z + w.z; acc[4 * j + 3] = u.w + w.w;
+          } else {
+            acc[4 * j + 0] = 0.0f; acc[4 * j + 1] = 0.0f; acc[4 * j + 2] = 0.0f; acc[4 * j + 3] = 0.0f;
+          }
+        }
+        const float* wp = w1 + ((size_t)T * 9 * 64 + lane) * 4;
+#pragma unroll
+        for (int s4 = 0; s4 < 3; ++s4) {
+          const float4 a = ld4(wp + s4 * 64 * 4);
+          acc = MFMA(a.x, bin[4 * s4 + 0], acc);
+          acc = MFMA(a.y, bin[4 * s4 + 1], acc);
+          acc = MFMA(a.z, bin[4 * s4 + 2], acc);
+          acc = MFMA(a.w, bin[4 * s4 + 3], acc);
+        }
+        if (T < 2) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) h[16 * T + r] = fmaxf(acc[r], 0.0f);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h[32 + r] = fmaxf(acc[r], 0.0f);
+        }
+      }
+    } else {
     float bin[36];
     {
       const float *pe, *pxs, *pxd;
@@ -193,7 +242,6 @@ __global__ __launch_bounds__(64 * ConvTraits<MODE>::WAVES) void conv_fused_kerne
         bin[24 + 4 * j + 0] = c.x; bin[24 + 4 * j + 1] = c.y; bin[24 + 4 * j + 2] = c.z; bin[24 + 4 * j + 3] = c.w;
       }
     }
-    float h[36];
     {
       const float* w1 = A.w1p + (size_t)g * (3 * 9 * 64 * 4);
       const float* b1 = A.b1p + (size_t)g * (3 * 2 * 16);
@@ -223,6 +271,7 @@ __global__ __launch_bounds__(64 * ConvTraits<MODE>::WAVES) void conv_fused_kerne
           for (int r = 0; r < 4; ++r) h[32 + r] = fmaxf(acc[r], 0.0f);
         }
       }
+    }
     }
 
     // ---- F row of this edge: TP row operands derived from x[dst] and sh (written by both lane halves) ----
@@ -416,26 +465,101 @@ __global__ void node_finalize_kernel(float* sum, const int32_t* deg, const float
   out[i] = v;
 }
 
-template <bool GATHER, int MODE>
-static hipError_t launch_conv_t(const ConvKArgs& k, int n_cu, hipStream_t s) {
-  // one persistent workgroup per CU (its F rows + the W2 ring fill the LDS), dynamic block queue
-  hipLaunchKernelGGL((conv_fused_kernel<GATHER, MODE>), dim3(n_cu), dim3(64 * ConvTraits<MODE>::WAVES), conv_lds_bytes<MODE>(), s, k);
+// node_finalize of one layer (FINALIZE) + the per-node terms of the NEXT layer's GEMM1 (ConvLayerDev::wn): one workgroup = PRE_TILE nodes
+// of one node type, thread t = (role slot t / 72, hidden position t % 72) with its 24 weights in registers; the node scalars are read
+// from LDS as broadcast 16-B words (one LDS instruction per four FMAs).  Bound by the 1152 B per node it writes.
+constexpr int PRE_TILE = 32;
+template <bool FINALIZE>
+__global__ __launch_bounds__(PRE_W) void node_finalize_pre_kernel(NodePreArgs A) {
+  __shared__ __attribute__((aligned(16))) float xs[PRE_TILE][NS];
+  const int tid = threadIdx.x;
+  if (FINALIZE && A.zero_extra != nullptr)
+    for (int64_t i = (int64_t)blockIdx.x * PRE_W + tid; i < A.n_extra; i += (int64_t)gridDim.x * PRE_W) A.zero_extra[i] = 0.0f;
+  const int lig_tiles = (A.n_lig_total + PRE_TILE - 1) / PRE_TILE;
+  const bool lig = (int)blockIdx.x < lig_tiles;
+  const int tile = lig ? blockIdx.x : blockIdx.x - lig_tiles;
+  const int node0 = (lig ? 0 : A.n_lig_total) + tile * PRE_TILE;
+  const int cnt = min(PRE_TILE, (lig ? A.n_lig_total : A.n_lig_total + A.n_rec_total) - node0);
+  // this thread's weights: requested first, they arrive while the finalize phase runs
+  float w[NS];
+  float bias = 0.0f;
+  if (A.pre != nullptr) {
+    const float* wrow = A.wn + ((size_t)(lig ? 0 : 4 * NE) + tid) * NS;
+#pragma unroll
+    for (int k4 = 0; k4 < NS / 4; ++k4) {
+      const float4 t = ld4(wrow + 4 * k4);
+      w[4 * k4] = t.x; w[4 * k4 + 1] = t.y; w[4 * k4 + 2] = t.z; w[4 * k4 + 3] = t.w;
+    }
+    bias = A.bnp[(lig ? 0 : 4 * NE) + tid];
+  }
+  if (FINALIZE) {
+    for (int idx = tid; idx < cnt * XW; idx += PRE_W) {
+      const int n = idx / XW, c = idx - n * XW;
+      const int64_t r = node0 + n;
+      float v = 0.0f;
+      if (c < A.dout) {
+        const int d = A.deg[r];
+        float sv = A.sum[r * XW + c];
+        A.sum[r * XW + c] = 0.0f;             // every accumulator that is read is cleared behind the read (see node_finalize_kernel)
+        if (A.sum_rr0 != nullptr && !lig) sv += A.sum_rr0[((r - A.n_lig_total) % A.n_rec) * XW + c];
+        v = sv / (float)(d > 1 ? d : 1);
+        v = (v - A.bn_mean[c]) * A.bn_scale[c] + A.bn_bias[c];
+      }
+      v += A.x_in[r * XW + c];
+      A.x_out[r * XW + c] = v;
+      if (c < NS) xs[n][c] = v;
+    }
+  } else {
+    for (int idx = tid; idx < cnt * NS; idx += PRE_W) {
+      const int n = idx / NS, c = idx - n * NS;
+      xs[n][c] = A.x_out[(size_t)(node0 + n) * XW + c];
+    }
+  }
+  if (A.pre == nullptr) return;
+  __syncthreads();
+  float* out = A.pre + (size_t)node0 * PRE_W + tid;
+#pragma unroll 4
+  for (int n = 0; n < cnt; ++n) {
+    float a0 = bias, a1 = 0.0f;
+#pragma unroll
+    for (int k4 = 0; k4 < NS / 4; ++k4) {
+      const float4 x = *reinterpret_cast<const float4*>(&xs[n][4 * k4]);
+      a0 = fmaf(w[4 * k4], x.x, a0); a1 = fmaf(w[4 * k4 + 1], x.y, a1);
+      a0 = fmaf(w[4 * k4 + 2], x.z, a0); a1 = fmaf(w[4 * k4 + 3], x.w, a1);
+    }
+    out[(size_t)n * PRE_W] = a0 + a1;
+  }
+}
+
+hipError_t launch_node_finalize_pre(const NodePreArgs& a, bool finalize, hipStream_t s) {
+  const int tiles = (a.n_lig_total + PRE_TILE - 1) / PRE_TILE + (a.n_rec_total + PRE_TILE - 1) / PRE_TILE;
+  if (tiles == 0) return hipSuccess;
+  if (finalize) hipLaunchKernelGGL(node_finalize_pre_kernel<true>, dim3(tiles), dim3(PRE_W), 0, s, a);
+  else hipLaunchKernelGGL(node_finalize_pre_kernel<false>, dim3(tiles), dim3(PRE_W), 0, s, a);
   return hipGetLastError();
 }
 
-template <bool GATHER, int MODE>
+template <bool GATHER, int MODE, bool SPLIT>
+static hipError_t launch_conv_t(const ConvKArgs& k, int n_cu, hipStream_t s) {
+  // one persistent workgroup per CU (its F rows + the W2 ring fill the LDS), dynamic block queue
+  hipLaunchKernelGGL((conv_fused_kernel<GATHER, MODE, SPLIT>), dim3(n_cu), dim3(64 * ConvTraits<MODE>::WAVES), conv_lds_bytes<MODE>(), s, k);
+  return hipGetLastError();
+}
+
+template <bool GATHER, int MODE, bool SPLIT>
 static hipError_t conv_attr_t() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fused_kernel<GATHER, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fused_kernel<GATHER, MODE, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)conv_lds_bytes<MODE>());
 }
 
 // opt the fused kernels into > 64 KB of dynamic LDS on the CURRENT device (ddk_create calls this after hipSetDevice: the attribute
 // is per device, and a failure is reported by that context instead of being cached for the process)
 hipError_t conv_prepare_device() {
-  hipError_t e = conv_attr_t<true, 0>();
-  if (e == hipSuccess) e = conv_attr_t<false, 0>();
-  if (e == hipSuccess) e = conv_attr_t<true, 1>();
-  if (e == hipSuccess) e = conv_attr_t<false, 1>();
+  hipError_t e = conv_attr_t<true, 0, true>();
+  if (e == hipSuccess) e = conv_attr_t<true, 0, false>();
+  if (e == hipSuccess) e = conv_attr_t<false, 0, false>();
+  if (e == hipSuccess) e = conv_attr_t<true, 1, false>();
+  if (e == hipSuccess) e = conv_attr_t<false, 1, false>();
   if (e == hipSuccess) e = conv_prepare_device_h();
   return e;
 }
@@ -454,8 +578,10 @@ hipError_t launch_conv_fused(const ConvLayerDev& L, const ConvLaunch& a, int n_c
   k.n_groups = a.n_groups; k.n_active = a.n_active; k.n_slots = a.n_slots; k.slots = a.slots;
   if (a.gbeg) { k.gbeg = a.gbeg; k.gend = a.gend; }
   else { k.gbeg = a.tile_info + 5; k.gend = a.tile_info + 6; }   // 4 contiguous groups go[g] .. go[g+1] (explicit-boundary entry point)
-  if (a.mode == 1) return a.gather ? launch_conv_t<true, 1>(k, n_cu, s) : launch_conv_t<false, 1>(k, n_cu, s);
-  return a.gather ? launch_conv_t<true, 0>(k, n_cu, s) : launch_conv_t<false, 0>(k, n_cu, s);
+  k.pre = a.pre;
+  if (a.mode == 1) return a.gather ? launch_conv_t<true, 1, false>(k, n_cu, s) : launch_conv_t<false, 1, false>(k, n_cu, s);
+  if (a.gather && a.pre != nullptr) return launch_conv_t<true, 0, true>(k, n_cu, s);
+  return a.gather ? launch_conv_t<true, 0, false>(k, n_cu, s) : launch_conv_t<false, 0, false>(k, n_cu, s);
 }
 
 hipError_t launch_conv_setup(int32_t* tile_info, const int64_t* go, hipStream_t s) {

@@ -12,6 +12,7 @@ struct ConvKArgs {
   const int32_t* dst;
   const float* edge_attr;
   const float* sh;
+  const float* pre;   // [N, PRE_W] per-node terms of GEMM1 (SPLIT kernels)
   float* sum;
   const int32_t* tile_info;
   int32_t* counter;

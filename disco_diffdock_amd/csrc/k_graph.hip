@@ -74,10 +74,19 @@ __device__ void block_exclusive_scan(int* a, int n, int* tmp) {
 // and sent from edge_dst, tensor_layers.py:153-159.)  lvl[j]: 0 = A, 1 = B \ A, 2 = C \ B, 3 = the rest.
 // On entry lvl[j] is 0 or 3 and a barrier has passed; ends with a barrier.
 __device__ void propagate_levels(uint8_t* lvl, const GraphArgs& G) {
+  constexpr int U = 8;                              // independent index loads in flight per thread (the loop is L2-latency bound)
   for (int pass = 0; pass < 2; ++pass) {
-    for (int k = threadIdx.x; k < G.E_rr; k += 256) {
-      const int r = G.rr_src[k], d = G.rr_dst[k];
-      if (lvl[r] == pass && lvl[d] == 3) lvl[d] = (uint8_t)(pass + 1);   // (concurrent writers store the same value)
+    for (int k0 = threadIdx.x; k0 < G.E_rr; k0 += 256 * U) {
+      int r[U], d[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = k0 + 256 * u;
+        r[u] = k < G.E_rr ? G.rr_src[k] : -1;
+        d[u] = k < G.E_rr ? G.rr_dst[k] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (r[u] >= 0 && lvl[r[u]] == pass && lvl[d[u]] == 3) lvl[d[u]] = (uint8_t)(pass + 1);   // (concurrent writers store the same value)
     }
     __syncthreads();
   }
@@ -147,6 +156,7 @@ __global__ __launch_bounds__(256) void graph_count_kernel(GraphArgs G) {
   level_scan(lvl, G.rr_outdeg, G.n_rec, nullptr, lvl_tmp, lvl_tot);
   if (tid < 2) G.counts[CNT_STRIDE * b + tid] = s_cnt[tid];
   if (tid < 3) G.counts[CNT_STRIDE * b + 2 + tid] = lvl_tot[tid];
+  for (int j = tid; j < G.n_rec; j += 256) G.levels[(size_t)b * G.n_rec + j] = lvl[j];      // the fill kernel's four slices read them back
 }
 
 // one thread: prefixes over the samples, group offsets, the per-layer group tables (InfoSlot / GroupTable in model.h)
@@ -229,7 +239,7 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(GraphArgs G) {
     int cnt = 0;
     for (int i = 0; i < n_lig; ++i) cnt += cross_within_scaled(lps + 3 * i, rp + 3 * j) ? 1 : 0;
     c_rl[j] = cnt;
-    lvl[j] = (G.prune && cnt == 0) ? 3 : 0;
+    lvl[j] = G.levels[(size_t)b * n_rec + j];        // receptive-field level, computed by graph_count_kernel
   }
   __syncthreads();
   for (int j = tid; j < n_lig; j += 256) {
@@ -253,7 +263,6 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(GraphArgs G) {
       lr_pre[i] = c; c += c_lr[i];
     }
   }
-  if (G.prune) propagate_levels(lvl, G);
   block_exclusive_scan(c_rl, n_rec, scan_tmp);   // exclusive prefix of the per-residue rec->lig counts (in place; ends with a barrier)
   const int g1 = G.info[I_GO + 1], g3 = G.info[I_GO + 3];
   const int32_t* offs = G.offs + CNT_STRIDE * b;

@@ -233,29 +233,43 @@ hipError_t launch_randomize(const RandPosArgs& A, hipStream_t s) {
 }
 
 // pose metrics of evaluate.py:297-338, one workgroup per pose (see include/ddk.h: ddk_pose_metrics)
-__global__ __launch_bounds__(256) void pose_metrics_kernel(const float* pos, const float* ref, const uint8_t* mask, const float* rec_pos,
-                                                           int n_lig, int n_rec, float* out) {
-  __shared__ float p[MAX_LIG * 3];
+__global__ __launch_bounds__(256) void pose_metrics_kernel(const float* pos, const float* ref, const uint8_t* mask, const int32_t* perms, int n_perms,
+                                                           const float* rec_pos, int n_lig, int n_rec, float* out) {
+  __shared__ float p[MAX_LIG * 3], rf[MAX_LIG * 3];
   __shared__ unsigned char keep[MAX_LIG];
   __shared__ float red[4][256];
   const int b = blockIdx.x, tid = threadIdx.x;
-  for (int i = tid; i < n_lig * 3; i += 256) p[i] = pos[(size_t)b * n_lig * 3 + i];
+  for (int i = tid; i < n_lig * 3; i += 256) { p[i] = pos[(size_t)b * n_lig * 3 + i]; rf[i] = ref[i]; }
   for (int i = tid; i < n_lig; i += 256) keep[i] = mask ? (mask[i] != 0) : 1;
   __syncthreads();
-  float s2 = 0.f, cnt = 0.f, cx = 0.f, cy = 0.f, cz = 0.f, rx = 0.f, ry = 0.f, rz = 0.f;
+  float cnt = 0.f, cx = 0.f, cy = 0.f, cz = 0.f, rx = 0.f, ry = 0.f, rz = 0.f;
   float mcross = INFINITY, mself = INFINITY;
   for (int i = tid; i < n_lig; i += 256)
     if (keep[i]) {
-      const float dx = p[3 * i] - ref[3 * i], dy = p[3 * i + 1] - ref[3 * i + 1], dz = p[3 * i + 2] - ref[3 * i + 2];
-      s2 += dx * dx + dy * dy + dz * dz; cnt += 1.f;
+      cnt += 1.f;
       cx += p[3 * i]; cy += p[3 * i + 1]; cz += p[3 * i + 2];
-      rx += ref[3 * i]; ry += ref[3 * i + 1]; rz += ref[3 * i + 2];
+      rx += rf[3 * i]; ry += rf[3 * i + 1]; rz += rf[3 * i + 2];
       for (int j = 0; j < n_lig; ++j)
         if (j != i && keep[j]) {
           const float ex = p[3 * i] - p[3 * j], ey = p[3 * i + 1] - p[3 * j + 1], ez = p[3 * i + 2] - p[3 * j + 2];
           mself = fminf(mself, ex * ex + ey * ey + ez * ez);
         }
     }
+  // RMSD: the symmetry-corrected one of evaluate.py:308-310 (spyrmsd symmrmsd without minimisation) = the minimum over the graph
+  // automorphisms G of sqrt(mean_i |pos[G(i)] - ref[i]|^2); n_perms = 0 / perms = null: identity only (the fallback of :313).
+  // One thread per permutation (each sum is n_lig terms in atom order: deterministic), then a block minimum.
+  float best = INFINITY;
+  const int K = perms ? n_perms : 1;
+  for (int k = tid; k < K; k += 256) {
+    float s2 = 0.f;
+    for (int i = 0; i < n_lig; ++i)
+      if (keep[i]) {
+        const int j = perms ? perms[(size_t)k * n_lig + i] : i;
+        const float dx = p[3 * j] - rf[3 * i], dy = p[3 * j + 1] - rf[3 * i + 1], dz = p[3 * j + 2] - rf[3 * i + 2];
+        s2 += dx * dx + dy * dy + dz * dz;
+      }
+    best = fminf(best, s2);
+  }
   for (int r = tid; r < n_rec; r += 256) {
     const float qx = rec_pos[3 * r], qy = rec_pos[3 * r + 1], qz = rec_pos[3 * r + 2];
     for (int i = 0; i < n_lig; ++i)
@@ -264,35 +278,38 @@ __global__ __launch_bounds__(256) void pose_metrics_kernel(const float* pos, con
         mcross = fminf(mcross, ex * ex + ey * ey + ez * ez);
       }
   }
-  // block reductions: sums of (s2, cnt, centroid components) and the two minima
-  float vals[8] = {s2, cnt, cx, cy, cz, rx, ry, rz};
-  float sums[8];
-  for (int k = 0; k < 8; ++k) {
+  // block reductions: sums of (cnt, centroid components) and the three minima
+  float vals[7] = {cnt, cx, cy, cz, rx, ry, rz};
+  float sums[7];
+  for (int k = 0; k < 7; ++k) {
     red[0][tid] = vals[k];
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[0][tid] += red[0][tid + o]; __syncthreads(); }
     sums[k] = red[0][0];
     __syncthreads();
   }
-  red[1][tid] = mcross; red[2][tid] = mself;
+  red[1][tid] = mcross; red[2][tid] = mself; red[3][tid] = best;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
-    if (tid < o) { red[1][tid] = fminf(red[1][tid], red[1][tid + o]); red[2][tid] = fminf(red[2][tid], red[2][tid + o]); }
+    if (tid < o) {
+      red[1][tid] = fminf(red[1][tid], red[1][tid + o]); red[2][tid] = fminf(red[2][tid], red[2][tid + o]);
+      red[3][tid] = fminf(red[3][tid], red[3][tid + o]);
+    }
     __syncthreads();
   }
   if (tid == 0) {
-    const float n = fmaxf(sums[1], 1.f);
-    const float dx = (sums[2] - sums[5]) / n, dy = (sums[3] - sums[6]) / n, dz = (sums[4] - sums[7]) / n;
-    out[4 * b + 0] = sqrtf(sums[0] / n);
+    const float n = fmaxf(sums[0], 1.f);
+    const float dx = (sums[1] - sums[4]) / n, dy = (sums[2] - sums[5]) / n, dz = (sums[3] - sums[6]) / n;
+    out[4 * b + 0] = sqrtf(red[3][0] / n);
     out[4 * b + 1] = sqrtf(dx * dx + dy * dy + dz * dz);
     out[4 * b + 2] = sqrtf(red[1][0]);
     out[4 * b + 3] = sqrtf(red[2][0]);
   }
 }
 
-hipError_t launch_pose_metrics(const float* pos, const float* ref, const uint8_t* mask, const float* rec_pos, int B, int n_lig, int n_rec,
-                               float* out, hipStream_t s) {
-  hipLaunchKernelGGL(pose_metrics_kernel, dim3(B), dim3(256), 0, s, pos, ref, mask, rec_pos, n_lig, n_rec, out);
+hipError_t launch_pose_metrics(const float* pos, const float* ref, const uint8_t* mask, const int32_t* perms, int n_perms, const float* rec_pos,
+                               int B, int n_lig, int n_rec, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(pose_metrics_kernel, dim3(B), dim3(256), 0, s, pos, ref, mask, perms, n_perms, rec_pos, n_lig, n_rec, out);
   return hipGetLastError();
 }
 

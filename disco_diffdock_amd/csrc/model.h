@@ -134,6 +134,7 @@ struct GraphArgs {
   int32_t* counts;          // [B, CNT_STRIDE]: ll radius edges, lr edges, rec-rec edges of level A / B / C
   int32_t* offs;            // [B, CNT_STRIDE]: exclusive prefix of counts over the samples
   int32_t* info;            // InfoSlot table
+  uint8_t* levels;          // [B, n_rec] receptive-field level of every residue (graph_count_kernel -> graph_fill_kernel)
   int prune = 0;            // 1: order group 2 by receptive-field level (0: every residue is level A -> the reference order)
   int shared_rr = 0;        // 1: append the shared rec-rec copy (layer-0 de-duplication) behind the four groups
   int32_t* e_src;
@@ -210,8 +211,8 @@ struct RandPosArgs {
 hipError_t launch_randomize(const RandPosArgs& A, hipStream_t s);
 hipError_t launch_debug_kabsch(const float* A, const float* Bp, int B, int n, float* R_out, float* t_out, hipStream_t s);
 hipError_t launch_debug_axis_angle(const float* aa, int n, float* R_out, hipStream_t s);
-hipError_t launch_pose_metrics(const float* pos, const float* ref, const uint8_t* mask, const float* rec_pos, int B, int n_lig, int n_rec,
-                               float* out, hipStream_t s);
+hipError_t launch_pose_metrics(const float* pos, const float* ref, const uint8_t* mask, const int32_t* perms, int n_perms, const float* rec_pos,
+                               int B, int n_lig, int n_rec, float* out, hipStream_t s);
 
 int conf_model_finalize(ddk_ctx* ctx);   // conf.hip (all-atom confidence model)
 void conf_complex_free(ddk_complex* cx);
@@ -243,6 +244,7 @@ struct ddk_complex {
   // per-forward workspaces (sized for max_batch)
   int64_t edge_cap = 0;
   int32_t *e_src = nullptr, *e_dst = nullptr, *e_aux = nullptr, *deg = nullptr, *counts = nullptr, *offs = nullptr, *info = nullptr;
+  uint8_t* levels = nullptr;
   float *e_emb = nullptr, *e_sh = nullptr, *xa = nullptr, *xb = nullptr, *sum = nullptr;
   float *pos_tmp = nullptr, *scores = nullptr;
   const float *lig_latent = nullptr, *rec_latent = nullptr;   // caller-owned device arrays set by ddk_set_latents
@@ -250,6 +252,7 @@ struct ddk_complex {
   float cfg_weight = 0.0f, cfg_start = 1.0f, cfg_end = 0.0f;   // ddk_set_guidance
   float *zero_lat = nullptr, *scores2 = nullptr;
   float* sum_rr0 = nullptr;   // [n_rec, XW] layer-0 rec-rec messages shared by all samples
+  float* pre = nullptr;       // [N, PRE_W] per-node terms of the upcoming layer's GEMM1 (ddk_internal.h: ConvLayerDev::wn)
   float* x_last = nullptr;    // node features after the conv stack of the last forward
   int last_B = 0;
   bool sum_clean = false;             // the accumulators are all zero (the last forward completed; node_finalize clears behind itself)

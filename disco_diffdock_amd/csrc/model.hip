@@ -415,7 +415,7 @@ static hipError_t build_graph(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
   G.prune = prune ? 1 : 0; G.shared_rr = shared_rr ? 1 : 0;
   G.B = B; G.n_lig = cx->n_lig; G.n_rec = cx->n_rec; G.M = cx->M; G.E_rr = cx->E_rr;
   G.lig_r2 = c.lig_max_radius * c.lig_max_radius; G.cross_cutoff = cross_cutoff;
-  G.counts = cx->counts; G.offs = cx->offs; G.info = cx->info; G.e_src = cx->e_src; G.e_dst = cx->e_dst; G.e_aux = cx->e_aux;
+  G.counts = cx->counts; G.offs = cx->offs; G.info = cx->info; G.levels = cx->levels; G.e_src = cx->e_src; G.e_dst = cx->e_dst; G.e_aux = cx->e_aux;
   G.deg = cx->deg;
   return launch_graph(G, cx->edge_cap, s);
 }
@@ -452,6 +452,14 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
   NE_.x = xin; NE_.lig_latent = cx->lig_latent; NE_.rec_latent = cx->rec_latent; NE_.lig_w_lat = M->dev.lig_w_lat; NE_.rec_w_lat = M->dev.rec_w_lat;
   NE_.lig_unc = M->dev.lig_node_unc; NE_.rec_unc = M->dev.rec_node_unc; NE_.unconditional = cx->unconditional; NE_.latent_dim = c.latent_dim;
   CK(launch_node_embed(NE_, s), "node embed");
+  // per-node terms of layer 0's GEMM1 (ConvLayerDev::wn); the 3 x f16 kernel keeps the unsplit GEMM1
+  const bool split = ctx->conv[0].wn != nullptr && ctx->conv[0].w2h == nullptr && cx->pre != nullptr;
+  if (split) {
+    NodePreArgs PA = {};
+    PA.x_out = xin; PA.n_lig_total = B * n_lig; PA.n_rec_total = B * n_rec; PA.n_rec = n_rec;
+    PA.wn = ctx->conv[0].wn; PA.bnp = ctx->conv[0].bnp; PA.pre = cx->pre;
+    CK(launch_node_finalize_pre(PA, false, s), "node_pre");
+  }
   // accumulators: node_finalize zeroes what it reads, so a forward that ran to its end leaves them clean for the next one
   if (!cx->sum_clean) {
     CK(hipMemsetAsync(cx->sum, 0, (size_t)cx->max_batch * (n_lig + n_rec) * XW * sizeof(float), s), "memset sum");
@@ -467,6 +475,7 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
     ConvLaunch a;
     a.x = xin; a.src = cx->e_src; a.dst = cx->e_dst; a.edge_attr = cx->e_emb; a.sh = cx->e_sh; a.sum = cx->sum;
     a.tile_info = cx->info; a.counter = cx->info + I_CNT + (l % 8); a.gather = 1;
+    a.pre = split ? cx->pre : nullptr;
     // which rec-rec messages this layer evaluates: layer 0 the shared copy (de-duplication); layers L-2, L-3, L-4 only those received by
     // the residues inside the backward receptive field of the heads (levels A, B, C of k_graph.hip); the last layer none (and no
     // rec->lig... group 3 either): only ligand rows are read downstream unless the caller asked for the receptor rows
@@ -496,6 +505,14 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
       ctx->prof_recs.push_back(pr);
     }
     const bool clear_rr0 = rr0_dirty && !shared0;     // one launch after the layer whose finalize read the shared rows
+    if (split && l + 1 < NL) {     // finalize fused with the node terms of the next layer's GEMM1
+      NodePreArgs PA = {};
+      PA.sum = cx->sum; PA.deg = cx->deg; PA.x_in = xin; PA.bn_mean = L.bn_mean; PA.bn_scale = L.bn_scale; PA.bn_bias = L.bn_bias;
+      PA.dout = L.dout; PA.x_out = xout; PA.sum_rr0 = shared0 ? cx->sum_rr0 : nullptr; PA.n_lig_total = B * n_lig; PA.n_rec_total = B * n_rec;
+      PA.n_rec = n_rec; PA.zero_extra = clear_rr0 ? cx->sum_rr0 : nullptr; PA.n_extra = clear_rr0 ? (int64_t)n_rec * XW : 0;
+      PA.wn = ctx->conv[l + 1].wn; PA.bnp = ctx->conv[l + 1].bnp; PA.pre = cx->pre;
+      CK(launch_node_finalize_pre(PA, true, s), "node_finalize_pre");
+    } else
     CK(launch_node_finalize(cx->sum, cx->deg, xin, L.bn_mean, L.bn_scale, L.bn_bias, lig_only ? (int64_t)B * n_lig : N, L.dout, XW, xout, s,
                             shared0 ? cx->sum_rr0 : nullptr, (int64_t)B * n_lig, n_rec, 1, clear_rr0 ? cx->sum_rr0 : nullptr,
                             clear_rr0 ? (int64_t)n_rec * XW : 0), "node_finalize");
@@ -559,7 +576,7 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
     const size_t E0 = (size_t)d->n_rec_edges, Bm0 = (size_t)max_batch, R0 = (size_t)(d->n_rot > 0 ? d->n_rot : 1);
     const size_t cap0 = Bm0 * ((size_t)M + (size_t)n_lig * (LIG_CAP - 1) + 2 * (size_t)n_lig * n_rec + E0) + E0 + 64, N0 = Bm0 * (size_t)(n_lig + n_rec);
     size_t need = (size_t)M * 24 + R0 * 8 + R0 * n_lig + (size_t)n_rec * 12 + (size_t)(n_lig + n_rec) * NS * 4 + E0 * (8 + NS * 4 + 16) + (size_t)n_rec * 4;
-    need += cap0 * (12 + NS * 4 + 16) + N0 * 4 + Bm0 * 2 * CNT_STRIDE * 4 + INFO_INTS * 4 + (size_t)n_rec * 4 + 3 * N0 * XW * 4 + (size_t)n_rec * XW * 4 + Bm0 * n_lig * 12 + 2 * Bm0 * (6 + R0) * 4;
+    need += cap0 * (12 + NS * 4 + 16) + N0 * 4 + N0 * PRE_W * 4 + Bm0 * 2 * CNT_STRIDE * 4 + INFO_INTS * 4 + (size_t)n_rec * 4 + Bm0 * n_rec + 3 * N0 * XW * 4 + (size_t)n_rec * XW * 4 + Bm0 * n_lig * 12 + 2 * Bm0 * (6 + R0) * 4;
     if (c.latent_dim > 0) need += N0 * c.latent_dim * 4;
     cx_reserve(cx, need + 64 * 256);
     // everything uploaded below (topology, static embeddings, receptor-edge geometry) goes through one pinned staging buffer
@@ -680,10 +697,12 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
   cx->counts = cx_upload<int32_t>(cx, nullptr, Bm * CNT_STRIDE);
   cx->offs = cx_upload<int32_t>(cx, nullptr, Bm * CNT_STRIDE);
   cx->info = cx_upload<int32_t>(cx, nullptr, INFO_INTS);
+  cx->levels = cx_upload<uint8_t>(cx, nullptr, Bm * n_rec);
   cx->xa = cx_upload<float>(cx, nullptr, N * XW);
   cx->xb = cx_upload<float>(cx, nullptr, N * XW);
   cx->sum = cx_upload<float>(cx, nullptr, N * XW);
   cx->sum_rr0 = cx_upload<float>(cx, nullptr, (int64_t)n_rec * XW);
+  if (has_model && !c.conv_f16x3) cx->pre = cx_upload<float>(cx, nullptr, N * PRE_W);
   cx->pos_tmp = cx_upload<float>(cx, nullptr, Bm * n_lig * 3);
   cx->scores = cx_upload<float>(cx, nullptr, Bm * (6 + (d->n_rot > 0 ? d->n_rot : 1)));
   cx->scores2 = cx_upload<float>(cx, nullptr, Bm * (6 + (d->n_rot > 0 ? d->n_rot : 1)));
@@ -784,13 +803,16 @@ int ddk_randomize_position(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float
   return DDK_OK;
 }
 
-int ddk_pose_metrics(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* pos, const float* ref_pos, const uint8_t* atom_mask, float* out,
-                     void* stream) {
+int ddk_pose_metrics(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* pos, const float* ref_pos, const uint8_t* atom_mask,
+                     const int32_t* perms, int32_t n_perms, const float* rec_atom_pos, int32_t n_rec_atoms, float* out, void* stream) {
   if (!ctx) return DDK_ERR_INVALID;
   if (ctx->host_only) return fail(ctx, DDK_ERR_STATE, "host-only context (device < 0) cannot launch kernels");
   if (!cx || B < 1 || !pos || !ref_pos || !out) return fail(ctx, DDK_ERR_INVALID, "ddk_pose_metrics: bad complex / batch / null argument");
+  if ((perms != nullptr) != (n_perms > 0) || (rec_atom_pos != nullptr) != (n_rec_atoms > 0))
+    return fail(ctx, DDK_ERR_INVALID, "ddk_pose_metrics: perms / n_perms and rec_atom_pos / n_rec_atoms come in pairs");
   { hipError_t we = cx_wait_ready(cx, (hipStream_t)stream); if (we != hipSuccess) return hip_fail(ctx, we, "wait for the complex upload"); }
-  hipError_t e = launch_pose_metrics(pos, ref_pos, atom_mask, cx->rec_pos, B, cx->n_lig, cx->n_rec, out, (hipStream_t)stream);
+  hipError_t e = launch_pose_metrics(pos, ref_pos, atom_mask, perms, n_perms, rec_atom_pos ? rec_atom_pos : cx->rec_pos, B, cx->n_lig,
+                                     rec_atom_pos ? n_rec_atoms : cx->n_rec, out, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail(ctx, e, "pose_metrics launch");
   return DDK_OK;
 }

@@ -103,3 +103,54 @@ def load_complexes(path, mmap=True):
         c['mask_rotate'] = c['mask_rotate'].astype(bool)
         out.append(c)
     return out
+
+
+def complex_from_heterodata(g):
+    """One graph of the reference's ``heterographs.pkl`` (datasets_utils/pdbbind.py:101-117: PyG ``HeteroData`` built by
+    process_mols.py; any object with the same accessors works, including :class:`disco_diffdock_amd.data.HeteroData`) -> the
+    array dict :func:`save_complexes` / ``runtime.Complex`` / ``data.from_arrays`` take.  Runs on the reference side (where
+    torch_geometric can unpickle the file); nothing here imports PyG."""
+    def arr(t, dt):
+        if hasattr(t, 'detach'):
+            t = t.detach().cpu().numpy()
+        return np.ascontiguousarray(np.asarray(t), dtype=dt)
+    lig, rec = g['ligand'], g['receptor']
+    mr = lig.mask_rotate
+    while isinstance(mr, (list, tuple)):          # batch_size=1 loaders wrap it in a list (utils/sampling.py:57)
+        mr = mr[0]
+    n_lig = int(arr(lig.x, np.int64).shape[0])
+    name = getattr(g, 'name', 'complex')
+    while isinstance(name, (list, tuple)):
+        name = name[0]
+    c = dict(name=str(name),
+             lig_x=arr(lig.x, np.int32), lig_pos=arr(lig.pos, np.float32),
+             bond_index=arr(g['ligand', 'lig_bond', 'ligand'].edge_index, np.int32),
+             bond_attr=arr(g['ligand', 'lig_bond', 'ligand'].edge_attr, np.float32),
+             edge_mask=arr(lig.edge_mask, bool), mask_rotate=arr(mr, bool).reshape(-1, n_lig),
+             rec_x=arr(rec.x, np.float32), rec_pos=arr(rec.pos, np.float32),
+             rec_edge_index=arr(g['receptor', 'rec_contact', 'receptor'].edge_index, np.int32),
+             original_center=arr(getattr(g, 'original_center', np.zeros((1, 3))), np.float32).reshape(1, 3))
+    order = np.argsort(c['rec_edge_index'][0], kind='stable')      # ddk_complex_create wants the receptor edges grouped by row 0
+    c['rec_edge_index'] = np.ascontiguousarray(c['rec_edge_index'][:, order])
+    has_atoms = 'atom' in g if hasattr(g, '__contains__') else hasattr(g, 'atom')
+    if has_atoms and hasattr(g['atom'], 'x'):       # all-atom graphs of the confidence model (process_mols.py:474-477)
+        c.update(atom_x=arr(g['atom'].x, np.int32), atom_pos=arr(g['atom'].pos, np.float32),
+                 atom_edge_index=arr(g['atom', 'atom_contact', 'atom'].edge_index, np.int32),
+                 atom_rec_index=arr(g['atom', 'atom_rec_contact', 'receptor'].edge_index, np.int32))
+    return c
+
+
+def convert_heterographs(pkl_path, out_path):
+    """``heterographs.pkl`` (a pickled list of HeteroData, pdbbind.py:101-117) -> one DDKG file.  Needs the reference's environment
+    (torch_geometric) for ``pickle.load`` only."""
+    import pickle
+    with open(pkl_path, 'rb') as f:
+        graphs = pickle.load(f)
+    return save_complexes(out_path, [complex_from_heterodata(g) for g in graphs])
+
+
+if __name__ == '__main__':
+    import sys
+    if len(sys.argv) != 3:
+        raise SystemExit('usage: python -m disco_diffdock_amd.graph_cache <heterographs.pkl> <out.ddkg>')
+    print(convert_heterographs(sys.argv[1], sys.argv[2]), 'complexes written to', sys.argv[2])

@@ -330,14 +330,21 @@ class Complex:
         self.ctx._check(self.ctx.L.ddk_last_node_features(self.ctx.h, self.h, B, _ptr(lig), None, _stream()), 'ddk_last_node_features')
         return lig
 
-    def pose_metrics(self, pos, ref_pos, atom_mask=None):
-        """evaluate.py:297-338 for B poses: tensor [B,4] = rmsd, centroid distance, min cross distance, min self distance."""
+    def pose_metrics(self, pos, ref_pos, atom_mask=None, perms=None, rec_atom_pos=None):
+        """evaluate.py:297-338 for B poses: tensor [B,4] = rmsd, centroid distance, min cross distance, min self distance.
+        perms [K, n_lig] (int): graph automorphisms of the ligand -> symmetry-corrected RMSD (evaluate.py:308-310); None: uncorrected
+        (:313).  rec_atom_pos [n, 3]: receptor atom coordinates for the cross distance (default: the C-alpha coordinates)."""
         pos = pos.contiguous().float().reshape(-1, self.n_lig, 3)
         ref = ref_pos.contiguous().float().reshape(self.n_lig, 3).to(pos.device)
         m = None if atom_mask is None else atom_mask.to(pos.device).to(torch.uint8).contiguous()
+        pm = None if perms is None else torch.as_tensor(perms).to(pos.device).to(torch.int32).reshape(-1, self.n_lig).contiguous()
+        if pm is not None and (int(pm.min()) < 0 or int(pm.max()) >= self.n_lig):
+            raise RuntimeError('ddk: permutation table entries must be ligand atom indices')
+        ra = None if rec_atom_pos is None else torch.as_tensor(rec_atom_pos).to(pos.device).float().reshape(-1, 3).contiguous()
         out = torch.empty((pos.shape[0], 4), dtype=torch.float32, device=pos.device)
-        self.ctx._check(self.ctx.L.ddk_pose_metrics(self.ctx.h, self.h, pos.shape[0], _ptr(pos), _ptr(ref), _ptr(m), _ptr(out), _stream()),
-                        'ddk_pose_metrics')
+        self.ctx._check(self.ctx.L.ddk_pose_metrics(self.ctx.h, self.h, pos.shape[0], _ptr(pos), _ptr(ref), _ptr(m), _ptr(pm),
+                                                    0 if pm is None else pm.shape[0], _ptr(ra), 0 if ra is None else ra.shape[0], _ptr(out),
+                                                    _stream()), 'ddk_pose_metrics')
         return out
 
     def randomize_position(self, pos0, rot, tor=None, tr=None):

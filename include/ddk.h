@@ -193,14 +193,21 @@ int ddk_randomize_position(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float
 
 /* ---- pose metrics of evaluate.py:297-338 for B poses of one complex, one launch:
  *      out[b] = { rmsd, centroid_distance, min_cross_distance, min_self_distance } with
- *        rmsd = sqrt(mean_i |pos_i - ref_i|^2)                    (the symmetry-uncorrected fallback of evaluate.py:313)
+ *        rmsd = min over k < n_perms of sqrt(mean_i |pos[perms[k][i]] - ref[i]|^2)
+ *               = the symmetry-corrected RMSD of evaluate.py:308-310 (spyrmsd.rmsd.symmrmsd, no minimisation: the minimum over the
+ *               graph automorphisms of the ligand).  perms [n_perms, n_lig] int32 DEVICE: row k maps every ligand atom i to its image
+ *               (computed once per ligand on the caller's side, INTEGRATION.md shows the spyrmsd / networkx recipe; row 0 should be
+ *               the identity; entries of masked-out atoms are ignored).  perms = NULL, n_perms = 0: identity only = the uncorrected
+ *               fallback of evaluate.py:313.
  *        centroid_distance = |mean_i pos_i - mean_i ref_i|         (:315)
- *        min_cross_distance = min over residues r, atoms i of |rec_pos_r - pos_i|   (:331-332)
+ *        min_cross_distance = min over receptor points r, atoms i of |rec_r - pos_i|   (:331-332): rec_atom_pos [n_rec_atoms, 3] DEVICE,
+ *               the receptor ATOM coordinates the reference reads from the PDB file minus original_center; NULL, 0: the C-alpha
+ *               coordinates of the complex
  *        min_self_distance  = min over atom pairs i != j of |pos_i - pos_j|          (:333-335)
  *      all over the atoms with atom_mask[i] != 0 (filterHs, evaluate.py:297).  pos [B,n_lig,3], ref_pos [n_lig,3] (already minus
  *      original_center), atom_mask [n_lig] uint8 (NULL = all atoms), out [B,4]; all DEVICE pointers. */
 int ddk_pose_metrics(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* pos, const float* ref_pos, const uint8_t* atom_mask,
-                     float* out, void* stream);
+                     const int32_t* perms, int32_t n_perms, const float* rec_atom_pos, int32_t n_rec_atoms, float* out, void* stream);
 
 /* ---- a1-a2: the reverse-diffusion loop of sampling()  utils/sampling.py:105-198 for one batch:
  *      per step  perturb = score_coeff*score + noise_coeff*z  (coefficients are the host scalars of

@@ -32,9 +32,11 @@ def mfma(a, b, Dl):
     return out
 
 
-def emulate(ctx, layer, x_pad, src, dst, group_offsets, edge_attr, sh, mode=0, slots=None):
+def emulate(ctx, layer, x_pad, src, dst, group_offsets, edge_attr, sh, mode=0, slots=None, split=False):
     """returns sum[N, n_slots, XW] squeezed to [N, XW] when slots is None (pre-mean) in float64.
-    mode 1: l<=2 FCTP layer of the confidence model (9 groups, extra F parts); slots[g] = accumulator slot of group g."""
+    mode 1: l<=2 FCTP layer of the confidence model (9 groups, extra F parts); slots[g] = accumulator slot of group g.
+    split=True: the SPLIT kernel's GEMM1 (score model, gather mode): edge_attr[:, :24] is the edge embedding, the x[src][:24] / x[dst][:24]
+    columns are replaced by the packed per-node terms (conv.<l>.wn / bnp: node_finalize_pre_kernel) read in the accumulator's order."""
     N = x_pad.shape[0]
     n_groups = len(group_offsets) - 1
     n_slots = 1 if slots is None else max(slots) + 1
@@ -58,7 +60,26 @@ def emulate(ctx, layer, x_pad, src, dst, group_offsets, edge_attr, sh, mode=0, s
             kin = np.stack([24 * (s // 12) + 12 * HH + (s % 12) for s in range(36)], 1)   # [64,36]
             bin_ = edge_attr[e[:, None], kin]
             h = np.zeros((64, 36))
+            if split:
+                wn = ctx.export(f'conv.{layer}.wn').reshape(2, 4, NE, NS).astype(np.float64)
+                bnp = ctx.export(f'conv.{layer}.bnp').reshape(2, 4, NE).astype(np.float64)
+                recv_type, send_type = [0, 0, 1, 1][g], [0, 1, 1, 0][g]       # ligand atom = 0, residue = 1 (group order ll, lr, rr, rl)
+                ps = x_pad[sn][:, :NS] @ wn[recv_type, g & 1].T + bnp[recv_type, g & 1]          # [64, 72] in 'pos' order
+                pd = x_pad[dn][:, :NS] @ wn[send_type, 2 + (g >> 1)].T + bnp[send_type, 2 + (g >> 1)]
             for T in range(3):
+                if split:
+                    D = np.zeros((64, 16))
+                    nreg = 16 if T < 2 else 4
+                    for r in range(nreg):
+                        pos = 36 * HH + 16 * T + r
+                        D[:, r] = ps[LANES, pos] + pd[LANES, pos]
+                    for s in range(12):
+                        D = mfma(w1p[T, s // 4, :, s % 4], bin_[:, s], D)
+                    if T < 2:
+                        h[:, 16 * T:16 * T + 16] = np.maximum(D, 0)
+                    else:
+                        h[:, 32:36] = np.maximum(D[:, :4], 0)
+                    continue
                 D = b1p[T][HH]                                   # [64,16]
                 for s in range(36):
                     D = mfma(w1p[T, s // 4, :, s % 4], bin_[:, s], D)

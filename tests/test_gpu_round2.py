@@ -234,3 +234,41 @@ def test_ar_multinomial_decode_vs_oracle(dev):
         for j in range(2):
             k = int(ch[i, j])
             assert (got_l[i * n_l + k, j] if k < n_l else got_r[i * len(c['rec_pos']) + k - n_l, j]) == 1
+
+
+def test_pose_metrics_symmetry_corrected(dev, golden):
+    """f4: the reference's PRIMARY RMSD (evaluate.py:308-310, spyrmsd symmrmsd = minimum over the ligand's graph
+    automorphisms) from a caller-supplied permutation table, against a numpy minimum over the same permutations; K = 1 identity
+    reproduces the uncorrected value; min cross distance over receptor ATOM coordinates (evaluate.py:268-271,331-332)."""
+    from helpers import complex_from_npz
+    from disco_diffdock_amd.runtime import Complex
+    from disco_diffdock_amd.tensor_layers import _shape_context
+    c = complex_from_npz(golden('complex_diffdockS_score_model'))
+    B, n = 6, len(c['lig_pos'])
+    rng = np.random.default_rng(5)
+    ref = c['lig_pos'].astype(np.float32)
+    mask = rng.random(n) > 0.25
+    # automorphism-like table: identity + permutations that move kept atoms among kept atoms (as spyrmsd's isomorphisms of the H-free graph do)
+    kept = np.flatnonzero(mask)
+    perms = [np.arange(n)]
+    for _ in range(300):
+        pm = np.arange(n)
+        sub = rng.choice(kept, size=min(len(kept), int(rng.integers(2, 7))), replace=False)
+        pm[sub] = np.roll(sub, 1)
+        perms.append(pm)
+    perms = np.stack(perms).astype(np.int32)
+    # poses = the reference pose with a symmetry-equivalent relabelling + noise: the corrected RMSD must see through the relabelling
+    pos = np.stack([ref[np.argsort(perms[int(rng.integers(len(perms)))])] + rng.normal(0, 0.2, size=(n, 3)) for _ in range(B)]).astype(np.float32)
+    atoms = (c['rec_pos'][:, None, :] + rng.normal(0, 1.5, size=(len(c['rec_pos']), 5, 3))).reshape(-1, 3).astype(np.float32)
+    cx = Complex(_shape_context(0), c, max_batch=B)
+    got = cx.pose_metrics(T(pos).to(dev), T(ref), T(mask), perms=perms, rec_atom_pos=atoms).cpu().numpy()
+    d2 = ((pos[:, perms][:, :, mask] - ref[None, None, mask]) ** 2).sum(-1).mean(-1)       # [B, K]
+    want = np.sqrt(d2.min(1))
+    plain = np.sqrt(d2[:, 0])
+    assert (want < plain - 1e-3).any()                           # the correction matters on this input
+    assert np.allclose(got[:, 0], want, rtol=1e-5, atol=1e-6)
+    cross = np.linalg.norm(atoms[None, :, None, :] - pos[:, None, mask, :], axis=-1).min(axis=(1, 2))
+    assert np.allclose(got[:, 2], cross, rtol=1e-5, atol=1e-5)
+    ident = cx.pose_metrics(T(pos).to(dev), T(ref), T(mask), perms=perms[:1]).cpu().numpy()
+    none = cx.pose_metrics(T(pos).to(dev), T(ref), T(mask)).cpu().numpy()
+    assert np.array_equal(ident, none) and np.allclose(none[:, 0], plain, rtol=1e-5, atol=1e-6)

@@ -281,3 +281,25 @@ def test_strict_state_dict_key_set(lat):
     ref = smr.state_dict_spec(smr.ScoreModelConfig(**(lat or dict(latent_vocab=64))))
     assert {k: tuple(v) for k, v in spec.items()} == {k: tuple(v) for k, v in ref.items()}
     assert len(spec) == (176 if lat else 171)
+
+
+def test_heterographs_pickle_to_graph_cache(tmp_path):
+    """f4: the converter a maintainer runs on the reference side - a pickled list of HeteroData-like graphs
+    (datasets_utils/pdbbind.py:101-117) -> DDKG file -> the arrays the device path consumes; score-only and all-atom graphs."""
+    import pickle
+    from disco_diffdock_amd import synthetic, graph_cache
+    from disco_diffdock_amd.data import from_arrays
+    cs = [synthetic.make_complex(5, n_res=30, n_lig=17), synthetic.make_complex(6, n_res=25, n_lig=12)]
+    synthetic.add_receptor_atoms(cs[1], np.random.default_rng(1))
+    graphs = [from_arrays(c) for c in cs]
+    pkl, out = tmp_path / 'heterographs.pkl', tmp_path / 'graphs.ddkg'
+    with open(pkl, 'wb') as f:
+        pickle.dump(graphs, f)
+    assert graph_cache.convert_heterographs(str(pkl), str(out)) == 2
+    back = graph_cache.load_complexes(str(out))
+    for c, r in zip(cs, back):
+        keys = [k for k, _ in graph_cache._FIELDS] + ([k for k, _ in graph_cache._ATOM_FIELDS] if 'atom_x' in c else [])
+        assert ('atom_x' in r) == ('atom_x' in c)
+        for k in keys:
+            want = np.asarray(c[k])
+            assert np.array_equal(np.asarray(r[k]).astype(want.dtype if want.dtype != np.int64 else np.int32), want.astype(r[k].dtype)), k

@@ -93,6 +93,28 @@ def test_packing_by_lane_emulation(built, golden, l):
 
 
 @pytest.mark.parametrize('l', range(5))
+def test_gemm1_split_packing_by_lane_emulation(built, l):
+    """GEMM1 split (SURVEY.md §7.2; ConvLayerDev::wn): W1 [edge_emb | x[src][:24] | x[dst][:24]] with the two node parts taken from the packed
+    per-node terms in the accumulator's register order == the unsplit GEMM1, for every group's pair of (receiver, sender) role slots."""
+    from disco_diffdock_amd.runtime import Context
+    import emu_conv
+    P = smr.random_conv_layer_params(CFG, l, 77 + l, True)
+    ctx = Context(device=-1)
+    ctx.load_state_dict({f'conv_layers.{l}.{k}': v for k, v in P.items()})
+    rng = np.random.default_rng(l)
+    N, per = 14, 37                     # 37 edges per group: a full and a ragged 32-edge tile
+    x_pad = rng.normal(size=(N, 84))
+    src, dst = np.sort(rng.integers(0, N, size=4 * per).reshape(4, per), axis=1).reshape(-1), rng.integers(0, N, size=4 * per)
+    emb = rng.normal(size=(4 * per, 24))
+    edge_attr = np.concatenate([emb, x_pad[src][:, :24], x_pad[dst][:, :24]], 1)
+    sh = np.concatenate([np.ones((4 * per, 1)), rng.normal(size=(4 * per, 3))], 1)
+    offs = [per * k for k in range(5)]
+    full = emu_conv.emulate(ctx, l, x_pad, src, dst, offs, edge_attr, sh)
+    split = emu_conv.emulate(ctx, l, x_pad, src, dst, offs, edge_attr, sh, split=True)
+    assert np.abs(full).max() > 0.1 and np.abs(full - split).max() < 1e-9 * np.abs(full).max()
+
+
+@pytest.mark.parametrize('l', range(5))
 def test_confidence_layer_packing_by_lane_emulation(built, l):
     """l<=2 e3nn FullyConnectedTensorProduct layers of the confidence model: packed weights (instruction
     offsets, path coefficients, wigner constants, extra 1x2->1 rows) -> emulated wave algorithm == oracle conv layer."""

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof
 rm -rf "$OUT"; mkdir -p "$OUT"
-CMD="python $ROOT/bench.py --no-cpu-baseline --no-alt"   # the default timed region (8 steps, 2 warm-up) without the CPU leg and the opt-in pass
+CMD="python $ROOT/bench.py --no-cpu-baseline --no-alt --no-device-loop"   # the default timed region (8 steps, 2 warm-up) without the CPU leg and the opt-in pass
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- $CMD > "$OUT/trace.log" 2>&1
 i=0

@@ -86,8 +86,11 @@ static int build_layout(ddk_ctx* ctx, int mode, int l, ConvLayerDev& L, std::vec
   const ddk_config& c = ctx->cfg;
   const int ns = c.ns, nv = c.nv;
   const int seq[4][4] = {{ns, 0, 0, 0}, {ns, nv, 0, 0}, {ns, nv, nv, 0}, {ns, nv, nv, ns}};
-  const int* in = seq[l < 3 ? l : 3];
-  const int* out = seq[l + 1 < 3 ? l + 1 : 3];
+  // modes 2 / 3: the output heads as layouts of the same kernel (score_model.py:132-161: tor_bond_conv / final_conv read the full irreps);
+  // their "out" multiplicities are per FasterTensorProduct-style block (0e, 1o, 1e, 0o), the output columns are set below
+  const int head_out[2][4] = {{ns, 0, 0, ns}, {0, 2, 2, 0}};
+  const int* in = seq[(mode >= 2 || l >= 3) ? 3 : l];
+  const int* out = mode >= 2 ? head_out[mode - 2] : seq[l + 1 < 3 ? l + 1 : 3];
   for (int b = 0; b < 4; ++b) { L.in_mul[b] = in[b]; L.out_mul[b] = out[b]; }
   L.n_out[0] = out[0]; L.n_out[1] = out[1]; L.n_out[2] = out[2]; L.n_out[3] = out[3];
   L.din = in[0] + 3 * in[1] + 3 * in[2] + in[3];
@@ -118,6 +121,30 @@ static int build_layout(ddk_ctx* ctx, int mode, int l, ConvLayerDev& L, std::vec
     if (in[3]) parts[2].push_back({T_RA, F_C, -1, blk(2, in[1] + in[2], in[3])});                 // c (x) v
     if (in[2]) parts[3].push_back({T_RT, 0, 1, blk(3, 0, in[2])});                                // (q.v)/sqrt3
     if (in[3]) parts[3].push_back({T_RA, F_C, -1, blk(3, in[2], in[3])});                         // c * s0
+  } else if (mode == 2) {
+    // tor_bond_conv: e3nn FullyConnectedTensorProduct(84, sh (x) sh_2e, '24x0o + 24x0e') keeps two paths (score_model.py:152-156): 1o (x) T -> 0e
+    // (weights [nv][ns] at 0) and 1e (x) T -> 0o (at nv*ns), T = the 1o block of the full tensor product, path coefficient sqrt(1/nv) and
+    // w3j(1,1,0) = delta/sqrt3.  The kernel forms (p.v)/sqrt3 and (q.v)/sqrt3 with v := T (heads_pre_kernel puts T into the edge's sh), which
+    // leaves 1/sqrt(nv) for the packed weights.  Output columns: [0o | 0e].
+    for (int b = 0; b < 4; ++b) { L.n_in[b] = (b == 0 || b == 3) ? nv : 0; L.blk_off[b] = 0; }
+    L.W = 2 * nv * ns;
+    const float sc = 1.0f / sqrtf((float)nv);
+    parts[0].push_back({T_RT, 0, 0, rows_of(0, ns, nv, sc)});
+    parts[3].push_back({T_RT, 0, 1, rows_of(nv * ns, ns, nv, sc)});
+  } else if (mode == 3) {
+    // final_conv: FullyConnectedTensorProduct(84, 0e+1o, '2x1o + 2x1e'), weight blocks in instruction order (score_model.py:132-139):
+    //   A 0e(x)1o->1o [ns][2] | B 1o(x)0e->1o [nv][2] | C 1o(x)1o->1e [nv][2] | D 1e(x)0e->1e [nv][2] | E 1e(x)1o->1o [nv][2] | F 0o(x)1o->1e [ns][2]
+    // path coefficient sqrt(3 / (ns + 2 nv)) = 1/sqrt12 for both outputs; w3j(0,1,1) = w3j(1,0,1) = delta/sqrt3, w3j(1,1,1) = eps/sqrt6;
+    // the kernel's rows are a (x) v, p*s0, (q x v)/sqrt2 | (p x v)/sqrt2, q*s0, c (x) v  with s0 = 1, v = sh[1:4]
+    for (int b = 0; b < 4; ++b) { L.n_in[b] = (b == 1 || b == 2) ? ns + 2 * nv : 0; L.blk_off[b] = 0; }
+    L.W = 2 * 2 * (ns + 2 * nv);
+    const float pc = sqrtf(3.0f / (float)(ns + 2 * nv));
+    const float cS = pc * 0.57735026918962576451f, cX = pc * 0.40824829046386301637f * 1.41421356237309504880f;
+    const int oA = 0, oB = 2 * ns, oC = oB + 2 * nv, oD = oC + 2 * nv, oE = oD + 2 * nv, oF = oE + 2 * nv;
+    parts[1].push_back({T_RA, F_A, -1, rows_of(oA, 2, ns, cS)});
+    parts[1].push_back({T_TV, F_T1O, -1, cat(rows_of(oB, 2, nv, cS), rows_of(oE, 2, nv, cX))});
+    parts[2].push_back({T_TV, F_T1E, -1, cat(rows_of(oC, 2, nv, cX), rows_of(oD, 2, nv, cS))});
+    parts[2].push_back({T_RA, F_C, -1, rows_of(oF, 2, ns, cS)});
   } else {
     // irreps as (l, parity): node 0e,1o,1e,0o ; sh 0e,1o,2e
     const int nl[4] = {0, 1, 1, 0}, np_[4] = {+1, -1, +1, -1}, sl[3] = {0, 1, 2}, sp[3] = {+1, -1, +1};
@@ -167,7 +194,9 @@ static int build_layout(ddk_ctx* ctx, int mode, int l, ConvLayerDev& L, std::vec
     }
   }
 
-  const int oc[4] = {0, out[0], out[0] + 3 * out[1], out[0] + 3 * out[1] + 3 * out[2]};
+  int oc[4] = {0, out[0], out[0] + 3 * out[1], out[0] + 3 * out[1] + 3 * out[2]};
+  if (mode == 2) { oc[0] = ns; oc[3] = 0; L.dout = 2 * ns; }       // '24x0o + 24x0e': the 0o channels come first
+  if (mode == 3) { oc[1] = 0; oc[2] = 6; L.dout = 12; }
   struct TRow { int blk, col; RowSrc r[4]; bool ok[4]; };
   std::vector<TRow> trows;
   tiles.clear();
@@ -197,6 +226,19 @@ static int build_layout(ddk_ctx* ctx, int mode, int l, ConvLayerDev& L, std::vec
         }
       }
       tiles.back().w0 |= (vec ? FL_V : FL_S) << 2;
+    }
+  }
+  if (mode == 3) {
+    // final_conv has a handful of edge blocks (B * n_lig edges): the kernel's short-queue split hands out COLUMNS, so cut its two 9-tile columns
+    // into flush columns of two tiles (a flush adds the partial sums to the same output channels: the sum is what counts)
+    L.n_cols = 0;
+    for (int t = 0; t < (int)tiles.size(); ++t) {
+      const bool prev_flushes = t > 0 && ((tiles[t - 1].w0 >> 2) & 3) != FL_NONE;
+      if (t == 0 || prev_flushes || t - L.col_start[L.n_cols - 1] == 2) {
+        if (L.n_cols >= 16) return fail(ctx, DDK_ERR_INVALID, "too many output columns");
+        if (t > 0 && !prev_flushes) tiles[t - 1].w0 |= FL_V << 2;
+        L.col_start[L.n_cols++] = t;
+      }
     }
   }
   L.n_tiles = (int)tiles.size();
@@ -435,6 +477,64 @@ static int build_conv_layer(ddk_ctx* ctx, int mode, int l, ConvLayerDev& L) {
   return DDK_OK;
 }
 
+// tor_bond_conv (mode 2, radial MLP 72 -> 72 -> 288) and final_conv (mode 3, 48 -> 48 -> 144, zero padded to the kernel's 72-wide GEMMs)
+// packed like one edge group of a conv layer: the heads run through conv_fused_kernel<GATHER = false> on explicit edge attributes
+int build_head_layer(ddk_ctx* ctx, int mode, ConvLayerDev& L) {
+  std::vector<int> rowmap;
+  std::vector<float> rowscale;
+  std::vector<TileDesc> tiles;
+  int rc = build_layout(ctx, mode, 3, L, rowmap, rowscale, tiles);
+  if (rc) return rc;
+  L.n_groups = 1;
+  const std::string pre = mode == 2 ? "tor_bond_conv.fc" : "final_conv.fc";
+  const int kin = mode == 2 ? NE : 2 * NS;          // true width of the MLP's input and hidden layer
+  const HostTensor* W1 = find_w(ctx, pre + ".0.weight", {kin, kin});
+  const HostTensor* B1 = find_w(ctx, pre + ".0.bias", {kin});
+  const HostTensor* W2 = find_w(ctx, pre + ".4.weight", {L.W, kin});
+  const HostTensor* B2 = find_w(ctx, pre + ".4.bias", {L.W});
+  if (!W1 || !B1 || !W2 || !B2) return DDK_ERR_INVALID;
+  L.has_weights = true;
+  std::vector<float> w1(3 * 9 * 64 * 4, 0.f), b1(3 * 2 * 16, 0.f), w2((size_t)L.n_tiles * 9 * 64 * 4, 0.f), b2((size_t)L.n_tiles * 32, 0.f);
+  for (int T = 0; T < 3; ++T) {
+    for (int s = 0; s < 36; ++s)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int hidden = 32 * T + (lane & 31), k = kin_of(s, lane >> 5);
+        w1[(((size_t)T * 9 + s / 4) * 64 + lane) * 4 + (s & 3)] = (hidden < kin && k < kin) ? W1->data[(size_t)hidden * kin + k] : 0.f;
+      }
+    for (int hh = 0; hh < 2; ++hh)
+      for (int r = 0; r < 16; ++r) {
+        const int hidden = 32 * T + d_row(r, hh);
+        b1[(T * 2 + hh) * 16 + r] = hidden < kin ? B1->data[hidden] : 0.f;
+      }
+  }
+  for (int t = 0; t < L.n_tiles; ++t) {
+    for (int s = 0; s < 36; ++s)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int row = rowmap[(size_t)t * 32 + (lane & 31)], hd = hid_of(s, lane >> 5);
+        w2[(((size_t)t * 9 + s / 4) * 64 + lane) * 4 + (s & 3)] =
+            (row >= 0 && hd < kin) ? W2->data[(size_t)row * kin + hd] * rowscale[(size_t)t * 32 + (lane & 31)] : 0.f;
+      }
+    for (int hh = 0; hh < 2; ++hh)
+      for (int r = 0; r < 16; ++r) {
+        const int row = rowmap[(size_t)t * 32 + d_row(r, hh)];
+        b2[((size_t)t * 2 + hh) * 16 + r] = row >= 0 ? B2->data[row] * rowscale[(size_t)t * 32 + d_row(r, hh)] : 0.f;
+      }
+  }
+  L.h_w1p.assign(1, w1); L.h_b1p.assign(1, b1); L.h_w2p.assign(1, w2); L.h_b2p.assign(1, b2);
+  L.h_bn_mean.assign(XW, 0.f); L.h_bn_scale.assign(XW, 1.f); L.h_bn_bias.assign(XW, 0.f);
+  if (ctx->host_only) return DDK_OK;
+  std::vector<float> w2rec((size_t)L.n_tiles * W2_TILE_FLOATS);
+  for (int t = 0; t < L.n_tiles; ++t) {
+    float* rec = w2rec.data() + (size_t)t * W2_TILE_FLOATS;
+    memcpy(rec, w2.data() + (size_t)t * 2304, 2304 * sizeof(float));
+    memcpy(rec + 2304, b2.data() + (size_t)t * 32, 32 * sizeof(float));
+    memcpy(rec + 2336, &tiles[t], 2 * sizeof(int32_t));
+  }
+  L.w1p[0] = dev_upload(ctx, w1); L.b1p[0] = dev_upload(ctx, b1); L.w2r[0] = dev_upload(ctx, w2rec);
+  if (!L.w1p[0] || !L.b1p[0] || !L.w2r[0]) return fail(ctx, DDK_ERR_NOMEM, "device allocation failed while packing the head weights");
+  return DDK_OK;
+}
+
 int model_finalize(ddk_ctx* ctx);   // model.hip
 int conf_model_finalize(ddk_ctx* ctx);   // conf.hip
 void conf_model_destroy(ddk_ctx* ctx);
@@ -469,6 +569,10 @@ int ddk_create(const ddk_config* cfg, ddk_ctx** out) {
   ctx->n_cu = prop.multiProcessorCount;
   e = hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking);
   if (e != hipSuccess) return hip_fail(ctx, e, "hipStreamCreate (upload stream)");
+  e = hipStreamCreateWithFlags(&ctx->head_stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
+  if (e != hipSuccess) return hip_fail(ctx, e, "hipStreamCreate (head stream)");
   e = conv_prepare_device();
   if (e != hipSuccess) return hip_fail(ctx, e, "hipFuncSetAttribute(dynamic LDS)");
   ctx->ws.tile_info = (int32_t*)dev_alloc(ctx, 64 * sizeof(int32_t));
@@ -487,6 +591,9 @@ void ddk_destroy(ddk_ctx* ctx) {
     for (auto& c : ctx->chunk_pool) { if (c.free_after) hipEventDestroy(c.free_after); hipFree(c.p); }
     for (auto& b : ctx->stage_pool) { if (b.done) hipEventDestroy(b.done); hipHostFree(b.p); }
     if (ctx->up_stream) hipStreamDestroy(ctx->up_stream);
+    if (ctx->head_stream) hipStreamDestroy(ctx->head_stream);
+    if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
     for (void* p : ctx->dev_allocs) hipFree(p);
     if (ctx->ws.xpad) hipFree(ctx->ws.xpad);
     if (ctx->ws.sum) hipFree(ctx->ws.sum);
@@ -521,6 +628,13 @@ int ddk_finalize_weights(ddk_ctx* ctx) {
   for (int l = 0; l < ctx->cfg.num_conv_layers; ++l) {
     int rc = build_conv_layer(ctx, ctx->cfg.all_atoms ? 1 : 0, l, ctx->conv[l]);
     if (rc != DDK_OK) return rc;
+  }
+  // the score model's two heads as layouts of the fused conv kernel (also in host-only contexts: the CPU emulation tests read the packing)
+  ctx->head[0] = ConvLayerDev(); ctx->head[1] = ConvLayerDev();
+  if (!ctx->cfg.all_atoms && ctx->weights.find("final_conv.fc.0.weight") != ctx->weights.end()) {
+    int rch = build_head_layer(ctx, 3, ctx->head[1]);
+    if (rch == DDK_OK && !ctx->cfg.no_torsion) rch = build_head_layer(ctx, 2, ctx->head[0]);
+    if (rch != DDK_OK) return rch;
   }
   int rc = ctx->cfg.all_atoms ? conf_model_finalize(ctx) : model_finalize(ctx);
   if (rc != DDK_OK) return rc;
@@ -614,8 +728,10 @@ int64_t ddk_debug_export(ddk_ctx* ctx, const char* what, void* buf, int64_t cap_
   const void* src = nullptr;
   int64_t n = 0;
   if (sscanf(what, "conv.%d.%31[a-z0-9_].%d", &l, item, &g) >= 2) {
-    if (l < 0 || l >= (int)ctx->conv.size() || g < 0 || g >= ctx->conv[l].n_groups) return fail(ctx, DDK_ERR_INVALID, "bad export index");
-    ConvLayerDev& L = ctx->conv[l];
+    const bool head = (l == 100 || l == 101) && ctx->head[l - 100].n_tiles > 0;      // conv.100 = tor_bond_conv, conv.101 = final_conv layouts
+    if (!head && (l < 0 || l >= (int)ctx->conv.size())) return fail(ctx, DDK_ERR_INVALID, "bad export index");
+    ConvLayerDev& L = head ? ctx->head[l - 100] : ctx->conv[l];
+    if (g < 0 || g >= L.n_groups) return fail(ctx, DDK_ERR_INVALID, "bad export index");
     const std::string it(item);
     if (it == "w1p") { src = L.h_w1p[g].data(); n = L.h_w1p[g].size(); }
     else if (it == "b1p") { src = L.h_b1p[g].data(); n = L.h_b1p[g].size(); }

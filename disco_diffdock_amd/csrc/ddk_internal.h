@@ -155,6 +155,7 @@ struct ddk_ctx {
   int n_cu = 256;
   std::map<std::string, ddk::HostTensor> weights;
   std::vector<ddk::ConvLayerDev> conv;
+  ddk::ConvLayerDev head[2];      // [0] tor_bond_conv, [1] final_conv as layouts of the fused conv kernel (build_head_layer)
   std::vector<double> so3_table, torus_table;
   ddk::Workspace ws;
   std::vector<void*> dev_allocs;
@@ -164,6 +165,8 @@ struct ddk_ctx {
   // asynchronous complex upload (model.hip): a non-blocking upload stream, pinned staging buffers and a pool of device chunks, so
   // that ddk_complex_create / ddk_complex_destroy never synchronise with a sampling loop in flight on the compute stream
   hipStream_t up_stream = nullptr;
+  hipStream_t head_stream = nullptr;   // final_conv runs beside tor_bond_conv (two short launches that fill a fraction of the CUs each)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   struct StageBuf { char* p = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool in_flight = false; };
   std::vector<StageBuf> stage_pool;
   struct PoolChunk { void* p = nullptr; size_t cap = 0; hipEvent_t free_after = nullptr; };   // free_after: last use by the previous owner
@@ -213,6 +216,7 @@ struct ConvLaunch {
 };
 hipError_t launch_conv_fused(const ConvLayerDev& L, const ConvLaunch& a, int n_cu, hipStream_t s);
 hipError_t launch_conv_fused_h(const ConvLayerDev& L, const ConvLaunch& a, int n_cu, hipStream_t s);   // k_conv_h.hip (3 x f16)
+int build_head_layer(ddk_ctx* ctx, int mode, ConvLayerDev& L);      // ddk_capi.hip: mode 2 = tor_bond_conv, 3 = final_conv
 hipError_t conv_prepare_device();     // per-device kernel attributes (dynamic LDS opt-in), called by ddk_create
 hipError_t conv_prepare_device_h();   // k_conv_h.hip
 hipError_t launch_conv_setup(int32_t* tile_info, const int64_t* group_offsets_host, hipStream_t s);

@@ -187,6 +187,8 @@ __global__ void graph_scan_kernel(GraphArgs G, int64_t edge_cap) {
   G.info[I_E] = go[4];
   G.info[I_OVF] = ((int64_t)go[4] + n_shared > edge_cap) ? 1 : 0;
   G.info[I_SHARED] = G.shared_rr ? go[4] : -1;
+  G.info[I_HEAD] = 0; G.info[I_HEAD + 1] = G.B * G.n_lig; G.info[I_HEAD + 2] = G.B * G.n_lig; G.info[I_HEAD + 3] = G.B * G.n_lig;
+  G.info[I_HEAD + 4] = 0; G.info[I_HEAD + 5] = 0;
   G.info[I_EXEC] = go[4];
   G.info[I_EXEC + 1] = go[2];
   for (int k = 0; k < N_TAB; ++k) {

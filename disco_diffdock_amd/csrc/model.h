@@ -24,6 +24,8 @@ enum InfoSlot : int {
   I_SHARED = 26,  // first edge of the shared rec-rec copy (= go[4]; E_rr edges in sample-0 numbering, layer-0 de-duplication) or -1
   I_TAB = 32,     // group tables: [32 + 8k + g] = gbeg, [36 + 8k + g] = gend of table k (N_TAB tables)
   I_EXEC = 80,    // [80] = E, [81] = go[2] (edges of groups 0+1), [82 + k] = edges table k evaluates over all four groups
+  I_HEAD = 96,    // heads' edge list (k_heads.hip): [96] = 0, [97] = B*n_lig (centre edges), [98] = B*n_lig, [99] = end of the bond edges (atomic
+                  // cursor of heads_pre_kernel), [100], [101] = work-queue counters of the two head launches
   INFO_INTS = 128
 };
 // group tables: which rec-rec edges a layer evaluates
@@ -181,6 +183,9 @@ struct HeadArgs {
   float* tr_out;          // [B,3]
   float* rot_out;         // [B,3]
   float* tor_out;         // [B*R]
+  // the heads' own edge list [centre edges (B*n_lig) | bond-neighbour edges (<= B*R*32)] and accumulators [B graphs | B*R bonds] (ddk_complex)
+  int32_t *h_src, *h_dst, *h_deg, *h_info;
+  float *h_attr, *h_sh, *h_sum;
 };
 
 struct Se3Args {
@@ -226,7 +231,8 @@ struct NodeEmbedArgs {
   const float *lig_latent, *rec_latent, *lig_w_lat, *rec_w_lat, *lig_unc, *rec_unc; float unconditional; int latent_dim;
 };
 hipError_t launch_node_embed(const NodeEmbedArgs& a, hipStream_t s);
-hipError_t launch_heads(const HeadArgs& A, bool torsion, hipStream_t s);
+hipError_t launch_heads_pre(const HeadArgs& A, bool torsion, hipStream_t s);
+hipError_t launch_heads_post(const HeadArgs& A, bool torsion, hipStream_t s);
 hipError_t launch_se3(const Se3Args& A, hipStream_t s);
 hipError_t launch_cfg_combine(float* score, const float* uncond, float weight, int64_t n, hipStream_t s);
 
@@ -252,6 +258,8 @@ struct ddk_complex {
   float cfg_weight = 0.0f, cfg_start = 1.0f, cfg_end = 0.0f;   // ddk_set_guidance
   float *zero_lat = nullptr, *scores2 = nullptr;
   float* sum_rr0 = nullptr;   // [n_rec, XW] layer-0 rec-rec messages shared by all samples
+  int32_t *h_src = nullptr, *h_dst = nullptr, *h_deg = nullptr;      // heads' edge list and accumulators (k_heads.hip)
+  float *h_attr = nullptr, *h_sh = nullptr, *h_sum = nullptr;
   float* pre = nullptr;       // [N, PRE_W] per-node terms of the upcoming layer's GEMM1 (ddk_internal.h: ConvLayerDev::wn)
   float* x_last = nullptr;    // node features after the conv stack of the last forward
   int last_B = 0;

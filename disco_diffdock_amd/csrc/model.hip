@@ -527,11 +527,33 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
     CK(hipMemcpyAsync(prof_slot, cx->info + I_EXEC, PROF_INTS * sizeof(int32_t), hipMemcpyDeviceToHost, s), "profile edge counts");
     ctx->prof_slots += 1;
   }
+  // heads: both are tensor-product convolutions -> the fused conv kernel on their own small edge lists (k_heads.hip)
+  const bool torsion = !c.no_torsion && tor_out != nullptr && cx->R > 0;
   HeadArgs Hd;
   Hd.lig_pos = lig_pos; Hd.x = xin; Hd.md = M->dev; Hd.sp = sp; Hd.B = B; Hd.n_lig = n_lig; Hd.R = cx->R;
   Hd.scale_by_sigma = c.scale_by_sigma; Hd.rot_u = cx->rot_u; Hd.rot_v = cx->rot_v; Hd.lig_r2 = c.lig_max_radius * c.lig_max_radius;
   Hd.tr_out = tr_out; Hd.rot_out = rot_out; Hd.tor_out = tor_out;
-  CK(launch_heads(Hd, !c.no_torsion && tor_out != nullptr, s), "heads");
+  Hd.h_src = cx->h_src; Hd.h_dst = cx->h_dst; Hd.h_deg = cx->h_deg; Hd.h_info = cx->info + I_HEAD; Hd.h_attr = cx->h_attr; Hd.h_sh = cx->h_sh;
+  Hd.h_sum = cx->h_sum;
+  CK(launch_heads_pre(Hd, torsion, s), "heads_pre");
+  // final_conv on the context's side stream beside tor_bond_conv on the caller's stream (disjoint accumulator rows and work queues)
+  if (torsion) {
+    CK(hipEventRecord(ctx->ev_fork, s), "head fork");
+    CK(hipStreamWaitEvent(ctx->head_stream, ctx->ev_fork, 0), "head fork");
+  }
+  for (int hd = 1; hd >= (torsion ? 0 : 1); --hd) {       // final_conv (centre), then tor_bond_conv
+    ConvLaunch a;
+    a.x = xin; a.src = cx->h_src; a.dst = cx->h_dst; a.edge_attr = cx->h_attr; a.sh = cx->h_sh; a.sum = cx->h_sum;
+    a.tile_info = cx->info; a.counter = cx->info + I_HEAD + 4 + hd; a.gather = 0; a.pre = nullptr;
+    a.n_groups = 1; a.n_active = 1; a.n_slots = 1; a.slots = 0;
+    a.gbeg = cx->info + I_HEAD + (hd == 1 ? 0 : 2); a.gend = a.gbeg + 1;
+    CK(launch_conv_fused(ctx->head[hd], a, ctx->n_cu, (hd == 1 && torsion) ? ctx->head_stream : s), "conv_fused (head)");
+  }
+  if (torsion) {
+    CK(hipEventRecord(ctx->ev_join, ctx->head_stream), "head join");
+    CK(hipStreamWaitEvent(s, ctx->ev_join, 0), "head join");
+  }
+  CK(launch_heads_post(Hd, torsion, s), "heads_post");
 #undef CK
   return DDK_OK;
 }
@@ -576,7 +598,7 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
     const size_t E0 = (size_t)d->n_rec_edges, Bm0 = (size_t)max_batch, R0 = (size_t)(d->n_rot > 0 ? d->n_rot : 1);
     const size_t cap0 = Bm0 * ((size_t)M + (size_t)n_lig * (LIG_CAP - 1) + 2 * (size_t)n_lig * n_rec + E0) + E0 + 64, N0 = Bm0 * (size_t)(n_lig + n_rec);
     size_t need = (size_t)M * 24 + R0 * 8 + R0 * n_lig + (size_t)n_rec * 12 + (size_t)(n_lig + n_rec) * NS * 4 + E0 * (8 + NS * 4 + 16) + (size_t)n_rec * 4;
-    need += cap0 * (12 + NS * 4 + 16) + N0 * 4 + N0 * PRE_W * 4 + Bm0 * 2 * CNT_STRIDE * 4 + INFO_INTS * 4 + (size_t)n_rec * 4 + Bm0 * n_rec + 3 * N0 * XW * 4 + (size_t)n_rec * XW * 4 + Bm0 * n_lig * 12 + 2 * Bm0 * (6 + R0) * 4;
+    need += cap0 * (12 + NS * 4 + 16) + N0 * 4 + N0 * PRE_W * 4 + Bm0 * ((size_t)n_lig + R0 * BOND_CAP + 2) * (8 + NE * 4 + 16) + Bm0 * (1 + R0) * (XW * 4 + 4) + 8 * 256 + Bm0 * 2 * CNT_STRIDE * 4 + INFO_INTS * 4 + (size_t)n_rec * 4 + Bm0 * n_rec + 3 * N0 * XW * 4 + (size_t)n_rec * XW * 4 + Bm0 * n_lig * 12 + 2 * Bm0 * (6 + R0) * 4;
     if (c.latent_dim > 0) need += N0 * c.latent_dim * 4;
     cx_reserve(cx, need + 64 * 256);
     // everything uploaded below (topology, static embeddings, receptor-edge geometry) goes through one pinned staging buffer
@@ -703,6 +725,16 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
   cx->sum = cx_upload<float>(cx, nullptr, N * XW);
   cx->sum_rr0 = cx_upload<float>(cx, nullptr, (int64_t)n_rec * XW);
   if (has_model && !c.conv_f16x3) cx->pre = cx_upload<float>(cx, nullptr, N * PRE_W);
+  if (has_model) {      // heads (k_heads.hip): edge list [B*n_lig centre edges | <= B*R*BOND_CAP bond-neighbour edges], accumulators [B | B*R] rows
+    const int64_t Eh = Bm * ((int64_t)n_lig + (int64_t)(d->n_rot > 0 ? d->n_rot : 0) * BOND_CAP) + 64, Nh = Bm * (1 + (int64_t)(d->n_rot > 0 ? d->n_rot : 0));
+    cx->h_src = cx_upload<int32_t>(cx, nullptr, Eh);
+    cx->h_dst = cx_upload<int32_t>(cx, nullptr, Eh);
+    cx->h_attr = cx_upload<float>(cx, nullptr, Eh * NE);
+    cx->h_sh = cx_upload<float>(cx, nullptr, Eh * 4);
+    cx->h_deg = cx_upload<int32_t>(cx, nullptr, Nh);
+    cx->h_sum = cx_upload<float>(cx, nullptr, Nh * XW);
+    if (cx->h_sum) hipMemsetAsync(cx->h_sum, 0, (size_t)Nh * XW * sizeof(float), ctx->up_stream);
+  }
   cx->pos_tmp = cx_upload<float>(cx, nullptr, Bm * n_lig * 3);
   cx->scores = cx_upload<float>(cx, nullptr, Bm * (6 + (d->n_rot > 0 ? d->n_rot : 1)));
   cx->scores2 = cx_upload<float>(cx, nullptr, Bm * (6 + (d->n_rot > 0 ? d->n_rot : 1)));

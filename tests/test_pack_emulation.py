@@ -148,3 +148,69 @@ def test_confidence_layer_packing_by_lane_emulation(built, l):
         deg = np.bincount(ei[0, sl].numpy(), minlength=N)
         got = (summed[:, k] / np.maximum(deg, 1)[:, None] - bn_mean[k]) * bn_scale[k] + bn_bias[k]
         assert rel_err(got[:, :dout], want) < 5e-6, (l, k)
+
+
+def test_head_layouts_by_lane_emulation(built, tables):
+    """tor_bond_conv (12 tiles, W = 288) and final_conv (W = 144, MLP width 48 padded to 72) as layouts of the fused conv
+    kernel.  The packed tables (conv.100 / conv.101) driven through the lane-level emulation on the oracle's own head graphs and node
+    features must reproduce the oracle's e3nn-style FullyConnectedTensorProduct convolutions (scatter-mean, before BatchNorm)."""
+    from disco_diffdock_amd import synthetic
+    from disco_diffdock_amd.runtime import Context
+    from oracle import e3nn_lite as o3
+    from helpers import batch_of
+    import emu_conv
+    import torch.nn.functional as F
+    P = smr.random_state_dict(CFG, seed=19)
+    ctx = Context(device=-1)
+    ctx.load_state_dict(P)
+    assert len(ctx.export('conv.100.tiles', np.int32)) // 4 == 12 and len(ctx.export('conv.101.tiles', np.int32)) // 4 == 18
+    c = synthetic.make_complex(9, n_res=30, n_lig=18)
+    B, t = 2, 0.4
+    rng = np.random.default_rng(0)
+    pos = np.stack([c['lig_pos'] + rng.normal(0, 2.0, size=(1, 3)) for _ in range(B)]).astype(np.float32)
+    b = batch_of(c, B, pos)
+    from oracle import sampler_ref as spr
+    spr.set_time(b, t, t, t, B)
+    dt = torch.float64
+    P64 = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in P.items()}
+    for nt in ('ligand', 'receptor'):
+        b[nt].pos = b[nt].pos.to(dt)
+    lig, rec, tr_s, rot_s, tor_s, lig_sig, graph = smr.embed(P64, CFG, b, dt, True)
+    ns = CFG.ns
+    sh_irreps = o3.Irreps.spherical_harmonics(CFG.sh_lmax)
+    conv_out = CFG.conv_irreps(CFG.num_conv_layers - 1)[1]
+    x_pad = lig.numpy()
+    # ---- final_conv ----
+    ei, ea, esh = smr.build_center_conv_graph(b, CFG, lig_sig, dt)
+    ea = torch.cat([smr.mlp2(ea, P64, 'center_edge_embedding', 0, 3), lig[ei[1], :ns]], -1)
+    want = smr.tp_conv_layer(P64, 'final_conv', lig, ei, ea, esh, conv_out, sh_irreps, '2x1o + 2x1e', residual=False, batch_norm=False,
+                             faster=False, out_nodes=B).numpy()
+    attr72 = np.concatenate([ea.numpy(), np.zeros((ea.shape[0], 24))], 1)
+    got = emu_conv.emulate(ctx, 101, x_pad, ei[0].numpy(), ei[1].numpy(), [0, ei.shape[1]], attr72, esh.numpy())
+    got = got[:B, :12] / np.bincount(ei[0].numpy(), minlength=B)[:, None]
+    assert np.abs(want).max() > 1e-3 and rel_err(got, want) < 2e-6
+    # ---- tor_bond_conv ----
+    bonds, tei, tea, tesh = smr.build_bond_conv_graph(P64, b, CFG, dt)
+    bvec = b['ligand'].pos[bonds[1]] - b['ligand'].pos[bonds[0]]
+    tp_tor = o3.FullTensorProduct(sh_irreps, '2e')
+    full_sh = tp_tor(tesh, smr._sh(bvec, '2e')[tei[0]])
+    assert str(tp_tor.irreps_out[0].ir) == '1o'
+    Tvec = full_sh[:, :3].numpy()                        # the 1o block: what heads_pre_kernel writes into sh[1:4]
+    bond_attr = lig[bonds[0]] + lig[bonds[1]]
+    tattr = torch.cat([tea, lig[tei[1], :ns], bond_attr[tei[0], :ns]], -1)
+    want = smr.tp_conv_layer(P64, 'tor_bond_conv', lig, tei, tattr, full_sh, conv_out, tp_tor.irreps_out, f'{ns}x0o + {ns}x0e', residual=False,
+                             batch_norm=False, faster=False, out_nodes=bonds.shape[1]).numpy()
+    sh4 = np.concatenate([np.ones((len(Tvec), 1)), Tvec], 1)
+    got = emu_conv.emulate(ctx, 100, np.concatenate([x_pad, np.zeros((bonds.shape[1], 84))]), tei[0].numpy(), tei[1].numpy(), [0, tei.shape[1]],
+                           tattr.numpy(), sh4)
+    got = got[:bonds.shape[1], :2 * ns] / np.maximum(np.bincount(tei[0].numpy(), minlength=bonds.shape[1]), 1)[:, None]
+    assert np.abs(want).max() > 1e-3 and rel_err(got, want) < 2e-6
+    # the kernel's closed form of T (k_heads.hip) == the oracle's FullTensorProduct 1o block
+    s1 = tesh[:, 1:4].numpy()
+    bx, by, bz = (bvec / bvec.norm(dim=-1, keepdim=True))[tei[0]].numpy().T
+    s3, s5, ca, cb = np.sqrt(3.0), np.sqrt(5.0), 1 / np.sqrt(10.0), 1 / np.sqrt(30.0)
+    y0, y1, y2, y3, y4 = s5 * s3 * bx * bz, s5 * s3 * bx * by, s5 * (by * by - 0.5 * (bx * bx + bz * bz)), s5 * s3 * by * bz, s5 * (s3 * 0.5) * (bz * bz - bx * bx)
+    T0 = s3 * (-cb * s1[:, 0] * y2 - ca * s1[:, 0] * y4 + ca * s1[:, 1] * y1 + ca * s1[:, 2] * y0)
+    T1 = s3 * (ca * s1[:, 0] * y1 + 2.0 * cb * s1[:, 1] * y2 + ca * s1[:, 2] * y3)
+    T2 = s3 * (ca * s1[:, 0] * y0 + ca * s1[:, 1] * y3 - cb * s1[:, 2] * y2 + ca * s1[:, 2] * y4)
+    assert np.abs(np.stack([T0, T1, T2], 1) - Tvec).max() < 1e-12

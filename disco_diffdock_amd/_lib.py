@@ -18,7 +18,7 @@ class ddk_config(C.Structure):
                 ('tr_sigma_min', C.c_float), ('tr_sigma_max', C.c_float), ('rot_sigma_min', C.c_float),
                 ('rot_sigma_max', C.c_float), ('tor_sigma_min', C.c_float), ('tor_sigma_max', C.c_float),
                 ('device', C.c_int32), ('all_atoms', C.c_int32), ('num_confidence_outputs', C.c_int32),
-                ('confidence_no_batchnorm', C.c_int32), ('conv_f16x3', C.c_int32)]
+                ('confidence_no_batchnorm', C.c_int32), ('conv_f16x3', C.c_int32), ('deterministic', C.c_int32)]
 
 
 class ddk_complex_desc(C.Structure):

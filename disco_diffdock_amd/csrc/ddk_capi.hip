@@ -228,7 +228,7 @@ static int build_layout(ddk_ctx* ctx, int mode, int l, ConvLayerDev& L, std::vec
       tiles.back().w0 |= (vec ? FL_V : FL_S) << 2;
     }
   }
-  if (mode == 3) {
+  if (mode == 3 && !ctx->cfg.deterministic) {      // (the deterministic scatter STORES: every output channel must be flushed exactly once)
     // final_conv has a handful of edge blocks (B * n_lig edges): the kernel's short-queue split hands out COLUMNS, so cut its two 9-tile columns
     // into flush columns of two tiles (a flush adds the partial sums to the same output channels: the sum is what counts)
     L.n_cols = 0;
@@ -557,6 +557,8 @@ int ddk_create(const ddk_config* cfg, ddk_ctx** out) {
     return fail(ctx, DDK_ERR_INVALID, "num_conv_layers must be in [4,16] (heads assume the full 0e+1o+1e+0o irreps)");
   if (cfg->sigma_embed_dim != 32 || cfg->distance_embed_dim != 32 || cfg->cross_distance_embed_dim != 32)
     return fail(ctx, DDK_ERR_INVALID, "only 32-wide sigma / distance embeddings are compiled in");
+  if (cfg->deterministic && (cfg->conv_f16x3 || cfg->all_atoms))
+    return fail(ctx, DDK_ERR_INVALID, "deterministic scatter is implemented for the fp32 score model (not with conv_f16x3 / all_atoms)");
   if (cfg->device < 0) {
     ctx->host_only = true;   // packing-only context (CPU tests); every launch entry point refuses to run
     return DDK_OK;

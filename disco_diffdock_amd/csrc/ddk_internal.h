@@ -198,6 +198,8 @@ struct ConvLaunch {
   float* sum;                // [N_out, XW] fp32 accumulators (zeroed by the caller)
   const int32_t* tile_info;  // device: tile_start[5], group_off[5]
   int32_t* counter;          // device tile counter (zeroed by the caller)
+  float* part = nullptr;        // deterministic mode (ddk_config.deterministic): [edge_bound / 32 + 8][2][XW] partial rows; null: fp32 atomics
+  int64_t edge_bound = 0;       // host upper bound of the last edge index of the launch (sizes the fix-up grid)
   const float* pre = nullptr;   // [N, PRE_W] node terms of GEMM1 (gather mode, score model) or null: GEMM1 over all 72 inputs
   int gather;                // 1: edge_attr is edge_emb[E,24] and x[src][:24], x[dst][:24] are gathered
   // layer-0 receptor-receptor de-duplication (all samples of a batch share the receptor and, before the first conv,
@@ -226,7 +228,7 @@ hipError_t launch_count_deg(const int32_t* src, int64_t E, int32_t* deg, hipStre
 // node_finalize of layer l fused with the node terms of layer l+1's GEMM1 (x_in == null, sum == null: the node terms of `x_out` alone)
 struct NodePreArgs {
   float* sum; const int32_t* deg; const float* x_in; const float* bn_mean; const float* bn_scale; const float* bn_bias;
-  int dout; float* x_out; const float* sum_rr0; int n_lig_total, n_rec_total, n_rec; float* zero_extra; int64_t n_extra;
+  int dout; float* x_out; const float* sum_rr0; int n_lig_total, n_rec_total, n_rec; float* zero_extra; int64_t n_extra; int n_slots;
   const float* wn; const float* bnp; float* pre;
 };
 hipError_t launch_node_finalize_pre(const NodePreArgs& a, bool finalize, hipStream_t s);
@@ -234,7 +236,7 @@ hipError_t launch_node_finalize(float* sum, const int32_t* deg, const float* x_i
                                 const float* bn_mean, const float* bn_scale, const float* bn_bias, int64_t n, int dout,
                                 int out_stride, float* out, hipStream_t s, const float* sum_rr0 = nullptr,
                                 int64_t n_lig_total = 0, int n_rec = 1, int clear_sum = 0, float* zero_extra = nullptr,
-                                int64_t n_extra = 0);
+                                int64_t n_extra = 0, int n_slots = 1);
 // k_tp.hip
 hipError_t launch_tp_forward(const ConvLayerDev& L, const float* x_dst, const float* sh, const float* w, int64_t E,
                              float* out, hipStream_t s);

@@ -77,9 +77,10 @@ __device__ __forceinline__ void lds_frags(float4 (&a)[9], f32x16& B, const float
 
 // SPLIT (score model, gather mode): the x[src][:ns] / x[dst][:ns] columns of GEMM1 are per-NODE terms computed once per layer
 // (node_finalize_pre_kernel below); GEMM1 here contracts the 24 edge-embedding inputs only and starts from their sum (K 72 -> 24)
-template <bool GATHER, int MODE, bool SPLIT>
+template <bool GATHER, int MODE, bool SPLIT, bool DET>
 __global__ __launch_bounds__(64 * ConvTraits<MODE>::WAVES) void conv_fused_kernel(ConvKArgs A) {
   static_assert(!SPLIT || (GATHER && MODE == 0), "the GEMM1 split exists for the score model's gather path");
+  static_assert(!DET || MODE == 0, "the deterministic scatter exists for the score model");
   constexpr int WAVES = ConvTraits<MODE>::WAVES, FS = ConvTraits<MODE>::FS, BLOCK_EDGES = 32 * WAVES;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -325,8 +326,19 @@ __global__ __launch_bounds__(64 * ConvTraits<MODE>::WAVES) void conv_fused_kerne
     __syncthreads();   // ring stages 0/1 and the F rows are visible
 
     // ---- GEMM2 over the W2 tiles + fused tensor-product epilogue ----
-    float* const node_row = (g2_shared && g == 2) ? A.sum_g2 + (size_t)(sn - A.g2_node_off) * XW
-                                                  : A.sum + ((size_t)sn * A.n_slots + ((A.slots >> (2 * g)) & 3)) * XW;
+    float* node_row = (g2_shared && g == 2) ? A.sum_g2 + (size_t)(sn - A.g2_node_off) * XW
+                                            : A.sum + ((size_t)sn * A.n_slots + ((A.slots >> (2 * g)) & 3)) * XW;
+    if constexpr (DET) {
+      // runs of equal edge_src are contiguous inside a group: only the tile's first / last run can continue in the neighbouring tile
+      if (nvalid > 0) {
+        const int sn0 = __shfl(sn, 0, 32), snl = __shfl(sn, nvalid - 1, 32);
+        const bool first_cont = e0 > gbeg && A.src[e0 - 1] == sn0;
+        const bool last_cont = e0 + nvalid < gend && A.src[e0 + nvalid] == snl;
+        float* prow = A.part + ((size_t)(blk * WAVES + wave) * 2) * XW;    // this tile's two partial rows (tile id = global block index x 8 + wave)
+        if (sn == sn0 && first_cont) node_row = prow;
+        else if (sn == snl && last_cont) node_row = prow + XW;
+      }
+    }
     f32x2 accA[4], accV[4][3];
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) { accA[rq] = 0.0f; accV[rq][0] = 0.0f; accV[rq][1] = 0.0f; accV[rq][2] = 0.0f; }
@@ -368,13 +380,13 @@ __global__ __launch_bounds__(64 * ConvTraits<MODE>::WAVES) void conv_fused_kerne
         _Pragma("unroll") for (int rq = 0; rq < 4; ++rq) {                                                     \
           if (rq < nrq) {                                                                                      \
             if (fl == FL_S) {                                                                                  \
-              seg_add(node_row + chan0 + 2 * rq + hh, fmaf(PSUM(accA[rq]), s0, PSUM(accV[rq][0])), seg);       \
+              seg_add<DET>(node_row + chan0 + 2 * rq + hh, fmaf(PSUM(accA[rq]), s0, PSUM(accV[rq][0])), seg);       \
             } else {                                                                                           \
               float* d = node_row + chan0 + 3 * (2 * rq + hh);                                                 \
               const float sa = PSUM(accA[rq]);                                                                 \
-              seg_add(d + 0, fmaf(sa, vx, PSUM(accV[rq][0])), seg);                                            \
-              seg_add(d + 1, fmaf(sa, vy, PSUM(accV[rq][1])), seg);                                            \
-              seg_add(d + 2, fmaf(sa, vz, PSUM(accV[rq][2])), seg);                                            \
+              seg_add<DET>(d + 0, fmaf(sa, vx, PSUM(accV[rq][0])), seg);                                            \
+              seg_add<DET>(d + 1, fmaf(sa, vy, PSUM(accV[rq][1])), seg);                                            \
+              seg_add<DET>(d + 2, fmaf(sa, vz, PSUM(accV[rq][2])), seg);                                            \
             }                                                                                                  \
           }                                                                                                    \
           accA[rq] = 0.0f; accV[rq][0] = 0.0f; accV[rq][1] = 0.0f; accV[rq][2] = 0.0f;                         \
@@ -446,7 +458,7 @@ __global__ void count_deg_kernel(const int32_t* src, int64_t E, int32_t* deg) {
 __global__ void node_finalize_kernel(float* sum, const int32_t* deg, const float* x_in, const float* bn_mean,
                                      const float* bn_scale, const float* bn_bias, int64_t n, int dout, int out_stride,
                                      float* out, const float* sum_rr0, int64_t n_lig_total, int n_rec, int clear_sum,
-                                     float* zero_extra, int64_t n_extra) {
+                                     float* zero_extra, int64_t n_extra, int n_slots) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (zero_extra != nullptr && i < n_extra) zero_extra[i] = 0.0f;
   if (i >= n * out_stride) return;
@@ -455,8 +467,11 @@ __global__ void node_finalize_kernel(float* sum, const int32_t* deg, const float
   float v = 0.0f;
   if (c < dout) {
     const int d = deg[r];
-    float sv = sum[r * XW + c];
-    if (clear_sum) sum[r * XW + c] = 0.0f;
+    float sv = 0.0f;
+    for (int sl = 0; sl < n_slots; ++sl) {      // deterministic mode keeps one accumulator per (node, receiving group): added in group order
+      sv += sum[(r * n_slots + sl) * XW + c];
+      if (clear_sum) sum[(r * n_slots + sl) * XW + c] = 0.0f;
+    }
     if (sum_rr0 != nullptr && r >= n_lig_total) sv += sum_rr0[((r - n_lig_total) % n_rec) * XW + c];   // shared layer-0 rec-rec messages
     v = sv / (float)(d > 1 ? d : 1);
     v = (v - bn_mean[c]) * bn_scale[c] + bn_bias[c];
@@ -499,8 +514,11 @@ __global__ __launch_bounds__(PRE_W) void node_finalize_pre_kernel(NodePreArgs A)
       float v = 0.0f;
       if (c < A.dout) {
         const int d = A.deg[r];
-        float sv = A.sum[r * XW + c];
-        A.sum[r * XW + c] = 0.0f;             // every accumulator that is read is cleared behind the read (see node_finalize_kernel)
+        float sv = 0.0f;
+        for (int sl = 0; sl < A.n_slots; ++sl) {
+          sv += A.sum[(r * A.n_slots + sl) * XW + c];
+          A.sum[(r * A.n_slots + sl) * XW + c] = 0.0f;      // every accumulator that is read is cleared behind the read (see node_finalize_kernel)
+        }
         if (A.sum_rr0 != nullptr && !lig) sv += A.sum_rr0[((r - A.n_lig_total) % A.n_rec) * XW + c];
         v = sv / (float)(d > 1 ? d : 1);
         v = (v - A.bn_mean[c]) * A.bn_scale[c] + A.bn_bias[c];
@@ -539,16 +557,16 @@ hipError_t launch_node_finalize_pre(const NodePreArgs& a, bool finalize, hipStre
   return hipGetLastError();
 }
 
-template <bool GATHER, int MODE, bool SPLIT>
+template <bool GATHER, int MODE, bool SPLIT, bool DET = false>
 static hipError_t launch_conv_t(const ConvKArgs& k, int n_cu, hipStream_t s) {
   // one persistent workgroup per CU (its F rows + the W2 ring fill the LDS), dynamic block queue
-  hipLaunchKernelGGL((conv_fused_kernel<GATHER, MODE, SPLIT>), dim3(n_cu), dim3(64 * ConvTraits<MODE>::WAVES), conv_lds_bytes<MODE>(), s, k);
+  hipLaunchKernelGGL((conv_fused_kernel<GATHER, MODE, SPLIT, DET>), dim3(n_cu), dim3(64 * ConvTraits<MODE>::WAVES), conv_lds_bytes<MODE>(), s, k);
   return hipGetLastError();
 }
 
-template <bool GATHER, int MODE, bool SPLIT>
+template <bool GATHER, int MODE, bool SPLIT, bool DET = false>
 static hipError_t conv_attr_t() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fused_kernel<GATHER, MODE, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fused_kernel<GATHER, MODE, SPLIT, DET>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)conv_lds_bytes<MODE>());
 }
 
@@ -560,8 +578,49 @@ hipError_t conv_prepare_device() {
   if (e == hipSuccess) e = conv_attr_t<false, 0, false>();
   if (e == hipSuccess) e = conv_attr_t<true, 1, false>();
   if (e == hipSuccess) e = conv_attr_t<false, 1, false>();
+  if (e == hipSuccess) e = conv_attr_t<true, 0, true, true>();
+  if (e == hipSuccess) e = conv_attr_t<false, 0, false, true>();
   if (e == hipSuccess) e = conv_prepare_device_h();
   return e;
+}
+
+// deterministic mode, after a conv launch: fold the partial rows of every run that straddles 32-edge tiles, in tile order, into the run's
+// accumulator row.  One wave per tile; the wave whose tile holds the START of a straddling run walks the chain.
+__global__ __launch_bounds__(256) void conv_det_fix_kernel(ConvKArgs A, int dout) {
+  const int lane = threadIdx.x & 63;
+  int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int g = 0, gb = 0, ge = 0, bstart = 0;                 // bstart: first 256-edge block of the group in the launch's work queue
+  for (; g < A.n_active; ++g) {
+    gb = A.gbeg[g]; ge = A.gend[g];
+    const int nt = (ge - gb + 31) / 32;
+    if (tile < nt) break;
+    tile -= nt;
+    bstart += (ge - gb + CONV_BLOCK_EDGES - 1) / CONV_BLOCK_EDGES;
+  }
+  if (g >= A.n_active) return;
+  auto prow_of = [&](int t, int which) { return A.part + ((size_t)((bstart + t / CONV_WAVES) * CONV_WAVES + t % CONV_WAVES) * 2 + which) * XW; };
+  int e0 = gb + 32 * tile;
+  int n = min(32, ge - e0);
+  const int s_last = A.src[e0 + n - 1];
+  if (!(e0 + n < ge && A.src[e0 + n] == s_last)) return;                         // the last run ends here
+  if (A.src[e0] == s_last && e0 > gb && A.src[e0 - 1] == s_last) return;          // ... and did not start here: not the head of its chain
+  float acc0 = 0.0f, acc1 = 0.0f;
+  const float* prow = prow_of(tile, 1);
+  if (lane < dout) acc0 = prow[lane];
+  if (lane + 64 < dout) acc1 = prow[lane + 64];
+  for (;;) {
+    ++tile;
+    e0 += 32;
+    n = min(32, ge - e0);
+    prow = prow_of(tile, 0);
+    if (lane < dout) acc0 += prow[lane];
+    if (lane + 64 < dout) acc1 += prow[lane + 64];
+    if (!(A.src[e0 + n - 1] == s_last && e0 + n < ge && A.src[e0 + n] == s_last)) break;   // the run ends inside this tile
+  }
+  float* row = (A.sum_g2 != nullptr && g == 2) ? A.sum_g2 + (size_t)(s_last - A.g2_node_off) * XW
+                                               : A.sum + ((size_t)s_last * A.n_slots + ((A.slots >> (2 * g)) & 3)) * XW;
+  if (lane < dout) row[lane] = acc0;
+  if (lane + 64 < dout) row[lane + 64] = acc1;
 }
 
 hipError_t launch_conv_fused(const ConvLayerDev& L, const ConvLaunch& a, int n_cu, hipStream_t s) {
@@ -578,7 +637,16 @@ hipError_t launch_conv_fused(const ConvLayerDev& L, const ConvLaunch& a, int n_c
   k.n_groups = a.n_groups; k.n_active = a.n_active; k.n_slots = a.n_slots; k.slots = a.slots;
   if (a.gbeg) { k.gbeg = a.gbeg; k.gend = a.gend; }
   else { k.gbeg = a.tile_info + 5; k.gend = a.tile_info + 6; }   // 4 contiguous groups go[g] .. go[g+1] (explicit-boundary entry point)
-  k.pre = a.pre;
+  k.pre = a.pre; k.part = a.part;
+  if (a.part != nullptr) {       // deterministic scatter (score model paths only)
+    if (a.mode != 0 || L.w2h != nullptr) return hipErrorInvalidValue;
+    hipError_t e = (a.gather && a.pre != nullptr) ? launch_conv_t<true, 0, true, true>(k, n_cu, s)
+                                                  : (!a.gather ? launch_conv_t<false, 0, false, true>(k, n_cu, s) : hipErrorInvalidValue);
+    if (e != hipSuccess) return e;
+    const int64_t tiles = a.edge_bound / 32 + 8 * CONV_MAX_GROUPS;
+    hipLaunchKernelGGL(conv_det_fix_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s, k, L.dout);
+    return hipGetLastError();
+  }
   if (a.mode == 1) return a.gather ? launch_conv_t<true, 1, false>(k, n_cu, s) : launch_conv_t<false, 1, false>(k, n_cu, s);
   if (a.gather && a.pre != nullptr) return launch_conv_t<true, 0, true>(k, n_cu, s);
   return a.gather ? launch_conv_t<true, 0, false>(k, n_cu, s) : launch_conv_t<false, 0, false>(k, n_cu, s);
@@ -611,12 +679,12 @@ hipError_t launch_count_deg(const int32_t* src, int64_t E, int32_t* deg, hipStre
 hipError_t launch_node_finalize(float* sum, const int32_t* deg, const float* x_in, const float* bn_mean,
                                 const float* bn_scale, const float* bn_bias, int64_t n, int dout, int out_stride,
                                 float* out, hipStream_t s, const float* sum_rr0, int64_t n_lig_total, int n_rec, int clear_sum,
-                                float* zero_extra, int64_t n_extra) {
+                                float* zero_extra, int64_t n_extra, int n_slots) {
   int64_t tot = n * out_stride;
   if (zero_extra != nullptr && n_extra > tot) tot = n_extra;
   if (tot == 0) return hipSuccess;
   hipLaunchKernelGGL(node_finalize_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, sum, deg, x_in, bn_mean,
-                     bn_scale, bn_bias, n, dout, out_stride, out, sum_rr0, n_lig_total, n_rec, clear_sum, zero_extra, n_extra);
+                     bn_scale, bn_bias, n, dout, out_stride, out, sum_rr0, n_lig_total, n_rec, clear_sum, zero_extra, n_extra, n_slots);
   return hipGetLastError();
 }
 

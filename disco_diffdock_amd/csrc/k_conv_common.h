@@ -26,6 +26,7 @@ struct ConvKArgs {
   int n_tiles;
   int n_cols;         // flush columns; col_start[c] .. col_start[c+1] = tiles of column c
   int col_start[17];
+  float* part;        // deterministic mode: [tiles][2][XW] partial rows of the runs that straddle a 32-edge tile (see seg_add)
   float* sum_g2;      // != null: group 2 is the shared rec-rec copy; its messages go to sum_g2[(src - g2_node_off)] (see ConvLaunch)
   int g2_node_off;
   int n_groups, n_active, n_slots;   // edge groups [gbeg[g], gend[g]); the first n_active run; sum row = (node*n_slots + slot(g))
@@ -85,6 +86,10 @@ __device__ __forceinline__ void tile_epilogue(int kind, const f32x16& D, f32x4 f
 
 // control words of the 5-step segmented scan over runs of equal edge_src (identical for every channel of an edge tile)
 struct SegCtl { bool m1, m2, m4, m8, m16, tail, valid; };
+// DET: the run tail STORES (every (node, accumulator slot, channel) has exactly one writer per launch: complete runs write the node row,
+// runs that straddle a 32-edge tile write that tile's partial row and conv_det_fix_kernel folds the chain in tile order) instead of
+// adding atomically - a fixed summation order per node (ddk_config.deterministic)
+template <bool DET = false>
 __device__ __forceinline__ void seg_add(float* dst, float xv, const SegCtl& c) {
   xv = c.valid ? xv : 0.0f;
   float up;
@@ -93,7 +98,10 @@ __device__ __forceinline__ void seg_add(float* dst, float xv, const SegCtl& c) {
   up = __shfl_up(xv, 4, 32);  if (c.m4) xv += up;
   up = __shfl_up(xv, 8, 32);  if (c.m8) xv += up;
   up = __shfl_up(xv, 16, 32); if (c.m16) xv += up;
-  if (c.tail) unsafeAtomicAdd(dst, xv);
+  if (c.tail) {
+    if (DET) *dst = xv;
+    else unsafeAtomicAdd(dst, xv);
+  }
 }
 
 

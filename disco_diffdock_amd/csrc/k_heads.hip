@@ -119,7 +119,12 @@ __global__ __launch_bounds__(256) void heads_pre_kernel(HeadArgs A, int n_tor_bl
     }
     if (tid == 0) {
       s_cnt = cnt < BOND_CAP ? cnt : BOND_CAP;
-      s_base = atomicAdd(A.h_info + 3, s_cnt);       // this bond's contiguous edge range (the order of the bonds in the list is irrelevant)
+      if (A.deterministic) {      // fixed ranges of BOND_CAP edges per bond (the unused tail becomes null edges): the same tiles every run
+        s_base = A.B * n + (int)blockIdx.x * BOND_CAP;
+        if (blockIdx.x == 0) A.h_info[3] = A.B * n + n_tor_blocks * BOND_CAP;
+      } else {
+        s_base = atomicAdd(A.h_info + 3, s_cnt);     // this bond's contiguous edge range (the order of the bonds in the list is irrelevant)
+      }
       A.h_deg[blockIdx.x] = s_cnt;
     }
   }
@@ -131,9 +136,20 @@ __global__ __launch_bounds__(256) void heads_pre_kernel(HeadArgs A, int n_tor_bl
   const float d = sqrtf(vx * vx + vy * vy + vz * vz);
   float e3[3];
   edge_embed8(A.md.final_edge, A.md.final_edge_b1, d, act, el, p, e3);
-  if (!live) return;
   const int e = s_base + el;
   float* at = A.h_attr + (size_t)e * NE;
+  if (!live) {
+    if (A.deterministic) {      // null edge: zero attributes and sh, accumulates into the scratch row behind the bonds' rows
+#pragma unroll
+      for (int q = 0; q < 9; ++q) at[9 * p + q] = 0.0f;
+      if (p == 0) {
+        *reinterpret_cast<float4*>(A.h_sh + (size_t)e * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        A.h_src[e] = A.B + n_tor_blocks;
+        A.h_dst[e] = b * n + u;
+      }
+    }
+    return;
+  }
   const float* xk = A.x + ((size_t)b * n + k) * XW;
   const float* xu = A.x + ((size_t)b * n + u) * XW;
   const float* xv = A.x + ((size_t)b * n + v) * XW;

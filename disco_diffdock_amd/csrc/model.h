@@ -186,6 +186,7 @@ struct HeadArgs {
   // the heads' own edge list [centre edges (B*n_lig) | bond-neighbour edges (<= B*R*32)] and accumulators [B graphs | B*R bonds] (ddk_complex)
   int32_t *h_src, *h_dst, *h_deg, *h_info;
   float *h_attr, *h_sh, *h_sum;
+  int deterministic;      // 1: fixed-stride bond edge ranges (BOND_CAP per bond, padded with null edges into a scratch row) instead of an atomic cursor
 };
 
 struct Se3Args {
@@ -257,6 +258,7 @@ struct ddk_complex {
   float unconditional = 0.0f;
   float cfg_weight = 0.0f, cfg_start = 1.0f, cfg_end = 0.0f;   // ddk_set_guidance
   float *zero_lat = nullptr, *scores2 = nullptr;
+  float* part = nullptr;      // deterministic mode: partial rows of the conv launches (ConvLaunch::part)
   float* sum_rr0 = nullptr;   // [n_rec, XW] layer-0 rec-rec messages shared by all samples
   int32_t *h_src = nullptr, *h_dst = nullptr, *h_deg = nullptr;      // heads' edge list and accumulators (k_heads.hip)
   float *h_attr = nullptr, *h_sh = nullptr, *h_sum = nullptr;

@@ -457,12 +457,12 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
   if (split) {
     NodePreArgs PA = {};
     PA.x_out = xin; PA.n_lig_total = B * n_lig; PA.n_rec_total = B * n_rec; PA.n_rec = n_rec;
-    PA.wn = ctx->conv[0].wn; PA.bnp = ctx->conv[0].bnp; PA.pre = cx->pre;
+    PA.wn = ctx->conv[0].wn; PA.bnp = ctx->conv[0].bnp; PA.pre = cx->pre; PA.n_slots = 1;
     CK(launch_node_finalize_pre(PA, false, s), "node_pre");
   }
   // accumulators: node_finalize zeroes what it reads, so a forward that ran to its end leaves them clean for the next one
   if (!cx->sum_clean) {
-    CK(hipMemsetAsync(cx->sum, 0, (size_t)cx->max_batch * (n_lig + n_rec) * XW * sizeof(float), s), "memset sum");
+    CK(hipMemsetAsync(cx->sum, 0, (size_t)cx->max_batch * (n_lig + n_rec) * XW * sizeof(float) * (c.deterministic ? 2 : 1), s), "memset sum");
     CK(hipMemsetAsync(cx->sum_rr0, 0, (size_t)n_rec * XW * sizeof(float), s), "memset sum_rr0");
   }
   cx->sum_clean = false;
@@ -488,6 +488,10 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
     else if (prune && l == NL - 4) tab = TAB_C;
     a.gbeg = cx->info + I_TAB + 8 * tab; a.gend = a.gbeg + 4;
     a.n_groups = 4; a.n_active = lig_only ? 2 : 4; a.n_slots = 1; a.slots = 0;
+    if (c.deterministic) {     // ligand atoms receive in groups 0,1, residues in 2,3: slot = g & 1 -> one writer per (node, slot, channel)
+      a.n_slots = 2; a.slots = (0u) | (1u << 2) | (0u << 4) | (1u << 6);
+      a.part = cx->part; a.edge_bound = cap_b;
+    }
     if (shared0) {
       rr0_dirty = true;
       a.sum_g2 = cx->sum_rr0; a.g2_node_off = B * n_lig;
@@ -510,12 +514,12 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
       PA.sum = cx->sum; PA.deg = cx->deg; PA.x_in = xin; PA.bn_mean = L.bn_mean; PA.bn_scale = L.bn_scale; PA.bn_bias = L.bn_bias;
       PA.dout = L.dout; PA.x_out = xout; PA.sum_rr0 = shared0 ? cx->sum_rr0 : nullptr; PA.n_lig_total = B * n_lig; PA.n_rec_total = B * n_rec;
       PA.n_rec = n_rec; PA.zero_extra = clear_rr0 ? cx->sum_rr0 : nullptr; PA.n_extra = clear_rr0 ? (int64_t)n_rec * XW : 0;
-      PA.wn = ctx->conv[l + 1].wn; PA.bnp = ctx->conv[l + 1].bnp; PA.pre = cx->pre;
+      PA.wn = ctx->conv[l + 1].wn; PA.bnp = ctx->conv[l + 1].bnp; PA.pre = cx->pre; PA.n_slots = c.deterministic ? 2 : 1;
       CK(launch_node_finalize_pre(PA, true, s), "node_finalize_pre");
     } else
     CK(launch_node_finalize(cx->sum, cx->deg, xin, L.bn_mean, L.bn_scale, L.bn_bias, lig_only ? (int64_t)B * n_lig : N, L.dout, XW, xout, s,
                             shared0 ? cx->sum_rr0 : nullptr, (int64_t)B * n_lig, n_rec, 1, clear_rr0 ? cx->sum_rr0 : nullptr,
-                            clear_rr0 ? (int64_t)n_rec * XW : 0), "node_finalize");
+                            clear_rr0 ? (int64_t)n_rec * XW : 0, c.deterministic ? 2 : 1), "node_finalize");
     if (clear_rr0) rr0_dirty = false;
     float* t = xin; xin = xout; xout = t;
   }
@@ -534,7 +538,7 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
   Hd.scale_by_sigma = c.scale_by_sigma; Hd.rot_u = cx->rot_u; Hd.rot_v = cx->rot_v; Hd.lig_r2 = c.lig_max_radius * c.lig_max_radius;
   Hd.tr_out = tr_out; Hd.rot_out = rot_out; Hd.tor_out = tor_out;
   Hd.h_src = cx->h_src; Hd.h_dst = cx->h_dst; Hd.h_deg = cx->h_deg; Hd.h_info = cx->info + I_HEAD; Hd.h_attr = cx->h_attr; Hd.h_sh = cx->h_sh;
-  Hd.h_sum = cx->h_sum;
+  Hd.h_sum = cx->h_sum; Hd.deterministic = c.deterministic;
   CK(launch_heads_pre(Hd, torsion, s), "heads_pre");
   // final_conv on the context's side stream beside tor_bond_conv on the caller's stream (disjoint accumulator rows and work queues)
   if (torsion) {
@@ -547,6 +551,10 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
     a.tile_info = cx->info; a.counter = cx->info + I_HEAD + 4 + hd; a.gather = 0; a.pre = nullptr;
     a.n_groups = 1; a.n_active = 1; a.n_slots = 1; a.slots = 0;
     a.gbeg = cx->info + I_HEAD + (hd == 1 ? 0 : 2); a.gend = a.gbeg + 1;
+    if (c.deterministic) {     // (the two head launches run side by side: each its own half of the partial-row buffer)
+      const int64_t eh = (int64_t)B * (n_lig + (int64_t)cx->R * BOND_CAP);
+      a.part = cx->part + (hd == 1 ? 0 : ((size_t)B * n_lig / CONV_BLOCK_EDGES + 2) * CONV_WAVES * 2 * XW); a.edge_bound = eh;
+    }
     CK(launch_conv_fused(ctx->head[hd], a, ctx->n_cu, (hd == 1 && torsion) ? ctx->head_stream : s), "conv_fused (head)");
   }
   if (torsion) {
@@ -598,7 +606,7 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
     const size_t E0 = (size_t)d->n_rec_edges, Bm0 = (size_t)max_batch, R0 = (size_t)(d->n_rot > 0 ? d->n_rot : 1);
     const size_t cap0 = Bm0 * ((size_t)M + (size_t)n_lig * (LIG_CAP - 1) + 2 * (size_t)n_lig * n_rec + E0) + E0 + 64, N0 = Bm0 * (size_t)(n_lig + n_rec);
     size_t need = (size_t)M * 24 + R0 * 8 + R0 * n_lig + (size_t)n_rec * 12 + (size_t)(n_lig + n_rec) * NS * 4 + E0 * (8 + NS * 4 + 16) + (size_t)n_rec * 4;
-    need += cap0 * (12 + NS * 4 + 16) + N0 * 4 + N0 * PRE_W * 4 + Bm0 * ((size_t)n_lig + R0 * BOND_CAP + 2) * (8 + NE * 4 + 16) + Bm0 * (1 + R0) * (XW * 4 + 4) + 8 * 256 + Bm0 * 2 * CNT_STRIDE * 4 + INFO_INTS * 4 + (size_t)n_rec * 4 + Bm0 * n_rec + 3 * N0 * XW * 4 + (size_t)n_rec * XW * 4 + Bm0 * n_lig * 12 + 2 * Bm0 * (6 + R0) * 4;
+    need += cap0 * (12 + NS * 4 + 16) + N0 * 4 + N0 * PRE_W * 4 + (c.deterministic ? N0 * XW * 4 + (cap0 / 32 + 128) * 2 * XW * 4 : 0) + Bm0 * ((size_t)n_lig + R0 * BOND_CAP + 2) * (8 + NE * 4 + 16) + Bm0 * (1 + R0) * (XW * 4 + 4) + 8 * 256 + Bm0 * 2 * CNT_STRIDE * 4 + INFO_INTS * 4 + (size_t)n_rec * 4 + Bm0 * n_rec + 3 * N0 * XW * 4 + (size_t)n_rec * XW * 4 + Bm0 * n_lig * 12 + 2 * Bm0 * (6 + R0) * 4;
     if (c.latent_dim > 0) need += N0 * c.latent_dim * 4;
     cx_reserve(cx, need + 64 * 256);
     // everything uploaded below (topology, static embeddings, receptor-edge geometry) goes through one pinned staging buffer
@@ -722,11 +730,13 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
   cx->levels = cx_upload<uint8_t>(cx, nullptr, Bm * n_rec);
   cx->xa = cx_upload<float>(cx, nullptr, N * XW);
   cx->xb = cx_upload<float>(cx, nullptr, N * XW);
-  cx->sum = cx_upload<float>(cx, nullptr, N * XW);
+  const int det = c.deterministic ? 1 : 0;
+  cx->sum = cx_upload<float>(cx, nullptr, N * XW * (det ? 2 : 1));      // deterministic: one accumulator per (node, receiving group)
+  if (det) cx->part = cx_upload<float>(cx, nullptr, (cx->edge_cap / CONV_BLOCK_EDGES + 16) * CONV_WAVES * 2 * XW);
   cx->sum_rr0 = cx_upload<float>(cx, nullptr, (int64_t)n_rec * XW);
   if (has_model && !c.conv_f16x3) cx->pre = cx_upload<float>(cx, nullptr, N * PRE_W);
   if (has_model) {      // heads (k_heads.hip): edge list [B*n_lig centre edges | <= B*R*BOND_CAP bond-neighbour edges], accumulators [B | B*R] rows
-    const int64_t Eh = Bm * ((int64_t)n_lig + (int64_t)(d->n_rot > 0 ? d->n_rot : 0) * BOND_CAP) + 64, Nh = Bm * (1 + (int64_t)(d->n_rot > 0 ? d->n_rot : 0));
+    const int64_t Eh = Bm * ((int64_t)n_lig + (int64_t)(d->n_rot > 0 ? d->n_rot : 0) * BOND_CAP) + 64, Nh = Bm * (1 + (int64_t)(d->n_rot > 0 ? d->n_rot : 0)) + 1;   // (+ a scratch row for the deterministic mode's null edges)
     cx->h_src = cx_upload<int32_t>(cx, nullptr, Eh);
     cx->h_dst = cx_upload<int32_t>(cx, nullptr, Eh);
     cx->h_attr = cx_upload<float>(cx, nullptr, Eh * NE);

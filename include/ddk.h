@@ -53,6 +53,12 @@ typedef struct ddk_config {
    *    (w = w_hi + w_lo/2^11, h = h_hi + h_lo/2^11, fp32 accumulation; the dropped lo.lo term is 2^-22 relative) instead of the
    *    fp32 MFMA.  Same fp32-level accuracy; 0 (default) keeps the plain fp32 MFMA. */
   int32_t conv_f16x3;
+  /* 1: fixed summation order per node in the score model's conv layers and heads (scatter_mean of tensor_layers.py:159): edges are
+   *    sorted by the receiving node, so run tails STORE and the runs that straddle 32-edge tiles are folded in tile order by a second
+   *    small kernel; one accumulator per (node, receiving edge group); no float atomics -> bit-identical outputs run to run.
+   *    0 (default): wave-level segmented sums + fp32 atomics on the run tails (~1e-7 relative run-to-run noise).  Applies to
+   *    ddk_score_forward / ddk_sample; ddk_conv_forward (caller-ordered edges) keeps the atomics; not with conv_f16x3 or all_atoms. */
+  int32_t deterministic;
 } ddk_config;
 
 /* ---- lifetime ---------------------------------------------------------------------------- */

@@ -197,34 +197,67 @@ static int build_layout(ddk_ctx* ctx, int mode, int l, ConvLayerDev& L, std::vec
   int oc[4] = {0, out[0], out[0] + 3 * out[1], out[0] + 3 * out[1] + 3 * out[2]};
   if (mode == 2) { oc[0] = ns; oc[3] = 0; L.dout = 2 * ns; }       // '24x0o + 24x0e': the 0o channels come first
   if (mode == 3) { oc[1] = 0; oc[2] = 6; L.dout = 12; }
-  struct TRow { int blk, col; RowSrc r[4]; bool ok[4]; };
+  struct TRow { int blk[4], col; RowSrc r[4]; bool ok[4]; };     // per tile row j: the block it belongs to (the shared tail tile holds two)
   std::vector<TRow> trows;
   tiles.clear();
   L.n_cols = 0;
+  auto chan0_of = [&](int b, int col) { return oc[b] + ((b == 1 || b == 2) ? 3 : 1) * 8 * col; };
+  auto nch_of = [&](int b, int col) { return L.n_out[b] - 8 * col < 8 ? L.n_out[b] - 8 * col : 8; };
+  auto emit = [&](int b, int col, const Part& p, int f_off, int row0, int jlo, int cnt) {
+    tiles.push_back(make_tile(p.kind, f_off, FL_NONE, nch_of(b, col) / 2, chan0_of(b, col)));
+    TRow t; t.col = col;
+    for (int j = 0; j < 4; ++j) { t.blk[j] = b; t.ok[j] = j >= jlo && j < jlo + cnt; if (t.ok[j]) t.r[j] = p.rows[row0 + j - jlo]; }
+    trows.push_back(t);
+  };
+  // all tiles of one part of one output column; a dot-product part's tail (rows 4, 5: the [pv4 pv5 qv4 qv5] quad) can be left to the caller
+  auto emit_part = [&](int b, int col, const Part& p, bool with_tail) -> int {
+    const int n = (int)p.rows.size();
+    if (p.dot_which >= 0) {     // F_PQ = [pv0..3 | qv0..3 | pv4 pv5 qv4 qv5]
+      if (n > 6) return fail(ctx, DDK_ERR_INVALID, "dot-product parts hold at most 6 rows");
+      emit(b, col, p, F_PQ + 4 * p.dot_which, 0, 0, n < 4 ? n : 4);
+      if (n > 4 && with_tail) emit(b, col, p, F_PQ + 8, 4, 2 * p.dot_which, n - 4);
+    } else {
+      for (int q = 0; 4 * q < n; ++q) emit(b, col, p, p.f_off + (p.kind == T_TV ? 12 * q : 4 * q), 4 * q, 0, n - 4 * q < 4 ? n - 4 * q : 4);
+    }
+    return DDK_OK;
+  };
+  auto dot_part = [&](int b) -> const Part* {
+    for (const Part& p : parts[b]) if (p.dot_which >= 0 && p.rows.size() > 4) return &p;
+    return nullptr;
+  };
+  // The 0e and 0o blocks' dot-product parts (p.v, q.v: 6 rows each) would each end in a half-empty tile (pv4 pv5 . . / . . qv4 qv5).  When both
+  // exist with the same output width they share ONE tile (kind T_RTS): the two columns of the same channel slots are laid out back to back,
+  // [0e column ... | shared tail: flushes the 0e column, opens the 0o column | 0o column ...]  (3 tiles less for W = 1872 and W = 1152).
+  // The 3 x f16 kernel keeps the unshared table.
+  const Part *dp0 = dot_part(0), *dp3 = dot_part(3);
+  const bool share = mode == 0 && !c.conv_f16x3 && dp0 && dp3 && dp0->rows.size() == 6 && dp3->rows.size() == 6 && L.n_out[0] == L.n_out[3] &&
+                     L.n_out[0] % 2 == 0;
+  bool done[4] = {false, false, false, false};
+  if (share) {
+    for (int col = 0; 8 * col < L.n_out[0]; ++col) {
+      if (L.n_cols >= 16) return fail(ctx, DDK_ERR_INVALID, "too many output columns");
+      L.col_start[L.n_cols++] = (int)tiles.size();            // (one split point per PAIR of columns: the shared tile binds them)
+      for (const Part& p : parts[0])
+        if (int rc = emit_part(0, col, p, false)) return rc;
+      tiles.push_back(make_tile(T_RTS, F_PQ + 8, FL_S, nch_of(0, col) / 2, chan0_of(0, col)));
+      TRow t; t.col = col;
+      for (int j = 0; j < 4; ++j) { t.blk[j] = j < 2 ? 0 : 3; t.ok[j] = true; t.r[j] = j < 2 ? dp0->rows[4 + j] : dp3->rows[4 + j - 2]; }
+      trows.push_back(t);
+      for (const Part& p : parts[3])
+        if (int rc = emit_part(3, col, p, false)) return rc;
+      tiles.back().w0 |= FL_S << 2;
+    }
+    done[0] = done[3] = true;
+  }
   for (int b = 0; b < 4; ++b) {
-    if (parts[b].empty() || L.n_out[b] == 0) continue;
+    if (done[b] || parts[b].empty() || L.n_out[b] == 0) continue;
     if (L.n_out[b] % 2) return fail(ctx, DDK_ERR_INVALID, "odd output multiplicity unsupported");
     const bool vec = (b == 1 || b == 2);
     for (int col = 0; 8 * col < L.n_out[b]; ++col) {
       if (L.n_cols >= 16) return fail(ctx, DDK_ERR_INVALID, "too many output columns");
       L.col_start[L.n_cols++] = (int)tiles.size();
-      const int nch = L.n_out[b] - 8 * col < 8 ? L.n_out[b] - 8 * col : 8;
-      for (const Part& p : parts[b]) {
-        const int n = (int)p.rows.size();
-        auto emit = [&](int f_off, int row0, int jlo, int cnt) {
-          tiles.push_back(make_tile(p.kind, f_off, FL_NONE, nch / 2, oc[b] + (vec ? 3 : 1) * 8 * col));
-          TRow t; t.blk = b; t.col = col;
-          for (int j = 0; j < 4; ++j) { t.ok[j] = j >= jlo && j < jlo + cnt; if (t.ok[j]) t.r[j] = p.rows[row0 + j - jlo]; }
-          trows.push_back(t);
-        };
-        if (p.dot_which >= 0) {     // F_PQ = [pv0..3 | qv0..3 | pv4 pv5 qv4 qv5]
-          if (n > 6) return fail(ctx, DDK_ERR_INVALID, "dot-product parts hold at most 6 rows");
-          emit(F_PQ + 4 * p.dot_which, 0, 0, n < 4 ? n : 4);
-          if (n > 4) emit(F_PQ + 8, 4, 2 * p.dot_which, n - 4);
-        } else {
-          for (int q = 0; 4 * q < n; ++q) emit(p.f_off + (p.kind == T_TV ? 12 * q : 4 * q), 4 * q, 0, n - 4 * q < 4 ? n - 4 * q : 4);
-        }
-      }
+      for (const Part& p : parts[b])
+        if (int rc = emit_part(b, col, p, true)) return rc;
       tiles.back().w0 |= (vec ? FL_V : FL_S) << 2;
     }
   }
@@ -254,7 +287,7 @@ static int build_layout(ddk_ctx* ctx, int mode, int l, ConvLayerDev& L, std::vec
       for (int hh = 0; hh < 2; ++hh)
         for (int j = 0; j < 4; ++j) {
           const int k = 8 * tr.col + 2 * rq + hh;
-          if (!tr.ok[j] || k >= L.n_out[tr.blk]) continue;
+          if (!tr.ok[j] || k >= L.n_out[tr.blk[j]]) continue;
           rowmap[(size_t)t * 32 + 8 * rq + 4 * hh + j] = tr.r[j].wbase + k;
           rowscale[(size_t)t * 32 + 8 * rq + 4 * hh + j] = tr.r[j].scale;
         }

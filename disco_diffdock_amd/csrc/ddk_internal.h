@@ -72,7 +72,9 @@ static_assert(CONV_H_LDS_BYTES <= 160 * 1024 && W2H_TILE_BYTES % 16 == 0, "LDS b
 enum TileKind : int {
   T_RA = 0,   // scalar features F[f_off..+4); accumulate into accA (multiplied by s0 or v when the column is flushed)
   T_RT = 1,   // scalar features F[f_off..+4); accumulate into accV[0] (already complete: (p.v)/sqrt3, (q.v)/sqrt3)
-  T_TV = 2    // vector features F[f_off..+12) (4 rows x xyz); accumulate into accV[0..2]
+  T_TV = 2,   // vector features F[f_off..+12) (4 rows x xyz); accumulate into accV[0..2]
+  T_RTS = 3   // the shared tail of the two dot-product parts, F[F_PQ+8..+4) = [pv4 pv5 | qv4 qv5]: rows j = 0,1 finish the 0e column
+              // (accumulated, the column is flushed), rows j = 2,3 START the 0o column of the same channel slots behind the flush
 };
 enum FlushMode : int { FL_NONE = 0, FL_S = 1 /* out = accA*s0 + accV0 */, FL_V = 2 /* out_c = accA*v_c + accV_c */ };
 

@@ -391,6 +391,9 @@ __global__ __launch_bounds__(64 * ConvTraits<MODE>::WAVES) void conv_fused_kerne
           }                                                                                                    \
           accA[rq] = 0.0f; accV[rq][0] = 0.0f; accV[rq][1] = 0.0f; accV[rq][2] = 0.0f;                         \
         }                                                                                                      \
+        if ((w0 & 3) == T_RTS) {   /* rows j = 2,3 of the shared tail open the next (0o) column */              \
+          _Pragma("unroll") for (int rq = 0; rq < 4; ++rq) accV[rq][0] = D_HI(D, rq) * V_HI(f0);                \
+        }                                                                                                      \
       }                                                                                                        \
       float* stg = ring + (((T) - t_begin) & 1) * W2_TILE_FLOATS;                                              \
       *reinterpret_cast<float4*>(stg + 4 * tid) = st0;                                                         \

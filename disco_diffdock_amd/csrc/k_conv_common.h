@@ -71,6 +71,9 @@ __device__ __forceinline__ void tile_epilogue(int kind, const f32x16& D, f32x4 f
       accV[rq][1] = __builtin_elementwise_fma(dh, V_HI(f1), __builtin_elementwise_fma(dl, V_LO(f1), accV[rq][1]));
       accV[rq][2] = __builtin_elementwise_fma(dh, V_HI(f2), __builtin_elementwise_fma(dl, V_LO(f2), accV[rq][2]));
     }
+  } else if (kind == T_RTS) {     // only rows j = 0,1 belong to the column that is about to be flushed (the caller adds j = 2,3 behind the flush)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) accV[rq][0] = __builtin_elementwise_fma(D_LO(D, rq), V_LO(f0), accV[rq][0]);
   } else if (kind == T_RA) {
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) accA[rq] = __builtin_elementwise_fma(D_LO(D, rq), V_LO(f0), accA[rq]);

@@ -895,11 +895,9 @@ int ddk_sample(ddk_ctx* ctx, ddk_complex* cx, int32_t B, int32_t steps, const fl
     A.noise = noise ? noise + (size_t)k * B * (6 + R) : nullptr;
     for (int j = 0; j < 3; ++j) { A.sc[j] = score_coeff[3 * k + j]; A.nc[j] = noise_coeff[3 * k + j]; }
     A.rot_u = cx->rot_u; A.rot_v = cx->rot_v; A.mask_rotate = cx->mask_rotate; A.B = B; A.n_lig = cx->n_lig; A.R = R;
-    A.pos_out = cx->pos_tmp;
+    A.pos_out = pos;       // in place: the workgroup of sample b stages pos[b] in LDS before it writes pos[b] (k_se3.hip)
     hipError_t e = launch_se3(A, s);
     if (e != hipSuccess) return hip_fail(ctx, e, "se3_update launch");
-    e = hipMemcpyAsync(pos, cx->pos_tmp, (size_t)B * cx->n_lig * 3 * sizeof(float), hipMemcpyDeviceToDevice, s);
-    if (e != hipSuccess) return hip_fail(ctx, e, "pos copy");
   }
   return DDK_OK;
 }

@@ -9,7 +9,7 @@ NS, NV, XW, NE = 24, 6, 84, 72
 F_A, F_C, F_T1O, F_T1E, F_PQ, F_STRIDE = 0, 24, 48, 84, 120, 132
 F_T2O, F_T2E, F_STRIDE2 = 132, 156, 180       # l<=2 tensor product of the confidence model (mode 1)
 OFF_P, OFF_Q, OFF_C = 24, 42, 60
-T_RA, T_RT, T_TV = range(3)
+T_RA, T_RT, T_TV, T_RTS = range(4)
 FL_NONE, FL_S, FL_V = range(3)
 LANES = np.arange(64)
 EL, HH = LANES & 31, LANES >> 5
@@ -127,6 +127,8 @@ def emulate(ctx, layer, x_pad, src, dst, group_offsets, edge_attr, sh, mode=0, s
                 if kind == T_TV:
                     f = Fl[:, f_off:f_off + 12].reshape(64, 3, 4)    # [lane, c, j]
                     accV += np.einsum('lcj,lqj->lqc', f, d)
+                elif kind == T_RTS:      # shared tail [pv4 pv5 | qv4 qv5]: rows 0,1 close the column that is flushed below, rows 2,3 open the next
+                    accV[:, :, 0] += np.einsum('lj,lqj->lq', Fl[:, f_off:f_off + 2], d[:, :, :2])
                 else:
                     part = np.einsum('lj,lqj->lq', Fl[:, f_off:f_off + 4], d)
                     if kind == T_RA:
@@ -144,6 +146,8 @@ def emulate(ctx, layer, x_pad, src, dst, group_offsets, edge_attr, sh, mode=0, s
                                 np.add.at(out, (sn[valid], chan[valid] + c), (accA[:, rq] * vl[:, c] + accV[:, rq, c])[valid])
                     accA[:] = 0
                     accV[:] = 0
+                    if kind == T_RTS:
+                        accV[:, :, 0] = np.einsum('lj,lqj->lq', Fl[:, f_off + 2:f_off + 4], d[:, :, 2:])
     return out_all[:, 0] if slots is None else out_all
 
 

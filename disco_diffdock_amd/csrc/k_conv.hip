@@ -490,6 +490,7 @@ constexpr int PRE_TILE = 32;
 template <bool FINALIZE>
 __global__ __launch_bounds__(PRE_W) void node_finalize_pre_kernel(NodePreArgs A) {
   __shared__ __attribute__((aligned(16))) float xs[PRE_TILE][NS];
+  __shared__ unsigned char dead[PRE_TILE];      // residues outside the heads' backward receptive field at this depth: nothing reads their rows
   const int tid = threadIdx.x;
   if (FINALIZE && A.zero_extra != nullptr)
     for (int64_t i = (int64_t)blockIdx.x * PRE_W + tid; i < A.n_extra; i += (int64_t)gridDim.x * PRE_W) A.zero_extra[i] = 0.0f;
@@ -498,6 +499,15 @@ __global__ __launch_bounds__(PRE_W) void node_finalize_pre_kernel(NodePreArgs A)
   const int tile = lig ? blockIdx.x : blockIdx.x - lig_tiles;
   const int node0 = (lig ? 0 : A.n_lig_total) + tile * PRE_TILE;
   const int cnt = min(PRE_TILE, (lig ? A.n_lig_total : A.n_lig_total + A.n_rec_total) - node0);
+  if (tid < PRE_TILE) {
+    bool d = false;
+    if (!lig && A.levels != nullptr && tid < cnt) {
+      const int r = node0 - A.n_lig_total + tid;              // residue row: sample r / n_rec, residue r % n_rec
+      d = A.levels[r] > A.max_level;
+    }
+    dead[tid] = d;
+  }
+  __syncthreads();
   // this thread's weights: requested first, they arrive while the finalize phase runs
   float w[NS];
   float bias = 0.0f;
@@ -513,6 +523,7 @@ __global__ __launch_bounds__(PRE_W) void node_finalize_pre_kernel(NodePreArgs A)
   if (FINALIZE) {
     for (int idx = tid; idx < cnt * XW; idx += PRE_W) {
       const int n = idx / XW, c = idx - n * XW;
+      if (dead[n]) continue;                    // (it received no message in this layer either: its accumulators are still zero)
       const int64_t r = node0 + n;
       float v = 0.0f;
       if (c < A.dout) {
@@ -541,6 +552,7 @@ __global__ __launch_bounds__(PRE_W) void node_finalize_pre_kernel(NodePreArgs A)
   float* out = A.pre + (size_t)node0 * PRE_W + tid;
 #pragma unroll 4
   for (int n = 0; n < cnt; ++n) {
+    if (dead[n]) continue;
     float a0 = bias, a1 = 0.0f;
 #pragma unroll
     for (int k4 = 0; k4 < NS / 4; ++k4) {

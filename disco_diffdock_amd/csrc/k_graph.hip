@@ -336,6 +336,7 @@ __global__ __launch_bounds__(256) void edge_features_kernel(EdgeFeatArgs A) {
   const int bstart = fg == 0 ? 0 : (fg == 1 ? bs1 : (fg == 2 ? bs2 : (fg == 3 ? bs3 : bs4)));
   const int e = (fg < 4 ? A.info[I_GO + fg] : A.info[I_SHARED]) + 256 * (blk - bstart) + threadIdx.x;
   if (e >= (fg < 4 ? A.info[I_GO + 1 + fg] : A.info[I_SHARED] + A.n_shared)) return;
+  if (fg == 2 && A.g2_live_only && e >= A.info[I_SEG + 3]) return;      // behind the level-C segment: no layer evaluates these messages
   const int g = fg == 4 ? 2 : fg;
   const int sn = A.e_src[e], dn = A.e_dst[e], aux = A.e_aux[e];
   const EdgeMlpDev& M = g == 0 ? A.lig : (g == 2 ? A.rec : A.cross);

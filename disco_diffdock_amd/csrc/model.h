@@ -164,6 +164,7 @@ struct EdgeFeatArgs {
   int rec_node_base = -1;  // -1: n_lig_total
   int n_rec;
   int n_shared = 0;        // edges of the shared rec-rec copy (E_rr or 0)
+  int g2_live_only = 0;    // 1: only the rec-rec edges of the level segments A, B, C get features (no layer evaluates the rest)
   const float* lig_latent; // [B*n_lig, latent_dim] or null
   const float* rec_latent; // [B*n_rec, latent_dim] or null
   float unconditional;     // data[...].unconditional (same value on every node of a forward, sampling.py:114-115,121-122)

@@ -439,6 +439,9 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
   F.e_src = cx->e_src; F.e_dst = cx->e_dst; F.e_aux = cx->e_aux; F.info = cx->info; F.e_emb = cx->e_emb; F.e_sh = cx->e_sh;
   F.lig = M->dev.lig_edge; F.rec = M->dev.rec_edge; F.cross = M->dev.cross_edge; F.sp = sp;
   F.n_lig_total = B * n_lig; F.n_rec = n_rec; F.n_shared = dedup ? cx->E_rr : 0;
+  // 5-layer model with the layer-0 de-duplication and the pruning on: layers 1..3 evaluate the rec-rec messages of levels C, B, A only, layer 0 the
+  // shared copy, layer 4 none -> the per-sample rec-rec edges behind the level-C segment never need their embedding / sh
+  F.g2_live_only = (dedup && prune && c.num_conv_layers == 5) ? 1 : 0;
   F.latent_dim = c.latent_dim; F.lig_latent = cx->lig_latent; F.rec_latent = cx->rec_latent; F.unconditional = cx->unconditional;
   if (c.latent_dim > 0 && (!cx->lig_latent || !cx->rec_latent))
     return fail(ctx, DDK_ERR_STATE, "latent-conditioned model: call ddk_set_latents before the forward");
@@ -515,6 +518,8 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
       PA.dout = L.dout; PA.x_out = xout; PA.sum_rr0 = shared0 ? cx->sum_rr0 : nullptr; PA.n_lig_total = B * n_lig; PA.n_rec_total = B * n_rec;
       PA.n_rec = n_rec; PA.zero_extra = clear_rr0 ? cx->sum_rr0 : nullptr; PA.n_extra = clear_rr0 ? (int64_t)n_rec * XW : 0;
       PA.wn = ctx->conv[l + 1].wn; PA.bnp = ctx->conv[l + 1].bnp; PA.pre = cx->pre; PA.n_slots = c.deterministic ? 2 : 1;
+      // rows nothing downstream reads (the same receptive-field argument as for the rec-rec messages) are neither finalised nor given node terms
+      PA.levels = prune ? cx->levels : nullptr; PA.max_level = l == NL - 2 ? 0 : (l == NL - 3 ? 1 : (l == NL - 4 ? 2 : 3));
       CK(launch_node_finalize_pre(PA, true, s), "node_finalize_pre");
     } else
     CK(launch_node_finalize(cx->sum, cx->deg, xin, L.bn_mean, L.bn_scale, L.bn_bias, lig_only ? (int64_t)B * n_lig : N, L.dout, XW, xout, s,

@@ -759,6 +759,12 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
   }
   if (cx->oom || !cx->bond_src || !cx->rr_sh || !cx->scores) return fail(ctx, DDK_ERR_NOMEM, "device allocation failed in ddk_complex_create");
   hipMemsetAsync(cx->info, 0, INFO_INTS * sizeof(int32_t), ctx->up_stream);
+  // the accumulators start clean (node_finalize clears behind itself): cleared here, on the upload stream, beside the previous complex' loop
+  if (cx->sum && cx->sum_rr0) {
+    hipMemsetAsync(cx->sum, 0, (size_t)N * XW * sizeof(float) * (det ? 2 : 1), ctx->up_stream);
+    hipMemsetAsync(cx->sum_rr0, 0, (size_t)n_rec * XW * sizeof(float), ctx->up_stream);
+    cx->sum_clean = true;
+  }
   return cx_stage_flush(ctx, cx);   // the copies are in flight on the upload stream; every launch entry point waits for cx->ready
 }
 

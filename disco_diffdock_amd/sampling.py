@@ -82,15 +82,17 @@ def randomize_position_device(data_list, no_torsion, no_random, tr_sigma_max, de
 def draw_noise(inference_steps, b, R_total, R, nc, device):
     """N(0,1) draws of one batch from the device generator in the reference's order (tr, rot, tor per step, utils/sampling.py:146-164);
     steps whose noise coefficients are all zero (no_final_step_noise) draw nothing, like the reference.  -> [steps, b, 6 + R_total]"""
-    z = torch.zeros((inference_steps, b, 6 + R_total), device=device)
+    ztr = torch.zeros((inference_steps, b, 3), device=device)
+    zrot = torch.zeros((inference_steps, b, 3), device=device)
+    ztor = torch.zeros((inference_steps, b, R_total), device=device)
     for t_idx in range(inference_steps):
         if not nc[t_idx].any():
             continue
-        z[t_idx, :, 0:3] = torch.normal(mean=0, std=1, size=(b, 3), device=device)
-        z[t_idx, :, 3:6] = torch.normal(mean=0, std=1, size=(b, 3), device=device)
+        ztr[t_idx].normal_(mean=0, std=1)          # one kernel per draw (contiguous slices), the reference's order tr, rot, tor
+        zrot[t_idx].normal_(mean=0, std=1)
         if R:
-            z[t_idx, :, 6:] = torch.normal(mean=0, std=1, size=(b * R,), device=device).reshape(b, R)
-    return z
+            ztor[t_idx, :, :R].normal_(mean=0, std=1) if R != R_total else ztor[t_idx].normal_(mean=0, std=1)
+    return torch.cat([ztr, zrot, ztor], dim=2)
 
 
 def step_coefficients(inference_steps, tr_schedule, rot_schedule, tor_schedule, t_to_sigma, model_args, ode, no_random,

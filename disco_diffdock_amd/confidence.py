@@ -90,7 +90,9 @@ class ConfidenceModel(nn.Module):
         if not pos.is_cuda:
             raise RuntimeError('ddk confidence model runs on the GPU only (no CPU fallback)')
         t = data.complex_t['tr'] if hasattr(data, 'complex_t') else None
-        if t is not None and float(torch.as_tensor(t).abs().max()) != 0.0:
+        # (check=False is sampling()'s own call, which has just set the times to 0 itself: reading a device tensor here would wait for the
+        # whole reverse-diffusion loop queued in front of it)
+        if check and t is not None and float(torch.as_tensor(t).abs().max()) != 0.0:
             raise RuntimeError('ddk confidence model: implemented for complex_t = 0 (utils/sampling.py:236)')
         cx, B = self.complex_for(data)
         self.last_complex = cx

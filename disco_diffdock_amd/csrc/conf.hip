@@ -508,9 +508,12 @@ int ddk_complex_set_atoms(ddk_ctx* ctx, ddk_complex* cx, const ddk_atoms_desc* d
       ax[(size_t)i * NS + o] = a;
     }
   for (int j = 0; j < n_rec; ++j) {
+    const int res = (int)rec_x[(size_t)j * rec_feat_dim];
+    if (res < 0 || res >= REC_DIM_C) return fail(ctx, DDK_ERR_INVALID, "residue id out of range");
+  }
+  host_parallel_for(n_rec, [&](int j) {
     const float* xr = rec_x + (size_t)j * rec_feat_dim;      // [res id | ESM(lm)]; node_attr = [x | sigma_emb]
     const int res = (int)xr[0];
-    if (res < 0 || res >= REC_DIM_C) return fail(ctx, DDK_ERR_INVALID, "residue id out of range");
     float emb[NS];
     for (int o = 0; o < NS; ++o) {
       // OldAtomEncoder quirk (layers.py:112): the "scalar feature" slice x[:, 1:1+32] is ESM[:32] when lm features are present
@@ -530,7 +533,7 @@ int ddk_complex_set_atoms(ddk_ctx* ctx, ddk_complex* cx, const ddk_atoms_desc* d
     } else {
       for (int o = 0; o < NS; ++o) rx[(size_t)j * NS + o] = emb[o];
     }
-  }
+  });
   K->lig_x0 = cxu(cx, lx.data(), lx.size()); K->atom_x0 = cxu(cx, ax.data(), ax.size()); K->rec_x0 = cxu(cx, rx.data(), rx.size());
   K->atom_pos = cxu(cx, d->atom_pos, (size_t)n_atom * 3);
   // ---- receptor-edge first layer with THIS model's rec_edge_embedding (the shared edge-feature kernel reads cx->rr_pre1) ----
@@ -538,7 +541,7 @@ int ddk_complex_set_atoms(ddk_ctx* ctx, ddk_complex* cx, const ddk_atoms_desc* d
     const std::vector<int32_t>& ei = cx->h_rr;          // host copies kept by ddk_complex_create (no read-back: the upload may be in flight)
     const std::vector<float>& rp = cx->h_rec_pos;
     std::vector<float> pre1((size_t)cx->E_rr * NS);
-    for (int k = 0; k < cx->E_rr; ++k) {
+    host_parallel_for(cx->E_rr, [&](int k) {
       const int a = ei[k], b = ei[cx->E_rr + k];
       const float vx = rp[3 * b] - rp[3 * a], vy = rp[3 * b + 1] - rp[3 * a + 1], vz = rp[3 * b + 2] - rp[3 * a + 2];
       const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
@@ -549,7 +552,7 @@ int ddk_complex_set_atoms(ddk_ctx* ctx, ddk_complex* cx, const ddk_atoms_desc* d
         for (int q = 0; q < DE; ++q) a2 += M->h_rec.w1d[(size_t)o * DE + q] * gs[q];
         pre1[(size_t)k * NS + o] = a2;
       }
-    }
+    });
     if (!cx_put(cx, cx->rr_pre1, pre1.data(), pre1.size() * 4)) return fail(ctx, DDK_ERR_HIP, "rr_pre1 upload failed");
     // static sets need rec_pos on the host below
     // ---- edge arrays: [4-group region of the shared graph kernel | la | al | aa | ar | ra] -------------
@@ -572,17 +575,24 @@ int ddk_complex_set_atoms(ddk_ctx* ctx, ddk_complex* cx, const ddk_atoms_desc* d
       const int a = d->atom_edge_index[k], b = d->atom_edge_index[E_aa + k];
       if (a < 0 || a >= n_atom || b < 0 || b >= n_atom) return fail(ctx, DDK_ERR_INVALID, "atom edge index out of range");
       a1[k] = a; b1[k] = b;
-      host_edge(M->h_atom, d->atom_pos[3 * b] - d->atom_pos[3 * a], d->atom_pos[3 * b + 1] - d->atom_pos[3 * a + 1],
-                d->atom_pos[3 * b + 2] - d->atom_pos[3 * a + 2], emb1.data() + (size_t)k * NS, sh1.data() + (size_t)k * 4);
     }
     for (int i = 0; i < n_atom; ++i) {
       if (d->atom_rec_index[i] != i) return fail(ctx, DDK_ERR_INVALID, "atom_rec_index row 0 must be arange(n_atom) (process_mols.py:472)");
       const int r = d->atom_rec_index[n_atom + i];
       if (r < 0 || r >= n_rec) return fail(ctx, DDK_ERR_INVALID, "atom residue index out of range");
       a1[E_aa + i] = i; b1[E_aa + i] = r;
-      host_edge(M->h_ar, rp[3 * r] - d->atom_pos[3 * i], rp[3 * r + 1] - d->atom_pos[3 * i + 1], rp[3 * r + 2] - d->atom_pos[3 * i + 2],
-                emb1.data() + (size_t)(E_aa + i) * NS, sh1.data() + (size_t)(E_aa + i) * 4);
     }
+    host_parallel_for(n1, [&](int k) {       // edge embedding + sh of the static sets: 32 exp + 1.3 k MAC per edge on a few host threads
+      if (k < E_aa) {
+        const int a = a1[k], b = b1[k];
+        host_edge(M->h_atom, d->atom_pos[3 * b] - d->atom_pos[3 * a], d->atom_pos[3 * b + 1] - d->atom_pos[3 * a + 1],
+                  d->atom_pos[3 * b + 2] - d->atom_pos[3 * a + 2], emb1.data() + (size_t)k * NS, sh1.data() + (size_t)k * 4);
+      } else {
+        const int i = k - E_aa, r = b1[k];
+        host_edge(M->h_ar, rp[3 * r] - d->atom_pos[3 * i], rp[3 * r + 1] - d->atom_pos[3 * i + 1], rp[3 * r + 2] - d->atom_pos[3 * i + 2],
+                  emb1.data() + (size_t)k * NS, sh1.data() + (size_t)k * 4);
+      }
+    });
     int32_t* d_a1 = cxu(cx, a1.data(), a1.size());
     int32_t* d_b1 = cxu(cx, b1.data(), b1.size());
     float* d_emb1 = cxu(cx, emb1.data(), emb1.size());

@@ -1,5 +1,7 @@
 // Score-model level device structures (internal; see include/ddk.h for the ABI).
 #pragma once
+#include <thread>
+
 #include "ddk_internal.h"
 
 namespace ddk {
@@ -289,6 +291,26 @@ struct ddk_complex {
 };
 
 namespace ddk {
+// static per-complex precompute on a few host threads (independent rows; results do not depend on the thread count)
+template <typename F>
+inline void host_parallel_for(int n, F&& body) {
+  unsigned nt = std::thread::hardware_concurrency();
+  nt = nt < 1 ? 1 : (nt > 8 ? 8 : nt);
+  if (n < 512 || nt == 1) {
+    for (int i = 0; i < n; ++i) body(i);
+    return;
+  }
+  std::vector<std::thread> th;
+  const int per = (n + (int)nt - 1) / (int)nt;
+  for (unsigned t = 0; t < nt; ++t) {
+    const int lo = (int)t * per, hi = lo + per < n ? lo + per : n;
+    if (lo >= hi) break;
+    th.emplace_back([lo, hi, &body]() { for (int i = lo; i < hi; ++i) body(i); });
+  }
+  for (auto& x : th) x.join();
+}
+
+
 // Device memory of a complex comes from a few large chunks instead of one hipMalloc per array (34 + of them per complex, each a
 // driver call), and the chunks come from / return to a pool of the context: hipFree synchronises the device, which would stall
 // a caller that drops complexes while the GPU is busy.

@@ -282,25 +282,6 @@ static int make_step_params(ddk_ctx* ctx, float t_tr, float t_rot, float t_tor, 
   return DDK_OK;
 }
 
-// static per-complex precompute on a few host threads (independent rows; results do not depend on the thread count)
-template <typename F>
-static void host_parallel_for(int n, F&& body) {
-  unsigned nt = std::thread::hardware_concurrency();
-  nt = nt < 1 ? 1 : (nt > 8 ? 8 : nt);
-  if (n < 512 || nt == 1) {
-    for (int i = 0; i < n; ++i) body(i);
-    return;
-  }
-  std::vector<std::thread> th;
-  const int per = (n + (int)nt - 1) / (int)nt;
-  for (unsigned t = 0; t < nt; ++t) {
-    const int lo = (int)t * per, hi = lo + per < n ? lo + per : n;
-    if (lo >= hi) break;
-    th.emplace_back([lo, hi, &body]() { for (int i = lo; i < hi; ++i) body(i); });
-  }
-  for (auto& x : th) x.join();
-}
-
 // ---- asynchronous upload machinery (see ddk_ctx / ddk_complex) -----------------------------------------------------------------
 constexpr size_t CHUNK_POOL_MAX_BYTES = (size_t)24 << 30;   // device memory parked in the pool (288 GB of HBM per GPU)
 

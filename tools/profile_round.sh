@@ -18,3 +18,5 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" 
 done
 cd "$ROOT"
 python tools/summarize_profile.py "$OUT" gpurun_out/prof_summary
+# the raw per-launch csv files are tens of MB: only the summaries travel back
+find "$OUT" -name "*kernel_trace.csv" -delete; find "$OUT" -name "*counter_collection.csv" -delete

@@ -6,7 +6,7 @@ from collections import defaultdict
 
 src, out = sys.argv[1], sys.argv[2]
 os.makedirs(out, exist_ok=True)
-KERNEL = 'conv_fused_kernel'
+KERNEL = 'conv_fused_kernel<true, 0, true'      # the score model's conv layers (the two head launches are conv_fused_kernel<false, ...>)
 
 
 def find(d, suffix):
@@ -26,13 +26,13 @@ for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
     lines.append(f'| {k[:92]} | {len(v)} | {sum(v) / 1e3:.2f} | {sum(v) / len(v):.1f} | {min(v):.1f} | {max(v):.1f} | {100 * sum(v) / tot:.1f} |')
 conv = [v for k, v in agg.items() if KERNEL in k]
 conv = conv[0] if conv else []
-head = (f'# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-alt (MI355X)\n\n'
+head = (f'# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-alt --no-device-loop (MI355X)\n\n'
         f'{len(conv)} fused TP-conv launches, average {sum(conv) / max(len(conv), 1):.1f} us.\n\n')
 open(os.path.join(out, 'kernel_stats.md'), 'w').write(head + '\n'.join(lines) + '\n')
 
 # ---- counters
-res = {'command': 'rocprofv3 --kernel-trace --pmc <group> (one group per pass) -- python bench.py --no-cpu-baseline --no-alt',
-       'kernel': 'ddk::' + KERNEL + '<true>', 'avg_launch_us_kernel_trace': sum(conv) / max(len(conv), 1)}
+res = {'command': 'rocprofv3 --kernel-trace --pmc <group> (one group per pass) -- python bench.py --no-cpu-baseline --no-alt --no-device-loop',
+       'kernel': 'ddk::' + KERNEL + ', false>', 'avg_launch_us_kernel_trace': sum(conv) / max(len(conv), 1)}
 for d in sorted(glob.glob(os.path.join(src, 'pmc*'))):
     if not os.path.isdir(d):
         continue

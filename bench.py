@@ -276,14 +276,17 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    final, confs = {}, {}
+    final, confs, outs = {}, {}, []
     for k in range(a.warmup, a.warmup + a.steps):
         if (k - a.warmup) % len(mine) == 0 and k > a.warmup:
             sm_mod._complex_cache.clear()    # K > #complexes: the second pass over the shard must not hit the cache either
         out, conf = one_call(k)
+        outs.append(out)
         final[order[k]] = torch.stack([d['ligand'].pos for d in out])
         if with_conf:
             confs[order[k]] = conf
+    if disco:        # the latent bookkeeping of utils/sampling.py:205-221 (filled on first access): inside the bracket like the reference's
+        assert all(len(o[0].latent_str) >= 2 and all(hasattr(d, 'latent_pos') for d in o) for o in outs)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -41,7 +41,7 @@ SYMBOLS = ['ddk_create', 'ddk_destroy', 'ddk_last_error', 'ddk_version', 'ddk_lo
            'ddk_score_forward', 'ddk_se3_update', 'ddk_sample', 'ddk_last_graph_stats', 'ddk_last_node_features',
            'ddk_profile_enable', 'ddk_profile_read', 'ddk_set_latents', 'ddk_set_guidance',
            'ddk_set_keep_receptor_features', 'ddk_randomize_position', 'ddk_complex_set_atoms',
-           'ddk_confidence_forward', 'ddk_pose_metrics', 'ddk_build_graph', 'ddk_set_receptive_field_pruning', 'ddk_ar_logits', 'ddk_ar_decode']
+           'ddk_confidence_forward', 'ddk_pose_metrics', 'ddk_build_graph', 'ddk_set_receptive_field_pruning', 'ddk_ar_logits', 'ddk_ar_decode', 'ddk_confidence_status']
 
 # test hooks (include/ddk_debug.h): not part of the drop-in boundary
 DEBUG_SYMBOLS = ['ddk_debug_export', 'ddk_debug_read_edges', 'ddk_debug_conf_counts', 'ddk_debug_conf_nodes', 'ddk_debug_conf_edges', 'ddk_debug_kabsch', 'ddk_debug_axis_angle']
@@ -86,6 +86,7 @@ def lib():
     L.ddk_profile_enable.argtypes = [vp, i32]
     L.ddk_set_receptive_field_pruning.argtypes = [vp, i32]
     L.ddk_ar_logits.argtypes = [vp, vp, i32, vp, vp]
+    L.ddk_confidence_status.argtypes = [vp, vp, vp, vp]
     L.ddk_ar_decode.argtypes = [vp, vp, i32, vp, f32, vp, i32, i32, vp, vp, vp, vp]
     L.ddk_profile_read.argtypes = [vp, vp, i32]
     L.ddk_debug_export.argtypes = [vp, C.c_char_p, vp, i64]

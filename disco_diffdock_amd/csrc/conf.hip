@@ -703,6 +703,13 @@ int ddk_confidence_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float
   return DDK_OK;
 }
 
+// group table of the last confidence forward, copied asynchronously (include/ddk.h)
+int ddk_confidence_status(ddk_ctx* ctx, ddk_complex* cx, int32_t* host_out20, void* stream) {
+  if (!ctx || !cx || !cx->conf || !host_out20) return DDK_ERR_INVALID;
+  hipError_t e = hipMemcpyAsync(host_out20, cx->conf->gtab, 20 * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream);
+  return e == hipSuccess ? DDK_OK : hip_fail(ctx, e, "confidence status copy");
+}
+
 // Test hook: edge counts of the nine groups of the last confidence forward ([ll lr la aa al ar rr rl ra]) + la overflow flag.
 int ddk_debug_conf_counts(ddk_ctx* ctx, ddk_complex* cx, int32_t* out10) {
   if (!ctx || !cx || !cx->conf || !out10) return DDK_ERR_INVALID;

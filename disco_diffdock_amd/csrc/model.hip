@@ -290,6 +290,9 @@ void* cx_new_chunk(ddk_complex* cx, size_t cap) {
   int best = -1;
   for (int i = 0; i < (int)ctx->chunk_pool.size(); ++i) {
     const auto& c = ctx->chunk_pool[i];
+    // only chunks whose previous owner has finished: a chunk that is still read by a loop in flight would make the staged copies (and with
+    // them the pinned staging buffers) wait for that loop - a fresh hipMalloc is cheap and HBM is plentiful
+    if (c.free_after && hipEventQuery(c.free_after) != hipSuccess) continue;
     if (c.cap >= cap && c.cap <= 4 * cap + ((size_t)64 << 20) && (best < 0 || c.cap < ctx->chunk_pool[best].cap)) best = i;
   }
   void* p = nullptr;
@@ -297,10 +300,7 @@ void* cx_new_chunk(ddk_complex* cx, size_t cap) {
     ddk_ctx::PoolChunk c = ctx->chunk_pool[best];
     ctx->chunk_pool.erase(ctx->chunk_pool.begin() + best);
     ctx->chunk_pool_bytes -= c.cap;
-    if (c.free_after) {        // the previous owner's last launch must have finished before anything of the new owner lands here
-      hipStreamWaitEvent(ctx->up_stream, c.free_after, 0);
-      hipEventDestroy(c.free_after);
-    }
+    if (c.free_after) hipEventDestroy(c.free_after);      // (complete: checked above)
     p = c.p; cap = c.cap;
   } else if (hipMalloc(&p, cap) != hipSuccess) {
     return nullptr;
@@ -320,7 +320,7 @@ int cx_stage_begin(ddk_ctx* ctx, ddk_complex* cx, size_t bytes) {
   }
   if (idx < 0) {
     ddk_ctx::StageBuf b;
-    b.cap = bytes < ((size_t)4 << 20) ? ((size_t)4 << 20) : bytes;
+    b.cap = bytes < ((size_t)8 << 20) ? ((size_t)8 << 20) : bytes;      // (pinned allocations are slow while the GPU is busy: few, large, reused)
     if (hipHostMalloc((void**)&b.p, b.cap) != hipSuccess) return fail(ctx, DDK_ERR_NOMEM, "hipHostMalloc failed (staging buffer)");
     if (hipEventCreateWithFlags(&b.done, hipEventDisableTiming) != hipSuccess) return fail(ctx, DDK_ERR_HIP, "event create failed");
     ctx->stage_pool.push_back(b);

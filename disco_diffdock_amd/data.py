@@ -49,6 +49,16 @@ class HeteroData:
     def __contains__(self, key):
         return self._key(key) in self._stores or key in self.__dict__
 
+    def __getattr__(self, name):
+        """only reached for attributes that are not set: results that sampling() fills in on first access (``latent_str`` /
+        ``latent_pos`` come from a device read-back that is not awaited inside sampling(), see sampling._Bookkeeping)"""
+        lazy = self.__dict__.get('_lazy')
+        if lazy is not None and not name.startswith('_'):
+            lazy.resolve()
+            if name in self.__dict__:
+                return self.__dict__[name]
+        raise AttributeError(name)
+
     @property
     def node_types(self):
         return [k for k in self._stores if not isinstance(k, tuple)]

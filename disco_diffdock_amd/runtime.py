@@ -301,6 +301,13 @@ class Complex:
             self.confidence_counts()      # one host sync per confidence batch: fails loudly if the ligand-atom edge capacity overflowed
         return out
 
+    def confidence_status_async(self):
+        """-> pinned int32[20] that holds the group table / overflow flag of the last confidence forward once the current stream has
+        passed this point (ddk_confidence_status); no synchronisation here"""
+        out = torch.empty(20, dtype=torch.int32, pin_memory=True)
+        self.ctx._check(self.ctx.L.ddk_confidence_status(self.ctx.h, self.h, C.c_void_p(out.data_ptr()), _stream()), 'ddk_confidence_status')
+        return out
+
     def confidence_counts(self):
         out = (C.c_int32 * 10)()
         self.ctx._check(self.ctx.L.ddk_debug_conf_counts(self.ctx.h, self.h, out), 'ddk_debug_conf_counts')

@@ -79,6 +79,71 @@ def randomize_position_device(data_list, no_torsion, no_random, tr_sigma_max, de
     return pos
 
 
+_pending = []      # bookkeeping objects whose device read-back has not been looked at yet
+
+
+class _Bookkeeping:
+    """The host-side results of one sampling() batch that need a device read-back: the latent bookkeeping of utils/sampling.py:205-221
+    (``latent_str`` / ``latent_pos`` from the AR picks and the final poses) and the confidence model's edge-capacity flag.  The copies
+    are enqueued behind the sampler into pinned memory; nothing waits for them inside sampling(), so the host goes on to the next
+    complex while the GPU works.  ``resolve()`` (first access of ``d.latent_str`` / ``d.latent_pos`` on this module's graph
+    container, or immediately for foreign containers) waits once and fills every graph of the batch."""
+
+    def __init__(self, graphs, choices, flat, len_lig, latent_dim, conf_cx):
+        self.graphs, self.len_lig, self.latent_dim, self.conf_cx = graphs, len_lig, latent_dim, conf_cx
+        self.done = False
+        self.choices = self.flat = None
+        self.conf_status = conf_cx.confidence_status_async() if conf_cx is not None else None
+        if choices is not None:
+            self.choices = torch.empty(choices.shape, dtype=choices.dtype, pin_memory=True)
+            self.choices.copy_(choices, non_blocking=True)
+            self.flat = torch.empty(flat.shape, dtype=flat.dtype, pin_memory=True)
+            self.flat.copy_(flat.detach(), non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+
+    def _check_conf(self):
+        st, self.conf_status = self.conf_status, None
+        if st is not None and int(st[19]) != 0:
+            raise RuntimeError('ddk: ligand-atom edge capacity overflow in a confidence batch (its confidences are invalid)')
+
+    def resolve(self):
+        if self.done:
+            return
+        self.done = True
+        self.event.synchronize()
+        if self in _pending:
+            _pending.remove(self)
+        self._check_conf()
+        if self.choices is None:
+            return
+        ch, n = self.choices.tolist(), self.len_lig
+        for i, d_i in enumerate(self.graphs):
+            lat_str, lat_pos = "", []
+            center = d_i.original_center.detach().cpu()
+            for j in range(self.latent_dim):
+                idx = ch[i][j]
+                if idx < n:
+                    lat_str += 'L' + str(idx)
+                    lat_pos.append(self.flat[i * n + idx:i * n + idx + 1] + center)
+                else:
+                    idx -= n
+                    lat_str += 'R' + str(idx)
+                    lat_pos.append(d_i['receptor'].pos[idx:idx + 1].detach().cpu() + center)
+            d_i.__dict__.pop('_lazy', None)
+            d_i.latent_str = lat_str
+            d_i.latent_pos = torch.cat(lat_pos, dim=0)
+
+
+def _poll_pending():
+    """look (without waiting) at the read-backs of earlier calls: an overflow of an earlier confidence batch surfaces here at the latest"""
+    for bk in list(_pending):
+        if bk.event.query():
+            if bk.choices is None:
+                _pending.remove(bk)
+            bk._check_conf()
+
+
 def draw_noise(inference_steps, b, R_total, R, nc, device):
     """N(0,1) draws of one batch from the device generator in the reference's order (tr, rot, tor per step, utils/sampling.py:146-164);
     steps whose noise coefficients are all zero (no_final_step_noise) draw nothing, like the reference.  -> [steps, b, 6 + R_total]"""
@@ -164,6 +229,7 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
     device = torch.device(device)
     if device.type != 'cuda':
         raise RuntimeError('ddk sampling runs on the GPU only (no CPU fallback)')
+    _poll_pending()
     N = len(data_list)
     loader = DataLoader(data_list, batch_size=batch_size)
     score_model = model.module.score_model if hasattr(model, 'module') else getattr(model, 'score_model', model)
@@ -216,29 +282,25 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
                 confidence.append(out[0] if type(out) is tuple else out)
             len_lig = pos.shape[1]
             flat = pos.reshape(-1, 3)
-            if latent_model:   # latent bookkeeping of utils/sampling.py:205-221 from ONE read-back behind the sampler (the reference syncs 6x per pose)
-                ch = choices.cpu().tolist()
-                lig_latent = any(c < len_lig for row in ch for c in row)
-                flat_cpu = flat.detach().cpu() if lig_latent else None
-            for i in range(b):
-                d_i = data_list[batch_id * batch_size + i]
+            graphs = [data_list[batch_id * batch_size + i] for i in range(b)]
+            for i, d_i in enumerate(graphs):
                 d_i['ligand'].pos = flat[i * len_lig:len_lig * (i + 1)]
-                if latent_model:
-                    lat_str, lat_pos = "", []
-                    center = d_i.original_center.detach().cpu()
-                    for j in range(model_args.latent_dim):
-                        idx = ch[i][j]
-                        if idx < len_lig:
-                            lat_str += 'L' + str(idx)
-                            lat_pos.append(flat_cpu[i * len_lig + idx:i * len_lig + idx + 1] + center)
-                        else:
-                            idx -= len_lig
-                            lat_str += 'R' + str(idx)
-                            lat_pos.append(d_i['receptor'].pos[idx:idx + 1].detach().cpu() + center)
-                    d_i.latent_str = lat_str
-                    d_i.latent_pos = torch.cat(lat_pos, dim=0)
+            if latent_model or conf_checks:
+                # latent bookkeeping of utils/sampling.py:205-221 and the confidence model's capacity flag: ONE read-back, enqueued behind the
+                # sampler and not awaited here (the reference synchronises 6x per pose)
+                from .data import HeteroData
+                bk = _Bookkeeping(graphs, choices if latent_model else None, flat, len_lig, getattr(model_args, 'latent_dim', 0),
+                                  conf_checks.pop() if conf_checks else None)
+                if latent_model and all(isinstance(d_i, HeteroData) for d_i in graphs):
+                    for d_i in graphs:
+                        d_i.__dict__.pop('latent_str', None)
+                        d_i.__dict__.pop('latent_pos', None)
+                        d_i.__dict__['_lazy'] = bk
+                    _pending.append(bk)
+                elif latent_model:
+                    bk.resolve()              # foreign graph containers (PyG) cannot fill attributes lazily: wait now
+                else:
+                    _pending.append(bk)
     if confidence_model is not None:          # utils/sampling.py:245-247
         confidence = torch.nan_to_num(torch.cat(confidence, dim=0), nan=-1000)
-        for ccx in conf_checks:               # fails loudly if a ligand-atom edge capacity overflowed (one read-back, at the end of the call)
-            ccx.confidence_counts()
     return data_list, confidence

@@ -134,6 +134,12 @@ int ddk_complex_set_atoms(ddk_ctx* ctx, ddk_complex* cx, const ddk_atoms_desc* a
  * models/all_atom_score_model.py:203-284): lig_pos [B, n_lig, 3] DEVICE, out [B, num_confidence_outputs] DEVICE. */
 int ddk_confidence_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* lig_pos, float* out, void* stream);
 
+/* Status words of the last ddk_confidence_forward of `cx`, copied WITHOUT synchronising: enqueues an asynchronous copy of 20 int32 into
+ * host_out (HOST, pinned memory if the copy is to overlap): [0..8] first edge and [9..17] end of the nine edge groups [ll lr la aa al ar
+ * rr rl ra], [18] ligand-atom edge cursor, [19] != 0: the ligand-atom edge capacity overflowed (the confidences of that batch are invalid;
+ * the Python shim raises).  Valid once the stream has passed the copy. */
+int ddk_confidence_status(ddk_ctx* ctx, ddk_complex* cx, int32_t* host_out, void* stream);
+
 /* ---- DisCo latent conditioning (models/score_model.py:170-184, 209-215, 329-337, 358-366, 392-402; latent_vocab == 1):
  *      lig_latent [B*n_lig, latent_dim], rec_latent [B*n_rec, latent_dim] (data['ligand'|'receptor'].latent_h, DEVICE,
  *      caller-owned, must stay valid for the following forwards) and the value of data[...].unconditional.

@@ -164,13 +164,17 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-alt', action='store_true', help='skip the opt-in 3 x f16 measurement')
     ap.add_argument('--no-device-loop', action='store_true', help='skip the resident-loop comparison figure')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl == RCCL; gloo for smoke tests)')
+    ap.add_argument('--single-device', action='store_true', help='smoke test of the N > 1 path on a one-GPU box: every rank uses cuda:0')
     a = ap.parse_args()
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
     import torch.distributed as dist
+    if a.single_device:
+        local = 0
     if world > 1:
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.init_process_group(a.backend, rank=rank, world_size=world)
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
 

@@ -283,17 +283,22 @@ static int make_step_params(ddk_ctx* ctx, float t_tr, float t_rot, float t_tor, 
 }
 
 // ---- asynchronous upload machinery (see ddk_ctx / ddk_complex) -----------------------------------------------------------------
-constexpr size_t CHUNK_POOL_MAX_BYTES = (size_t)24 << 30;   // device memory parked in the pool (288 GB of HBM per GPU)
+constexpr size_t CHUNK_POOL_MAX_BYTES = (size_t)96 << 30;   // device memory parked in the pool (288 GB of HBM per GPU); beyond it hipFree (device sync)
 
 void* cx_new_chunk(ddk_complex* cx, size_t cap) {
   ddk_ctx* ctx = cx->owner;
+  {   // size classes {2^k, 1.5 * 2^k}: complexes of similar size take each other's chunks (ligands of 20-40 atoms differ by +-30 %)
+    size_t c2 = (size_t)1 << 20;
+    while (c2 < cap) c2 = (c2 & (c2 - 1)) ? (c2 / 3) * 4 : c2 + c2 / 2;
+    cap = c2;
+  }
   int best = -1;
   for (int i = 0; i < (int)ctx->chunk_pool.size(); ++i) {
     const auto& c = ctx->chunk_pool[i];
     // only chunks whose previous owner has finished: a chunk that is still read by a loop in flight would make the staged copies (and with
     // them the pinned staging buffers) wait for that loop - a fresh hipMalloc is cheap and HBM is plentiful
     if (c.free_after && hipEventQuery(c.free_after) != hipSuccess) continue;
-    if (c.cap >= cap && c.cap <= 4 * cap + ((size_t)64 << 20) && (best < 0 || c.cap < ctx->chunk_pool[best].cap)) best = i;
+    if (c.cap >= cap && c.cap <= 2 * cap && (best < 0 || c.cap < ctx->chunk_pool[best].cap)) best = i;
   }
   void* p = nullptr;
   if (best >= 0) {

@@ -118,7 +118,16 @@ __global__ __launch_bounds__(64 * ConvTraits<MODE>::WAVES) void conv_fused_kerne
   const int nwg = gridDim.x;
   const int full = bs4 >= nwg ? (bs4 / nwg) * nwg : 0;
   const int rest = bs4 - full;
-  const int split = rest > 0 ? max(1, min(A.n_cols, nwg / rest)) : 1;
+  // column chunks per block of the tail: the value that minimises (rounds of the persistent workgroups over the chunk units) / split, with 5 %
+  // per extra chunk for the GEMM1 + gather prologue every chunk repeats (rest = 131 of 256: one whole extra round unsplit, 0.7 of one in 5 chunks)
+  int split = 1;
+  if (rest > 0) {
+    float best = 1e30f;
+    for (int sp = 1; sp <= A.n_cols; ++sp) {
+      const float cost = (float)((rest * sp + nwg - 1) / nwg) / (float)sp * (1.0f + 0.05f * (float)(sp - 1));
+      if (cost < best - 1e-6f) { best = cost; split = sp; }
+    }
+  }
   const int n_units = full + rest * split;
 
   // work queue: the first unit of workgroup w is w itself; every later one comes from the device counter (zeroed by the caller),

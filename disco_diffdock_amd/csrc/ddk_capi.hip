@@ -430,15 +430,12 @@ static int build_conv_layer(ddk_ctx* ctx, int mode, int l, ConvLayerDev& L) {
     float* d1 = dev_upload(ctx, w1all);
     float* db1 = dev_upload(ctx, b1all);
     float* d2 = dev_upload(ctx, w2rec);
-    L.tiles = (TileDesc*)dev_alloc(ctx, tiles.size() * sizeof(TileDesc));
     if (mode == 0) { L.wn = dev_upload(ctx, L.h_wn); L.bnp = dev_upload(ctx, L.h_bnp); if (!L.wn || !L.bnp) return fail(ctx, DDK_ERR_NOMEM, "device allocation failed while packing conv weights"); }
     L.bn_mean = dev_upload(ctx, L.h_bn_mean);
     L.bn_scale = dev_upload(ctx, L.h_bn_scale);
     L.bn_bias = dev_upload(ctx, L.h_bn_bias);
-    if (!d1 || !db1 || !d2 || !L.tiles || !L.bn_mean || !L.bn_scale || !L.bn_bias)
+    if (!d1 || !db1 || !d2 || !L.bn_mean || !L.bn_scale || !L.bn_bias)
       return fail(ctx, DDK_ERR_NOMEM, "device allocation failed while packing conv weights");
-    if (hipMemcpy(L.tiles, tiles.data(), tiles.size() * sizeof(TileDesc), hipMemcpyHostToDevice) != hipSuccess)
-      return fail(ctx, DDK_ERR_HIP, "tile table upload failed");
     if (mode == 0 && c.conv_f16x3) {   // error-compensated f16 split of the same (scaled) weights
       auto split = [](float v, uint16_t& hi, uint16_t& lo) {
         const _Float16 h = (_Float16)v;

@@ -98,7 +98,6 @@ struct ConvLayerDev {          // device copies for one TensorProductConvLayer w
   float* w1p[4] = {};          // [3][9][64][4]
   float* b1p[4] = {};          // [3][2][16]
   float* w2r[4] = {};          // [n_tiles][W2_TILE_FLOATS]: per tile the fragments [9][64][4], the bias [2][16], the TileDesc words
-  TileDesc* tiles = nullptr;   // [n_tiles]
   uint16_t* w1h = nullptr;     // 3 x f16 mode: [groups][3][W1H_TILE_BYTES/2]
   uint8_t* w2h = nullptr;      // 3 x f16 mode: [groups][n_tiles][W2H_TILE_BYTES]
   float w1s[4] = {1, 1, 1, 1}, w2s[4] = {1, 1, 1, 1};   // 3 x f16 mode: power-of-two range scale of the packed W1 / (W2, b2) of each group

@@ -653,8 +653,8 @@ hipError_t launch_conv_fused(const ConvLayerDev& L, const ConvLaunch& a, int n_c
   k.w1h = nullptr; k.w2h = nullptr;
   for (int g = 0; g < 4; ++g) { k.w1s[g] = 1.0f; k.w1u[g] = 1.0f; k.w2u[g] = 1.0f; }
   k.x = a.x; k.src = a.src; k.dst = a.dst; k.edge_attr = a.edge_attr; k.sh = a.sh; k.sum = a.sum;
-  k.tile_info = a.tile_info; k.counter = a.counter;
-  k.w1p = L.w1p[0]; k.b1p = L.b1p[0]; k.w2r = L.w2r[0]; k.tiles = L.tiles; k.n_tiles = L.n_tiles;
+  k.counter = a.counter;
+  k.w1p = L.w1p[0]; k.b1p = L.b1p[0]; k.w2r = L.w2r[0]; k.n_tiles = L.n_tiles;
   k.n_cols = L.n_cols;
   for (int c = 0; c <= L.n_cols; ++c) k.col_start[c] = L.col_start[c];
   k.sum_g2 = a.sum_g2; k.g2_node_off = a.g2_node_off;

@@ -14,12 +14,10 @@ struct ConvKArgs {
   const float* sh;
   const float* pre;   // [N, PRE_W] per-node terms of GEMM1 (SPLIT kernels)
   float* sum;
-  const int32_t* tile_info;
   int32_t* counter;
   const float* w1p;   // [4][3][9][64][4]
   const float* b1p;   // [4][3][2][16]
   const float* w2r;   // [4][n_tiles][W2_TILE_FLOATS]
-  const TileDesc* tiles;  // [n_tiles]
   const uint16_t* w1h;   // 3 x f16 mode: [groups][3][2][5][64][8] fp16 (hi, lo*2^11) GEMM1 fragments
   const uint8_t* w2h;    // 3 x f16 mode: [groups][n_tiles][W2H_TILE_BYTES] tile records
   float w1s[4], w1u[4], w2u[4];   // 3 x f16 mode: weight range scale of GEMM1 (and its inverse), inverse weight scale of GEMM2
@@ -40,15 +38,7 @@ __device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-// tile descriptors are wave-uniform: read them through the constant address space (s_load -> SGPRs)
-typedef const int32_t __attribute__((address_space(4))) cint32;
-struct TileQ { int w0, chan0; };
-__device__ __forceinline__ TileQ load_tile(const TileDesc* p) {
-  cint32* q = (cint32*)(uintptr_t)p;
-  TileQ r;
-  r.w0 = q[0]; r.chan0 = q[1];
-  return r;
-}
+struct TileQ { int w0, chan0; };     // the two descriptor words of a W2 tile (they ride in the tile's record)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -427,8 +427,8 @@ hipError_t conv_prepare_device_h() {
 hipError_t launch_conv_fused_h(const ConvLayerDev& L, const ConvLaunch& a, int n_cu, hipStream_t s) {
   ConvKArgs k;
   k.x = a.x; k.src = a.src; k.dst = a.dst; k.edge_attr = a.edge_attr; k.sh = a.sh; k.sum = a.sum;
-  k.tile_info = a.tile_info; k.counter = a.counter;
-  k.w1p = L.w1p[0]; k.b1p = L.b1p[0]; k.w2r = nullptr; k.w1h = L.w1h; k.w2h = L.w2h; k.tiles = L.tiles; k.n_tiles = L.n_tiles;
+  k.counter = a.counter;
+  k.w1p = L.w1p[0]; k.b1p = L.b1p[0]; k.w2r = nullptr; k.w1h = L.w1h; k.w2h = L.w2h; k.n_tiles = L.n_tiles;
   for (int g = 0; g < 4; ++g) { k.w1s[g] = L.w1s[g]; k.w1u[g] = 1.0f / L.w1s[g]; k.w2u[g] = 1.0f / L.w2s[g]; }
   k.n_cols = L.n_cols;
   for (int c = 0; c <= L.n_cols; ++c) k.col_start[c] = L.col_start[c];

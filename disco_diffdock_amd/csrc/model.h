@@ -256,7 +256,7 @@ struct ddk_complex {
   int32_t *e_src = nullptr, *e_dst = nullptr, *e_aux = nullptr, *deg = nullptr, *counts = nullptr, *offs = nullptr, *info = nullptr;
   uint8_t* levels = nullptr;
   float *e_emb = nullptr, *e_sh = nullptr, *xa = nullptr, *xb = nullptr, *sum = nullptr;
-  float *pos_tmp = nullptr, *scores = nullptr;
+  float* scores = nullptr;
   const float *lig_latent = nullptr, *rec_latent = nullptr;   // caller-owned device arrays set by ddk_set_latents
   float unconditional = 0.0f;
   float cfg_weight = 0.0f, cfg_start = 1.0f, cfg_end = 0.0f;   // ddk_set_guidance

@@ -736,7 +736,6 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
     cx->h_sum = cx_upload<float>(cx, nullptr, Nh * XW);
     if (cx->h_sum) hipMemsetAsync(cx->h_sum, 0, (size_t)Nh * XW * sizeof(float), ctx->up_stream);
   }
-  cx->pos_tmp = cx_upload<float>(cx, nullptr, Bm * n_lig * 3);
   cx->scores = cx_upload<float>(cx, nullptr, Bm * (6 + (d->n_rot > 0 ? d->n_rot : 1)));
   cx->scores2 = cx_upload<float>(cx, nullptr, Bm * (6 + (d->n_rot > 0 ? d->n_rot : 1)));
   if (c.latent_dim > 0) {

@@ -10,7 +10,8 @@ from torch import nn
 
 from .runtime import Context, Complex, config_from_args
 
-_conf_cache = {}
+import collections
+_conf_cache = collections.OrderedDict()        # content key -> Complex (+ atoms), least recently used first
 
 
 def confidence_config(args, device_index=0):
@@ -69,8 +70,8 @@ class ConfidenceModel(nn.Module):
         key = (id(self.ctx),) + _fingerprint(batch, B) + (n_a0, ha.hexdigest())
         cx = _conf_cache.get(key)
         if cx is None or cx.max_batch < B:
-            if len(_conf_cache) > 4:
-                _conf_cache.clear()
+            while len(_conf_cache) > 2:            # evicted complexes hand their device chunks back to the context's pool
+                _conf_cache.popitem(last=False)
             arr = arrays_from_batch(batch, B)
             g, B0 = _first_view(batch, B)          # the first graph itself when the batch knows it (no concatenation of the 40 copies)
             n_a = g['atom'].num_nodes // B0
@@ -79,6 +80,7 @@ class ConfidenceModel(nn.Module):
             cx.set_atoms(g['atom'].x[:n_a].cpu(), g['atom'].pos[:n_a].cpu(), g['atom', 'atom'].edge_index[:, :E_aa].cpu(),
                          g['atom', 'receptor'].edge_index[:, :n_a].cpu())
             _conf_cache[key] = cx
+        _conf_cache.move_to_end(key)
         return cx, B
 
     def forward(self, data, check=True):

@@ -231,6 +231,7 @@ struct NodePreArgs {
   float* sum; const int32_t* deg; const float* x_in; const float* bn_mean; const float* bn_scale; const float* bn_bias;
   int dout; float* x_out; const float* sum_rr0; int n_lig_total, n_rec_total, n_rec; float* zero_extra; int64_t n_extra; int n_slots;
   const float* wn; const float* bnp; float* pre;
+  int lig_roles, rec_roles;                  // bit r: role slot r (ConvLayerDev::wn) is needed by the layer the terms are for
   const uint8_t* levels; int max_level;      // [B * n_rec] receptive-field level of the residues (k_graph.hip) and the deepest one this layer still needs; null: all
 };
 hipError_t launch_node_finalize_pre(const NodePreArgs& a, bool finalize, hipStream_t s);

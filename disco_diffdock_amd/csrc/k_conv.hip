@@ -558,6 +558,7 @@ __global__ __launch_bounds__(PRE_W) void node_finalize_pre_kernel(NodePreArgs A)
   }
   if (A.pre == nullptr) return;
   __syncthreads();
+  if (!(((lig ? A.lig_roles : A.rec_roles) >> (tid / NE)) & 1)) return;      // a role the next layer does not evaluate (its last layer: ligand side only)
   float* out = A.pre + (size_t)node0 * PRE_W + tid;
 #pragma unroll 4
   for (int n = 0; n < cnt; ++n) {

@@ -161,16 +161,35 @@ __global__ __launch_bounds__(256) void graph_count_kernel(GraphArgs G) {
 
 // one thread: prefixes over the samples, group offsets, the per-layer group tables (InfoSlot / GroupTable in model.h)
 __global__ void graph_scan_kernel(GraphArgs G, int64_t edge_cap) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  int ll = 0, lr = 0, ra = 0, rb = 0, rc = 0;
-  for (int b = 0; b < G.B; ++b) {
-    int32_t* o = G.offs + CNT_STRIDE * b;
-    const int32_t* c = G.counts + CNT_STRIDE * b;
-    o[0] = ll; o[1] = lr; o[2] = ra; o[3] = rb; o[4] = rc; o[5] = b * G.E_rr - (ra + rb + rc);
-    ll += G.M + c[0];
-    lr += c[1];
-    ra += c[2]; rb += c[3]; rc += c[4];
+  if (blockIdx.x != 0) return;
+  // exclusive prefix over the samples of the five counts: one wave, lane = sample (chunks of 64 for larger batches)
+  const int lane = threadIdx.x;
+  int tot[5] = {0, 0, 0, 0, 0};
+  for (int b0 = 0; b0 < G.B; b0 += 64) {
+    const int b = b0 + lane;
+    int v[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) v[k] = b < G.B ? G.counts[CNT_STRIDE * b + k] + (k == 0 ? G.M : 0) : 0;
+    int inc[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      int x = v[k];
+#pragma unroll
+      for (int d = 1; d < 64; d *= 2) { const int t = __shfl_up(x, d, 64); if (lane >= d) x += t; }
+      inc[k] = x;
+    }
+    if (b < G.B) {
+      int32_t* o = G.offs + CNT_STRIDE * b;
+      int ex[5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) { ex[k] = tot[k] + inc[k] - v[k]; o[k] = ex[k]; }
+      o[5] = b * G.E_rr - (ex[2] + ex[3] + ex[4]);
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) tot[k] += __shfl(inc[k], 63, 64);
   }
+  if (lane != 0) return;
+  const int ll = tot[0], lr = tot[1], ra = tot[2], rb = tot[3], rc = tot[4];
   int go[5];
   go[0] = 0; go[1] = ll; go[2] = ll + lr; go[3] = go[2] + G.B * G.E_rr; go[4] = go[3] + lr;
   const int seg[4] = {go[2], go[2] + ra, go[2] + ra + rb, go[2] + ra + rb + rc};     // first edge of the level segments of group 2

@@ -184,6 +184,7 @@ __global__ __launch_bounds__(256) void heads_pre_kernel(HeadArgs A, int n_tor_bl
 __global__ __launch_bounds__(64) void heads_post_kernel(HeadArgs A, int n_tor_blocks) {
   __shared__ float v48[2 * NS], hid[NS], g12[12];
   const int tid = threadIdx.x;
+  if (A.prof_out != nullptr && blockIdx.x == gridDim.x - 1 && tid < PROF_INTS) A.prof_out[tid] = A.exec_info[tid];   // profile mode: edge counts of this forward -> pinned host slot
   if ((int)blockIdx.x < n_tor_blocks) {
     float* row = A.h_sum + (size_t)(A.B + blockIdx.x) * XW;
     const int ne = A.h_deg[blockIdx.x];

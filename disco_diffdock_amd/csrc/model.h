@@ -189,6 +189,8 @@ struct HeadArgs {
   // the heads' own edge list [centre edges (B*n_lig) | bond-neighbour edges (<= B*R*32)] and accumulators [B graphs | B*R bonds] (ddk_complex)
   int32_t *h_src, *h_dst, *h_deg, *h_info;
   float *h_attr, *h_sh, *h_sum;
+  int32_t* prof_out = nullptr;          // profile mode: pinned host slot that receives exec_info[0..PROF_INTS) (heads_post_kernel), else null
+  const int32_t* exec_info = nullptr;
   int deterministic;      // 1: fixed-stride bond edge ranges (BOND_CAP per bond, padded with null edges into a scratch row) instead of an atomic cursor
 };
 

@@ -446,7 +446,7 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
   if (split) {
     NodePreArgs PA = {};
     PA.x_out = xin; PA.n_lig_total = B * n_lig; PA.n_rec_total = B * n_rec; PA.n_rec = n_rec;
-    PA.wn = ctx->conv[0].wn; PA.bnp = ctx->conv[0].bnp; PA.pre = cx->pre; PA.n_slots = 1;
+    PA.wn = ctx->conv[0].wn; PA.bnp = ctx->conv[0].bnp; PA.pre = cx->pre; PA.n_slots = 1; PA.lig_roles = 15; PA.rec_roles = 15;
     CK(launch_node_finalize_pre(PA, false, s), "node_pre");
   }
   // accumulators: node_finalize zeroes what it reads, so a forward that ran to its end leaves them clean for the next one
@@ -505,6 +505,10 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
       PA.n_rec = n_rec; PA.zero_extra = clear_rr0 ? cx->sum_rr0 : nullptr; PA.n_extra = clear_rr0 ? (int64_t)n_rec * XW : 0;
       PA.wn = ctx->conv[l + 1].wn; PA.bnp = ctx->conv[l + 1].bnp; PA.pre = cx->pre; PA.n_slots = c.deterministic ? 2 : 1;
       // rows nothing downstream reads (the same receptive-field argument as for the rec-rec messages) are neither finalised nor given node terms
+      // the last layer evaluates groups 0 and 1 only (unless the receptor rows were asked for): ligand atoms receive in both and send in group 0,
+      // residues only send in group 1 -> 3 of 4 resp. 1 of 4 role slots
+      const bool next_lig_only = (l + 1 == NL - 1) && !cx->keep_rec;
+      PA.lig_roles = next_lig_only ? 0x7 : 0xF; PA.rec_roles = next_lig_only ? 0x4 : 0xF;
       PA.levels = prune ? cx->levels : nullptr; PA.max_level = l == NL - 2 ? 0 : (l == NL - 3 ? 1 : (l == NL - 4 ? 2 : 3));
       CK(launch_node_finalize_pre(PA, true, s), "node_finalize_pre");
     } else
@@ -518,10 +522,6 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
   cx->last_B = B;
   cx->last_full = cx->keep_rec;
   cx->sum_clean = !rr0_dirty;       // (a one-layer model leaves the shared rows to the memset of the next forward)
-  if (prof_slot) {    // E, edges of groups 0+1 and the edges each group table evaluates, of THIS forward (read at ddk_profile_read)
-    CK(hipMemcpyAsync(prof_slot, cx->info + I_EXEC, PROF_INTS * sizeof(int32_t), hipMemcpyDeviceToHost, s), "profile edge counts");
-    ctx->prof_slots += 1;
-  }
   // heads: both are tensor-product convolutions -> the fused conv kernel on their own small edge lists (k_heads.hip)
   const bool torsion = !c.no_torsion && tor_out != nullptr && cx->R > 0;
   HeadArgs Hd;
@@ -530,6 +530,10 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
   Hd.tr_out = tr_out; Hd.rot_out = rot_out; Hd.tor_out = tor_out;
   Hd.h_src = cx->h_src; Hd.h_dst = cx->h_dst; Hd.h_deg = cx->h_deg; Hd.h_info = cx->info + I_HEAD; Hd.h_attr = cx->h_attr; Hd.h_sh = cx->h_sh;
   Hd.h_sum = cx->h_sum; Hd.deterministic = c.deterministic;
+  if (prof_slot) {    // E, edges of groups 0+1 and the edges each group table evaluates, of THIS forward: written by heads_post_kernel into the
+    Hd.prof_out = prof_slot; Hd.exec_info = cx->info + I_EXEC;      // pinned slot (read at ddk_profile_read), no copy launch of its own
+    ctx->prof_slots += 1;
+  }
   CK(launch_heads_pre(Hd, torsion, s), "heads_pre");
   // final_conv on the context's side stream beside tor_bond_conv on the caller's stream (disjoint accumulator rows and work queues)
   if (torsion) {

@@ -145,19 +145,13 @@ def _poll_pending():
 
 
 def draw_noise(inference_steps, b, R_total, R, nc, device):
-    """N(0,1) draws of one batch from the device generator in the reference's order (tr, rot, tor per step, utils/sampling.py:146-164);
-    steps whose noise coefficients are all zero (no_final_step_noise) draw nothing, like the reference.  -> [steps, b, 6 + R_total]"""
-    ztr = torch.zeros((inference_steps, b, 3), device=device)
-    zrot = torch.zeros((inference_steps, b, 3), device=device)
-    ztor = torch.zeros((inference_steps, b, R_total), device=device)
-    for t_idx in range(inference_steps):
-        if not nc[t_idx].any():
-            continue
-        ztr[t_idx].normal_(mean=0, std=1)          # one kernel per draw (contiguous slices), the reference's order tr, rot, tor
-        zrot[t_idx].normal_(mean=0, std=1)
-        if R:
-            ztor[t_idx, :, :R].normal_(mean=0, std=1) if R != R_total else ztor[t_idx].normal_(mean=0, std=1)
-    return torch.cat([ztr, zrot, ztor], dim=2)
+    """N(0,1) draws of one batch from the device generator: ONE launch for the whole trajectory [steps, b, 6 + R_total] (tr xyz, rot xyz,
+    torsions; utils/sampling.py:146-164 draws them step by step on the host).  Steps whose noise coefficients are zero
+    (no_final_step_noise) multiply their draws by 0 in ddk_sample; torsion columns past R are zeroed."""
+    z = torch.randn((inference_steps, b, 6 + R_total), device=device)
+    if R != R_total:
+        z[:, :, 6 + R:] = 0
+    return z
 
 
 def step_coefficients(inference_steps, tr_schedule, rot_schedule, tor_schedule, t_to_sigma, model_args, ode, no_random,

@@ -7,7 +7,9 @@ from torch import nn
 
 from .runtime import Context, Complex, config_from_args, DEFAULTS
 
-_complex_cache = {}
+import collections
+_complex_cache = collections.OrderedDict()     # (id(ctx), content key) -> Complex, least recently used first
+_CACHE_PER_CTX = 3       # complexes kept per context: evicted ones hand their device chunks back to the context's pool (no hipMalloc in steady state)
 _default_ctx = {}
 
 
@@ -79,10 +81,12 @@ def complex_for_batch(batch, device, ctx=None, mask_rotate=None, need_model=True
     key = (id(ctx),) + _fingerprint(batch, B, mask_rotate)
     cx = _complex_cache.get(key)
     if cx is None or cx.max_batch < B:
-        if len(_complex_cache) > 8:
-            _complex_cache.clear()
+        mine = [k for k in _complex_cache if k[0] == key[0] and k != key]
+        for k in mine[:max(0, len(mine) - (_CACHE_PER_CTX - 1))]:      # oldest first
+            del _complex_cache[k]
         cx = Complex(ctx, arrays_from_batch(batch, B, mask_rotate), max_batch=B)
         _complex_cache[key] = cx
+    _complex_cache.move_to_end(key)
     return cx, B
 
 

@@ -281,10 +281,13 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     final, confs, outs = {}, {}, []
+    call_ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]      # device time stamps behind every call (no host wait)
+    call_ev[0].record()
     for k in range(a.warmup, a.warmup + a.steps):
         if (k - a.warmup) % len(mine) == 0 and k > a.warmup:
             sm_mod._complex_cache.clear()    # K > #complexes: the second pass over the shard must not hit the cache either
         out, conf = one_call(k)
+        call_ev[k - a.warmup + 1].record()
         outs.append(out)
         final[order[k]] = torch.stack([d['ligand'].pos for d in out])
         if with_conf:
@@ -298,6 +301,7 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = ctx.profile_read()
     ctx.profile_enable(False)
+    per_call_ms = [round(call_ev[k].elapsed_time(call_ev[k + 1]), 2) for k in range(a.steps)]
 
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -385,7 +389,7 @@ def main():
                                         'TFLOPs_executed': p['edges'] * (2 * 72 * (72 + W_LAYER[l]) + TP_FLOP[l]) / max(p['ms'], 1e-9) / 1e9,
                                         'edges_executed_frac': p['edges'] / max(p['edges_unpruned'], 1)}
                                        for l, p in enumerate(prof)]},
-            'extra': {'device_loop': device_loop},
+            'extra': {'device_loop': device_loop, 'per_call_ms': per_call_ms},
         }
         if world == 1 and not a.no_cpu_baseline and not disco:
             c0 = complexes[mine[0]]

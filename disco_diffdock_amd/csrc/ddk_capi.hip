@@ -197,7 +197,9 @@ static int build_layout(ddk_ctx* ctx, int mode, int l, ConvLayerDev& L, std::vec
   int oc[4] = {0, out[0], out[0] + 3 * out[1], out[0] + 3 * out[1] + 3 * out[2]};
   if (mode == 2) { oc[0] = ns; oc[3] = 0; L.dout = 2 * ns; }       // '24x0o + 24x0e': the 0o channels come first
   if (mode == 3) { oc[1] = 0; oc[2] = 6; L.dout = 12; }
-  struct TRow { int blk[4], col; RowSrc r[4]; bool ok[4]; };     // per tile row j: the block it belongs to (the shared tail tile holds two)
+  // per tile row j: the block it belongs to (the shared tail tile holds two); has_x: accumulator quad rq = 3 of a 6-channel column carries
+  // the rows xr[] of ANOTHER row quad for the channel pair xpair (see pack_quads below)
+  struct TRow { int blk[4], col; RowSrc r[4]; bool ok[4]; bool has_x = false; int xpair = 0; RowSrc xr[4]; };
   std::vector<TRow> trows;
   tiles.clear();
   L.n_cols = 0;
@@ -249,6 +251,11 @@ static int build_layout(ddk_ctx* ctx, int mode, int l, ConvLayerDev& L, std::vec
     }
     done[0] = done[3] = true;
   }
+  // A column of 6 output channels (the vector blocks: nv = 6) fills only 3 of a tile's 4 accumulator quads.  The 4th quad of the column's
+  // first tiles carries the (row quad, channel pair) units of the column's LAST a (x) v / c (x) v row quads instead, whose own tiles disappear:
+  // Q row quads -> ceil(3Q/4) tiles (9 -> 7 for in = 36 rows, 8 -> 6, 6 -> 5).  Tile word: bit 7 = extra unit present, bits 8-9 = its channel
+  // pair, bits 10-13 = its F offset / 4 (an a / c quad).  The 3 x f16 kernel keeps the unpacked table.
+  const bool pack_quads = (mode == 0 || mode == 1) && !c.conv_f16x3;
   for (int b = 0; b < 4; ++b) {
     if (done[b] || parts[b].empty() || L.n_out[b] == 0) continue;
     if (L.n_out[b] % 2) return fail(ctx, DDK_ERR_INVALID, "odd output multiplicity unsupported");
@@ -256,8 +263,33 @@ static int build_layout(ddk_ctx* ctx, int mode, int l, ConvLayerDev& L, std::vec
     for (int col = 0; 8 * col < L.n_out[b]; ++col) {
       if (L.n_cols >= 16) return fail(ctx, DDK_ERR_INVALID, "too many output columns");
       L.col_start[L.n_cols++] = (int)tiles.size();
+      const int t_first = (int)tiles.size();
       for (const Part& p : parts[b])
         if (int rc = emit_part(b, col, p, true)) return rc;
+      if (pack_quads && vec && nch_of(b, col) == 6) {
+        const int Q = (int)tiles.size() - t_first, T = (3 * Q + 3) / 4, n_x = Q - T;
+        // the extras: the last n_x full scalar-row quads (kind T_RA, rows a or c) of the column
+        std::vector<int> xs;
+        for (int t = (int)tiles.size() - 1; t >= t_first && (int)xs.size() < n_x; --t) {
+          const TRow& tr = trows[t];
+          if ((tiles[t].w0 & 3) == T_RA && tr.ok[0] && tr.ok[1] && tr.ok[2] && tr.ok[3] && (tiles[t].w0 >> 16) % 4 == 0 && (tiles[t].w0 >> 16) < 64) xs.push_back(t);
+        }
+        if (n_x > 0 && (int)xs.size() == n_x) {
+          std::vector<TileDesc> keep_t; std::vector<TRow> keep_r, x_r; std::vector<int> x_off;
+          for (int t = t_first; t < (int)tiles.size(); ++t) {
+            if (std::find(xs.begin(), xs.end(), t) != xs.end()) { x_r.push_back(trows[t]); x_off.push_back(tiles[t].w0 >> 16); }
+            else { keep_t.push_back(tiles[t]); keep_r.push_back(trows[t]); }
+          }
+          for (int u = 0; u < 3 * n_x; ++u) {       // unit u = (extra quad u / 3, channel pair u % 3) rides on the column's tile u
+            keep_r[u].has_x = true; keep_r[u].xpair = u % 3;
+            for (int j = 0; j < 4; ++j) keep_r[u].xr[j] = x_r[u / 3].r[j];
+            keep_t[u].w0 |= 0x80 | ((u % 3) << 8) | ((x_off[u / 3] / 4) << 10);
+          }
+          tiles.resize(t_first); trows.resize(t_first);
+          tiles.insert(tiles.end(), keep_t.begin(), keep_t.end());
+          trows.insert(trows.end(), keep_r.begin(), keep_r.end());
+        }
+      }
       tiles.back().w0 |= (vec ? FL_V : FL_S) << 2;
     }
   }
@@ -286,6 +318,11 @@ static int build_layout(ddk_ctx* ctx, int mode, int l, ConvLayerDev& L, std::vec
     for (int rq = 0; rq < 4; ++rq)
       for (int hh = 0; hh < 2; ++hh)
         for (int j = 0; j < 4; ++j) {
+          if (tr.has_x && rq == 3) {      // the extra unit: rows of another quad, channel pair xpair of the same column
+            rowmap[(size_t)t * 32 + 8 * rq + 4 * hh + j] = tr.xr[j].wbase + 8 * tr.col + 2 * tr.xpair + hh;
+            rowscale[(size_t)t * 32 + 8 * rq + 4 * hh + j] = tr.xr[j].scale;
+            continue;
+          }
           const int k = 8 * tr.col + 2 * rq + hh;
           if (!tr.ok[j] || k >= L.n_out[tr.blk[j]]) continue;
           rowmap[(size_t)t * 32 + 8 * rq + 4 * hh + j] = tr.r[j].wbase + k;

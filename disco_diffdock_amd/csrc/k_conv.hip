@@ -383,6 +383,12 @@ __global__ __launch_bounds__(64 * ConvTraits<MODE>::WAVES) void conv_fused_kerne
       const f32x16 D = burst(AC, h, BC);                                                                       \
       __builtin_amdgcn_sched_barrier(0);                                                                       \
       DDK_EPILOGUE                                                                                             \
+      if (w0 & 0x80) {   /* 6-channel column: accumulator quad 3 holds another a / c row quad for channel pair xp */ \
+        const f32x4 g0 = ldv4(Fr + ((w0 >> 8) & 0x3c));                                                        \
+        const f32x2 xv = __builtin_elementwise_fma(D_HI(D, 3), V_HI(g0), D_LO(D, 3) * V_LO(g0));               \
+        const int xp = (w0 >> 8) & 3;                                                                          \
+        if (xp == 0) accA[0] += xv; else if (xp == 1) accA[1] += xv; else accA[2] += xv;                       \
+      }                                                                                                        \
       const int fl = DDK_FLUSH_COND;                                                                           \
       if (fl) {                                                                                                \
         const int nrq = (w0 >> 4) & 7;                                                                         \

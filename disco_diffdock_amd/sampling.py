@@ -197,6 +197,27 @@ def step_coefficients(inference_steps, tr_schedule, rot_schedule, tor_schedule, 
     return t_arr, sc, nc
 
 
+def _host_single_thread(fn):
+    """The host side of a call is a few ms of small tensor bookkeeping that must stay ahead of the GPU; it runs with ONE torch CPU thread:
+    on a 128-thread host an OpenMP-parallel torch CPU op (a collate ``torch.cat``, a checksum) was measured to stall for a whole
+    reverse-diffusion loop (70-100 ms) while the HIP runtime is busy, which starves the GPU queue (tools/host_calls.py).  The caller's
+    thread setting is restored on return."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        n_thr = torch.get_num_threads()
+        if n_thr > 1:
+            torch.set_num_threads(1)
+        try:
+            return fn(*args, **kwargs)
+        finally:
+            if n_thr > 1:
+                torch.set_num_threads(n_thr)
+    return wrapper
+
+
+@_host_single_thread
 def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_schedule, device, t_to_sigma, model_args,
              no_random=False, ode=False, visualization_list=None, confidence_model=None, confidence_data_list=None,
              confidence_model_args=None, batch_size=32, no_final_step_noise=False, use_latent=True,

@@ -48,7 +48,12 @@ def _fingerprint_of(batch, B, mask_rotate=None):
               rec.pos[:n_r], rec.x[:n_r, :17], batch['receptor', 'receptor'].edge_index[:, :E]):
         h.update(_bytes_of(a))
         h.update(b'|')
-    h.update(np.float64(rec.x[:n_r].double().sum().item()).tobytes())
+    # (numpy, not torch: an OpenMP-parallel torch CPU op was measured to stall for a whole GPU loop (~80 ms) on a many-core host while the
+    # HIP runtime is busy; the sums below are single-threaded and need no temporary)
+    xr = rec.x[:n_r]
+    xr = xr.detach().cpu().numpy() if torch.is_tensor(xr) else np.asarray(xr)
+    h.update(np.float64(xr.sum(dtype=np.float64)).tobytes())
+    h.update(np.ascontiguousarray(xr[:, 17::97]).tobytes())       # + a strided sample of the language-model features
     return (B, n_l, n_r, M, E, h.hexdigest())
 
 

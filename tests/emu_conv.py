@@ -135,6 +135,9 @@ def emulate(ctx, layer, x_pad, src, dst, group_offsets, edge_attr, sh, mode=0, s
                         accA += part
                     else:
                         accV[:, :, 0] += part
+                if w0 & 0x80:        # 6-channel column: accumulator quad 3 carries another a / c row quad for channel pair xp
+                    xp, xoff = (w0 >> 8) & 3, (w0 >> 8) & 0x3c
+                    accA[:, xp] += np.einsum('lj,lj->l', Fl[:, xoff:xoff + 4], d[:, 3, :])
                 if fl:
                     for rq in range(nrq):
                         if fl == FL_S:

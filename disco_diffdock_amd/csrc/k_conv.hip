@@ -170,20 +170,7 @@ __global__ __launch_bounds__(64 * ConvTraits<MODE>::WAVES) void conv_fused_kerne
     }
 
     // ---- segmented-scan control words (identical for every output channel of this wave's 32 edges) ----
-    SegCtl seg;
-    {
-      const int prev = __shfl_up(sn, 1, 32);
-      const int next = __shfl_down(sn, 1, 32);
-      int f = (el == 0) || (prev != sn);
-      seg.tail = valid && ((el == nvalid - 1) || (next != sn));   // lanes past nvalid are clamped duplicates of the last edge
-      seg.valid = valid;
-      int fu;
-      fu = __shfl_up(f, 1, 32);  seg.m1 = (el >= 1) && !f;   if (seg.m1) f |= fu;
-      fu = __shfl_up(f, 2, 32);  seg.m2 = (el >= 2) && !f;   if (seg.m2) f |= fu;
-      fu = __shfl_up(f, 4, 32);  seg.m4 = (el >= 4) && !f;   if (seg.m4) f |= fu;
-      fu = __shfl_up(f, 8, 32);  seg.m8 = (el >= 8) && !f;   if (seg.m8) f |= fu;
-      fu = __shfl_up(f, 16, 32); seg.m16 = (el >= 16) && !f; (void)fu;
-    }
+    const SegCtl seg = make_segctl(sn, el, nvalid, valid);
 
     // ---- GEMM1: h = relu(W1 [edge_emb | x_src[:ns] | x_dst[:ns]] + b1), K order kappa(s,hh) = 24*(s/12)+12*hh+s%12 ----
     float h[36];

@@ -77,8 +77,37 @@ __device__ __forceinline__ void tile_epilogue(int kind, const f32x16& D, f32x4 f
   }
 }
 
-// control words of the 5-step segmented scan over runs of equal edge_src (identical for every channel of an edge tile)
+// Control words of the segmented inclusive scan over runs of equal edge_src (identical for every channel of an edge tile).  The scan runs
+// on the VALU's DPP lane crossbar, not through the LDS: four Hillis-Steele steps inside each 16-lane row (row_shr:1,2,4,8) and one
+// row_bcast:15 step that hands lane 15's sum of the half's first row to the lanes of the second row whose run started in the first
+// (a 64-lane wave = two independent halves of 32 edges = rows {0,1} and {2,3}).
 struct SegCtl { bool m1, m2, m4, m8, m16, tail, valid; };
+
+// sn = edge_src of this lane's edge (lanes past nvalid are clamped duplicates of the last edge)
+__device__ __forceinline__ SegCtl make_segctl(int sn, int el, int nvalid, bool valid) {
+  SegCtl c;
+  const int prev = __shfl_up(sn, 1, 32);
+  const int next = __shfl_down(sn, 1, 32);
+  const int r = (el == 0) || (prev != sn);          // a run starts at this lane
+  c.tail = valid && ((el == nvalid - 1) || (next != sn));
+  c.valid = valid;
+  const int rl = el & 15;
+  int f = r | (rl == 0);                            // in-row flag: "a start (or the row start) lies inside the window behind this lane"
+  int g = r;                                        // real starts only: inclusive OR over the lane's row (for the cross-row step)
+  int fu, gu;
+  fu = __shfl_up(f, 1, 32); gu = __shfl_up(g, 1, 32); c.m1 = !f; if (rl >= 1) { f |= fu; g |= gu; }
+  fu = __shfl_up(f, 2, 32); gu = __shfl_up(g, 2, 32); c.m2 = !f; if (rl >= 2) { f |= fu; g |= gu; }
+  fu = __shfl_up(f, 4, 32); gu = __shfl_up(g, 4, 32); c.m4 = !f; if (rl >= 4) { f |= fu; g |= gu; }
+  fu = __shfl_up(f, 8, 32); gu = __shfl_up(g, 8, 32); c.m8 = !f; if (rl >= 8) { f |= fu; g |= gu; }
+  c.m16 = (el >= 16) && !g;                         // the lane's run began in the first row of this half
+  return c;
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float x) {    // lanes without a source (outside the row / row mask) read 0
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROW_MASK, 0xF, true));
+}
+
 // DET: the run tail STORES (every (node, accumulator slot, channel) has exactly one writer per launch: complete runs write the node row,
 // runs that straddle a 32-edge tile write that tile's partial row and conv_det_fix_kernel folds the chain in tile order) instead of
 // adding atomically - a fixed summation order per node (ddk_config.deterministic)
@@ -86,11 +115,11 @@ template <bool DET = false>
 __device__ __forceinline__ void seg_add(float* dst, float xv, const SegCtl& c) {
   xv = c.valid ? xv : 0.0f;
   float up;
-  up = __shfl_up(xv, 1, 32);  if (c.m1) xv += up;
-  up = __shfl_up(xv, 2, 32);  if (c.m2) xv += up;
-  up = __shfl_up(xv, 4, 32);  if (c.m4) xv += up;
-  up = __shfl_up(xv, 8, 32);  if (c.m8) xv += up;
-  up = __shfl_up(xv, 16, 32); if (c.m16) xv += up;
+  up = dpp_f<0x111, 0xF>(xv); if (c.m1) xv += up;     // row_shr:1
+  up = dpp_f<0x112, 0xF>(xv); if (c.m2) xv += up;     // row_shr:2
+  up = dpp_f<0x114, 0xF>(xv); if (c.m4) xv += up;     // row_shr:4
+  up = dpp_f<0x118, 0xF>(xv); if (c.m8) xv += up;     // row_shr:8
+  up = dpp_f<0x142, 0xA>(xv); if (c.m16) xv += up;    // row_bcast:15 into rows 1 and 3
   if (c.tail) {
     if (DET) *dst = xv;
     else unsafeAtomicAdd(dst, xv);

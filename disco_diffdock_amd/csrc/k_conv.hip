@@ -379,16 +379,20 @@ __global__ __launch_bounds__(64 * ConvTraits<MODE>::WAVES) void conv_fused_kerne
       const int fl = DDK_FLUSH_COND;                                                                           \
       if (fl) {                                                                                                \
         const int nrq = (w0 >> 4) & 7;                                                                         \
+        if (fl == FL_S && nrq == 4) {   /* a full scalar column: its four channels in one pass */              \
+          float m4[4];                                                                                         \
+          _Pragma("unroll") for (int rq = 0; rq < 4; ++rq) m4[rq] = fmaf(PSUM(accA[rq]), s0, PSUM(accV[rq][0])); \
+          seg_add_n<DET, 4>(node_row + chan0 + hh, 2, m4, seg);                                                \
+        }                                                                                                      \
         _Pragma("unroll") for (int rq = 0; rq < 4; ++rq) {                                                     \
-          if (rq < nrq) {                                                                                      \
+          if (rq < nrq && !(fl == FL_S && nrq == 4)) {                                                         \
             if (fl == FL_S) {                                                                                  \
               seg_add<DET>(node_row + chan0 + 2 * rq + hh, fmaf(PSUM(accA[rq]), s0, PSUM(accV[rq][0])), seg);       \
             } else {                                                                                           \
               float* d = node_row + chan0 + 3 * (2 * rq + hh);                                                 \
               const float sa = PSUM(accA[rq]);                                                                 \
-              seg_add<DET>(d + 0, fmaf(sa, vx, PSUM(accV[rq][0])), seg);                                            \
-              seg_add<DET>(d + 1, fmaf(sa, vy, PSUM(accV[rq][1])), seg);                                            \
-              seg_add<DET>(d + 2, fmaf(sa, vz, PSUM(accV[rq][2])), seg);                                            \
+              float m3[3] = {fmaf(sa, vx, PSUM(accV[rq][0])), fmaf(sa, vy, PSUM(accV[rq][1])), fmaf(sa, vz, PSUM(accV[rq][2]))}; \
+              seg_add_n<DET, 3>(d, 1, m3, seg);                                                                \
             }                                                                                                  \
           }                                                                                                    \
           accA[rq] = 0.0f; accV[rq][0] = 0.0f; accV[rq][1] = 0.0f; accV[rq][2] = 0.0f;                         \

@@ -126,5 +126,40 @@ __device__ __forceinline__ void seg_add(float* dst, float xv, const SegCtl& c) {
   }
 }
 
+// N channels of the same edge tile at once (dst + i * stride): the N dependent DPP chains interleave, which fills the two wait states a
+// DPP read needs behind the VALU write of its source, and the run tails issue their N atomics under one branch
+template <bool DET, int N>
+__device__ __forceinline__ void seg_add_n(float* dst, int stride, float (&xv)[N], const SegCtl& c) {
+  float up[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) xv[i] = c.valid ? xv[i] : 0.0f;
+#pragma unroll
+  for (int i = 0; i < N; ++i) up[i] = dpp_f<0x111, 0xF>(xv[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) if (c.m1) xv[i] += up[i];
+#pragma unroll
+  for (int i = 0; i < N; ++i) up[i] = dpp_f<0x112, 0xF>(xv[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) if (c.m2) xv[i] += up[i];
+#pragma unroll
+  for (int i = 0; i < N; ++i) up[i] = dpp_f<0x114, 0xF>(xv[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) if (c.m4) xv[i] += up[i];
+#pragma unroll
+  for (int i = 0; i < N; ++i) up[i] = dpp_f<0x118, 0xF>(xv[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) if (c.m8) xv[i] += up[i];
+#pragma unroll
+  for (int i = 0; i < N; ++i) up[i] = dpp_f<0x142, 0xA>(xv[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) if (c.m16) xv[i] += up[i];
+  if (c.tail) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      if (DET) dst[i * stride] = xv[i];
+      else unsafeAtomicAdd(dst + i * stride, xv[i]);
+    }
+  }
+}
 
 }  // namespace ddk

@@ -53,27 +53,24 @@ __device__ __forceinline__ f32x4 ldv4(const float* p) { return *reinterpret_cast
 // (D[4rq+j], D[4rq+j+1]) x (f[j], f[j+1]) without any shuffling moves; the pair is added up when the column is flushed.
 __device__ __forceinline__ void tile_epilogue(int kind, const f32x16& D, f32x4 f0, f32x4 f1, f32x4 f2, f32x2 (&accA)[4],
                                               f32x2 (&accV)[4][3]) {
-  if (kind == T_TV) {   // f0/f1/f2 = x/y/z components of the 4 feature rows
+  // three independent wave-uniform branches, each updating its own accumulators in place (a four-way if / else-if chain made the
+  // compiler merge the accumulator sets with ~25 register copies per tile)
+  f32x2 fhi = V_HI(f0);
+  if (kind == T_RTS) fhi = 0.0f;     // shared tail: only rows j = 0,1 belong to the column that is about to be flushed (the caller adds j = 2,3 behind the flush)
+  if (kind == T_RA) {
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) accA[rq] = __builtin_elementwise_fma(D_HI(D, rq), fhi, __builtin_elementwise_fma(D_LO(D, rq), V_LO(f0), accA[rq]));
+  }
+  if (kind != T_RA) {                // T_RT, T_RTS, and the x components of T_TV
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) accV[rq][0] = __builtin_elementwise_fma(D_HI(D, rq), fhi, __builtin_elementwise_fma(D_LO(D, rq), V_LO(f0), accV[rq][0]));
+  }
+  if (kind == T_TV) {                // f1 / f2 = y / z components of the 4 feature rows
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) {
-      const f32x2 dl = D_LO(D, rq), dh = D_HI(D, rq);
-      accV[rq][0] = __builtin_elementwise_fma(dh, V_HI(f0), __builtin_elementwise_fma(dl, V_LO(f0), accV[rq][0]));
-      accV[rq][1] = __builtin_elementwise_fma(dh, V_HI(f1), __builtin_elementwise_fma(dl, V_LO(f1), accV[rq][1]));
-      accV[rq][2] = __builtin_elementwise_fma(dh, V_HI(f2), __builtin_elementwise_fma(dl, V_LO(f2), accV[rq][2]));
+      accV[rq][1] = __builtin_elementwise_fma(D_HI(D, rq), V_HI(f1), __builtin_elementwise_fma(D_LO(D, rq), V_LO(f1), accV[rq][1]));
+      accV[rq][2] = __builtin_elementwise_fma(D_HI(D, rq), V_HI(f2), __builtin_elementwise_fma(D_LO(D, rq), V_LO(f2), accV[rq][2]));
     }
-  } else if (kind == T_RTS) {     // only rows j = 0,1 belong to the column that is about to be flushed (the caller adds j = 2,3 behind the flush)
-#pragma unroll
-    for (int rq = 0; rq < 4; ++rq) accV[rq][0] = __builtin_elementwise_fma(D_LO(D, rq), V_LO(f0), accV[rq][0]);
-  } else if (kind == T_RA) {
-#pragma unroll
-    for (int rq = 0; rq < 4; ++rq) accA[rq] = __builtin_elementwise_fma(D_LO(D, rq), V_LO(f0), accA[rq]);
-#pragma unroll
-    for (int rq = 0; rq < 4; ++rq) accA[rq] = __builtin_elementwise_fma(D_HI(D, rq), V_HI(f0), accA[rq]);
-  } else {
-#pragma unroll
-    for (int rq = 0; rq < 4; ++rq) accV[rq][0] = __builtin_elementwise_fma(D_LO(D, rq), V_LO(f0), accV[rq][0]);
-#pragma unroll
-    for (int rq = 0; rq < 4; ++rq) accV[rq][0] = __builtin_elementwise_fma(D_HI(D, rq), V_HI(f0), accV[rq][0]);
   }
 }
 

@@ -317,3 +317,23 @@ def test_deterministic_scatter_is_bit_identical(dev, t):
         cx.sample(p, t_arr, sc, nc, z)
         runs.append(p.cpu())
     assert torch.equal(runs[0], runs[1])
+
+
+def test_batch_larger_than_one_scan_chunk(dev):
+    """graph_scan_kernel prefixes the per-sample edge counts one 64-sample chunk per pass: a batch of 70 samples must give every sample
+    the scores it gets in two batches of 35 (same poses, same complex; pruning on, t small enough for ragged per-sample counts)."""
+    from disco_diffdock_amd import synthetic
+    from disco_diffdock_amd.runtime import Context, Complex
+    c = synthetic.make_complex(9, n_res=80, n_lig=14)
+    ctx = Context(device=0)
+    ctx.load_state_dict(smr.random_state_dict(CFG, seed=6))
+    B = 70
+    pos = _poses(c, B, np.random.default_rng(2), spread=12.0)
+    big, half = Complex(ctx, c, B), Complex(ctx, c, B // 2)
+    t = 0.2
+    full = [x.cpu() for x in big.score_forward(T(pos).to(dev), t, t, t)]
+    parts = [[x.cpu() for x in half.score_forward(T(pos[k:k + B // 2]).to(dev), t, t, t)] for k in (0, B // 2)]
+    for k, name in enumerate(('tr', 'rot', 'tor')):
+        assert rel_err(full[k], torch.cat([parts[0][k], parts[1][k]])) < 2e-5, name      # (different atomic-add orders: ~5e-6 observed)
+    st = big.graph_stats()
+    assert st['E_rr'] == B * c['rec_edge_index'].shape[1]

@@ -176,6 +176,7 @@ struct ddk_ctx {
   // profiling (ddk_profile_enable / ddk_profile_read)
   bool prof = false;
   bool prune = true;                // backward receptive-field pruning of the rec-rec messages (ddk_set_receptive_field_pruning)
+  bool layer0_dedup = true;         // layer-0 rec-rec messages once per batch (+ per-sample patches for the latent-conditioned model); ddk_debug_set_layer0_dedup
   struct ProfRec { hipEvent_t a, b; int layer; int slot; int tab = 0; int64_t r01_skipped = 0; bool lig_only = false; };   // tab: group table of the launch
   std::vector<ProfRec> prof_recs;
   int32_t* prof_edges = nullptr;   // pinned host: PROF_INTS edge counts of forward #slot (InfoSlot I_EXEC block)
@@ -214,6 +215,7 @@ struct ConvLaunch {
   int mode = 0;              // ConvTraits MODE
   int n_groups = 4, n_active = 4, n_slots = 1;
   uint32_t slots = 0;        // 2 bits per group
+  uint64_t wmap = 0x876543210ull;   // 4 bits per group: weight set of group g (the DisCo patch group 4 uses the rec-rec weights: 0x23210)
   const int32_t* gbeg = nullptr;
   const int32_t* gend = nullptr;
 };
@@ -232,6 +234,7 @@ struct NodePreArgs {
   int dout; float* x_out; const float* sum_rr0; int n_lig_total, n_rec_total, n_rec; float* zero_extra; int64_t n_extra; int n_slots;
   const float* wn; const float* bnp; float* pre;
   int lig_roles, rec_roles;                  // bit r: role slot r (ConvLayerDev::wn) is needed by the layer the terms are for
+  const uint8_t* rr0_mask = nullptr;         // [n_rec_total] 1: this residue row takes no shared layer-0 rec-rec row (its messages came per sample)
   const uint8_t* levels; int max_level;      // [B * n_rec] receptive-field level of the residues (k_graph.hip) and the deepest one this layer still needs; null: all
 };
 hipError_t launch_node_finalize_pre(const NodePreArgs& a, bool finalize, hipStream_t s);
@@ -239,7 +242,7 @@ hipError_t launch_node_finalize(float* sum, const int32_t* deg, const float* x_i
                                 const float* bn_mean, const float* bn_scale, const float* bn_bias, int64_t n, int dout,
                                 int out_stride, float* out, hipStream_t s, const float* sum_rr0 = nullptr,
                                 int64_t n_lig_total = 0, int n_rec = 1, int clear_sum = 0, float* zero_extra = nullptr,
-                                int64_t n_extra = 0, int n_slots = 1);
+                                int64_t n_extra = 0, int n_slots = 1, const uint8_t* rr0_mask = nullptr);
 // k_tp.hip
 hipError_t launch_tp_forward(const ConvLayerDev& L, const float* x_dst, const float* sh, const float* w, int64_t E,
                              float* out, hipStream_t s);

@@ -154,7 +154,8 @@ __global__ __launch_bounds__(64 * ConvTraits<MODE>::WAVES) void conv_fused_kerne
     const int sn = A.src[e], dn = A.dst[e];
 
     // ---- stage the first two W2 tiles of this unit (the ring is idle: the previous block ended with a barrier) ----
-    const float* wrec = A.w2r + (size_t)g * n_tiles * W2_TILE_FLOATS;
+    const int gw = (int)((A.wmap >> (4 * g)) & 15);                 // weight set / node-term roles of this group
+    const float* wrec = A.w2r + (size_t)gw * n_tiles * W2_TILE_FLOATS;
     {
       const float* wr0 = wrec + (size_t)t_begin * W2_TILE_FLOATS;
       const float* wr1 = wrec + (size_t)min(t_begin + 1, t_end - 1) * W2_TILE_FLOATS;
@@ -186,9 +187,9 @@ __global__ __launch_bounds__(64 * ConvTraits<MODE>::WAVES) void conv_fused_kerne
           bin[4 * j + 0] = a.x; bin[4 * j + 1] = a.y; bin[4 * j + 2] = a.z; bin[4 * j + 3] = a.w;
         }
       }
-      const float* ps = A.pre + ((size_t)sn * 4 + (g & 1)) * NE + 36 * hh;
-      const float* pd = A.pre + ((size_t)dn * 4 + 2 + (g >> 1)) * NE + 36 * hh;
-      const float* w1 = A.w1p + (size_t)g * (3 * 9 * 64 * 4);
+      const float* ps = A.pre + ((size_t)sn * 4 + (gw & 1)) * NE + 36 * hh;
+      const float* pd = A.pre + ((size_t)dn * 4 + 2 + (gw >> 1)) * NE + 36 * hh;
+      const float* w1 = A.w1p + (size_t)gw * (3 * 9 * 64 * 4);
 #pragma unroll
       for (int T = 0; T < 3; ++T) {
         f32x16 acc;
@@ -240,8 +241,8 @@ __global__ __launch_bounds__(64 * ConvTraits<MODE>::WAVES) void conv_fused_kerne
       }
     }
     {
-      const float* w1 = A.w1p + (size_t)g * (3 * 9 * 64 * 4);
-      const float* b1 = A.b1p + (size_t)g * (3 * 2 * 16);
+      const float* w1 = A.w1p + (size_t)gw * (3 * 9 * 64 * 4);
+      const float* b1 = A.b1p + (size_t)gw * (3 * 2 * 16);
 #pragma unroll
       for (int T = 0; T < 3; ++T) {
         f32x16 acc;
@@ -467,7 +468,7 @@ __global__ void count_deg_kernel(const int32_t* src, int64_t E, int32_t* deg) {
 __global__ void node_finalize_kernel(float* sum, const int32_t* deg, const float* x_in, const float* bn_mean,
                                      const float* bn_scale, const float* bn_bias, int64_t n, int dout, int out_stride,
                                      float* out, const float* sum_rr0, int64_t n_lig_total, int n_rec, int clear_sum,
-                                     float* zero_extra, int64_t n_extra, int n_slots) {
+                                     float* zero_extra, int64_t n_extra, int n_slots, const uint8_t* rr0_mask) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (zero_extra != nullptr && i < n_extra) zero_extra[i] = 0.0f;
   if (i >= n * out_stride) return;
@@ -481,7 +482,8 @@ __global__ void node_finalize_kernel(float* sum, const int32_t* deg, const float
       sv += sum[(r * n_slots + sl) * XW + c];
       if (clear_sum) sum[(r * n_slots + sl) * XW + c] = 0.0f;
     }
-    if (sum_rr0 != nullptr && r >= n_lig_total) sv += sum_rr0[((r - n_lig_total) % n_rec) * XW + c];   // shared layer-0 rec-rec messages
+    if (sum_rr0 != nullptr && r >= n_lig_total && !(rr0_mask != nullptr && rr0_mask[r - n_lig_total]))
+      sv += sum_rr0[((r - n_lig_total) % n_rec) * XW + c];   // shared layer-0 rec-rec messages
     v = sv / (float)(d > 1 ? d : 1);
     v = (v - bn_mean[c]) * bn_scale[c] + bn_bias[c];
   }
@@ -545,7 +547,7 @@ __global__ __launch_bounds__(PRE_W) void node_finalize_pre_kernel(NodePreArgs A)
           *ps = make_float4(0.0f, 0.0f, 0.0f, 0.0f);       // every accumulator that is read is cleared behind the read (see node_finalize_kernel)
           sv[0] += t.x; sv[1] += t.y; sv[2] += t.z; sv[3] += t.w;
         }
-        if (A.sum_rr0 != nullptr && !lig) {
+        if (A.sum_rr0 != nullptr && !lig && !(A.rr0_mask != nullptr && A.rr0_mask[r - A.n_lig_total])) {
           const float4 t = ld4(A.sum_rr0 + ((r - A.n_lig_total) % A.n_rec) * XW + c);
           sv[0] += t.x; sv[1] += t.y; sv[2] += t.z; sv[3] += t.w;
         }
@@ -668,7 +670,7 @@ hipError_t launch_conv_fused(const ConvLayerDev& L, const ConvLaunch& a, int n_c
   k.n_cols = L.n_cols;
   for (int c = 0; c <= L.n_cols; ++c) k.col_start[c] = L.col_start[c];
   k.sum_g2 = a.sum_g2; k.g2_node_off = a.g2_node_off;
-  k.n_groups = a.n_groups; k.n_active = a.n_active; k.n_slots = a.n_slots; k.slots = a.slots;
+  k.n_groups = a.n_groups; k.n_active = a.n_active; k.n_slots = a.n_slots; k.slots = a.slots; k.wmap = a.wmap;
   if (a.gbeg) { k.gbeg = a.gbeg; k.gend = a.gend; }
   else { k.gbeg = a.tile_info + 5; k.gend = a.tile_info + 6; }   // 4 contiguous groups go[g] .. go[g+1] (explicit-boundary entry point)
   k.pre = a.pre; k.part = a.part;
@@ -713,12 +715,12 @@ hipError_t launch_count_deg(const int32_t* src, int64_t E, int32_t* deg, hipStre
 hipError_t launch_node_finalize(float* sum, const int32_t* deg, const float* x_in, const float* bn_mean,
                                 const float* bn_scale, const float* bn_bias, int64_t n, int dout, int out_stride,
                                 float* out, hipStream_t s, const float* sum_rr0, int64_t n_lig_total, int n_rec, int clear_sum,
-                                float* zero_extra, int64_t n_extra, int n_slots) {
+                                float* zero_extra, int64_t n_extra, int n_slots, const uint8_t* rr0_mask) {
   int64_t tot = n * out_stride;
   if (zero_extra != nullptr && n_extra > tot) tot = n_extra;
   if (tot == 0) return hipSuccess;
   hipLaunchKernelGGL(node_finalize_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, sum, deg, x_in, bn_mean,
-                     bn_scale, bn_bias, n, dout, out_stride, out, sum_rr0, n_lig_total, n_rec, clear_sum, zero_extra, n_extra, n_slots);
+                     bn_scale, bn_bias, n, dout, out_stride, out, sum_rr0, n_lig_total, n_rec, clear_sum, zero_extra, n_extra, n_slots, rr0_mask);
   return hipGetLastError();
 }
 

@@ -29,6 +29,7 @@ struct ConvKArgs {
   int g2_node_off;
   int n_groups, n_active, n_slots;   // edge groups [gbeg[g], gend[g]); the first n_active run; sum row = (node*n_slots + slot(g))
   uint32_t slots;
+  uint64_t wmap;      // 4 bits per group: which radial MLP (weight set, node-term role) group g uses (identity unless a group is split in two)
   const int32_t* gbeg;
   const int32_t* gend;
 };

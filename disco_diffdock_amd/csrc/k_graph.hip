@@ -219,8 +219,88 @@ __global__ void graph_scan_kernel(GraphArgs G, int64_t edge_cap) {
     if (k == TAB_C) tb[4 + 2] = seg[3];
     if (k == TAB_SHARED) { tb[2] = go[4]; tb[4 + 2] = go[4] + n_shared; }
     for (int g = 0; g < 4; ++g) tot += tb[4 + g] - tb[g];
+    if (k == TAB_SHARED && G.patch_off >= 0 && G.shared_rr) tot += G.info[I_PATCH];
     G.info[I_EXEC + 2 + k] = tot;
   }
+  if (G.patch_off >= 0 && G.shared_rr) {      // latent-conditioned model: [ll | lr | shared rr | rl | per-sample patches] for layer 0
+    const int np = G.info[I_PATCH];
+    const int32_t* ts = G.info + I_TAB + 8 * TAB_SHARED;
+    for (int g = 0; g < 4; ++g) { G.info[I_TABX + g] = ts[g]; G.info[I_TABX + 5 + g] = ts[4 + g]; }
+    G.info[I_TABX + 4] = (int)G.patch_off; G.info[I_TABX + 9] = (int)G.patch_off + np;
+    G.info[I_FBX] = bs + (np + 255) / 256;
+  } else {
+    G.info[I_FBX] = bs;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// DisCo layer-0 patches.  The shared rec-rec pass runs on sample 0's receptor rows (its latents included).  For sample s > 0 a
+// residue j is "marked" when its latent row differs from zero in sample s OR in sample 0; every receiver that is marked or has a marked
+// sender gets ALL its rec-rec messages evaluated per sample (patch group, sorted by (sample, receiver, static order)) and takes no
+// shared row (rr_mask).  With one-hot latents at latent_dim nodes per sample that is ~1/3 of the rec-rec edges.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool latent_nonzero(const float* lat, int64_t row, int ld) {
+  bool nz = false;
+  for (int j = 0; j < ld; ++j) nz |= lat[row * ld + j] != 0.0f;
+  return nz;
+}
+
+// one workgroup per sample: rr_mask + the sample's patch-edge count
+__global__ __launch_bounds__(256) void disco_patch_count_kernel(PatchArgs A) {
+  extern __shared__ unsigned char mk[];          // [n_rec] marked
+  __shared__ int red[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int j = tid; j < A.n_rec; j += 256)
+    mk[j] = b > 0 && (latent_nonzero(A.rec_latent, (int64_t)b * A.n_rec + j, A.latent_dim) || latent_nonzero(A.rec_latent, j, A.latent_dim));
+  __syncthreads();
+  int cnt = 0;
+  for (int i = tid; i < A.n_rec; i += 256) {
+    bool a = mk[i];
+    const int k0 = A.rr_start[i], k1 = k0 + A.rr_outdeg[i];
+    for (int k = k0; k < k1 && !a; ++k) a = mk[A.rr_dst[k]];
+    A.rr_mask[(size_t)b * A.n_rec + i] = a;
+    if (a) cnt += k1 - k0;
+  }
+  red[tid] = cnt;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) { if (tid < d) red[tid] += red[tid + d]; __syncthreads(); }
+  if (tid == 0) A.patch_cnt[b] = red[0];
+}
+
+// one wave: exclusive prefix of the per-sample counts, total -> info[I_PATCH]
+__global__ void disco_patch_scan_kernel(PatchArgs A) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int tot = 0;
+  for (int b = 0; b < A.B; ++b) { const int c = A.patch_cnt[b]; A.patch_cnt[b] = tot; tot += c; }
+  A.patch_cnt[A.B] = tot;
+  A.info[I_PATCH] = tot;
+}
+
+// one workgroup per sample: the patch edges of the masked receivers in (receiver, static order)
+__global__ __launch_bounds__(256) void disco_patch_fill_kernel(PatchArgs A) {
+  extern __shared__ int pre_[];                  // [n_rec] exclusive prefix of the masked receivers' edge counts
+  __shared__ int scan_tmp[8];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < A.n_rec; i += 256) pre_[i] = A.rr_mask[(size_t)b * A.n_rec + i] ? A.rr_outdeg[i] : 0;
+  __syncthreads();
+  block_exclusive_scan(pre_, A.n_rec, scan_tmp);
+  const int rec0 = A.B * A.n_lig + b * A.n_rec;
+  const int64_t base = A.patch_off + A.patch_cnt[b];
+  for (int i = tid; i < A.n_rec; i += 256) {
+    if (!A.rr_mask[(size_t)b * A.n_rec + i]) continue;
+    const int k0 = A.rr_start[i], n = A.rr_outdeg[i];
+    for (int q = 0; q < n; ++q) {
+      const int64_t pos = base + pre_[i] + q;
+      A.e_src[pos] = rec0 + i; A.e_dst[pos] = rec0 + A.rr_dst[k0 + q]; A.e_aux[pos] = k0 + q;
+    }
+  }
+}
+
+hipError_t launch_disco_patch(const PatchArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(disco_patch_count_kernel, dim3(a.B), dim3(256), (size_t)a.n_rec, s, a);
+  hipLaunchKernelGGL(disco_patch_scan_kernel, dim3(1), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(disco_patch_fill_kernel, dim3(a.B), dim3(256), (size_t)a.n_rec * sizeof(int), s, a);
+  return hipGetLastError();
 }
 
 constexpr int FILL_SLICES = 4;
@@ -350,13 +430,17 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(GraphArgs G) {
 __global__ __launch_bounds__(256) void edge_features_kernel(EdgeFeatArgs A) {
   const int blk = blockIdx.x;
   const int bs1 = A.info[I_FB + 1], bs2 = A.info[I_FB + 2], bs3 = A.info[I_FB + 3], bs4 = A.info[I_FB + 4], bs5 = A.info[I_FB + 5];
-  if (blk >= bs5) return;
-  const int fg = (blk >= bs1) + (blk >= bs2) + (blk >= bs3) + (blk >= bs4);      // feature group: the four edge groups + the shared rec-rec copy
-  const int bstart = fg == 0 ? 0 : (fg == 1 ? bs1 : (fg == 2 ? bs2 : (fg == 3 ? bs3 : bs4)));
-  const int e = (fg < 4 ? A.info[I_GO + fg] : A.info[I_SHARED]) + 256 * (blk - bstart) + threadIdx.x;
-  if (e >= (fg < 4 ? A.info[I_GO + 1 + fg] : A.info[I_SHARED] + A.n_shared)) return;
+  const int bs6 = A.patch_off >= 0 ? A.info[I_FBX] : bs5;
+  if (blk >= bs6) return;
+  // feature group: the four edge groups + the shared rec-rec copy + the DisCo patch group (rec-rec edges with per-sample latents)
+  const int fg = (blk >= bs1) + (blk >= bs2) + (blk >= bs3) + (blk >= bs4) + (blk >= bs5);
+  const int bstart = fg == 0 ? 0 : (fg == 1 ? bs1 : (fg == 2 ? bs2 : (fg == 3 ? bs3 : (fg == 4 ? bs4 : bs5))));
+  const int first = fg < 4 ? A.info[I_GO + fg] : (fg == 4 ? A.info[I_SHARED] : (int)A.patch_off);
+  const int last = fg < 4 ? A.info[I_GO + 1 + fg] : (fg == 4 ? A.info[I_SHARED] + A.n_shared : (int)A.patch_off + A.info[I_PATCH]);
+  const int e = first + 256 * (blk - bstart) + threadIdx.x;
+  if (e >= last) return;
   if (fg == 2 && A.g2_live_only && e >= A.info[I_SEG + 3]) return;      // behind the level-C segment: no layer evaluates these messages
-  const int g = fg == 4 ? 2 : fg;
+  const int g = fg >= 4 ? 2 : fg;
   const int sn = A.e_src[e], dn = A.e_dst[e], aux = A.e_aux[e];
   const EdgeMlpDev& M = g == 0 ? A.lig : (g == 2 ? A.rec : A.cross);
   const float* sigb = g == 0 ? A.sp.lig_edge_sigb : (g == 2 ? A.sp.rec_edge_sigb : A.sp.cross_edge_sigb);

@@ -28,6 +28,11 @@ enum InfoSlot : int {
   I_EXEC = 80,    // [80] = E, [81] = go[2] (edges of groups 0+1), [82 + k] = edges table k evaluates over all four groups
   I_HEAD = 96,    // heads' edge list (k_heads.hip): [96] = 0, [97] = B*n_lig (centre edges), [98] = B*n_lig, [99] = end of the bond edges (atomic
                   // cursor of heads_pre_kernel), [100], [101] = work-queue counters of the two head launches
+  // latent-conditioned (DisCo) model, layer-0 de-duplication with per-sample patches (model.hip): a fifth edge group = ALL rec-rec edges of the
+  // receivers whose layer-0 sum depends on this sample's (or sample 0's) non-zero receptor latents, at a fixed offset behind the edge arrays
+  I_TABX = 104,   // [104..108] gbeg, [109..113] gend of the 5-group table [ll | lr | shared rr | rl | patch]
+  I_PATCH = 114,  // number of patch edges (disco_patch kernels; stays until the latents change)
+  I_FBX = 115,    // edge-feature block prefix end including the patch group
   INFO_INTS = 128
 };
 // group tables: which rec-rec edges a layer evaluates
@@ -146,7 +151,23 @@ struct GraphArgs {
   int32_t* e_aux;
   int32_t* deg;             // [B*(n_lig+n_rec)]
   int rec_node_base = -1;   // node id of sample 0's first residue (-1: B*n_lig, the score model's [lig | rec] numbering)
+  int64_t patch_off = -1;   // >= 0: first edge of the DisCo patch group (I_TABX / I_PATCH / I_FBX are maintained)
 };
+
+// DisCo layer-0 patches: receivers whose rec-rec messages differ from the shared (sample-0) evaluation
+struct PatchArgs {
+  const float* rec_latent;   // [B * n_rec, latent_dim]
+  const int32_t* rr_start;   // [n_rec]
+  const int32_t* rr_outdeg;  // [n_rec]
+  const int32_t* rr_dst;     // [E_rr]
+  int B, n_lig, n_rec, E_rr, latent_dim;
+  int64_t patch_off;
+  uint8_t* rr_mask;          // [B * n_rec]
+  int32_t* patch_cnt;        // [B + 1]
+  int32_t* info;
+  int32_t *e_src, *e_dst, *e_aux;
+};
+hipError_t launch_disco_patch(const PatchArgs& a, hipStream_t s);
 
 struct EdgeFeatArgs {
   const float* lig_pos;    // [B*n_lig,3]
@@ -167,6 +188,7 @@ struct EdgeFeatArgs {
   int n_rec;
   int n_shared = 0;        // edges of the shared rec-rec copy (E_rr or 0)
   int g2_live_only = 0;    // 1: only the rec-rec edges of the level segments A, B, C get features (no layer evaluates the rest)
+  int64_t patch_off = -1;  // >= 0: the DisCo patch group's edges start here (count in info[I_PATCH], feature blocks behind the shared copy's)
   const float* lig_latent; // [B*n_lig, latent_dim] or null
   const float* rec_latent; // [B*n_rec, latent_dim] or null
   float unconditional;     // data[...].unconditional (same value on every node of a forward, sampling.py:114-115,121-122)
@@ -261,6 +283,12 @@ struct ddk_complex {
   float* scores = nullptr;
   const float *lig_latent = nullptr, *rec_latent = nullptr;   // caller-owned device arrays set by ddk_set_latents
   float unconditional = 0.0f;
+  // layer-0 de-duplication of the latent-conditioned model (score_forward_impl): per-sample patch group behind the edge arrays
+  int64_t patch_off = -1;          // first edge of the patch region (capacity max_batch * E_rr) or -1: not allocated
+  uint8_t* rr_mask = nullptr;      // [max_batch * n_rec] 1: this receiver's rec-rec sum comes from the patch group, not from the shared rows
+  int32_t* patch_cnt = nullptr;    // [max_batch + 1] patch edges per sample -> exclusive prefix
+  bool latent_dirty = true;        // the latent arrays may have changed since the patch group was built
+  int patch_B = 0;                 // batch size the patch group was built for (node numbering depends on it)
   float cfg_weight = 0.0f, cfg_start = 1.0f, cfg_end = 0.0f;   // ddk_set_guidance
   float *zero_lat = nullptr, *scores2 = nullptr;
   float* part = nullptr;      // deterministic mode: partial rows of the conv launches (ConvLaunch::part)

@@ -393,12 +393,12 @@ static T* cx_upload(ddk_complex* cx, const T* src, size_t n) {
 
 // a6-a8 + the merge of score_model.py:218-225: counts, offsets and the sorted edge list of B poses into the complex' workspace
 static hipError_t build_graph(ddk_ctx* ctx, ddk_complex* cx, int B, const float* lig_pos, float cross_cutoff, bool prune, bool shared_rr,
-                              hipStream_t s) {
+                              hipStream_t s, int64_t patch_off = -1) {
   const ddk_config& c = ctx->cfg;
   GraphArgs G;
   G.lig_pos = lig_pos; G.rec_pos = cx->rec_pos; G.bond_src = cx->bond_src; G.bond_dst = cx->bond_dst;
   G.rr_src = cx->rr_src; G.rr_dst = cx->rr_dst; G.rr_outdeg = cx->rr_outdeg; G.rr_start = cx->rr_start;
-  G.prune = prune ? 1 : 0; G.shared_rr = shared_rr ? 1 : 0;
+  G.prune = prune ? 1 : 0; G.shared_rr = shared_rr ? 1 : 0; G.patch_off = patch_off;
   G.B = B; G.n_lig = cx->n_lig; G.n_rec = cx->n_rec; G.M = cx->M; G.E_rr = cx->E_rr;
   G.lig_r2 = c.lig_max_radius * c.lig_max_radius; G.cross_cutoff = cross_cutoff;
   G.counts = cx->counts; G.offs = cx->offs; G.info = cx->info; G.levels = cx->levels; G.e_src = cx->e_src; G.e_dst = cx->e_dst; G.e_aux = cx->e_aux;
@@ -416,10 +416,25 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
 #define CK(x, what) do { e = (x); if (e != hipSuccess) return hip_fail(ctx, e, what); } while (0)
   // layer 0: the receptor's node features and rec-rec edge features are the same for every sample of the batch
   // (no latents) -> evaluate the rec-rec messages once, exact in real arithmetic
-  const bool dedup = (c.latent_dim == 0 && B > 1 && cx->E_rr > 0);
+  // Latent-conditioned (DisCo) model: the latents are one-hot at a few nodes per sample, so the shared pass (on sample 0's rows) is right
+  // for every receiver whose senders and itself carry zero latents in sample s and in sample 0; all the other receivers get their
+  // rec-rec messages per sample from a fifth "patch" edge group (disco_patch kernels, rebuilt when the latents change)
+  const bool patched = c.latent_dim > 0 && ctx->layer0_dedup && !c.deterministic && !c.conv_f16x3 && cx->patch_off >= 0 && cx->pre != nullptr &&
+                       ctx->conv[0].wn != nullptr && c.num_conv_layers > 1;
+  const bool dedup = ((c.latent_dim == 0 && ctx->layer0_dedup) || patched) && B > 1 && cx->E_rr > 0;
+  if (c.latent_dim > 0 && (!cx->lig_latent || !cx->rec_latent))
+    return fail(ctx, DDK_ERR_STATE, "latent-conditioned model: call ddk_set_latents before the forward");
+  if (dedup && patched && (cx->latent_dirty || cx->patch_B != B)) {
+    PatchArgs P;
+    P.rec_latent = cx->rec_latent; P.rr_start = cx->rr_start; P.rr_outdeg = cx->rr_outdeg; P.rr_dst = cx->rr_dst;
+    P.B = B; P.n_lig = n_lig; P.n_rec = n_rec; P.E_rr = cx->E_rr; P.latent_dim = c.latent_dim; P.patch_off = cx->patch_off;
+    P.rr_mask = cx->rr_mask; P.patch_cnt = cx->patch_cnt; P.info = cx->info; P.e_src = cx->e_src; P.e_dst = cx->e_dst; P.e_aux = cx->e_aux;
+    CK(launch_disco_patch(P, s), "layer-0 patch group");
+    cx->latent_dirty = false; cx->patch_B = B;
+  }
   // backward receptive-field pruning of the rec-rec messages (k_graph.hip): off when the caller wants the receptor rows of the last layer
   const bool prune = ctx->prune && !cx->keep_rec && cx->E_rr > 0;
-  CK(build_graph(ctx, cx, B, lig_pos, sp.cross_cutoff, prune, dedup, s), "graph build");
+  CK(build_graph(ctx, cx, B, lig_pos, sp.cross_cutoff, prune, dedup, s, (dedup && patched) ? cx->patch_off : -1), "graph build");
   EdgeFeatArgs F;
   F.lig_pos = lig_pos; F.rec_pos = cx->rec_pos; F.bond_attr = cx->bond_attr; F.rr_pre1 = cx->rr_pre1; F.rr_sh = cx->rr_sh;
   F.e_src = cx->e_src; F.e_dst = cx->e_dst; F.e_aux = cx->e_aux; F.info = cx->info; F.e_emb = cx->e_emb; F.e_sh = cx->e_sh;
@@ -428,12 +443,11 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
   // 5-layer model with the layer-0 de-duplication and the pruning on: layers 1..3 evaluate the rec-rec messages of levels C, B, A only, layer 0 the
   // shared copy, layer 4 none -> the per-sample rec-rec edges behind the level-C segment never need their embedding / sh
   F.g2_live_only = (dedup && prune && c.num_conv_layers == 5) ? 1 : 0;
+  F.patch_off = (dedup && patched) ? cx->patch_off : -1;
   F.latent_dim = c.latent_dim; F.lig_latent = cx->lig_latent; F.rec_latent = cx->rec_latent; F.unconditional = cx->unconditional;
-  if (c.latent_dim > 0 && (!cx->lig_latent || !cx->rec_latent))
-    return fail(ctx, DDK_ERR_STATE, "latent-conditioned model: call ddk_set_latents before the forward");
   // worst-case edge count of THIS batch size bounds the launch
   const int64_t cap_b = (int64_t)B * ((int64_t)cx->M + (int64_t)n_lig * (LIG_CAP - 1) + 2LL * n_lig * n_rec + cx->E_rr) + cx->E_rr;
-  CK(launch_edge_features(F, cap_b < cx->edge_cap ? cap_b : cx->edge_cap, s), "edge features");
+  CK(launch_edge_features(F, (cap_b < cx->edge_cap ? cap_b : cx->edge_cap) + (F.patch_off >= 0 ? (int64_t)B * cx->E_rr + 256 : 0), s), "edge features");
   float* xin = cx->xa;
   float* xout = cx->xb;
   NodeEmbedArgs NE_;
@@ -477,6 +491,9 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
     else if (prune && l == NL - 4) tab = TAB_C;
     a.gbeg = cx->info + I_TAB + 8 * tab; a.gend = a.gbeg + 4;
     a.n_groups = 4; a.n_active = lig_only ? 2 : 4; a.n_slots = 1; a.slots = 0;
+    if (shared0 && patched) {      // [ll | lr | shared rr | rl | per-sample patches (rec-rec weights and node-term roles)]
+      a.gbeg = cx->info + I_TABX; a.gend = a.gbeg + 5; a.n_groups = 5; a.n_active = 5; a.wmap = 0x23210ull;
+    }
     if (c.deterministic) {     // ligand atoms receive in groups 0,1, residues in 2,3: slot = g & 1 -> one writer per (node, slot, channel)
       a.n_slots = 2; a.slots = (0u) | (1u << 2) | (0u << 4) | (1u << 6);
       a.part = cx->part; a.edge_bound = cap_b;
@@ -489,7 +506,7 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
     ddk_ctx::ProfRec pr;
     if (prof_slot) {
       CK(hipEventCreate(&pr.a), "event"); CK(hipEventCreate(&pr.b), "event");
-      pr.layer = l; pr.slot = ctx->prof_slots; pr.tab = tab; pr.lig_only = lig_only; pr.r01_skipped = shared0 ? (int64_t)(B - 1) * cx->E_rr : 0;
+      pr.layer = l; pr.slot = ctx->prof_slots; pr.tab = tab; pr.lig_only = lig_only; pr.r01_skipped = shared0 ? (patched ? -1 : (int64_t)(B - 1) * cx->E_rr) : 0;      // (-1: E - executed edges, the patch count lives on the device)
       CK(hipEventRecord(pr.a, s), "event record");
     }
     CK(launch_conv_fused(L, a, ctx->n_cu, s), "conv_fused");
@@ -502,6 +519,7 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
       NodePreArgs PA = {};
       PA.sum = cx->sum; PA.deg = cx->deg; PA.x_in = xin; PA.bn_mean = L.bn_mean; PA.bn_scale = L.bn_scale; PA.bn_bias = L.bn_bias;
       PA.dout = L.dout; PA.x_out = xout; PA.sum_rr0 = shared0 ? cx->sum_rr0 : nullptr; PA.n_lig_total = B * n_lig; PA.n_rec_total = B * n_rec;
+      PA.rr0_mask = (shared0 && patched) ? cx->rr_mask : nullptr;
       PA.n_rec = n_rec; PA.zero_extra = clear_rr0 ? cx->sum_rr0 : nullptr; PA.n_extra = clear_rr0 ? (int64_t)n_rec * XW : 0;
       PA.wn = ctx->conv[l + 1].wn; PA.bnp = ctx->conv[l + 1].bnp; PA.pre = cx->pre; PA.n_slots = c.deterministic ? 2 : 1;
       // rows nothing downstream reads (the same receptive-field argument as for the rec-rec messages) are neither finalised nor given node terms
@@ -514,7 +532,7 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
     } else
     CK(launch_node_finalize(cx->sum, cx->deg, xin, L.bn_mean, L.bn_scale, L.bn_bias, lig_only ? (int64_t)B * n_lig : N, L.dout, XW, xout, s,
                             shared0 ? cx->sum_rr0 : nullptr, (int64_t)B * n_lig, n_rec, 1, clear_rr0 ? cx->sum_rr0 : nullptr,
-                            clear_rr0 ? (int64_t)n_rec * XW : 0, c.deterministic ? 2 : 1), "node_finalize");
+                            clear_rr0 ? (int64_t)n_rec * XW : 0, c.deterministic ? 2 : 1, (shared0 && patched) ? cx->rr_mask : nullptr), "node_finalize");
     if (clear_rr0) rr0_dirty = false;
     float* t = xin; xin = xout; xout = t;
   }
@@ -602,7 +620,7 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
     const size_t cap0 = Bm0 * ((size_t)M + (size_t)n_lig * (LIG_CAP - 1) + 2 * (size_t)n_lig * n_rec + E0) + E0 + 64, N0 = Bm0 * (size_t)(n_lig + n_rec);
     size_t need = (size_t)M * 24 + R0 * 8 + R0 * n_lig + (size_t)n_rec * 12 + (size_t)(n_lig + n_rec) * NS * 4 + E0 * (8 + NS * 4 + 16) + (size_t)n_rec * 4;
     need += cap0 * (12 + NS * 4 + 16) + N0 * 4 + N0 * PRE_W * 4 + (c.deterministic ? N0 * XW * 4 + (cap0 / 32 + 128) * 2 * XW * 4 : 0) + Bm0 * ((size_t)n_lig + R0 * BOND_CAP + 2) * (8 + NE * 4 + 16) + Bm0 * (1 + R0) * (XW * 4 + 4) + 8 * 256 + Bm0 * 2 * CNT_STRIDE * 4 + INFO_INTS * 4 + (size_t)n_rec * 4 + Bm0 * n_rec + 3 * N0 * XW * 4 + (size_t)n_rec * XW * 4 + Bm0 * n_lig * 12 + 2 * Bm0 * (6 + R0) * 4;
-    if (c.latent_dim > 0) need += N0 * c.latent_dim * 4;
+    if (c.latent_dim > 0) need += N0 * c.latent_dim * 4 + Bm0 * E0 * (12 + NS * 4 + 16) + Bm0 * n_rec + (Bm0 + 1) * 4 + 3 * 256;
     cx_reserve(cx, need + 64 * 256);
     // everything uploaded below (topology, static embeddings, receptor-edge geometry) goes through one pinned staging buffer
     const size_t staged = (size_t)M * 24 + R0 * 8 + R0 * n_lig + (size_t)n_rec * 12 + (size_t)(n_lig + n_rec) * NS * 4 + E0 * (8 + NS * 4 + 16) +
@@ -713,11 +731,20 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
   cx->edge_cap = Bm * ((int64_t)M + (int64_t)n_lig * (LIG_CAP - 1) + 2LL * n_lig * n_rec + E) + E + 64;   // + the shared rec-rec copy
   if (cx->edge_cap >= ((int64_t)1 << 31)) return fail(ctx, DDK_ERR_INVALID, "edge capacity exceeds int32 (reduce max_batch)");
   const int64_t N = Bm * (n_lig + n_rec);
-  cx->e_src = cx_upload<int32_t>(cx, nullptr, cx->edge_cap);
-  cx->e_dst = cx_upload<int32_t>(cx, nullptr, cx->edge_cap);
-  cx->e_aux = cx_upload<int32_t>(cx, nullptr, cx->edge_cap);
-  cx->e_emb = cx_upload<float>(cx, nullptr, cx->edge_cap * NS);
-  cx->e_sh = cx_upload<float>(cx, nullptr, cx->edge_cap * 4);
+  // latent-conditioned model: room for the layer-0 patch group (at most every rec-rec edge of every sample) behind the regular edges
+  const int64_t patch_cap = (has_model && c.latent_dim > 0 && E > 0) ? Bm * (int64_t)E : 0;
+  if (cx->edge_cap + patch_cap >= ((int64_t)1 << 31)) return fail(ctx, DDK_ERR_INVALID, "edge capacity exceeds int32 (reduce max_batch)");
+  const int64_t e_alloc = cx->edge_cap + patch_cap;
+  cx->e_src = cx_upload<int32_t>(cx, nullptr, e_alloc);
+  cx->e_dst = cx_upload<int32_t>(cx, nullptr, e_alloc);
+  cx->e_aux = cx_upload<int32_t>(cx, nullptr, e_alloc);
+  cx->e_emb = cx_upload<float>(cx, nullptr, e_alloc * NS);
+  cx->e_sh = cx_upload<float>(cx, nullptr, e_alloc * 4);
+  if (patch_cap > 0) {
+    cx->patch_off = cx->edge_cap;
+    cx->rr_mask = cx_upload<uint8_t>(cx, nullptr, Bm * n_rec);
+    cx->patch_cnt = cx_upload<int32_t>(cx, nullptr, Bm + 1);
+  }
   cx->deg = cx_upload<int32_t>(cx, nullptr, N);
   cx->counts = cx_upload<int32_t>(cx, nullptr, Bm * CNT_STRIDE);
   cx->offs = cx_upload<int32_t>(cx, nullptr, Bm * CNT_STRIDE);
@@ -936,6 +963,7 @@ int ddk_set_latents(ddk_ctx* ctx, ddk_complex* cx, const float* lig_latent, cons
   if (!ctx || !cx) return DDK_ERR_INVALID;
   if ((lig_latent == nullptr) != (rec_latent == nullptr)) return fail(ctx, DDK_ERR_INVALID, "ddk_set_latents: pass both latent arrays or neither");
   cx->lig_latent = lig_latent; cx->rec_latent = rec_latent; cx->unconditional = unconditional;
+  cx->latent_dirty = true;      // (the arrays are caller-owned: every call may carry new values)
   return DDK_OK;
 }
 
@@ -972,6 +1000,7 @@ int ddk_ar_decode(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* logits,
   ArDecodeArgs A;
   A.logits = logits; A.uniforms = uniforms; A.temperature = temperature; A.n_lig = cx->n_lig; A.n_rec = cx->n_rec; A.idx = decoding_idx;
   A.latent_dim = latent_dim; A.lig_latent = lig_latent; A.rec_latent = rec_latent; A.choices = choices;
+  cx->latent_dirty = true;      // the decode writes into latent arrays that may be the ones ddk_set_latents registered
   hipError_t e = launch_ar_decode(A, B, (hipStream_t)stream);
   return e == hipSuccess ? DDK_OK : hip_fail(ctx, e, "ar_decode launch");
 }
@@ -1020,10 +1049,28 @@ int ddk_profile_read(ddk_ctx* ctx, double* out, int32_t n) {
     out[5 * r.layer] += ms;
     out[5 * r.layer + 1] += 1.0;
     out[5 * r.layer + 2] += r.lig_only ? E01 : (double)pe[2 + r.tab];            // edges the launch evaluated
-    out[5 * r.layer + 3] += r.lig_only ? E01 : E - (double)r.r01_skipped;          // without the receptive-field pruning (round-1 accounting)
+    out[5 * r.layer + 3] += r.lig_only ? E01 : (r.r01_skipped < 0 ? (double)pe[2 + r.tab] : E - (double)r.r01_skipped);   // without the receptive-field pruning (round-1 accounting; de-duplicated layer-0 messages are not work)
     out[5 * r.layer + 4] += E;                                                     // edges the reference evaluates in this layer
   }
   return DDK_OK;
+}
+
+// Test hook: layer-0 de-duplication of the rec-rec messages on / off (on by default; off = every sample evaluates all its rec-rec messages)
+int ddk_debug_set_layer0_dedup(ddk_ctx* ctx, int32_t on) {
+  if (!ctx) return DDK_ERR_INVALID;
+  ctx->layer0_dedup = on != 0;
+  return DDK_OK;
+}
+
+// Test hook: the layer-0 patch group of the last forward of the latent-conditioned model: counts[B + 1] = exclusive prefix of the patch edges per
+// sample (counts[B] = total), mask[B * n_rec] = receivers that take their rec-rec sum from the patch group (HOST pointers; synchronises)
+int ddk_debug_read_patch(ddk_ctx* ctx, ddk_complex* cx, int32_t B, int32_t* counts, uint8_t* mask) {
+  if (!ctx || !cx || !counts || !mask) return DDK_ERR_INVALID;
+  if (cx->patch_off < 0 || B < 1 || B > cx->max_batch) return fail(ctx, DDK_ERR_STATE, "no patch group on this complex (latent-conditioned models only)");
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(counts, cx->patch_cnt, (size_t)(B + 1) * sizeof(int32_t), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(mask, cx->rr_mask, (size_t)B * cx->n_rec, hipMemcpyDeviceToHost);
+  return e == hipSuccess ? DDK_OK : hip_fail(ctx, e, "ddk_debug_read_patch");
 }
 
 // Test hooks: the device Kabsch / axis-angle routines of k_se3.hip on caller-supplied DEVICE arrays (A, B [nb, n, 3] -> R [nb,3,3], t [nb,3];

@@ -167,6 +167,10 @@ class Context:
         """backward receptive-field pruning of the receptor-receptor messages (default on; exact)"""
         self._check(self.L.ddk_set_receptive_field_pruning(self.h, int(bool(on))), 'ddk_set_receptive_field_pruning')
 
+    def debug_set_layer0_dedup(self, on=True):
+        """test hook (include/ddk_debug.h): layer-0 de-duplication of the rec-rec messages on / off"""
+        self._check(self.L.ddk_debug_set_layer0_dedup(self.h, int(bool(on))), 'ddk_debug_set_layer0_dedup')
+
     # ---- operators ---------------------------------------------------------------------------
     def tp_forward(self, layer, x_dst, sh, w, dout):
         x_dst, sh, w = x_dst.contiguous().float(), sh.contiguous().float(), w.contiguous().float()
@@ -226,10 +230,23 @@ class Complex:
         except Exception:
             pass
 
+    def debug_read_patch(self, B):
+        """test hook: (exclusive prefix of the layer-0 patch edges per sample [B + 1], receiver mask [B, n_rec]) of the last forward"""
+        cnt, mask = np.zeros(B + 1, np.int32), np.zeros((B, self.n_rec), np.uint8)
+        self.ctx._check(self.ctx.L.ddk_debug_read_patch(self.ctx.h, self.h, B, cnt.ctypes.data_as(C.c_void_p), mask.ctypes.data_as(C.c_void_p)),
+                        'ddk_debug_read_patch')
+        return cnt, mask
+
     def set_latents(self, lig_latent=None, rec_latent=None, unconditional=0.0):
         """data['ligand'|'receptor'].latent_h of the batch ([B*n, latent_dim], device) for the following forwards."""
         if lig_latent is not None:
             lig_latent, rec_latent = lig_latent.contiguous().float(), rec_latent.contiguous().float()
+            ld = int(self.ctx.cfg.latent_dim)
+            nb = lig_latent.shape[0] // max(self.n_lig, 1)
+            if (lig_latent.dim() != 2 or rec_latent.dim() != 2 or lig_latent.shape[1] != ld or rec_latent.shape[1] != ld or nb < 1
+                    or lig_latent.shape[0] != nb * self.n_lig or rec_latent.shape[0] != nb * self.n_rec):
+                raise RuntimeError(f'ddk: latent arrays must be [B*{self.n_lig}, {ld}] and [B*{self.n_rec}, {ld}] for one batch size B, got '
+                                   f'{tuple(lig_latent.shape)} and {tuple(rec_latent.shape)} (the library reads them through raw pointers)')
         self._latents = (lig_latent, rec_latent)      # keep the device arrays alive
         self.ctx._check(self.ctx.L.ddk_set_latents(self.ctx.h, self.h, _ptr(lig_latent), _ptr(rec_latent), float(unconditional)),
                         'ddk_set_latents')

@@ -28,6 +28,14 @@ int ddk_debug_conf_nodes(ddk_ctx* ctx, ddk_complex* cx, float* x, int32_t* deg, 
 int ddk_debug_conf_edges(ddk_ctx* ctx, ddk_complex* cx, int64_t first, int64_t n, int32_t* src, int32_t* dst, float* emb, float* sh,
                          int32_t* gt);
 
+/* Layer-0 de-duplication of the receptor-receptor messages (one evaluation per batch; for the latent-conditioned model plus the per-sample
+ * patch group of the receivers that see a non-zero latent): on by default, `on = 0` makes every sample evaluate all its messages.  Exists
+ * for the equality test of the two paths. */
+int ddk_debug_set_layer0_dedup(ddk_ctx* ctx, int32_t on);
+/* The patch group of the last forward of a latent-conditioned model: counts[B + 1] = exclusive prefix of the patch edges per sample
+ * (counts[B] = total), mask[B * n_rec] = 1 for receivers whose rec-rec sum comes from the patch group.  HOST pointers; synchronises. */
+int ddk_debug_read_patch(ddk_ctx* ctx, ddk_complex* cx, int32_t B, int32_t* counts, uint8_t* mask);
+
 /* The device routines of csrc/k_se3.hip on caller-supplied DEVICE arrays (enqueue on `stream`, no synchronisation):
  *   kabsch:     A, B [nb, n, 3] -> R [nb, 3, 3], t [nb, 3] with R a + t ~ b   (utils/geometry.py:126-156, reflection case included)
  *   axis_angle: aa [n, 3] -> R [n, 3, 3]                                     (utils/geometry.py:71-85, small-angle branch included) */

@@ -337,3 +337,62 @@ def test_batch_larger_than_one_scan_chunk(dev):
         assert rel_err(full[k], torch.cat([parts[0][k], parts[1][k]])) < 2e-5, name      # (different atomic-add orders: ~5e-6 observed)
     st = big.graph_stats()
     assert st['E_rr'] == B * c['rec_edge_index'].shape[1]
+
+
+@pytest.mark.parametrize('t', [0.05, 1.0])
+def test_disco_layer0_patches_equal_full(dev, t):
+    """Latent-conditioned model: layer 0's rec-rec messages once per batch on sample 0's rows + the per-sample patch group of the receivers
+    that see a non-zero latent (their own, a sender's, or sample 0's) must equal the evaluation of every message of every sample
+    (ddk_debug_set_layer0_dedup(0)), <= 2e-6, for one-hot latents on residues, on ligand atoms only, for all-zero latents and for
+    dense latents (every residue marked: the patch group is then the whole rec-rec group)."""
+    from disco_diffdock_amd import synthetic
+    from disco_diffdock_amd.runtime import Context, Complex
+    cfg = smr.ScoreModelConfig(latent_dim=2, latent_vocab=1, latent_droprate=0.1)
+    c = synthetic.make_complex(21, n_res=120, n_lig=17)
+    ctx = Context(device=0, latent_dim=2, latent_vocab=1, latent_droprate=0.1)
+    ctx.load_state_dict(smr.random_state_dict(cfg, seed=9))
+    B = 7
+    rng = np.random.default_rng(5)
+    pos = T(_poses(c, B, rng, spread=8.0)).to(dev)
+    cx = Complex(ctx, c, B)
+    n_l, n_r = cx.n_lig, cx.n_rec          # (make_complex closes rings: the ligand has more atoms than asked for)
+
+    def latents(kind):
+        ll, lr = torch.zeros(B * n_l, 2), torch.zeros(B * n_r, 2)
+        if kind == 'picks':
+            for s in range(B):
+                for d in range(2):
+                    if s == 3 or (s == 5 and d == 0):            # sample 3: ligand picks only; sample 5: one of each
+                        ll[s * n_l + rng.integers(n_l), d] = 1
+                    else:
+                        lr[s * n_r + rng.integers(n_r), d] = 1
+        elif kind == 'ligand_only':
+            for s in range(B):
+                ll[s * n_l + rng.integers(n_l), 0] = 1
+        elif kind == 'dense':
+            lr = torch.from_numpy(rng.normal(size=(B * n_r, 2)).astype(np.float32))
+        return ll.to(dev), lr.to(dev)
+
+    for kind in ('picks', 'ligand_only', 'zero', 'dense'):
+        ll, lr = latents(kind)
+        res = {}
+        for on in (True, False):
+            ctx.debug_set_layer0_dedup(on)
+            cx.set_latents(ll, lr, 0.0)
+            tr, rot, tor = cx.score_forward(pos, t, t, t)
+            res[on] = (tr.cpu(), rot.cpu(), tor.cpu(), cx.lig_node_features(B, dev).cpu())
+        ctx.debug_set_layer0_dedup(True)
+        for k, name in enumerate(('tr', 'rot', 'tor', 'lig_node_attr')):
+            assert rel_err(res[True][k], res[False][k]) < 2e-6, (kind, name, t)
+        # the patch group of the last de-duplicated forward: empty without receptor latents, the whole rec-rec group of samples 1.. for dense ones
+        cx.set_latents(ll, lr, 0.0)
+        cx.score_forward(pos, t, t, t)
+        cnt, mask = cx.debug_read_patch(B)
+        E_rr = c['rec_edge_index'].shape[1]
+        assert cnt[0] == 0 and cnt[1] == 0 and not mask[0].any()          # sample 0 IS the shared evaluation
+        if kind in ('ligand_only', 'zero'):
+            assert cnt[B] == 0 and not mask.any()
+        elif kind == 'dense':
+            assert cnt[B] == (B - 1) * E_rr and mask[1:].all()
+        else:
+            assert 0 < cnt[B] < (B - 1) * E_rr and mask[1:].any()

@@ -143,7 +143,10 @@ int ddk_confidence_status(ddk_ctx* ctx, ddk_complex* cx, int32_t* host_out, void
 /* ---- DisCo latent conditioning (models/score_model.py:170-184, 209-215, 329-337, 358-366, 392-402; latent_vocab == 1):
  *      lig_latent [B*n_lig, latent_dim], rec_latent [B*n_rec, latent_dim] (data['ligand'|'receptor'].latent_h, DEVICE,
  *      caller-owned, must stay valid for the following forwards) and the value of data[...].unconditional.
- *      Applies to the subsequent ddk_score_forward / ddk_sample calls on this complex; NULL, NULL clears. */
+ *      Applies to the subsequent ddk_score_forward / ddk_sample calls on this complex; NULL, NULL clears.
+ *      The library derives a per-sample edge group from WHERE the receptor latents are non-zero (layer-0 de-duplication)
+ *      when the first forward after this call runs: call ddk_set_latents again after changing the arrays in place (ddk_ar_decode does
+ *      this bookkeeping itself). */
 int ddk_set_latents(ddk_ctx* ctx, ddk_complex* cx, const float* lig_latent, const float* rec_latent, float unconditional);
 
 /* ---- a22: the AR latent model (config 3).  A context that was given the AR checkpoint (its own score-model copy under the plain

@@ -325,6 +325,12 @@ __global__ void conf_gtab_kernel(int32_t* gtab, const int32_t* info, int B, int 
   const int beg[9] = {go0, go1, off_la, off_aa, off_al, off_ar, go2, go3, off_ra};
   const int end[9] = {go1, go2, off_la + n_la, off_aa + B * E_aa, off_al + n_la, off_ar + B * n_atom, go3, go4, off_ra + B * n_atom};
   for (int g = 0; g < 9; ++g) { gtab[g] = beg[g]; gtab[9 + g] = end[g]; }
+  // layer 0: before the first conv the atom and residue rows (and the static edge sets' features) are the same in every sample, so the
+  // pose-independent groups aa, ar, rr, ra are evaluated for sample 0 only (their edges are stored sample-major) and conf_finalize_kernel
+  // reads sample 0's accumulators for the other samples
+  int32_t* t0 = gtab + 32;
+  for (int g = 0; g < 9; ++g) { t0[g] = beg[g]; t0[9 + g] = end[g]; }
+  t0[9 + 3] = off_aa + E_aa; t0[9 + 5] = off_ar + n_atom; t0[9 + 6] = go2 + (go3 - go2) / B; t0[9 + 8] = off_ra + n_atom;
 }
 
 // in-degree of every (node, slot): slot = group % 3
@@ -354,8 +360,11 @@ __global__ void conf_node_init_kernel(const float* lig_x0, const float* atom_x0,
 }
 
 // x_out = pad(x_in) + sum over the 3 convs feeding the node type of BN_conv(sum / max(deg,1))   (all_atom_score_model.py:37-50,272-279)
+// share0 (layer 0): slots 0 and 2 of the atom / residue rows (groups aa, ar / rr, ra) were accumulated for sample 0 only: every sample
+// reads sample 0's row (n_atom, n_rec = nodes per sample)
 __global__ void conf_finalize_kernel(const float* sum3, const int32_t* deg3, const float* x_in, const float* bn_mean, const float* bn_scale,
-                                     const float* bn_bias, int64_t n_nodes, int64_t n_update, int64_t atom0, int64_t rec0, int dout, float* x_out) {
+                                     const float* bn_bias, int64_t n_nodes, int64_t n_update, int64_t atom0, int64_t rec0, int dout, float* x_out,
+                                     int share0, int n_atom, int n_rec) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_nodes * XW) return;
   const int64_t node = i / XW;
@@ -363,11 +372,15 @@ __global__ void conf_finalize_kernel(const float* sum3, const int32_t* deg3, con
   float v = x_in[i];
   if (node < n_update && c < dout) {
     const int type = node < atom0 ? 0 : (node < rec0 ? 1 : 2);
+    int64_t node_sh = node;        // sample 0's copy of this atom / residue
+    if (share0 && type == 1) node_sh = atom0 + (node - atom0) % n_atom;
+    if (share0 && type == 2) node_sh = rec0 + (node - rec0) % n_rec;
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
       const int g = 3 * type + s;
       const int d = deg3[node * 3 + s];
-      const float m = sum3[(node * 3 + s) * XW + c] / (float)(d > 1 ? d : 1);
+      const int64_t nd = (s != 1) ? node_sh : node;
+      const float m = sum3[(nd * 3 + s) * XW + c] / (float)(d > 1 ? d : 1);
       v += (m - bn_mean[g * XW + c]) * bn_scale[g * XW + c] + bn_bias[g * XW + c];
     }
   }
@@ -601,7 +614,7 @@ int ddk_complex_set_atoms(ddk_ctx* ctx, ddk_complex* cx, const ddk_atoms_desc* d
     K->st_a = d_a1; K->st_b = d_b1; K->st_emb = d_emb1; K->st_sh = d_sh1;
   }
   K->n_nodes = Bm * ((int64_t)n_lig + n_atom + n_rec);
-  K->gtab = cxu<int32_t>(cx, nullptr, 32);
+  K->gtab = cxu<int32_t>(cx, nullptr, 64);        // [0..17] group table, [18] la cursor, [19] la overflow flag, [32..49] layer-0 table
   K->deg_scratch = cxu<int32_t>(cx, nullptr, K->n_nodes);
   K->xa = cxu<float>(cx, nullptr, K->n_nodes * XW); K->xb = cxu<float>(cx, nullptr, K->n_nodes * XW);
   K->sum3 = cxu<float>(cx, nullptr, K->n_nodes * 3 * XW);
@@ -685,10 +698,11 @@ int ddk_confidence_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float
     a.mode = 1; a.n_groups = 9; a.n_active = last ? 3 : 9; a.n_slots = 3;
     a.slots = 0;
     for (int g = 0; g < 9; ++g) a.slots |= (uint32_t)(g % 3) << (2 * g);
-    a.gbeg = K->gtab; a.gend = K->gtab + 9;
+    const bool share0 = l == 0 && B > 1 && !last && ctx->layer0_dedup;      // pose-independent groups once per batch (conf_gtab_kernel)
+    a.gbeg = K->gtab + (share0 ? 32 : 0); a.gend = a.gbeg + 9;
     CK(launch_conv_fused(L, a, ctx->n_cu, s), "conv_fused (confidence)");
     hipLaunchKernelGGL(conf_finalize_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, K->sum3, K->deg3, xin, L.bn_mean, L.bn_scale,
-                       L.bn_bias, K->n_nodes, last ? atom_base : K->n_nodes, atom_base, rec_base, L.dout, xout);
+                       L.bn_bias, K->n_nodes, last ? atom_base : K->n_nodes, atom_base, rec_base, L.dout, xout, share0 ? 1 : 0, n_atom, n_rec);
     CK(hipGetLastError(), "conf finalize");
     float* t = xin; xin = xout; xout = t;
   }

@@ -396,3 +396,26 @@ def test_disco_layer0_patches_equal_full(dev, t):
             assert cnt[B] == (B - 1) * E_rr and mask[1:].all()
         else:
             assert 0 < cnt[B] < (B - 1) * E_rr and mask[1:].any()
+
+
+def test_confidence_layer0_shared_groups_equal_full(dev):
+    """Confidence model, layer 0: the pose-independent groups (atom-atom, atom<-residue, residue-residue, residue<-atom) evaluated for sample 0
+    only and read by every sample must equal their evaluation in every sample (ddk_debug_set_layer0_dedup(0)): confidences and ligand rows."""
+    from oracle import confidence_ref as cr
+    from disco_diffdock_amd import synthetic
+    from disco_diffdock_amd.runtime import Context, Complex
+    c = synthetic.make_complex(31, n_res=60, n_lig=15)
+    synthetic.add_receptor_atoms(c, np.random.default_rng(31))
+    ctx = Context(device=0, all_atoms=1, embedding_scale=10000.0, num_confidence_outputs=2)
+    ctx.load_state_dict(cr.random_state_dict(cr.ConfidenceModelConfig(), seed=3))
+    B = 6
+    pos = T(_poses(c, B, np.random.default_rng(8), spread=6.0)).to(dev)
+    cx = Complex(ctx, c, max_batch=B)
+    cx.set_atoms(c['atom_x'], c['atom_pos'], c['atom_edge_index'], c['atom_rec_index'])
+    res = {}
+    for on in (True, False):
+        ctx.debug_set_layer0_dedup(on)
+        conf = cx.confidence_forward(pos)
+        res[on] = (conf.cpu(), cx.lig_node_features(B, dev).cpu())
+    ctx.debug_set_layer0_dedup(True)
+    assert rel_err(res[True][0], res[False][0]) < 2e-6 and rel_err(res[True][1], res[False][1]) < 2e-6

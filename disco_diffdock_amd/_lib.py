@@ -54,6 +54,8 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f'{LIB_PATH} not found: build the HIP extension first (python -m disco_diffdock_amd.build). '
                            'disco_diffdock_amd has no CPU fallback.')
+    import torch  # noqa: F401  (first: libddk.so must bind to the HIP runtime PyTorch-ROCm ships; loaded before torch it binds to /opt/rocm's copy,
+    #                and two HIP runtimes in one process leave the second without a device: "no ROCm-capable device is detected")
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
     L.ddk_create.argtypes = [C.POINTER(ddk_config), C.POINTER(vp)]

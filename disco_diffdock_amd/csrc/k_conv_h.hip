@@ -420,7 +420,7 @@ hipError_t launch_conv_fused_h(const ConvLayerDev& L, const ConvLaunch& a, int n
   k.n_cols = L.n_cols;
   for (int c = 0; c <= L.n_cols; ++c) k.col_start[c] = L.col_start[c];
   k.sum_g2 = a.sum_g2; k.g2_node_off = a.g2_node_off; k.pre = nullptr; k.part = nullptr;
-  k.n_groups = 4; k.n_active = a.n_active; k.n_slots = 1; k.slots = 0;
+  k.n_groups = 4; k.n_active = a.n_active; k.n_slots = 1; k.slots = 0; k.wmap = 0x3210ull;
   if (a.gbeg) { k.gbeg = a.gbeg; k.gend = a.gend; }
   else { k.gbeg = a.tile_info + 5; k.gend = a.tile_info + 6; }
   return a.gather ? launch_h_t<true>(k, n_cu, s) : launch_h_t<false>(k, n_cu, s);

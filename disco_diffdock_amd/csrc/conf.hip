@@ -63,7 +63,11 @@ struct ConfComplex {
   float *e_emb = nullptr, *e_sh = nullptr;
   int32_t *st_a = nullptr, *st_b = nullptr;      // one copy of the static sets: aa (atom, atom) then ar (atom, residue) local endpoints
   float *st_emb = nullptr, *st_sh = nullptr;
-  int32_t* gtab = nullptr;     // [0..8] gbeg, [9..17] gend, [18] la counter, [19] overflow flag
+  int32_t* gtab = nullptr;     // [0..8] gbeg, [9..17] gend, [18] la counter, [19] overflow flag, [32..49] layer-0 table, [64..81] level-A table, [82..85] cursors
+  // backward receptive field of the pooled ligand rows: the second-to-last layer evaluates the static groups (aa, ar, rr, ra) only into the
+  // atoms / residues that SEND to a ligand atom in the last layer (level A); their edge records are compacted into a scratch region per forward
+  int64_t off_scr = 0, cap_scr = 0;
+  uint8_t *flag_a = nullptr, *flag_r = nullptr;      // [Bm * n_atom], [Bm * n_rec]
   int32_t* deg_scratch = nullptr;
   float *xa = nullptr, *xb = nullptr, *sum3 = nullptr;
   int32_t* deg3 = nullptr;
@@ -333,6 +337,76 @@ __global__ void conf_gtab_kernel(int32_t* gtab, const int32_t* info, int B, int 
   t0[9 + 3] = off_aa + E_aa; t0[9 + 5] = off_ar + n_atom; t0[9 + 6] = go2 + (go3 - go2) / B; t0[9 + 8] = off_ra + n_atom;
 }
 
+// ---- level A of the backward receptive field (second-to-last layer) ---------------------------------------------------------
+// The last layer updates ligand rows only (groups ll, lr, la), so the second-to-last layer has to PRODUCE only the ligand rows and the
+// rows of the atoms / residues that send in la / lr: exactly the receivers of the al / rl edges.  Of the static groups it therefore
+// evaluates only the edges received by those nodes.  Exact: a dropped message never reaches the pooled ligand rows.
+struct ConfLevelArgs {
+  const int32_t* gtab;
+  int32_t *e_src, *e_dst;
+  float *e_emb, *e_sh;
+  uint8_t *flag_a, *flag_r;
+  int B, n_atom, n_rec, E_aa, E_rr;
+  int64_t atom_base, rec_base, off_aa, off_ar, off_ra, off_scr, Bm;
+  int32_t* cursors;      // [4] (zeroed by the caller)
+  int32_t* tabA;         // [18]
+};
+
+__global__ void conf_level_flags_kernel(ConfLevelArgs A) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int al0 = A.gtab[4], al1 = A.gtab[9 + 4], rl0 = A.gtab[7], rl1 = A.gtab[9 + 7];
+  if (i < al1 - al0) A.flag_a[A.e_src[al0 + i] - A.atom_base] = 1;
+  else if (i - (al1 - al0) < rl1 - rl0) A.flag_r[A.e_src[rl0 + (i - (al1 - al0))] - A.rec_base] = 1;
+}
+
+// grid (B, 4): sample b, static group y in {aa, ar, rr, ra}: stable compaction of the edges whose receiver is flagged into the scratch region
+__global__ __launch_bounds__(256) void conf_level_compact_kernel(ConfLevelArgs A) {
+  __shared__ int part[256];
+  __shared__ int base_s;
+  const int b = blockIdx.x, y = blockIdx.y, tid = threadIdx.x;
+  const int n = y == 0 ? A.E_aa : (y == 2 ? A.E_rr : A.n_atom);
+  const int64_t first = y == 0 ? A.off_aa + (int64_t)b * A.E_aa : (y == 1 ? A.off_ar + (int64_t)b * A.n_atom
+                      : (y == 2 ? (int64_t)A.gtab[6] + (int64_t)b * A.E_rr : A.off_ra + (int64_t)b * A.n_atom));
+  const uint8_t* fl = y < 2 ? A.flag_a : A.flag_r;
+  const int64_t nb = y < 2 ? A.atom_base : A.rec_base;
+  const int per = (n + 255) / 256, k0 = min(tid * per, n), k1 = min(k0 + per, n);
+  int cnt = 0;
+  for (int k = k0; k < k1; ++k) cnt += fl[A.e_src[first + k] - nb] ? 1 : 0;
+  part[tid] = cnt;
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int t = 0; t < 256; ++t) { const int c = part[t]; part[t] = run; run += c; }
+    const int64_t region = A.off_scr + (y == 0 ? 0 : (y == 1 ? A.Bm * A.E_aa : (y == 2 ? A.Bm * ((int64_t)A.E_aa + A.n_atom)
+                                                                                          : A.Bm * ((int64_t)A.E_aa + A.n_atom + A.E_rr))));
+    base_s = (int)region + atomicAdd(A.cursors + y, run);
+  }
+  __syncthreads();
+  int64_t pos = (int64_t)base_s + part[tid];
+  for (int k = k0; k < k1; ++k) {
+    const int64_t e = first + k;
+    const int sn = A.e_src[e];
+    if (!fl[sn - nb]) continue;
+    A.e_src[pos] = sn; A.e_dst[pos] = A.e_dst[e];
+    const float4* es = reinterpret_cast<const float4*>(A.e_emb + (size_t)e * NS);
+    float4* ed = reinterpret_cast<float4*>(A.e_emb + (size_t)pos * NS);
+#pragma unroll
+    for (int q = 0; q < NS / 4; ++q) ed[q] = es[q];
+    *reinterpret_cast<float4*>(A.e_sh + (size_t)pos * 4) = *reinterpret_cast<const float4*>(A.e_sh + (size_t)e * 4);
+    ++pos;
+  }
+}
+
+// the group table of the pruned layer: the full table with the four static groups replaced by their compacted copies
+__global__ void conf_level_table_kernel(ConfLevelArgs A) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int g = 0; g < 18; ++g) A.tabA[g] = A.gtab[g];
+  const int64_t r[4] = {A.off_scr, A.off_scr + A.Bm * A.E_aa, A.off_scr + A.Bm * ((int64_t)A.E_aa + A.n_atom),
+                        A.off_scr + A.Bm * ((int64_t)A.E_aa + A.n_atom + A.E_rr)};
+  const int gid[4] = {3, 5, 6, 8};
+  for (int y = 0; y < 4; ++y) { A.tabA[gid[y]] = (int)r[y]; A.tabA[9 + gid[y]] = (int)r[y] + A.cursors[y]; }
+}
+
 // in-degree of every (node, slot): slot = group % 3
 __global__ void conf_deg_kernel(const int32_t* gtab, const int32_t* e_src, int32_t* deg3, int64_t cap_total) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -573,10 +647,14 @@ int ddk_complex_set_atoms(ddk_ctx* ctx, ddk_complex* cx, const ddk_atoms_desc* d
     K->cap_la = Bm * (int64_t)n_lig * 96 + 64;       // <= 96 receptor atoms within 5 A of a ligand atom (1.2 A spacing bound ~ 300)
     K->off_la = K->cap4; K->off_al = K->off_la + K->cap_la; K->off_aa = K->off_al + K->cap_la;
     K->off_ar = K->off_aa + Bm * E_aa; K->off_ra = K->off_ar + Bm * n_atom; K->cap_total = K->off_ra + Bm * n_atom;
-    if (K->cap_total >= ((int64_t)1 << 31)) return fail(ctx, DDK_ERR_INVALID, "edge capacity exceeds int32 (reduce max_batch)");
-    K->e_src = cxu<int32_t>(cx, nullptr, K->cap_total); K->e_dst = cxu<int32_t>(cx, nullptr, K->cap_total);
+    K->off_scr = K->cap_total; K->cap_scr = Bm * ((int64_t)E_aa + 2 * (int64_t)n_atom + cx->E_rr);     // level-A copies of aa | ar | rr | ra (worst case: all)
+    const int64_t e_all = K->cap_total + K->cap_scr;
+    if (e_all >= ((int64_t)1 << 31)) return fail(ctx, DDK_ERR_INVALID, "edge capacity exceeds int32 (reduce max_batch)");
+    K->e_src = cxu<int32_t>(cx, nullptr, e_all); K->e_dst = cxu<int32_t>(cx, nullptr, e_all);
     K->e_aux = cxu<int32_t>(cx, nullptr, K->cap4);
-    K->e_emb = cxu<float>(cx, nullptr, K->cap_total * NS); K->e_sh = cxu<float>(cx, nullptr, K->cap_total * 4);
+    K->e_emb = cxu<float>(cx, nullptr, e_all * NS); K->e_sh = cxu<float>(cx, nullptr, e_all * 4);
+    K->flag_a = cxu<uint8_t>(cx, nullptr, Bm * n_atom); K->flag_r = cxu<uint8_t>(cx, nullptr, Bm * n_rec);
+    if (!K->flag_a || !K->flag_r) return fail(ctx, DDK_ERR_NOMEM, "device allocation failed (confidence level flags)");
     if (!K->e_src || !K->e_dst || !K->e_aux || !K->e_emb || !K->e_sh) return fail(ctx, DDK_ERR_NOMEM, "device allocation failed (confidence edge arrays)");
     // static sets (atom-atom; atom->residue and its flip)
     // ONE copy of the static sets goes up (E_aa + n_atom edges: local endpoints, embedding, SH); a kernel writes the Bm per-sample
@@ -614,7 +692,7 @@ int ddk_complex_set_atoms(ddk_ctx* ctx, ddk_complex* cx, const ddk_atoms_desc* d
     K->st_a = d_a1; K->st_b = d_b1; K->st_emb = d_emb1; K->st_sh = d_sh1;
   }
   K->n_nodes = Bm * ((int64_t)n_lig + n_atom + n_rec);
-  K->gtab = cxu<int32_t>(cx, nullptr, 64);        // [0..17] group table, [18] la cursor, [19] la overflow flag, [32..49] layer-0 table
+  K->gtab = cxu<int32_t>(cx, nullptr, 96);        // see ConfComplex::gtab
   K->deg_scratch = cxu<int32_t>(cx, nullptr, K->n_nodes);
   K->xa = cxu<float>(cx, nullptr, K->n_nodes * XW); K->xb = cxu<float>(cx, nullptr, K->n_nodes * XW);
   K->sum3 = cxu<float>(cx, nullptr, K->n_nodes * 3 * XW);
@@ -681,6 +759,23 @@ int ddk_confidence_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float
   CK(hipMemsetAsync(K->deg3, 0, (size_t)K->n_nodes * 3 * sizeof(int32_t), s), "deg3");
   hipLaunchKernelGGL(conf_deg_kernel, dim3((unsigned)((K->cap_total + 255) / 256)), dim3(256), 0, s, K->gtab, K->e_src, K->deg3, K->cap_total);
   CK(hipGetLastError(), "degrees");
+  // level-A pruning of the second-to-last layer (ddk_set_receptive_field_pruning; needs a layer between the shared layer 0 and the last one)
+  const bool pruneA = ctx->prune && c.num_conv_layers >= 3 && cx->E_rr > 0;
+  if (pruneA) {
+    ConfLevelArgs LV;
+    LV.gtab = K->gtab; LV.e_src = K->e_src; LV.e_dst = K->e_dst; LV.e_emb = K->e_emb; LV.e_sh = K->e_sh; LV.flag_a = K->flag_a; LV.flag_r = K->flag_r;
+    LV.B = B; LV.n_atom = n_atom; LV.n_rec = n_rec; LV.E_aa = K->E_aa; LV.E_rr = cx->E_rr; LV.atom_base = atom_base; LV.rec_base = rec_base;
+    LV.off_aa = K->off_aa; LV.off_ar = K->off_ar; LV.off_ra = K->off_ra; LV.off_scr = K->off_scr; LV.Bm = Bm;
+    LV.cursors = K->gtab + 82; LV.tabA = K->gtab + 64;
+    CK(hipMemsetAsync(K->flag_a, 0, (size_t)Bm * n_atom, s), "level flags");
+    CK(hipMemsetAsync(K->flag_r, 0, (size_t)Bm * n_rec, s), "level flags");
+    CK(hipMemsetAsync(K->gtab + 82, 0, 4 * sizeof(int32_t), s), "level cursors");
+    const int64_t n_mark = K->cap_la + (int64_t)B * n_lig * n_rec;      // upper bounds of the al and rl edge counts
+    hipLaunchKernelGGL(conf_level_flags_kernel, dim3((unsigned)((n_mark + 255) / 256)), dim3(256), 0, s, LV);
+    hipLaunchKernelGGL(conf_level_compact_kernel, dim3(B, 4), dim3(256), 0, s, LV);
+    hipLaunchKernelGGL(conf_level_table_kernel, dim3(1), dim3(64), 0, s, LV);
+    CK(hipGetLastError(), "level-A compaction");
+  }
   // ---- node features and the conv stack ----------------------------------------------------------
   float *xin = K->xa, *xout = K->xb;
   const int64_t tot = K->n_nodes * XW;
@@ -699,7 +794,8 @@ int ddk_confidence_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float
     a.slots = 0;
     for (int g = 0; g < 9; ++g) a.slots |= (uint32_t)(g % 3) << (2 * g);
     const bool share0 = l == 0 && B > 1 && !last && ctx->layer0_dedup;      // pose-independent groups once per batch (conf_gtab_kernel)
-    a.gbeg = K->gtab + (share0 ? 32 : 0); a.gend = a.gbeg + 9;
+    const bool levelA = pruneA && l == c.num_conv_layers - 2 && !share0;     // only level-A receivers of the static groups
+    a.gbeg = K->gtab + (share0 ? 32 : (levelA ? 64 : 0)); a.gend = a.gbeg + 9;
     CK(launch_conv_fused(L, a, ctx->n_cu, s), "conv_fused (confidence)");
     hipLaunchKernelGGL(conf_finalize_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, K->sum3, K->deg3, xin, L.bn_mean, L.bn_scale,
                        L.bn_bias, K->n_nodes, last ? atom_base : K->n_nodes, atom_base, rec_base, L.dout, xout, share0 ? 1 : 0, n_atom, n_rec);

@@ -419,3 +419,28 @@ def test_confidence_layer0_shared_groups_equal_full(dev):
         res[on] = (conf.cpu(), cx.lig_node_features(B, dev).cpu())
     ctx.debug_set_layer0_dedup(True)
     assert rel_err(res[True][0], res[False][0]) < 2e-6 and rel_err(res[True][1], res[False][1]) < 2e-6
+
+
+def test_confidence_level_a_pruning_equal_full(dev):
+    """Confidence model, second-to-last layer: the static groups evaluated only into the atoms / residues that send to a ligand atom in the
+    last layer (ddk_set_receptive_field_pruning) must leave the confidences and the ligand rows unchanged."""
+    from oracle import confidence_ref as cr
+    from disco_diffdock_amd import synthetic
+    from disco_diffdock_amd.runtime import Context, Complex
+    c = synthetic.make_complex(33, n_res=80, n_lig=16)
+    synthetic.add_receptor_atoms(c, np.random.default_rng(33))
+    ctx = Context(device=0, all_atoms=1, embedding_scale=10000.0, num_confidence_outputs=2)
+    ctx.load_state_dict(cr.random_state_dict(cr.ConfidenceModelConfig(), seed=5))
+    B = 5
+    pos = _poses(c, B, np.random.default_rng(9), spread=5.0)
+    pos[0] += 200.0           # one pose far away: no receptor atom or residue is level A for it
+    pos = T(pos).to(dev)
+    cx = Complex(ctx, c, max_batch=B)
+    cx.set_atoms(c['atom_x'], c['atom_pos'], c['atom_edge_index'], c['atom_rec_index'])
+    res = {}
+    for on in (True, False):
+        ctx.set_pruning(on)
+        conf = cx.confidence_forward(pos)
+        res[on] = (conf.cpu(), cx.lig_node_features(B, dev).cpu())
+    ctx.set_pruning(True)
+    assert rel_err(res[True][0], res[False][0]) < 2e-6 and rel_err(res[True][1], res[False][1]) < 2e-6

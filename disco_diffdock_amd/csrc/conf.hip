@@ -67,7 +67,7 @@ struct ConfComplex {
   // backward receptive field of the pooled ligand rows: the second-to-last layer evaluates the static groups (aa, ar, rr, ra) only into the
   // atoms / residues that SEND to a ligand atom in the last layer (level A); their edge records are compacted into a scratch region per forward
   int64_t off_scr = 0, cap_scr = 0;
-  uint8_t *flag_a = nullptr, *flag_r = nullptr;      // [Bm * n_atom], [Bm * n_rec]
+  uint8_t *flag_a = nullptr, *flag_r = nullptr;      // [2][Bm * n_atom], [2][Bm * n_rec]: level A, level B (= A + the senders of the edges into A)
   int32_t* deg_scratch = nullptr;
   float *xa = nullptr, *xb = nullptr, *sum3 = nullptr;
   int32_t* deg3 = nullptr;
@@ -359,6 +359,31 @@ __global__ void conf_level_flags_kernel(ConfLevelArgs A) {
   else if (i - (al1 - al0) < rl1 - rl0) A.flag_r[A.e_src[rl0 + (i - (al1 - al0))] - A.rec_base] = 1;
 }
 
+// level B = level A + every atom / residue that sends along an edge the level-A layer evaluates (its row is read there): the senders of the
+// compacted level-A copies of aa, ra (atoms) and ar, rr (residues); flags B start as a copy of flags A (the caller copies)
+struct ConfLevelBArgs {
+  const int32_t* tabA;
+  const int32_t* e_dst;
+  uint8_t *flag_a, *flag_r;      // level-B flags
+  int64_t atom_base, rec_base;
+};
+__global__ void conf_level_b_flags_kernel(ConfLevelBArgs A, int64_t cap_scr) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cap_scr) return;
+  const int gid[4] = {3, 5, 6, 8};
+  int64_t k = i;
+  for (int y = 0; y < 4; ++y) {
+    const int64_t n = A.tabA[9 + gid[y]] - A.tabA[gid[y]];
+    if (k < n) {
+      const int dn = A.e_dst[A.tabA[gid[y]] + k];
+      if (y == 0 || y == 3) A.flag_a[dn - A.atom_base] = 1;      // aa, ra: the sender is an atom
+      else A.flag_r[dn - A.rec_base] = 1;                         // ar, rr: the sender is a residue
+      return;
+    }
+    k -= n;
+  }
+}
+
 // grid (B, 4): sample b, static group y in {aa, ar, rr, ra}: stable compaction of the edges whose receiver is flagged into the scratch region
 __global__ __launch_bounds__(256) void conf_level_compact_kernel(ConfLevelArgs A) {
   __shared__ int part[256];
@@ -648,12 +673,12 @@ int ddk_complex_set_atoms(ddk_ctx* ctx, ddk_complex* cx, const ddk_atoms_desc* d
     K->off_la = K->cap4; K->off_al = K->off_la + K->cap_la; K->off_aa = K->off_al + K->cap_la;
     K->off_ar = K->off_aa + Bm * E_aa; K->off_ra = K->off_ar + Bm * n_atom; K->cap_total = K->off_ra + Bm * n_atom;
     K->off_scr = K->cap_total; K->cap_scr = Bm * ((int64_t)E_aa + 2 * (int64_t)n_atom + cx->E_rr);     // level-A copies of aa | ar | rr | ra (worst case: all)
-    const int64_t e_all = K->cap_total + K->cap_scr;
+    const int64_t e_all = K->cap_total + 2 * K->cap_scr;       // (a second region for level B, the third-to-last layer)
     if (e_all >= ((int64_t)1 << 31)) return fail(ctx, DDK_ERR_INVALID, "edge capacity exceeds int32 (reduce max_batch)");
     K->e_src = cxu<int32_t>(cx, nullptr, e_all); K->e_dst = cxu<int32_t>(cx, nullptr, e_all);
     K->e_aux = cxu<int32_t>(cx, nullptr, K->cap4);
     K->e_emb = cxu<float>(cx, nullptr, e_all * NS); K->e_sh = cxu<float>(cx, nullptr, e_all * 4);
-    K->flag_a = cxu<uint8_t>(cx, nullptr, Bm * n_atom); K->flag_r = cxu<uint8_t>(cx, nullptr, Bm * n_rec);
+    K->flag_a = cxu<uint8_t>(cx, nullptr, 2 * Bm * n_atom); K->flag_r = cxu<uint8_t>(cx, nullptr, 2 * Bm * n_rec);
     if (!K->flag_a || !K->flag_r) return fail(ctx, DDK_ERR_NOMEM, "device allocation failed (confidence level flags)");
     if (!K->e_src || !K->e_dst || !K->e_aux || !K->e_emb || !K->e_sh) return fail(ctx, DDK_ERR_NOMEM, "device allocation failed (confidence edge arrays)");
     // static sets (atom-atom; atom->residue and its flip)
@@ -692,7 +717,7 @@ int ddk_complex_set_atoms(ddk_ctx* ctx, ddk_complex* cx, const ddk_atoms_desc* d
     K->st_a = d_a1; K->st_b = d_b1; K->st_emb = d_emb1; K->st_sh = d_sh1;
   }
   K->n_nodes = Bm * ((int64_t)n_lig + n_atom + n_rec);
-  K->gtab = cxu<int32_t>(cx, nullptr, 96);        // see ConfComplex::gtab
+  K->gtab = cxu<int32_t>(cx, nullptr, 128);       // see ConfComplex::gtab ([96..113] level-B table, [114..117] its cursors)
   K->deg_scratch = cxu<int32_t>(cx, nullptr, K->n_nodes);
   K->xa = cxu<float>(cx, nullptr, K->n_nodes * XW); K->xb = cxu<float>(cx, nullptr, K->n_nodes * XW);
   K->sum3 = cxu<float>(cx, nullptr, K->n_nodes * 3 * XW);
@@ -775,6 +800,21 @@ int ddk_confidence_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float
     hipLaunchKernelGGL(conf_level_compact_kernel, dim3(B, 4), dim3(256), 0, s, LV);
     hipLaunchKernelGGL(conf_level_table_kernel, dim3(1), dim3(64), 0, s, LV);
     CK(hipGetLastError(), "level-A compaction");
+    if (c.num_conv_layers >= 4) {      // level B for the third-to-last layer: the same compaction on the wider flag set, second scratch region
+      uint8_t* fb_a = K->flag_a + (size_t)Bm * n_atom;
+      uint8_t* fb_r = K->flag_r + (size_t)Bm * n_rec;
+      CK(hipMemcpyAsync(fb_a, K->flag_a, (size_t)Bm * n_atom, hipMemcpyDeviceToDevice, s), "level-B flags");
+      CK(hipMemcpyAsync(fb_r, K->flag_r, (size_t)Bm * n_rec, hipMemcpyDeviceToDevice, s), "level-B flags");
+      CK(hipMemsetAsync(K->gtab + 114, 0, 4 * sizeof(int32_t), s), "level cursors");
+      ConfLevelBArgs LB;
+      LB.tabA = K->gtab + 64; LB.e_dst = K->e_dst; LB.flag_a = fb_a; LB.flag_r = fb_r; LB.atom_base = atom_base; LB.rec_base = rec_base;
+      hipLaunchKernelGGL(conf_level_b_flags_kernel, dim3((unsigned)((K->cap_scr + 255) / 256)), dim3(256), 0, s, LB, K->cap_scr);
+      ConfLevelArgs L2 = LV;
+      L2.flag_a = fb_a; L2.flag_r = fb_r; L2.off_scr = K->off_scr + K->cap_scr; L2.cursors = K->gtab + 114; L2.tabA = K->gtab + 96;
+      hipLaunchKernelGGL(conf_level_compact_kernel, dim3(B, 4), dim3(256), 0, s, L2);
+      hipLaunchKernelGGL(conf_level_table_kernel, dim3(1), dim3(64), 0, s, L2);
+      CK(hipGetLastError(), "level-B compaction");
+    }
   }
   // ---- node features and the conv stack ----------------------------------------------------------
   float *xin = K->xa, *xout = K->xb;
@@ -795,7 +835,8 @@ int ddk_confidence_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float
     for (int g = 0; g < 9; ++g) a.slots |= (uint32_t)(g % 3) << (2 * g);
     const bool share0 = l == 0 && B > 1 && !last && ctx->layer0_dedup;      // pose-independent groups once per batch (conf_gtab_kernel)
     const bool levelA = pruneA && l == c.num_conv_layers - 2 && !share0;     // only level-A receivers of the static groups
-    a.gbeg = K->gtab + (share0 ? 32 : (levelA ? 64 : 0)); a.gend = a.gbeg + 9;
+    const bool levelB = pruneA && c.num_conv_layers >= 4 && l == c.num_conv_layers - 3 && !share0;
+    a.gbeg = K->gtab + (share0 ? 32 : (levelA ? 64 : (levelB ? 96 : 0))); a.gend = a.gbeg + 9;
     CK(launch_conv_fused(L, a, ctx->n_cu, s), "conv_fused (confidence)");
     hipLaunchKernelGGL(conf_finalize_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, K->sum3, K->deg3, xin, L.bn_mean, L.bn_scale,
                        L.bn_bias, K->n_nodes, last ? atom_base : K->n_nodes, atom_base, rec_base, L.dout, xout, share0 ? 1 : 0, n_atom, n_rec);

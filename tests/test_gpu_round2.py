@@ -444,3 +444,49 @@ def test_confidence_level_a_pruning_equal_full(dev):
         res[on] = (conf.cpu(), cx.lig_node_features(B, dev).cpu())
     ctx.set_pruning(True)
     assert rel_err(res[True][0], res[False][0]) < 2e-6 and rel_err(res[True][1], res[False][1]) < 2e-6
+
+
+@pytest.mark.parametrize('t', [1.0, 0.05])
+def test_full_size_disco_oracle_parity(dev, tables, t):
+    """The latent-conditioned (DisCo) score model at BASELINE config 3's size (300 residues, B = 3) against oracle.score_model_ref with
+    one-hot latents on residues and ligand atoms: the shipped path (layer-0 shared pass + per-sample patch group + pruning) AND the
+    reference-complete path (receptor rows kept); scores at the north-star bar, node features per channel."""
+    from disco_diffdock_amd import synthetic
+    from disco_diffdock_amd.runtime import Context, Complex
+    cfg = smr.ScoreModelConfig(latent_dim=2, latent_vocab=1, latent_droprate=0.1)
+    c = synthetic.make_complex(7, n_res=300)
+    P = smr.random_state_dict(cfg, seed=11)
+    ctx = Context(device=0, latent_dim=2, latent_vocab=1, latent_droprate=0.1)
+    ctx.load_state_dict(P)
+    B = 3
+    rng = np.random.default_rng(4)
+    pos = _poses(c, B, rng, spread=6.0)
+    cx = Complex(ctx, c, B)
+    n_l, n_r = cx.n_lig, cx.n_rec
+    ll, lr = torch.zeros(B * n_l, 2), torch.zeros(B * n_r, 2)
+    for s in range(B):
+        lr[s * n_r + rng.integers(n_r), 0] = 1
+        (ll if s == 1 else lr)[s * (n_l if s == 1 else n_r) + rng.integers(n_l if s == 1 else n_r), 1] = 1
+    cx.set_latents(ll.to(dev), lr.to(dev), 0.0)
+    p = T(pos).to(dev)
+    tr, rot, tor = cx.score_forward(p, t, t, t)
+    lig = cx.lig_node_features(B, dev).cpu()
+    cnt, mask = cx.debug_read_patch(B)
+    assert cnt[B] > 0 and mask[1:].any() and not mask[0].any()          # the patch path is what ran
+    cx.keep_receptor_features(True)
+    tr2, rot2, tor2 = cx.score_forward(p, t, t, t)
+    lig2, rec2 = [x.cpu() for x in cx.node_features(B, dev)]
+    cx.keep_receptor_features(False)
+    b = batch_of(c, B, pos)
+    spr.set_time(b, t, t, t, B)
+    b['ligand'].latent_h, b['receptor'].latent_h = ll, lr
+    b['ligand'].unconditional, b['receptor'].unconditional = torch.zeros(B * n_l, 1), torch.zeros(B * n_r, 1)
+    tr_r, rot_r, tor_r, inter = smr.score_model_forward(P, cfg, b, tables[0], tables[1], return_intermediates=True)
+    errs = {}
+    for name, a, a2, r in (('tr', tr, tr2, tr_r), ('rot', rot, rot2, rot_r), ('tor', tor, tor2, tor_r)):
+        errs[name] = max(rel_err(a.cpu(), r), rel_err(a2.cpu(), r))
+        assert errs[name] < 1e-4, (name, errs)
+    errs['lig'] = max(chan_err(lig, inter['lig_node_attr']), chan_err(lig2, inter['lig_node_attr']))
+    errs['rec'] = chan_err(rec2, inter['rec_node_attr'])
+    print(f'full-size DisCo parity t={t}: {errs}')
+    assert errs['lig'] < 1e-4 and errs['rec'] < 1e-4, errs

@@ -490,3 +490,38 @@ def test_full_size_disco_oracle_parity(dev, tables, t):
     errs['rec'] = chan_err(rec2, inter['rec_node_attr'])
     print(f'full-size DisCo parity t={t}: {errs}')
     assert errs['lig'] < 1e-4 and errs['rec'] < 1e-4, errs
+
+
+def test_full_size_confidence_oracle_parity(dev):
+    """The all-atom confidence model at BASELINE config 4's size (300 residues, ~2400 receptor atoms; B = 3: two poses in the pocket, one
+    far outside) against oracle.confidence_ref, with everything the shipped path does (layer-0 sharing, level-A / level-B pruning):
+    confidences and the ligand rows after the conv stack."""
+    from oracle import confidence_ref as cr, graph_lite
+    from disco_diffdock_amd import synthetic
+    from disco_diffdock_amd.runtime import Context, Complex
+    c = synthetic.make_complex(43, n_res=300)
+    synthetic.add_receptor_atoms(c, np.random.default_rng(43))
+    cfg = cr.ConfidenceModelConfig()
+    P = cr.random_state_dict(cfg, seed=7)
+    B = 3
+    rng = np.random.default_rng(6)
+    pos = _poses(c, B, rng, spread=2.0)
+    pos[2] += 150.0
+    b = graph_lite.collate([graph_lite.add_atoms(to_graph(c), c['atom_x'], c['atom_pos'], c['atom_edge_index'], c['atom_rec_index']) for _ in range(B)])
+    b['ligand'].pos = T(pos.reshape(-1, 3))
+    for nt in ('ligand', 'receptor', 'atom'):
+        b[nt].node_t = {k: torch.zeros(b[nt].num_nodes) for k in ('tr', 'rot', 'tor')}
+    b.complex_t = {k: torch.zeros(B) for k in ('tr', 'rot', 'tor')}
+    want, inter = cr.confidence_forward(P, cfg, b, return_intermediates=True)
+    assert inter['counts']['la'] > 0 and inter['counts']['lr'] > 0
+    ctx = Context(device=0, all_atoms=1, embedding_scale=10000.0, num_confidence_outputs=2)
+    ctx.load_state_dict(P)
+    cx = Complex(ctx, c, max_batch=B)
+    cx.set_atoms(c['atom_x'], c['atom_pos'], c['atom_edge_index'], c['atom_rec_index'])
+    got = cx.confidence_forward(T(pos).to(dev))
+    lig = cx.lig_node_features(B, dev).cpu()
+    cnt = cx.confidence_counts()
+    assert all(cnt[k] == inter['counts'][k] for k in ('ll', 'lr', 'la', 'rr'))
+    e_conf, e_lig = rel_err(got.cpu(), want.reshape(B, -1)), chan_err(lig, inter['lig_node_attr'])
+    print(f'full-size confidence parity: confidences {e_conf:.2e}, ligand rows (per channel) {e_lig:.2e}')
+    assert e_conf < 1e-4 and e_lig < 1e-4

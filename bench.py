@@ -184,7 +184,7 @@ def main():
     from disco_diffdock_amd.model_utils import get_model, get_ar_model
     from disco_diffdock_amd.sampling import sampling, step_coefficients, draw_noise
     from disco_diffdock_amd.diffusion_utils import t_to_sigma, get_t_schedule
-    from disco_diffdock_amd.distributed import shard_indices, shard_samples, gather_poses, gather_samples, gather_confidences
+    from disco_diffdock_amd.distributed import shard_samples, gather_poses, gather_samples, gather_confidences
     if rank == 0:
         build.build(verbose=False)       # no-op when the shipped libddk.so is current; never build concurrently
     if world > 1:
@@ -204,14 +204,16 @@ def main():
         lo, hi = shard_samples(SAMPLES, rank, world)
     else:
         n_total = n_cx * world
-        mine = [rank * n_cx + i for i in range(n_cx)] if world == 1 else shard_indices([1.0] * n_total, rank, world)
+        # weak scaling with the per-GPU work held EXACTLY fixed: every rank holds the same n_cx receptor / ligand pairs (content seed = id mod n_cx)
+        # under its own global ids, with its own start poses and noise (a real dataset is partitioned with distributed.shard_indices)
+        mine = [rank * n_cx + i for i in range(n_cx)]
         lo, hi = 0, SAMPLES
     b_local = hi - lo
     made = []
     for i in mine:
-        c = synthetic.make_complex(i, n_res=n_res)
+        c = synthetic.make_complex(i % n_cx, n_res=n_res)
         if with_conf:
-            synthetic.add_receptor_atoms(c, np.random.default_rng(i))
+            synthetic.add_receptor_atoms(c, np.random.default_rng(i % n_cx))
         made.append(c)
     cache_path = os.path.join(tempfile.gettempdir(), f'ddk_bench_cfg{cfg_id}_rank{rank}.ddkg')
     graph_cache.save_complexes(cache_path, made)
@@ -365,7 +367,7 @@ def main():
                                   'collation, ddk_complex_create, H2D, noise draws, the 20-step loop, pose write-back; K calls + one final synchronisation',
                        'samples_per_complex': SAMPLES, 'inference_steps': STEPS, 'complexes_per_gpu': n_cx,
                        'parallelism': (f'the {SAMPLES} samples of every complex sharded over {world} process(es) ({b_local} per GPU), final all_gather'
-                                       if big else f'complexes sharded over {world} process(es), one per GPU, final RCCL all_gather of the poses')},
+                                       if big else f'{world} process(es), one per GPU, each with the same {n_cx} complexes (own start poses and noise: per-GPU work fixed), final RCCL all_gather of the poses')},
             'roofline': {'bound': 'mfma', 'kernel': 'ddk::conv_fused_kernel<true, 0>', 'achieved': tf(flops), 'peak': PEAK_F32_MFMA_TFLOPS,
                          'unit': 'TFLOP/s', 'frac': tf(flops) / PEAK_F32_MFMA_TFLOPS,
                          'accounting': 'achieved / frac: algorithmic FLOPs of the edges the launches evaluated PLUS the receptor-receptor messages the '

@@ -384,7 +384,7 @@ __global__ void conf_level_b_flags_kernel(ConfLevelBArgs A, int64_t cap_scr) {
   }
 }
 
-// grid (B, 4): sample b, static group y in {aa, ar, rr, ra}: stable compaction of the edges whose receiver is flagged into the scratch region
+// grid (B, 4, slices): sample b, static group y in {aa, ar, rr, ra}: stable compaction of the edges whose receiver is flagged into the scratch region
 __global__ __launch_bounds__(256) void conf_level_compact_kernel(ConfLevelArgs A) {
   __shared__ int part[256];
   __shared__ int base_s;
@@ -394,7 +394,9 @@ __global__ __launch_bounds__(256) void conf_level_compact_kernel(ConfLevelArgs A
                       : (y == 2 ? (int64_t)A.gtab[6] + (int64_t)b * A.E_rr : A.off_ra + (int64_t)b * A.n_atom));
   const uint8_t* fl = y < 2 ? A.flag_a : A.flag_r;
   const int64_t nb = y < 2 ? A.atom_base : A.rec_base;
-  const int per = (n + 255) / 256, k0 = min(tid * per, n), k1 = min(k0 + per, n);
+  // blockIdx.z: one of gridDim.z contiguous slices of the set (each claims its own output range: receivers stay grouped inside a slice)
+  const int n_sl = (n + gridDim.z - 1) / gridDim.z, s0 = min((int)blockIdx.z * n_sl, n), s1 = min(s0 + n_sl, n);
+  const int per = (s1 - s0 + 255) / 256, k0 = min(s0 + tid * per, s1), k1 = min(k0 + per, s1);
   int cnt = 0;
   for (int k = k0; k < k1; ++k) cnt += fl[A.e_src[first + k] - nb] ? 1 : 0;
   part[tid] = cnt;
@@ -797,7 +799,7 @@ int ddk_confidence_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float
     CK(hipMemsetAsync(K->gtab + 82, 0, 4 * sizeof(int32_t), s), "level cursors");
     const int64_t n_mark = K->cap_la + (int64_t)B * n_lig * n_rec;      // upper bounds of the al and rl edge counts
     hipLaunchKernelGGL(conf_level_flags_kernel, dim3((unsigned)((n_mark + 255) / 256)), dim3(256), 0, s, LV);
-    hipLaunchKernelGGL(conf_level_compact_kernel, dim3(B, 4), dim3(256), 0, s, LV);
+    hipLaunchKernelGGL(conf_level_compact_kernel, dim3(B, 4, 8), dim3(256), 0, s, LV);
     hipLaunchKernelGGL(conf_level_table_kernel, dim3(1), dim3(64), 0, s, LV);
     CK(hipGetLastError(), "level-A compaction");
     if (c.num_conv_layers >= 4) {      // level B for the third-to-last layer: the same compaction on the wider flag set, second scratch region
@@ -811,7 +813,7 @@ int ddk_confidence_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float
       hipLaunchKernelGGL(conf_level_b_flags_kernel, dim3((unsigned)((K->cap_scr + 255) / 256)), dim3(256), 0, s, LB, K->cap_scr);
       ConfLevelArgs L2 = LV;
       L2.flag_a = fb_a; L2.flag_r = fb_r; L2.off_scr = K->off_scr + K->cap_scr; L2.cursors = K->gtab + 114; L2.tabA = K->gtab + 96;
-      hipLaunchKernelGGL(conf_level_compact_kernel, dim3(B, 4), dim3(256), 0, s, L2);
+      hipLaunchKernelGGL(conf_level_compact_kernel, dim3(B, 4, 8), dim3(256), 0, s, L2);
       hipLaunchKernelGGL(conf_level_table_kernel, dim3(1), dim3(64), 0, s, L2);
       CK(hipGetLastError(), "level-B compaction");
     }

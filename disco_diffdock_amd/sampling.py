@@ -145,10 +145,21 @@ def _poll_pending():
 
 
 def draw_noise(inference_steps, b, R_total, R, nc, device):
-    """N(0,1) draws of one batch from the device generator: ONE launch for the whole trajectory [steps, b, 6 + R_total] (tr xyz, rot xyz,
-    torsions; utils/sampling.py:146-164 draws them step by step on the host).  Steps whose noise coefficients are zero
-    (no_final_step_noise) multiply their draws by 0 in ddk_sample; torsion columns past R are zeroed."""
-    z = torch.randn((inference_steps, b, 6 + R_total), device=device)
+    """N(0,1) draws of one batch from the device generator, [steps, b, 6 + R_total] (tr xyz, rot xyz, torsions; utils/sampling.py:146-164
+    draws them step by step on the host): one launch per contiguous run of steps that use noise - normally ONE for the whole trajectory.
+    Steps whose noise coefficients are all zero (no_final_step_noise) draw nothing, like the reference; torsion columns past R stay zero."""
+    z = torch.empty((inference_steps, b, 6 + R_total), device=device)
+    active = [bool(nc[t].any()) for t in range(inference_steps)]
+    t = 0
+    while t < inference_steps:
+        u = t
+        while u < inference_steps and active[u] == active[t]:
+            u += 1
+        if active[t]:
+            z[t:u].normal_(mean=0, std=1)
+        else:
+            z[t:u].zero_()
+        t = u
     if R != R_total:
         z[:, :, 6 + R:] = 0
     return z

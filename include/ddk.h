@@ -182,7 +182,8 @@ int ddk_set_keep_receptor_features(ddk_ctx* ctx, ddk_complex* cx, int32_t on);
  *      senders of their receptor-receptor messages, and so on (csrc/k_graph.hip).  The receptor-receptor messages outside that
  *      set are not evaluated.  tr/rot/tor are unchanged (tests: test_pruned_layers_equal_full); 0 switches it off (every layer
  *      evaluates every receptor-receptor message, as the reference does).  Forwards with ddk_set_keep_receptor_features(on)
- *      never prune. */
+ *      never prune.  In a confidence-model context the same switch governs the level-A / level-B pruning of the static edge groups in its
+ *      second- and third-to-last layers (the predictor pools ligand rows only; DESIGN.md 3.2, test_confidence_level_a_pruning_equal_full). */
 int ddk_set_receptive_field_pruning(ddk_ctx* ctx, int32_t on);
 
 /* ---- a5-a17: model.score_model(batch) -> (tr[B,3], rot[B,3], tor[B*R])  models/score_model.py:259-308

@@ -511,7 +511,7 @@ def test_last_layer_receptor_rows_on_request(dev, model7, golden):
     lig, rec = cx.node_features(B, dev)
     assert rel_err(rec.cpu(), z['rec_node_attr']) < 1e-4
     for a, f_, name in zip(out_lean, out_full, ('tr', 'rot', 'tor')):
-        assert rel_err(a.cpu(), f_.cpu().numpy()) < 2e-6, name
+        assert rel_err(a.cpu(), f_.cpu().numpy()) < 5e-6, name          # (two evaluations with different atomic-add orders: ~1e-6 noise)
         assert rel_err(a.cpu(), z[name]) < 1e-4, name
 
 

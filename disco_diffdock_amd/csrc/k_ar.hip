@@ -15,8 +15,8 @@ constexpr int AR_TILE = 32;     // nodes per workgroup
 
 // one workgroup = AR_TILE nodes of ONE node type; thread j = hidden unit j (weights of its rows live in registers)
 __global__ __launch_bounds__(AR_H) void ar_logits_kernel(ArArgs A) {
-  __shared__ float xs[AR_TILE][2 * AR_NS_MAX];
-  __shared__ float h1[AR_TILE][AR_H];
+  __shared__ __attribute__((aligned(16))) float xs[AR_TILE][2 * AR_NS_MAX];
+  __shared__ __attribute__((aligned(16))) float h1[AR_TILE][AR_H];
   __shared__ float part[AR_TILE][AR_H / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lig_tiles = (A.n_lig_total + AR_TILE - 1) / AR_TILE;
@@ -45,9 +45,14 @@ __global__ __launch_bounds__(AR_H) void ar_logits_kernel(ArArgs A) {
   }
   __syncthreads();
   for (int n = 0; n < cnt; ++n) {
-    float a = b4;
+    float a = b4, a1 = 0.0f;      // (the hidden row is read as broadcast 16-B words: a quarter of the LDS instructions)
 #pragma unroll
-    for (int k = 0; k < AR_H; ++k) a += w4[k] * h1[n][k];
+    for (int k4 = 0; k4 < AR_H / 4; ++k4) {
+      const float4 hv = *reinterpret_cast<const float4*>(&h1[n][4 * k4]);
+      a = fmaf(w4[4 * k4], hv.x, a); a1 = fmaf(w4[4 * k4 + 1], hv.y, a1);
+      a = fmaf(w4[4 * k4 + 2], hv.z, a); a1 = fmaf(w4[4 * k4 + 3], hv.w, a1);
+    }
+    a += a1;
     float v = w8 * fmaxf(a, 0.0f);
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);

@@ -18,11 +18,17 @@ configs (BASELINE.json ``configs``; the driver's N = 1 line is config 2):
 N > 1: one process per GPU (torch.distributed, backend nccl == RCCL); configs 2-4 shard COMPLEXES (weak scaling: K complexes per
 rank), config 5 shards SAMPLES (strong scaling); no collective on the data path, one final all_gather of the poses.
 
+Without torchrun, ``--gpus N`` (N > 1) starts the N ranks itself (re-exec under ``python -m torch.distributed.run --nproc-per-node N``).
+
 Prints ONE JSON line on rank 0, with
-  roofline      fused TP-conv kernel, HIP events around every launch of the timed region: algorithmic FLOPs / event time vs the
-                fp32 MFMA peak; ``frac`` counts the rec-rec messages removed by the receptive-field pruning as work done (the
-                reference evaluates them), ``frac_executed`` counts only what the launches evaluated
-  extra         device_loop: the same workload with complexes and noise resident in HBM (round 1's bracket), for comparison
+  roofline      fused TP-conv kernel, HIP events around every launch of the timed region: ``achieved`` / ``frac`` = algorithmic FLOPs
+                of the edges the launches EVALUATED / event time vs the matrix-pipe peak (the kernel's own roofline fraction);
+                ``reference_equivalent_TFLOPs`` also counts the rec-rec messages the receptive-field pruning proves dead (no frac)
+  extra         pruning_off: the same bracket with ddk_set_receptive_field_pruning(ctx, 0) - the guaranteed floor of ``value``;
+                pocket_bound: the same bracket on start poses inside the pocket with noise scaled so that every sample keeps its
+                cross edges for all 20 steps (what a trained model's trajectories look like to the pruning);
+                per_step: executed-edge fraction and conv ms of each of the 20 reverse steps of the default workload;
+                device_loop: the same workload with complexes and noise resident in HBM (round 1's bracket), for comparison
   cpu_baseline  the CPU oracle (oracle/: PyTorch-CPU restatement of the reference) on this box's host cores, bounded sample;
                 its scores are asserted equal to the GPU's on the same inputs
 """
@@ -155,6 +161,34 @@ def cpu_baseline(c, P, coeffs, gpu_scores, n_res, seconds_budget=40.0):
                        f' s, mean {t_step:.2f} s extrapolated x{STEPS} steps x{SAMPLES // b} (batch {SAMPLES}); oracle scores == GPU scores to {worst:.1e}')
 
 
+def pocket_poses(c, rng, samples, sigma=1.0):
+    """start poses of the pocket-bound workload: the ligand at its pocket position, random rotation about the centroid, N(0, sigma) A
+    translation - every sample starts (and, with the scaled noise, stays) in cross-edge contact with the receptor"""
+    from scipy.spatial.transform import Rotation
+    lp = c['lig_pos'].astype(np.float64)
+    ctr = lp.mean(0, keepdims=True)
+    return np.stack([(lp - ctr) @ Rotation.random(random_state=rng).as_matrix().T + ctr + rng.normal(0, sigma, size=(1, 3))
+                     for _ in range(samples)]).astype(np.float32)
+
+
+def self_launch(a):
+    """``python bench.py --gpus N`` without torchrun: start the N ranks (one per GPU) ourselves and hand over to them"""
+    import socket
+    import subprocess
+    if not a.single_device and torch.cuda.device_count() < a.gpus:
+        sys.exit(f'bench.py: --gpus {a.gpus} but only {torch.cuda.device_count()} GPU(s) are visible (use --single-device for a smoke test of the '
+                 'N > 1 path on one GPU)')
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={a.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '8')
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -164,14 +198,21 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-alt', action='store_true', help='skip the opt-in 3 x f16 measurement')
     ap.add_argument('--no-device-loop', action='store_true', help='skip the resident-loop comparison figure')
+    ap.add_argument('--no-extras', action='store_true', help='skip the pruning-off and pocket-bound brackets')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl == RCCL; gloo for smoke tests)')
     ap.add_argument('--single-device', action='store_true', help='smoke test of the N > 1 path on a one-GPU box: every rank uses cuda:0')
     a = ap.parse_args()
+    if 'WORLD_SIZE' not in os.environ and a.gpus > 1:
+        self_launch(a)
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    if world != a.gpus:
+        sys.exit(f'bench.py: --gpus {a.gpus} but WORLD_SIZE = {world}')
     import torch.distributed as dist
     if a.single_device:
         local = 0
+    elif torch.cuda.device_count() <= local:
+        sys.exit(f'bench.py: rank {rank} has no GPU {local} ({torch.cuda.device_count()} visible)')
     if world > 1:
         torch.cuda.set_device(local)
         dist.init_process_group(a.backend, rank=rank, world_size=world)
@@ -253,62 +294,95 @@ def main():
         score_only = {k: v for k, v in c.items() if not k.startswith('atom_')}
         graphs0[i] = (from_arrays(score_only), from_arrays(c) if with_conf else None)
 
-    def data_lists(i):
+    def data_lists(i, poses):
         g0, gc = graphs0[i]
         dl = [copy.copy(g0) for _ in range(b_local)]
-        for d, p in zip(dl, poses_all[i][lo:hi]):
+        for d, p in zip(dl, poses[i][lo:hi]):
             d['ligand'].pos = torch.from_numpy(p)
             if disco:
                 d['ligand'].ar_pos = torch.from_numpy(p).clone()
         cdl = [copy.copy(gc) for _ in range(b_local)] if with_conf else None
         return dl, cdl
-    calls = [data_lists(i) for i in order]
 
-    def one_call(k):
-        dl, cdl = calls[k]
-        kw = dict(extra)
-        if with_conf:
-            kw['confidence_data_list'] = cdl
-        out, conf = sampling(dl, model, STEPS, sched, sched, sched, dev, tsig, margs, batch_size=b_local, no_final_step_noise=True, **temps, **kw)
-        return out, conf
+    def bracket(poses, warmup, prune=True, noise_scale=None):
+        """the reference's bracket (evaluate.py:259,293) over K = a.steps sampling() calls, a NEW complex every call; returns the wall
+        time and what the HIP events around the conv launches saw.  noise_scale: N(0,1) draws of every call pre-drawn and scaled (the
+        pocket-bound workload); None: drawn inside sampling() from the device generator like the headline."""
+        calls = [data_lists(i, poses) for i in order[:warmup + a.steps]]
+        torch.cuda.manual_seed(977 + rank)
+        noises = None
+        if noise_scale is not None:
+            Rs = {i: int(np.asarray(complexes[i]['mask_rotate']).shape[0]) for i in mine}
+            noises = [[noise_scale * draw_noise(STEPS, b_local, Rs[i], Rs[i], nc, dev)] for i in order[:warmup + a.steps]]
+        ctx.set_pruning(prune)
 
-    for k in range(a.warmup):
-        one_call(k)
-    torch.cuda.synchronize()
-    torch.cuda.manual_seed(4321 + rank)      # the device generator sampling() draws its noise from (the resident-loop figure below replays it)
-    sm_mod._complex_cache.clear()            # a NEW complex every timed call: no Complex of the warm-up survives
-    ctx.profile_enable(True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    final, confs, outs = {}, {}, []
-    call_ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]      # device time stamps behind every call (no host wait)
-    call_ev[0].record()
-    for k in range(a.warmup, a.warmup + a.steps):
-        if (k - a.warmup) % len(mine) == 0 and k > a.warmup:
-            sm_mod._complex_cache.clear()    # K > #complexes: the second pass over the shard must not hit the cache either
-        out, conf = one_call(k)
-        call_ev[k - a.warmup + 1].record()
-        outs.append(out)
-        final[order[k]] = torch.stack([d['ligand'].pos for d in out])
-        if with_conf:
-            confs[order[k]] = conf
-    if disco:        # the latent bookkeeping of utils/sampling.py:205-221 (filled on first access): inside the bracket like the reference's
-        assert all(len(o[0].latent_str) >= 2 and all(hasattr(d, 'latent_pos') for d in o) for o in outs)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    prof = ctx.profile_read()
-    ctx.profile_enable(False)
-    per_call_ms = [round(call_ev[k].elapsed_time(call_ev[k + 1]), 2) for k in range(a.steps)]
+        def one_call(k):
+            dl, cdl = calls[k]
+            kw = dict(extra)
+            if with_conf:
+                kw['confidence_data_list'] = cdl
+            if noises is not None:
+                kw['noise'] = noises[k]
+            return sampling(dl, model, STEPS, sched, sched, sched, dev, tsig, margs, batch_size=b_local, no_final_step_noise=True, **temps, **kw)
 
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        for k in range(warmup):
+            one_call(k)
+        torch.cuda.synchronize()
+        torch.cuda.manual_seed(4321 + rank)      # the device generator sampling() draws its noise from (the resident-loop figure below replays it)
+        sm_mod._complex_cache.clear()            # a NEW complex every timed call: no Complex of the warm-up survives
+        ctx.profile_enable(True)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        final, confs, outs = {}, {}, []
+        call_ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]      # device time stamps behind every call (no host wait)
+        call_ev[0].record()
+        for k in range(warmup, warmup + a.steps):
+            if (k - warmup) % len(mine) == 0 and k > warmup:
+                sm_mod._complex_cache.clear()    # K > #complexes: the second pass over the shard must not hit the cache either
+            out, conf = one_call(k)
+            call_ev[k - warmup + 1].record()
+            outs.append(out)
+            final[order[k]] = torch.stack([d['ligand'].pos for d in out])
+            if with_conf:
+                confs[order[k]] = conf
+        if disco:        # the latent bookkeeping of utils/sampling.py:205-221 (filled on first access): inside the bracket like the reference's
+            assert all(len(o[0].latent_str) >= 2 and all(hasattr(d, 'latent_pos') for d in o) for o in outs)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        prof, fw = ctx.profile_read(), ctx.profile_read_forwards()
+        ctx.profile_enable(False)
+        ctx.set_pruning(True)
+        per_call_ms = [round(call_ev[k].elapsed_time(call_ev[k + 1]), 2) for k in range(a.steps)]
+        if world > 1:
+            tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        for p in final.values():
+            assert bool(torch.isfinite(p).all()), 'non-finite pose'
+        return dict(elapsed=elapsed, prof=prof, fw=fw, per_call_ms=per_call_ms, final=final, confs=confs)
+
+    layer_flop = [2 * 72 * (72 + W_LAYER[l]) + TP_FLOP[l] for l in range(5)]
+
+    def summary(r, n_units):
+        """what a bracket reports beside the headline: rate, conv share, executed-edge fraction"""
+        e_x, e_u = sum(p['edges'] for p in r['prof']), sum(p['edges_unpruned'] for p in r['prof'])
+        conv_ms = sum(p['ms'] for p in r['prof'])
+        fl = sum(p['edges'] * layer_flop[l] for l, p in enumerate(r['prof']))
+        fw = r['fw']
+        cross = fw[:, 3].reshape(-1, STEPS) / b_local if len(fw) and len(fw) % STEPS == 0 else None
+        return {'value': n_units / r['elapsed'], 'unit': 'complexes/s', 'ms_per_step': 1e3 * r['elapsed'] / a.steps,
+                'edges_executed_over_unpruned': e_x / max(e_u, 1), 'conv_TFLOPs_executed': fl / max(conv_ms, 1e-9) / 1e9,
+                'conv_share_of_wall': conv_ms * 1e-3 / r['elapsed'],
+                'min_cross_edges_per_sample_over_steps': None if cross is None else float(cross.min())}
+
+    head = bracket(poses_all, a.warmup)
+    elapsed, prof, final, confs = head['elapsed'], head['prof'], head['final'], head['confs']
+
     # ---- the one exchange of the path: final poses (and confidences) of every complex to every rank (RCCL over xGMI) ----------
     if big:
         gathered = {i: gather_samples(p, SAMPLES, rank, world, dev) for i, p in final.items()}
@@ -327,8 +401,20 @@ def main():
             if with_conf:
                 assert len(gather_confidences(confs, n_total, dev)) == n_total
         n_done = world * a.steps
-    for p in final.values():
-        assert bool(torch.isfinite(p).all()), 'non-finite pose'
+
+    # ---- what the headline rests on: the same bracket without the receptive-field pruning (the floor) and on a pocket-bound workload ----
+    pruning_off = pocket_bound = None
+    if not a.no_extras:
+        w2 = min(a.warmup, 2)
+        pruning_off = summary(bracket(poses_all, w2, prune=False), n_done)
+        pruning_off['note'] = ('the same sampling() bracket, workload and noise with ddk_set_receptive_field_pruning(ctx, 0): every layer evaluates all '
+                               'rec-rec messages (layer-0 de-duplication and the last layer\'s ligand-only evaluation stay) - the guaranteed floor of value')
+        pk_poses = {i: pocket_poses(complexes[i], np.random.default_rng(1000 + i), SAMPLES) for i in mine}
+        pocket_bound = summary(bracket(pk_poses, w2, noise_scale=0.2), n_done)
+        pocket_bound['note'] = ('the same bracket with the pruning ON, start poses inside the pocket (rotation about the centroid + N(0, 1 A)) and the N(0,1) '
+                                'draws scaled by 0.2 (pre-drawn per call): every sample keeps cross edges for all 20 steps, as the trajectories of a '
+                                'trained model do; the default workload starts from randomize_position (N(0, 19 A)) and random-init weights let the '
+                                'ligand wander')
 
     # ---- comparison figure: the loop alone on resident complexes with pre-drawn noise (round 1's bracket) ----------------------
     device_loop = None
@@ -351,12 +437,18 @@ def main():
 
     if rank == 0:
         conv_ms = sum(p['ms'] for p in prof)
-        fl = lambda key: sum(p[key] * (2 * 72 * (72 + W_LAYER[l]) + TP_FLOP[l]) for l, p in enumerate(prof))
-        flops_exec, flops, flops_full = fl('edges'), fl('edges_unpruned'), fl('edges_reference')
+        fl = lambda key: sum(p[key] * layer_flop[l] for l, p in enumerate(prof))
+        flops_exec, flops_unpruned, flops_full = fl('edges'), fl('edges_unpruned'), fl('edges_reference')
         byts = sum(p['edges'] * FUSED_BYTES[l] for l, p in enumerate(prof))
         launches = sum(p['launches'] for p in prof)
         tf = lambda f: f / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         traffic, traffic_file = pmc_traffic()
+        fw = head['fw']
+        per_step = None
+        if len(fw) == a.steps * STEPS:
+            f3 = fw.reshape(a.steps, STEPS, 4)
+            per_step = [{'step': s_, 't': round(float(t_arr[s_, 0]), 3), 'edges_executed_over_unpruned': float(f3[:, s_, 1].sum() / max(f3[:, s_, 2].sum(), 1)),
+                         'conv_ms': float(f3[:, s_, 0].mean()), 'cross_edges_per_sample': float(f3[:, s_, 3].mean() / b_local)} for s_ in range(STEPS)]
         out = {
             'metric': 'complexes/sec, 20-step 40-sample inference',
             'value': n_done / elapsed, 'unit': 'complexes/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
@@ -368,30 +460,30 @@ def main():
                        'samples_per_complex': SAMPLES, 'inference_steps': STEPS, 'complexes_per_gpu': n_cx,
                        'parallelism': (f'the {SAMPLES} samples of every complex sharded over {world} process(es) ({b_local} per GPU), final all_gather'
                                        if big else f'{world} process(es), one per GPU, each with the same {n_cx} complexes (own start poses and noise: per-GPU work fixed), final RCCL all_gather of the poses')},
-            'roofline': {'bound': 'mfma', 'kernel': 'ddk::conv_fused_kernel<true, 0>', 'achieved': tf(flops), 'peak': PEAK_F32_MFMA_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': tf(flops) / PEAK_F32_MFMA_TFLOPS,
-                         'accounting': 'achieved / frac: algorithmic FLOPs of the edges the launches evaluated PLUS the receptor-receptor messages the '
-                                       'backward receptive-field pruning proved dead (round-1 accounting: layer-0 de-duplication and the last '
-                                       "layer's ligand-only evaluation are not counted as work); achieved_executed: only the edges the launches "
-                                       'evaluated; achieved_full_reference: every edge of the reference graph in every layer',
-                         'achieved_executed': tf(flops_exec), 'frac_executed': tf(flops_exec) / PEAK_F32_MFMA_TFLOPS,
-                         'achieved_full_reference': tf(flops_full),
+            'roofline': {'bound': 'mfma', 'kernel': 'ddk::conv_fused_kernel<true, 0>', 'achieved': tf(flops_exec), 'peak': PEAK_F32_MFMA_TFLOPS,
+                         'unit': 'TFLOP/s', 'frac': tf(flops_exec) / PEAK_F32_MFMA_TFLOPS,
+                         'accounting': 'achieved / frac: algorithmic FLOPs (2*72*(72+W) + TP per edge and layer, BASELINE.md section 3) of the edges the '
+                                       'launches EVALUATED / HIP-event time of the launches, against the fp32 MFMA peak; reference_equivalent_TFLOPs '
+                                       'additionally counts the receptor-receptor messages the backward receptive-field pruning proved dead (not a '
+                                       'roofline figure: no frac); full_reference_TFLOPs counts every edge of the reference graph in every layer',
+                         'reference_equivalent_TFLOPs': tf(flops_unpruned), 'full_reference_TFLOPs': tf(flops_full),
                          'edges_executed_over_unpruned': sum(p['edges'] for p in prof) / max(sum(p['edges_unpruned'] for p in prof), 1),
                          'traffic': traffic,
                          'traffic_source': f'profiles/{traffic_file}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over this command, '
                                            'bytes per conv_fused launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 FETCH correction)' if traffic_file else None,
                          'algorithmic_bytes_per_launch': byts / max(launches, 1),
                          'launches': launches, 'avg_launch_ms': conv_ms / max(launches, 1),
-                         'flop_per_launch': flops / max(launches, 1), 'flop_per_launch_executed': flops_exec / max(launches, 1),
+                         'flop_per_launch': flops_exec / max(launches, 1),
                          'algorithmic_hbm_GBps': byts / (conv_ms * 1e-3) / 1e9 if conv_ms > 0 else 0.0,
                          'algorithmic_hbm_frac_of_peak': (byts / (conv_ms * 1e-3) / 1e9) / PEAK_HBM_GBS if conv_ms > 0 else 0.0,
                          'conv_share_of_wall': conv_ms * 1e-3 / elapsed,
                          'per_layer': [{'layer': l, 'ms_per_launch': p['ms'] / max(p['launches'], 1),
-                                        'TFLOPs': p['edges_unpruned'] * (2 * 72 * (72 + W_LAYER[l]) + TP_FLOP[l]) / max(p['ms'], 1e-9) / 1e9,
-                                        'TFLOPs_executed': p['edges'] * (2 * 72 * (72 + W_LAYER[l]) + TP_FLOP[l]) / max(p['ms'], 1e-9) / 1e9,
+                                        'TFLOPs': p['edges'] * layer_flop[l] / max(p['ms'], 1e-9) / 1e9,
                                         'edges_executed_frac': p['edges'] / max(p['edges_unpruned'], 1)}
                                        for l, p in enumerate(prof)]},
-            'extra': {'device_loop': device_loop, 'per_call_ms': per_call_ms},
+            'extra': {'pruning_off': pruning_off, 'pocket_bound': pocket_bound, 'per_step': per_step,
+                      'headline': {k: v for k, v in summary(head, n_done).items() if k != 'value'},
+                      'device_loop': device_loop, 'per_call_ms': head['per_call_ms']},
         }
         if world == 1 and not a.no_cpu_baseline and not disco:
             c0 = complexes[mine[0]]

@@ -39,7 +39,7 @@ _lib = None
 SYMBOLS = ['ddk_create', 'ddk_destroy', 'ddk_last_error', 'ddk_version', 'ddk_load_weights', 'ddk_finalize_weights',
            'ddk_set_score_norm_tables', 'ddk_tp_forward', 'ddk_conv_forward', 'ddk_complex_create', 'ddk_complex_destroy',
            'ddk_score_forward', 'ddk_se3_update', 'ddk_sample', 'ddk_last_graph_stats', 'ddk_last_node_features',
-           'ddk_profile_enable', 'ddk_profile_read', 'ddk_set_latents', 'ddk_set_guidance',
+           'ddk_profile_enable', 'ddk_profile_read', 'ddk_profile_read_forwards', 'ddk_set_latents', 'ddk_set_guidance',
            'ddk_set_keep_receptor_features', 'ddk_randomize_position', 'ddk_complex_set_atoms',
            'ddk_confidence_forward', 'ddk_pose_metrics', 'ddk_build_graph', 'ddk_set_receptive_field_pruning', 'ddk_ar_logits', 'ddk_ar_decode', 'ddk_confidence_status']
 
@@ -91,6 +91,7 @@ def lib():
     L.ddk_confidence_status.argtypes = [vp, vp, vp, vp]
     L.ddk_ar_decode.argtypes = [vp, vp, i32, vp, f32, vp, i32, i32, vp, vp, vp, vp]
     L.ddk_profile_read.argtypes = [vp, vp, i32]
+    L.ddk_profile_read_forwards.argtypes = [vp, vp, i32]
     L.ddk_debug_export.argtypes = [vp, C.c_char_p, vp, i64]
     L.ddk_debug_export.restype = i64
     _declare_debug(L)

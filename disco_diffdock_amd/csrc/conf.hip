@@ -492,6 +492,7 @@ struct HeadCArgs {
   const float* x; int B, n_lig, n_out;
   const float *w0, *s0, *t0, *w4, *s4, *t4, *w8, *b8;
   float* out;
+  const int32_t* ovf;      // ligand-atom edge capacity overflow flag of this forward (gtab[19]): the batch's confidences become NaN
 };
 // scatter_mean of [x[:, :ns] | x[:, -ns:]] over each graph's ligand atoms, then the predictor MLP (:281-284)
 __global__ __launch_bounds__(64) void conf_head_kernel(HeadCArgs A) {
@@ -519,7 +520,9 @@ __global__ __launch_bounds__(64) void conf_head_kernel(HeadCArgs A) {
   if (t < A.n_out) {
     float a = A.b8[t];
     for (int k = 0; k < NS; ++k) a += A.w8[t * NS + k] * h2[k];
-    A.out[(size_t)b * A.n_out + t] = a;
+    // an overflowed edge list means a truncated graph: the result must not look like a confidence (sampling() maps NaN to -1000 like the
+    // reference's nan_to_num, utils/sampling.py:246)
+    A.out[(size_t)b * A.n_out + t] = *A.ovf ? __builtin_nanf("") : a;
   }
 }
 
@@ -849,7 +852,7 @@ int ddk_confidence_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float
   cx->last_B = B;
   HeadCArgs H;
   H.x = xin; H.B = B; H.n_lig = n_lig; H.n_out = M->n_out;
-  H.w0 = M->w0; H.s0 = M->s0; H.t0 = M->t0; H.w4 = M->w4; H.s4 = M->s4; H.t4 = M->t4; H.w8 = M->w8; H.b8 = M->b8; H.out = out;
+  H.w0 = M->w0; H.s0 = M->s0; H.t0 = M->t0; H.w4 = M->w4; H.s4 = M->s4; H.t4 = M->t4; H.w8 = M->w8; H.b8 = M->b8; H.out = out; H.ovf = K->gtab + 19;
   hipLaunchKernelGGL(conf_head_kernel, dim3(B), dim3(64), 0, s, H);
   CK(hipGetLastError(), "confidence head");
 #undef CK

@@ -82,12 +82,15 @@ __global__ __launch_bounds__(256) void ar_decode_kernel(ArDecodeArgs A) {
   const int per = (n + 255) / 256, beg = min(tid * per, n), end = min(beg + per, n);
   if (tid == 0) pick = n - 1;
   if (A.temperature >= 100.0f) {
-    float bv = -INFINITY; int bi = 0x7fffffff;
-    for (int i = beg; i < end; ++i) { const float v = lg[i] * A.temperature; if (v > bv) { bv = v; bi = i; } }
+    // torch.argmax order: NaN counts as the largest value, ties go to the lowest index (a graph whose logits are all -inf picks node 0)
+    auto gt = [](float a, float b) { return a > b || (isnan(a) && !isnan(b)); };
+    auto eq = [](float a, float b) { return a == b || (isnan(a) && isnan(b)); };
+    float bv = -INFINITY; int bi = beg < end ? beg : 0x7fffffff;
+    for (int i = beg; i < end; ++i) { const float v = lg[i] * A.temperature; if (gt(v, bv)) { bv = v; bi = i; } }
     bestv[tid] = bv; besti[tid] = bi;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
-      if (tid < o && (bestv[tid + o] > bestv[tid] || (bestv[tid + o] == bestv[tid] && besti[tid + o] < besti[tid]))) {
+      if (tid < o && (gt(bestv[tid + o], bestv[tid]) || (eq(bestv[tid + o], bestv[tid]) && besti[tid + o] < besti[tid]))) {
         bestv[tid] = bestv[tid + o]; besti[tid] = besti[tid + o];
       }
       __syncthreads();
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(256) void ar_decode_kernel(ArDecodeArgs A) {
     __syncthreads();
   }
   if (tid == 0) {
-    const int c = pick;
+    const int c = min(max(pick, 0), n - 1);      // (never outside the graph, whatever the logits held)
     if (A.choices) A.choices[(size_t)b * A.latent_dim + A.idx] = c;
     if (c < A.n_lig) A.lig_latent[((size_t)b * A.n_lig + c) * A.latent_dim + A.idx] = 1.0f;
     else A.rec_latent[((size_t)b * A.n_rec + (c - A.n_lig)) * A.latent_dim + A.idx] = 1.0f;

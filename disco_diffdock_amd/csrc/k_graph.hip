@@ -210,6 +210,7 @@ __global__ void graph_scan_kernel(GraphArgs G, int64_t edge_cap) {
   G.info[I_HEAD + 4] = 0; G.info[I_HEAD + 5] = 0;
   G.info[I_EXEC] = go[4];
   G.info[I_EXEC + 1] = go[2];
+  G.info[I_EXEC + 7] = lr;        // cross edges of this forward (ddk_profile_read_forwards)
   for (int k = 0; k < N_TAB; ++k) {
     int32_t* tb = G.info + I_TAB + 8 * k;
     int tot = 0;

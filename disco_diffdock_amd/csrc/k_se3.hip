@@ -265,6 +265,7 @@ __global__ __launch_bounds__(256) void pose_metrics_kernel(const float* pos, con
     for (int i = 0; i < n_lig; ++i)
       if (keep[i]) {
         const int j = perms ? perms[(size_t)k * n_lig + i] : i;
+        if ((unsigned)j >= (unsigned)n_lig) { s2 = INFINITY; break; }      // not a ligand atom: this table row can never be the minimum (rmsd = inf if none is valid)
         const float dx = p[3 * j] - rf[3 * i], dy = p[3 * j + 1] - rf[3 * i + 1], dz = p[3 * j + 2] - rf[3 * i + 2];
         s2 += dx * dx + dy * dy + dz * dz;
       }

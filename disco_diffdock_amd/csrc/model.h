@@ -25,7 +25,7 @@ enum InfoSlot : int {
   I_SEG = 27,     // [27..30] first edge of the four level segments [A | B | C | rest] of group 2
   I_SHARED = 26,  // first edge of the shared rec-rec copy (= go[4]; E_rr edges in sample-0 numbering, layer-0 de-duplication) or -1
   I_TAB = 32,     // group tables: [32 + 8k + g] = gbeg, [36 + 8k + g] = gend of table k (N_TAB tables)
-  I_EXEC = 80,    // [80] = E, [81] = go[2] (edges of groups 0+1), [82 + k] = edges table k evaluates over all four groups
+  I_EXEC = 80,    // [80] = E, [81] = go[2] (edges of groups 0+1), [82 + k] = edges table k evaluates over all four groups (k < 5), [87] = cross edges lig->rec
   I_HEAD = 96,    // heads' edge list (k_heads.hip): [96] = 0, [97] = B*n_lig (centre edges), [98] = B*n_lig, [99] = end of the bond edges (atomic
                   // cursor of heads_pre_kernel), [100], [101] = work-queue counters of the two head launches
   // latent-conditioned (DisCo) model, layer-0 de-duplication with per-sample patches (model.hip): a fifth edge group = ALL rec-rec edges of the
@@ -315,6 +315,7 @@ struct ddk_complex {
   hipEvent_t ready = nullptr;         // recorded on the upload stream behind the last staged copy
   bool ready_pending = false;         // compute streams still have to wait for `ready`
   hipStream_t last_stream = nullptr;  // stream of the last launch that used this complex (ordering of the chunks' reuse)
+  std::vector<hipStream_t> streams;   // every stream an entry point was given for this complex (ddk_complex_destroy joins them)
   bool used = false;
   std::vector<int32_t> h_rr;          // host copies the confidence level needs again (ddk_complex_set_atoms)
   std::vector<float> h_rec_pos;

@@ -3,6 +3,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <algorithm>
 #include <thread>
 
 #include "model.h"
@@ -378,6 +379,7 @@ int cx_stage_flush(ddk_ctx* ctx, ddk_complex* cx) {
 
 hipError_t cx_wait_ready(ddk_complex* cx, hipStream_t s) {
   cx->last_stream = s; cx->used = true;
+  if (std::find(cx->streams.begin(), cx->streams.end(), s) == cx->streams.end()) cx->streams.push_back(s);
   if (!cx->ready_pending) return hipSuccess;
   if (hipEventQuery(cx->ready) == hipSuccess) { cx->ready_pending = false; return hipSuccess; }
   return hipStreamWaitEvent(s, cx->ready, 0);
@@ -789,7 +791,19 @@ void ddk_complex_destroy(ddk_ctx* ctx, ddk_complex* cx) {
   if (!ctx) ctx = cx->owner;
   hipSetDevice(ctx->cfg.device);
   if (cx->stage_idx >= 0) { ctx->stage_pool[cx->stage_idx].in_flight = false; cx->stage_idx = -1; }   // a create that failed half way
-  // the chunks go back to the context's pool (hipFree would synchronise the device); whoever takes one waits for this complex' last launch
+  // the chunks go back to the context's pool (hipFree would synchronise the device); whoever takes one waits for this complex' last launch.
+  // A complex that was driven from several streams (the API takes a stream per call): the last one first waits for the work still in
+  // flight on the others, so that ONE event on it covers every launch that touched the chunks
+  bool joined = true;
+  for (hipStream_t o : cx->streams) {
+    if (o == cx->last_stream) continue;
+    hipEvent_t ev = nullptr;
+    bool ok = hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+    if (ok) ok = hipEventRecord(ev, o) == hipSuccess && hipStreamWaitEvent(cx->last_stream, ev, 0) == hipSuccess;
+    if (ev) hipEventDestroy(ev);      // (destroying a recorded event is deferred by the runtime until it has completed)
+    joined = joined && ok;
+  }
+  if (!joined) hipDeviceSynchronize();      // could not order the streams: give the memory back only when everything has drained
   for (auto& a : cx->allocs) {
     if (!a.p) continue;
     ddk_ctx::PoolChunk c;
@@ -1053,6 +1067,27 @@ int ddk_profile_read(ddk_ctx* ctx, double* out, int32_t n) {
     out[5 * r.layer + 4] += E;                                                     // edges the reference evaluates in this layer
   }
   return DDK_OK;
+}
+
+int ddk_profile_read_forwards(ddk_ctx* ctx, double* out, int32_t max_forwards) {
+  if (!ctx || !out || max_forwards < 0) return DDK_ERR_INVALID;
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) return hip_fail(ctx, e, "profile sync");
+  const int nf = ctx->prof_slots < max_forwards ? ctx->prof_slots : max_forwards;
+  for (int i = 0; i < 4 * nf; ++i) out[i] = 0.0;
+  for (auto& r : ctx->prof_recs) {
+    if (r.slot >= nf) continue;
+    float ms = 0.f;
+    e = hipEventElapsedTime(&ms, r.a, r.b);
+    if (e != hipSuccess) return hip_fail(ctx, e, "hipEventElapsedTime");
+    const int32_t* pe = ctx->prof_edges + (size_t)PROF_INTS * r.slot;
+    const double E = pe[0], E01 = pe[1];
+    out[4 * r.slot] += ms;
+    out[4 * r.slot + 1] += r.lig_only ? E01 : (double)pe[2 + r.tab];
+    out[4 * r.slot + 2] += r.lig_only ? E01 : (r.r01_skipped < 0 ? (double)pe[2 + r.tab] : E - (double)r.r01_skipped);
+    out[4 * r.slot + 3] = (double)pe[7];
+  }
+  return ctx->prof_slots;
 }
 
 // Test hook: layer-0 de-duplication of the rec-rec messages on / off (on by default; off = every sample evaluates all its rec-rec messages)

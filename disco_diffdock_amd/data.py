@@ -82,8 +82,33 @@ class HeteroData:
     def clone(self):
         return copy.deepcopy(self)
 
+    def _settle(self):
+        """fill the results sampling() left pending on this graph (one device wait): a copy, a deep copy or a pickle must carry values, not
+        the bookkeeping object with its CUDA event"""
+        lazy = self.__dict__.pop('_lazy', None)
+        if lazy is not None:
+            self.__dict__['_lazy'] = lazy
+            lazy.resolve()
+            self.__dict__.pop('_lazy', None)
+
+    def __getstate__(self):
+        self._settle()
+        return dict(self.__dict__)
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+
+    def __deepcopy__(self, memo):
+        self._settle()
+        new = HeteroData.__new__(HeteroData)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
+
     def __copy__(self):
         """shallow copy with its own storages (tensors are shared): rebinding attributes on the copy leaves the original intact"""
+        self._settle()
         new = HeteroData()
         for k, st in self._stores.items():
             cp = type(st).__new__(type(st))          # keeps a collated batch's stores lazy

@@ -87,11 +87,18 @@ class _Bookkeeping:
     (``latent_str`` / ``latent_pos`` from the AR picks and the final poses) and the confidence model's edge-capacity flag.  The copies
     are enqueued behind the sampler into pinned memory; nothing waits for them inside sampling(), so the host goes on to the next
     complex while the GPU works.  ``resolve()`` (first access of ``d.latent_str`` / ``d.latent_pos`` on this module's graph
-    container, or immediately for foreign containers) waits once and fills every graph of the batch."""
+    container, the next sampling() call once the copies have landed, or immediately for foreign containers) fills every graph of the
+    batch that is still alive (the graphs are held weakly: a batch nobody kept costs nothing).
+    A confidence batch whose ligand-atom edge list overflowed needs no host action to be SEEN: the device writes NaN into its
+    confidences (conf_head_kernel), which sampling() returns as -1000 like the reference's nan_to_num; the flag only adds a warning."""
 
     def __init__(self, graphs, choices, flat, len_lig, latent_dim, conf_cx):
-        self.graphs, self.len_lig, self.latent_dim, self.conf_cx = graphs, len_lig, latent_dim, conf_cx
+        import weakref
+        self.graphs = [weakref.ref(g) for g in graphs]
+        self.name = getattr(graphs[0], 'name', None) if graphs else None
+        self.len_lig, self.latent_dim = len_lig, latent_dim
         self.done = False
+        self.bound = False       # the graphs carry this object as ``_lazy`` (our HeteroData): a graph a later call re-used is skipped
         self.choices = self.flat = None
         self.conf_status = conf_cx.confidence_status_async() if conf_cx is not None else None
         if choices is not None:
@@ -105,7 +112,9 @@ class _Bookkeeping:
     def _check_conf(self):
         st, self.conf_status = self.conf_status, None
         if st is not None and int(st[19]) != 0:
-            raise RuntimeError('ddk: ligand-atom edge capacity overflow in a confidence batch (its confidences are invalid)')
+            import warnings
+            warnings.warn(f'ddk: ligand-atom edge capacity overflow in a confidence batch of complex {self.name!r}: its confidences were '
+                          'returned as -1000 (NaN on the device)', RuntimeWarning)
 
     def resolve(self):
         if self.done:
@@ -118,11 +127,16 @@ class _Bookkeeping:
         if self.choices is None:
             return
         ch, n = self.choices.tolist(), self.len_lig
-        for i, d_i in enumerate(self.graphs):
+        for i, ref in enumerate(self.graphs):
+            d_i = ref()
+            if d_i is None or (self.bound and d_i.__dict__.get('_lazy') is not self):      # collected, or re-used by a later sampling() call
+                continue
             lat_str, lat_pos = "", []
             center = d_i.original_center.detach().cpu()
             for j in range(self.latent_dim):
                 idx = ch[i][j]
+                if not 0 <= idx < n + d_i['receptor'].pos.shape[0]:
+                    raise RuntimeError(f'ddk: AR pick {idx} outside the graph of complex {self.name!r}')
                 if idx < n:
                     lat_str += 'L' + str(idx)
                     lat_pos.append(self.flat[i * n + idx:i * n + idx + 1] + center)
@@ -133,15 +147,15 @@ class _Bookkeeping:
             d_i.__dict__.pop('_lazy', None)
             d_i.latent_str = lat_str
             d_i.latent_pos = torch.cat(lat_pos, dim=0)
+        self.choices = self.flat = None      # the pinned buffers go back to the allocator
 
 
 def _poll_pending():
-    """look (without waiting) at the read-backs of earlier calls: an overflow of an earlier confidence batch surfaces here at the latest"""
+    """look (without waiting) at the read-backs of earlier calls: whatever has landed is resolved and dropped, so nothing accumulates
+    when a caller never reads ``latent_str`` (warm-up calls, re-used graphs)"""
     for bk in list(_pending):
         if bk.event.query():
-            if bk.choices is None:
-                _pending.remove(bk)
-            bk._check_conf()
+            bk.resolve()
 
 
 def draw_noise(inference_steps, b, R_total, R, nc, device):
@@ -242,7 +256,11 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
     confidence, confidence_loader = None, None
     if confidence_model is not None:      # utils/sampling.py:59-62
         if confidence_data_list is None:
-            raise RuntimeError('ddk: the confidence model needs confidence_data_list (all-atom graphs; the score graphs carry no atoms)')
+            # utils/sampling.py:239-240 evaluates a coarse-grained confidence model (TensorProductScoreModel in confidence_mode, reached by
+            # evaluate.py's use_original_model_cache / transfer_weights flags) on the score batch itself; the device path implements the
+            # all-atom confidence model of the shipped paper_confidence_model only (INTEGRATION.md "Not covered")
+            raise RuntimeError('ddk: the confidence model on the device is the all-atom model and needs confidence_data_list (the score '
+                               'graphs carry no atoms); coarse-grained confidence models (utils/sampling.py:239-240) are not covered')
         confidence_loader = iter(DataLoader(confidence_data_list, batch_size=batch_size))
         confidence = []
     conf_checks = []
@@ -322,6 +340,7 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
                         d_i.__dict__.pop('latent_str', None)
                         d_i.__dict__.pop('latent_pos', None)
                         d_i.__dict__['_lazy'] = bk
+                    bk.bound = True
                     _pending.append(bk)
                 elif latent_model:
                     bk.resolve()              # foreign graph containers (PyG) cannot fill attributes lazily: wait now

@@ -95,6 +95,34 @@ def complex_for_batch(batch, device, ctx=None, mask_rotate=None, need_model=True
     return cx, B
 
 
+def _is_e3nn_internal(key):
+    """Keys a real checkpoint carries for e3nn's own modules and that hold no model parameter: the tensor-product objects inside
+    every conv layer (``*.tp.weight`` is empty with shared_weights=False, ``*.tp.output_mask``), the weightless
+    ``final_tp_tor = o3.FullTensorProduct(...)`` of the torsion head (models/score_model.py:152: ``final_tp_tor.weight`` [0],
+    ``final_tp_tor.output_mask``) and the TorchScript sub-modules of e3nn's code generator (``_compiled_*``)."""
+    parts = key.split('.')
+    return ('tp' in parts[:-1] or parts[0] == 'final_tp_tor' or parts[-1] == 'output_mask'
+            or any(p.startswith('_compiled_') for p in parts))
+
+
+def check_state_dict(spec, state_dict, strict=True, what='ddk score model'):
+    """``nn.Module.load_state_dict`` key / shape validation of ``state_dict`` against ``spec`` (name -> shape) after dropping e3nn's internal
+    keys: returns (tensors of the spec'd keys, missing, unexpected); raises like torch on mis-shaped tensors, on missing / unexpected keys
+    with ``strict``, and on missing keys always (nothing on the device can run with a partial checkpoint)."""
+    have = {k: v for k, v in state_dict.items() if k in spec or not _is_e3nn_internal(k)}
+    missing = [k for k in spec if k not in have]
+    unexpected = [k for k in have if k not in spec]
+    bad = [f'{k}: checkpoint {tuple(have[k].shape)} vs model {tuple(spec[k])}' for k in spec
+           if k in have and tuple(have[k].shape) != tuple(spec[k])]
+    if bad:
+        raise RuntimeError(f'{what}: size mismatch for ' + '; '.join(bad))
+    if strict and (missing or unexpected):
+        raise RuntimeError(f'{what}: error(s) in loading state_dict: missing keys {missing}, unexpected keys {unexpected}')
+    if missing:
+        raise RuntimeError(f'{what}: the device path needs the complete checkpoint; missing {missing}')
+    return have, missing, unexpected
+
+
 class TensorProductScoreModel(nn.Module):
     """Constructor keywords follow models/score_model.py:15-24; only the coarse-grained sh_lmax=1 score model
     (DiffDock-S) is implemented on the device - anything else raises instead of silently falling back."""
@@ -145,20 +173,10 @@ class TensorProductScoreModel(nn.Module):
     # the parameters live in the ddk context (packed for the kernels), not in nn.Parameters
     def load_state_dict(self, state_dict, strict=True, extra=None):
         """``nn.Module.load_state_dict`` semantics on the reference key set: with ``strict`` a missing, unexpected or mis-shaped
-        key raises; e3nn's internal ``*.tp.*`` buffers of real checkpoints are ignored.  ``extra``: further tensors
+        key raises; e3nn's internal buffers of real checkpoints (:func:`_is_e3nn_internal`) are ignored.  ``extra``: further tensors
         for the same ddk context (the AR model's predictor weights, already validated by the caller)."""
         spec = self.expected_state_dict_spec()
-        have = {k: v for k, v in state_dict.items() if '.tp.' not in k}
-        missing = [k for k in spec if k not in have]
-        unexpected = [k for k in have if k not in spec]
-        bad = [f'{k}: checkpoint {tuple(have[k].shape)} vs model {spec[k]}' for k in spec
-               if k in have and tuple(have[k].shape) != tuple(spec[k])]
-        if bad:
-            raise RuntimeError('ddk score model: size mismatch for ' + '; '.join(bad))
-        if strict and (missing or unexpected):
-            raise RuntimeError(f'ddk score model: error(s) in loading state_dict: missing keys {missing}, unexpected keys {unexpected}')
-        if missing:      # non-strict: nothing on the device can run with a partial checkpoint
-            raise RuntimeError(f'ddk score model: the device path needs the complete checkpoint; missing {missing}')
+        have, missing, unexpected = check_state_dict(spec, state_dict, strict)
         if extra:
             self.ctx.load_state_dict(extra, finalize=False)
         self.ctx.load_state_dict({k: have[k] for k in spec})

@@ -213,7 +213,8 @@ int ddk_randomize_position(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float
  *               = the symmetry-corrected RMSD of evaluate.py:308-310 (spyrmsd.rmsd.symmrmsd, no minimisation: the minimum over the
  *               graph automorphisms of the ligand).  perms [n_perms, n_lig] int32 DEVICE: row k maps every ligand atom i to its image
  *               (computed once per ligand on the caller's side, INTEGRATION.md shows the spyrmsd / networkx recipe; row 0 should be
- *               the identity; entries of masked-out atoms are ignored).  perms = NULL, n_perms = 0: identity only = the uncorrected
+ *               the identity; entries of masked-out atoms are ignored; a row with an entry outside [0, n_lig) is checked on the device and
+ *               never wins the minimum - rmsd = inf if no row is valid).  perms = NULL, n_perms = 0: identity only = the uncorrected
  *               fallback of evaluate.py:313.
  *        centroid_distance = |mean_i pos_i - mean_i ref_i|         (:315)
  *        min_cross_distance = min over receptor points r, atoms i of |rec_r - pos_i|   (:331-332): rec_atom_pos [n_rec_atoms, 3] DEVICE,
@@ -263,6 +264,11 @@ int ddk_last_node_features(ddk_ctx* ctx, ddk_complex* cx, int32_t B, float* lig_
  *      still applied: the round-1 accounting), out[5l+4] = edges the reference evaluates in that layer (all of E every layer). */
 int ddk_profile_enable(ddk_ctx* ctx, int32_t on);
 int ddk_profile_read(ddk_ctx* ctx, double* out, int32_t n);
+/*      The same records per FORWARD, in launch order (a sampling loop of K steps = K consecutive forwards): out[4f] = conv kernel ms
+ *      of forward f (its conv launches together), out[4f+1] = edges they evaluated, out[4f+2] = edges without the receptive-field
+ *      pruning, out[4f+3] = cross edges lig->rec of the forward's graph.  Returns the number of forwards recorded since
+ *      ddk_profile_enable(on) (at most max_forwards are written), or a negative error code. */
+int ddk_profile_read_forwards(ddk_ctx* ctx, double* out, int32_t max_forwards);
 
 #ifdef __cplusplus
 }

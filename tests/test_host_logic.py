@@ -303,3 +303,55 @@ def test_heterographs_pickle_to_graph_cache(tmp_path):
         for k in keys:
             want = np.asarray(c[k])
             assert np.array_equal(np.asarray(r[k]).astype(want.dtype if want.dtype != np.int64 else np.int32), want.astype(r[k].dtype)), k
+
+
+def test_state_dict_check_ignores_e3nn_internal_keys():
+    """a real checkpoint also carries e3nn's own entries - ``conv_layers.*.tp.output_mask`` / ``.tp.weight`` ([0] with
+    shared_weights=False), ``final_tp_tor.weight`` / ``final_tp_tor.output_mask`` of the weightless FullTensorProduct in the torsion head
+    (models/score_model.py:152) and ``_compiled_*`` code-generator modules.  They must not count as unexpected under strict=True, while a
+    genuinely foreign key, a missing key and a mis-shaped tensor still raise."""
+    from types import SimpleNamespace
+    from disco_diffdock_amd.score_model import TensorProductScoreModel, check_state_dict
+    from disco_diffdock_amd.runtime import DEFAULTS
+    spec = TensorProductScoreModel.expected_state_dict_spec(SimpleNamespace(cfg=dict(DEFAULTS)))
+    sd = {k: torch.zeros(tuple(v)) for k, v in spec.items()}
+    extra = {'final_tp_tor.weight': torch.zeros(0), 'final_tp_tor.output_mask': torch.ones(9),
+             'conv_layers.0.tp.weight': torch.zeros(0), 'conv_layers.3.tp.output_mask': torch.ones(84),
+             'tor_bond_conv.tp.output_mask': torch.ones(48), 'final_conv.tp._compiled_main_left_right.foo': torch.zeros(1),
+             'final_tp_tor._compiled_main_left_right.bar': torch.zeros(1)}
+    have, missing, unexpected = check_state_dict(spec, dict(sd, **extra), strict=True)
+    assert set(have) == set(spec) and not missing and not unexpected
+    with pytest.raises(RuntimeError, match='unexpected keys'):
+        check_state_dict(spec, dict(sd, **{'encoder.weight': torch.zeros(3)}), strict=True)
+    k0 = next(iter(spec))
+    with pytest.raises(RuntimeError, match='missing'):
+        check_state_dict(spec, {k: v for k, v in sd.items() if k != k0}, strict=False)
+    with pytest.raises(RuntimeError, match='size mismatch'):
+        check_state_dict(spec, dict(sd, **{k0: torch.zeros(tuple(spec[k0]) + (2,))}), strict=True)
+
+
+def test_graph_copies_settle_pending_bookkeeping():
+    """a graph with results pending from sampling() (``_lazy``) settles them before a copy / deep copy / pickle, so the
+    copy carries values and never the bookkeeping object (which owns a CUDA event); graphs are held weakly by the bookkeeping."""
+    import copy
+    import pickle
+    from disco_diffdock_amd.data import HeteroData
+
+    class FakeBk:
+        def __init__(self, g):
+            self.g, self.calls = g, 0
+
+        def resolve(self):
+            self.calls += 1
+            self.g.__dict__.pop('_lazy', None)
+            self.g.latent_str = 'L1R2'
+
+    for op in (copy.copy, copy.deepcopy, lambda g: pickle.loads(pickle.dumps(g))):
+        g = HeteroData()
+        g['ligand'].pos = torch.zeros(4, 3)
+        g.name = 'c'
+        bk = FakeBk(g)
+        g.__dict__['_lazy'] = bk
+        h = op(g)
+        assert bk.calls == 1 and '_lazy' not in g.__dict__ and '_lazy' not in h.__dict__
+        assert h.latent_str == 'L1R2' and h.name == 'c' and tuple(h['ligand'].pos.shape) == (4, 3)

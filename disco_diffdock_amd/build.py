@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libddk.so')
-SOURCES = ['ddk_capi.hip', 'k_conv.hip', 'k_tp.hip', 'k_graph.hip', 'k_heads.hip', 'k_se3.hip', 'model.hip', 'conf.hip', 'k_conv_h.hip', 'k_ar.hip']
+SOURCES = ['ddk_capi.hip', 'k_conv.hip', 'k_tp.hip', 'k_graph.hip', 'k_heads.hip', 'k_se3.hip', 'model.hip', 'conf.hip', 'k_conv_x.hip', 'k_ar.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-mllvm', '-amdgpu-mfma-vgpr-form', '-Wall', '-Wno-unused-function', '-Wno-unused-value', '-Wno-unused-result']
 
 

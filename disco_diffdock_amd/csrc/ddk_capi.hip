@@ -230,9 +230,8 @@ static int build_layout(ddk_ctx* ctx, int mode, int l, ConvLayerDev& L, std::vec
   // The 0e and 0o blocks' dot-product parts (p.v, q.v: 6 rows each) would each end in a half-empty tile (pv4 pv5 . . / . . qv4 qv5).  When both
   // exist with the same output width they share ONE tile (kind T_RTS): the two columns of the same channel slots are laid out back to back,
   // [0e column ... | shared tail: flushes the 0e column, opens the 0o column | 0o column ...]  (3 tiles less for W = 1872 and W = 1152).
-  // The 3 x f16 kernel keeps the unshared table.
   const Part *dp0 = dot_part(0), *dp3 = dot_part(3);
-  const bool share = mode == 0 && !c.conv_f16x3 && dp0 && dp3 && dp0->rows.size() == 6 && dp3->rows.size() == 6 && L.n_out[0] == L.n_out[3] &&
+  const bool share = mode == 0 && dp0 && dp3 && dp0->rows.size() == 6 && dp3->rows.size() == 6 && L.n_out[0] == L.n_out[3] &&
                      L.n_out[0] % 2 == 0;
   bool done[4] = {false, false, false, false};
   if (share) {
@@ -254,8 +253,8 @@ static int build_layout(ddk_ctx* ctx, int mode, int l, ConvLayerDev& L, std::vec
   // A column of 6 output channels (the vector blocks: nv = 6) fills only 3 of a tile's 4 accumulator quads.  The 4th quad of the column's
   // first tiles carries the (row quad, channel pair) units of the column's LAST a (x) v / c (x) v row quads instead, whose own tiles disappear:
   // Q row quads -> ceil(3Q/4) tiles (9 -> 7 for in = 36 rows, 8 -> 6, 6 -> 5).  Tile word: bit 7 = extra unit present, bits 8-9 = its channel
-  // pair, bits 10-13 = its F offset / 4 (an a / c quad).  The 3 x f16 kernel keeps the unpacked table.
-  const bool pack_quads = (mode == 0 || mode == 1) && !c.conv_f16x3;
+  // pair, bits 10-13 = its F offset / 4 (an a / c quad).
+  const bool pack_quads = mode == 0 || mode == 1;
   for (int b = 0; b < 4; ++b) {
     if (done[b] || parts[b].empty() || L.n_out[b] == 0) continue;
     if (L.n_out[b] % 2) return fail(ctx, DDK_ERR_INVALID, "odd output multiplicity unsupported");
@@ -358,6 +357,72 @@ static int fold_batch_norm(ddk_ctx* ctx, const std::string& pre, const int* out,
   return DDK_OK;
 }
 
+// Three-limb fp16 records of a layer's radial-MLP weights for k_conv_x.hip: every (range-scaled) fp32 weight v becomes
+// hi + mid 2^-11 + lo 2^-22 with hi = fp16(v), mid = fp16((v - hi) 2^11), lo = fp16(((v - hi) 2^11 - mid) 2^11) - exact, and checked here
+// for every value.  w1all / w2all: the fp32 fragment arrays [.][s/4][lane][s&3] (s = register of the lane half), b2all [t][2][16].
+static int pack_x3(ddk_ctx* ctx, ConvLayerDev& L, int NG, const std::vector<float>& w1all, const std::vector<float>& w2all,
+                   const std::vector<float>& b2all) {
+  if (L.n_tiles > W2X_MAX_TILES) return fail(ctx, DDK_ERR_INVALID, "too many W2 tiles for the three-limb kernel's descriptor table");
+  const size_t w1sz = 3 * 9 * 64 * 4, w2sz = (size_t)L.n_tiles * 9 * 64 * 4, b2sz = (size_t)L.n_tiles * 32;
+  bool exact = true;
+  auto split = [&exact](float v, uint16_t& hi, uint16_t& mid, uint16_t& lo) {
+    const _Float16 h = (_Float16)v;
+    const float r1 = (v - (float)h) * 2048.0f;
+    const _Float16 m = (_Float16)r1;
+    const _Float16 l = (_Float16)((r1 - (float)m) * 2048.0f);
+    memcpy(&hi, &h, 2); memcpy(&mid, &m, 2); memcpy(&lo, &l, 2);
+    // the limbs must reproduce v bit for bit (values below 2^-23 - more than 2^-36 under the group's maximum - within 2^-46)
+    const double back = (double)(float)h + (double)(float)m * 0x1p-11 + (double)(float)l * 0x1p-22;
+    if (std::fabs(v) >= 0x1p-23f ? back != (double)v : std::fabs(back - (double)v) > 0x1p-46) exact = false;
+  };
+  // exact power-of-two range scaling: max|w| of a group is brought into [2^13, 2^14) so that no limb leaves the fp16 range whatever the
+  // scale of the checkpoint (the kernel scales the activations per edge the same way)
+  auto range_scale = [](const float* v, size_t n, const float* v2, size_t n2) {
+    float m = 0.f;
+    for (size_t i = 0; i < n; ++i) m = std::max(m, std::fabs(v[i]));
+    for (size_t i = 0; i < n2; ++i) m = std::max(m, std::fabs(v2[i]));
+    int e = 0;
+    std::frexp(std::max(m, 0x1p-40f), &e);      // m = f * 2^e, f in [0.5, 1)
+    return std::ldexp(1.0f, 14 - e);
+  };
+  std::vector<uint8_t> w2x((size_t)NG * L.n_tiles * W2X_TILE_BYTES, 0), w1x((size_t)NG * 3 * W1X_TILE_BYTES, 0);
+  // one tile of fp32 fragments [9][64][4] -> three limbs x [4 x [64][8] | [64][4]]
+  auto frags = [&](const float* src, float sc, uint8_t* dst) {
+    for (int r = 0; r < 36; ++r)
+      for (int lane = 0; lane < 64; ++lane) {
+        const float v = src[((size_t)(r / 4) * 64 + lane) * 4 + (r & 3)] * sc;
+        const int s_ = r / 8, i = r % 8;
+        const size_t off = s_ < 4 ? (size_t)s_ * 1024 + lane * 16 + 2 * i : (size_t)4096 + lane * 8 + 2 * i;
+        uint16_t h, m, l;
+        split(v, h, m, l);
+        memcpy(dst + off, &h, 2); memcpy(dst + W2X_LIMB_BYTES + off, &m, 2); memcpy(dst + 2 * W2X_LIMB_BYTES + off, &l, 2);
+      }
+  };
+  for (int g = 0; g < NG; ++g) {
+    const float* w2 = w2all.data() + g * w2sz;
+    const float* w1 = w1all.data() + g * w1sz;
+    const float* b2 = b2all.data() + g * b2sz;
+    const float sc1 = range_scale(w1, w1sz, nullptr, 0), sc2 = range_scale(w2, w2sz, nullptr, 0);
+    L.w1s[g] = sc1; L.w2s[g] = sc2;
+    for (int t = 0; t < L.n_tiles; ++t) {
+      uint8_t* rec = w2x.data() + ((size_t)g * L.n_tiles + t) * W2X_TILE_BYTES;
+      frags(w2 + (size_t)t * 2304, sc2, rec);
+      memcpy(rec + W2X_BIAS_OFF, b2 + (size_t)t * 32, 128);       // fp32 as is: the kernel scales it like the products
+    }
+    for (int T = 0; T < 3; ++T) frags(w1 + (size_t)T * 2304, sc1, w1x.data() + ((size_t)g * 3 + T) * W1X_TILE_BYTES);
+  }
+  if (!exact) return fail(ctx, DDK_ERR_INVALID, "internal: the three-limb fp16 split of a conv weight is not exact");
+  L.h_w2x = w2x; L.h_w1x = w1x;
+  if (ctx->host_only) return DDK_OK;
+  L.w2x = (uint8_t*)dev_alloc(ctx, w2x.size());
+  L.w1x = (uint8_t*)dev_alloc(ctx, w1x.size());
+  if (!L.w2x || !L.w1x) return fail(ctx, DDK_ERR_NOMEM, "device allocation failed while packing conv weights (three-limb f16)");
+  if (hipMemcpy(L.w2x, w2x.data(), w2x.size(), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(L.w1x, w1x.data(), w1x.size(), hipMemcpyHostToDevice) != hipSuccess)
+    return fail(ctx, DDK_ERR_HIP, "three-limb weight upload failed");
+  return DDK_OK;
+}
+
 // mode 0: score-model layer l = conv_layers.{l} with 4 edge groups (fc.{g}.{0,4}) and one BatchNorm;
 // mode 1: confidence-model layer l = the 9 convs conv_layers.{9l+g} (fc.{0,3}), each with its own BatchNorm.
 static int build_conv_layer(ddk_ctx* ctx, int mode, int l, ConvLayerDev& L) {
@@ -455,6 +520,7 @@ static int build_conv_layer(ddk_ctx* ctx, int mode, int l, ConvLayerDev& L) {
     L.h_w2p[g].assign(w2all.begin() + g * w2sz, w2all.begin() + (g + 1) * w2sz);
     L.h_b2p[g].assign(b2all.begin() + g * b2sz, b2all.begin() + (g + 1) * b2sz);
   }
+  if (mode == 0 && c.conv_kernel == 0 && (rc = pack_x3(ctx, L, NG, w1all, w2all, b2all))) return rc;
   if (!ctx->host_only) {
     std::vector<float> w2rec((size_t)NG * L.n_tiles * W2_TILE_FLOATS);
     for (int g = 0; g < NG; ++g)
@@ -473,67 +539,6 @@ static int build_conv_layer(ddk_ctx* ctx, int mode, int l, ConvLayerDev& L) {
     L.bn_bias = dev_upload(ctx, L.h_bn_bias);
     if (!d1 || !db1 || !d2 || !L.bn_mean || !L.bn_scale || !L.bn_bias)
       return fail(ctx, DDK_ERR_NOMEM, "device allocation failed while packing conv weights");
-    if (mode == 0 && c.conv_f16x3) {   // error-compensated f16 split of the same (scaled) weights
-      auto split = [](float v, uint16_t& hi, uint16_t& lo) {
-        const _Float16 h = (_Float16)v;
-        const _Float16 l = (_Float16)((v - (float)h) * 2048.0f);
-        memcpy(&hi, &h, 2); memcpy(&lo, &l, 2);
-      };
-      std::vector<uint8_t> w2h((size_t)NG * L.n_tiles * W2H_TILE_BYTES, 0);
-      std::vector<uint16_t> w1h((size_t)NG * 3 * (W1H_TILE_BYTES / 2), 0);
-      // exact power-of-two range scaling: max|w| of a group is brought into [2^13, 2^14) so that neither half of the split leaves
-      // the fp16 range whatever the scale of the checkpoint (the kernel scales the activations per edge the same way)
-      auto range_scale = [](const float* v, size_t n, const float* v2, size_t n2) {
-        float m = 0.f;
-        for (size_t i = 0; i < n; ++i) m = std::max(m, std::fabs(v[i]));
-        for (size_t i = 0; i < n2; ++i) m = std::max(m, std::fabs(v2[i]));
-        int e = 0;
-        std::frexp(std::max(m, 0x1p-40f), &e);      // m = f * 2^e, f in [0.5, 1)
-        return std::ldexp(1.0f, 14 - e);
-      };
-      for (int g = 0; g < NG; ++g) {
-        const float* w2 = w2all.data() + g * w2sz;    // fp32 fragment order: [t][s/4][lane][s&3], s = register of the lane half
-        const float* w1 = w1all.data() + g * w1sz;
-        const float sc1 = range_scale(w1, w1sz, nullptr, 0), sc2 = range_scale(w2, w2sz, b2all.data() + g * b2sz, b2sz);
-        L.w1s[g] = sc1; L.w2s[g] = sc2;
-        for (int t = 0; t < L.n_tiles; ++t) {
-          uint8_t* rec = w2h.data() + ((size_t)g * L.n_tiles + t) * W2H_TILE_BYTES;
-          uint16_t* hi = (uint16_t*)rec; uint16_t* lo = (uint16_t*)(rec + W2H_FRAG_BYTES);
-          for (int s = 0; s < 5; ++s)
-            for (int lane = 0; lane < 64; ++lane)
-              for (int i = 0; i < 8; ++i) {
-                const int r = 8 * s + i;
-                float v = r < 36 ? w2[(((size_t)t * 9 + r / 4) * 64 + lane) * 4 + (r & 3)] : 0.f;
-                if (r == 36 && lane < 32) {      // K slot 36 of lane half 0 multiplies the constant 1: the bias of tile row `lane`
-                  const float* b2t = b2all.data() + g * b2sz + (size_t)t * 32;   // [hh][16] in D-register order
-                  for (int hh2 = 0; hh2 < 2; ++hh2)
-                    for (int rr = 0; rr < 16; ++rr)
-                      if (d_row(rr, hh2) == lane) v = b2t[hh2 * 16 + rr];
-                }
-                split(v * sc2, hi[(s * 64 + lane) * 8 + i], lo[(s * 64 + lane) * 8 + i]);
-              }
-          memcpy(rec + 2 * W2H_FRAG_BYTES, b2all.data() + g * b2sz + (size_t)t * 32, 128);
-          memcpy(rec + 2 * W2H_FRAG_BYTES + 128, &tiles[t], 8);
-        }
-        for (int T = 0; T < 3; ++T) {
-          uint16_t* hi = w1h.data() + ((size_t)g * 3 + T) * (W1H_TILE_BYTES / 2);
-          uint16_t* lo = hi + W2H_FRAG_BYTES / 2;
-          for (int s = 0; s < 5; ++s)
-            for (int lane = 0; lane < 64; ++lane)
-              for (int i = 0; i < 8; ++i) {
-                const int r = 8 * s + i;
-                const float v = r < 36 ? w1[(((size_t)T * 9 + r / 4) * 64 + lane) * 4 + (r & 3)] : 0.f;
-                split(v * sc1, hi[(s * 64 + lane) * 8 + i], lo[(s * 64 + lane) * 8 + i]);
-              }
-        }
-      }
-      L.w2h = (uint8_t*)dev_alloc(ctx, w2h.size());
-      L.w1h = (uint16_t*)dev_alloc(ctx, w1h.size() * 2);
-      if (!L.w2h || !L.w1h) return fail(ctx, DDK_ERR_NOMEM, "device allocation failed while packing conv weights (f16 split)");
-      if (hipMemcpy(L.w2h, w2h.data(), w2h.size(), hipMemcpyHostToDevice) != hipSuccess ||
-          hipMemcpy(L.w1h, w1h.data(), w1h.size() * 2, hipMemcpyHostToDevice) != hipSuccess)
-        return fail(ctx, DDK_ERR_HIP, "f16 weight upload failed");
-    }
     L.w1p[0] = d1; L.b1p[0] = db1; L.w2r[0] = d2;    // group-major contiguous: group g at + g * stride
     for (int g = 1; g < 4; ++g) {
       L.w1p[g] = d1 + g * w1sz;
@@ -589,6 +594,7 @@ int build_head_layer(ddk_ctx* ctx, int mode, ConvLayerDev& L) {
   }
   L.h_w1p.assign(1, w1); L.h_b1p.assign(1, b1); L.h_w2p.assign(1, w2); L.h_b2p.assign(1, b2);
   L.h_bn_mean.assign(XW, 0.f); L.h_bn_scale.assign(XW, 1.f); L.h_bn_bias.assign(XW, 0.f);
+  if (ctx->cfg.conv_kernel == 0 && (rc = pack_x3(ctx, L, 1, w1, w2, b2))) return rc;
   if (ctx->host_only) return DDK_OK;
   std::vector<float> w2rec((size_t)L.n_tiles * W2_TILE_FLOATS);
   for (int t = 0; t < L.n_tiles; ++t) {
@@ -624,8 +630,9 @@ int ddk_create(const ddk_config* cfg, ddk_ctx** out) {
     return fail(ctx, DDK_ERR_INVALID, "num_conv_layers must be in [4,16] (heads assume the full 0e+1o+1e+0o irreps)");
   if (cfg->sigma_embed_dim != 32 || cfg->distance_embed_dim != 32 || cfg->cross_distance_embed_dim != 32)
     return fail(ctx, DDK_ERR_INVALID, "only 32-wide sigma / distance embeddings are compiled in");
-  if (cfg->deterministic && (cfg->conv_f16x3 || cfg->all_atoms))
-    return fail(ctx, DDK_ERR_INVALID, "deterministic scatter is implemented for the fp32 score model (not with conv_f16x3 / all_atoms)");
+  if (cfg->deterministic && cfg->all_atoms)
+    return fail(ctx, DDK_ERR_INVALID, "deterministic scatter is implemented for the score model (not with all_atoms)");
+  if (cfg->conv_kernel != 0 && cfg->conv_kernel != 1) return fail(ctx, DDK_ERR_INVALID, "conv_kernel must be 0 (three-limb f16) or 1 (fp32 MFMA)");
   if (cfg->device < 0) {
     ctx->host_only = true;   // packing-only context (CPU tests); every launch entry point refuses to run
     return DDK_OK;
@@ -812,6 +819,10 @@ int64_t ddk_debug_export(ddk_ctx* ctx, const char* what, void* buf, int64_t cap_
     else if (it == "bn_mean") { src = L.h_bn_mean.data(); n = L.h_bn_mean.size(); }
     else if (it == "bn_scale") { src = L.h_bn_scale.data(); n = L.h_bn_scale.size(); }
     else if (it == "bn_bias") { src = L.h_bn_bias.data(); n = L.h_bn_bias.size(); }
+    // three-limb f16 kernel: all groups' records (bytes, padded to words) and the power-of-two range scales [w1s[4] | w2s[4]]
+    else if (it == "w1x") { src = L.h_w1x.data(); n = L.h_w1x.size() / 4; }
+    else if (it == "w2x") { src = L.h_w2x.data(); n = L.h_w2x.size() / 4; }
+    else if (it == "xscale") { static thread_local float sc[8]; for (int k = 0; k < 4; ++k) { sc[k] = L.w1s[k]; sc[4 + k] = L.w2s[k]; } src = sc; n = 8; }
     else return fail(ctx, DDK_ERR_INVALID, "unknown export item");
   } else {
     return fail(ctx, DDK_ERR_INVALID, "unknown export name");
@@ -821,6 +832,16 @@ int64_t ddk_debug_export(ddk_ctx* ctx, const char* what, void* buf, int64_t cap_
     memcpy(buf, src, (size_t)n * 4);
   }
   return n;
+}
+
+// Test hook: the conv kernel's in-register limb split on a DEVICE array: x [n] is cut into groups of `group` consecutive values, each group is
+// range-scaled by its own power of two (like the per-edge scaling of the activations) and split; hi / mid / lo [n] come back as fp32 values
+// of the fp16 limbs, scale [n] is the group's power of two:  x * scale == hi + mid 2^-11 + lo 2^-22 exactly (tests/test_gpu_round3.py).
+int ddk_debug_split3(ddk_ctx* ctx, const float* x, int64_t n, int32_t group, float* hi, float* mid, float* lo, float* scale, void* stream) {
+  if (!ctx || ctx->host_only) return DDK_ERR_STATE;
+  if (n < 0 || group < 1 || !x || !hi || !mid || !lo || !scale) return fail(ctx, DDK_ERR_INVALID, "ddk_debug_split3: bad argument");
+  hipError_t e = launch_split3_probe(x, n, group, hi, mid, lo, scale, (hipStream_t)stream);
+  return e == hipSuccess ? DDK_OK : hip_fail(ctx, e, "split3 probe");
 }
 
 }  // extern "C"

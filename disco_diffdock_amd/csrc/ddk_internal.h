@@ -55,14 +55,16 @@ template <> struct ConvTraits<1> { static constexpr int WAVES = 6, FS = F_STRIDE
 template <int MODE> constexpr size_t conv_lds_bytes() { return (size_t)(ConvTraits<MODE>::WAVES * 32 * ConvTraits<MODE>::FS + 2 * W2_TILE_FLOATS + 16) * 4; }
 static_assert(conv_lds_bytes<1>() <= 160 * 1024, "LDS budget (l<=2)");
 constexpr int CONV_MAX_GROUPS = 9;
-// 3 x f16 mode (ddk_config.conv_f16x3): W2 tile record = hi fragments [5][64][8] fp16 | lo*2^11 fragments [5][64][8] fp16 |
-// bias [2][16] f32 | tile descriptor (2 x int32) | pad ; element (s, lane, i) of a fragment set = weight of tile row lane&31 for the
-// hidden unit held by register 8*s+i of lane half lane>>5 (zero for registers >= 36: K = 72 padded to 80)
-constexpr int W2H_FRAG_BYTES = 5 * 64 * 8 * 2;                      // 5,120
-constexpr int W2H_TILE_BYTES = 2 * W2H_FRAG_BYTES + 128 + 16;       // 10,384 = 649 x 16 B
-constexpr int W1H_TILE_BYTES = 2 * W2H_FRAG_BYTES;                  // GEMM1: hi + lo fragments of one 32-row tile
-constexpr size_t CONV_H_LDS_BYTES = (size_t)CONV_WAVES * 32 * F_STRIDE * 4 + 2 * W2H_TILE_BYTES + 64;   // 156,000 B
-static_assert(CONV_H_LDS_BYTES <= 160 * 1024 && W2H_TILE_BYTES % 16 == 0, "LDS budget (3 x f16)");
+// Exact three-limb f16 kernel (k_conv_x.hip, ddk_config.conv_kernel = 0): W2 tile record = three limbs (hi | mid 2^11 | lo 2^22, fp16) x
+// [4 fragments [64 lanes][8] of K steps 0..3 | tail fragment [64][4] of the last 8 K values] | bias [2][16] f32 | pad ; element (s, lane, i) of
+// a fragment = weight of tile row lane&31 for the hidden unit held by register 8*s+i of lane half lane>>5 (K = 72 = 4 x 16 + 8)
+constexpr int W2X_LIMB_BYTES = 4 * 1024 + 512;                      // 4,608
+constexpr int W2X_BIAS_OFF = 3 * W2X_LIMB_BYTES;                    // 13,824
+constexpr int W2X_TILE_BYTES = W2X_BIAS_OFF + 128 + 16;             // 13,968 = 873 x 16 B
+constexpr int W1X_TILE_BYTES = 3 * W2X_LIMB_BYTES;                  // GEMM1: the three limbs of one 32-row tile
+constexpr int W2X_MAX_TILES = 64;                                   // tile descriptors ride in the kernel arguments
+constexpr size_t CONV_X_LDS_BYTES = (size_t)CONV_WAVES * 32 * F_STRIDE * 4 + 2 * W2X_TILE_BYTES + 16;   // 163,120 B of the 163,840
+static_assert(CONV_X_LDS_BYTES <= 160 * 1024 && W2X_TILE_BYTES % 16 == 0, "LDS budget (three-limb f16)");
 
 // One W2 "tile" = 32 weight rows x 72 hidden units = one burst of 36 v_mfma_f32_32x32x2_f32 per 32 edges.
 // Tile row rho = 8*rq + 4*hh + j (rq = accumulator quad 0..3, hh = lane half, j = 0..3) holds the weight that multiplies
@@ -98,9 +100,9 @@ struct ConvLayerDev {          // device copies for one TensorProductConvLayer w
   float* w1p[4] = {};          // [3][9][64][4]
   float* b1p[4] = {};          // [3][2][16]
   float* w2r[4] = {};          // [n_tiles][W2_TILE_FLOATS]: per tile the fragments [9][64][4], the bias [2][16], the TileDesc words
-  uint16_t* w1h = nullptr;     // 3 x f16 mode: [groups][3][W1H_TILE_BYTES/2]
-  uint8_t* w2h = nullptr;      // 3 x f16 mode: [groups][n_tiles][W2H_TILE_BYTES]
-  float w1s[4] = {1, 1, 1, 1}, w2s[4] = {1, 1, 1, 1};   // 3 x f16 mode: power-of-two range scale of the packed W1 / (W2, b2) of each group
+  uint8_t* w1x = nullptr;      // three-limb f16 kernel: [groups][3][W1X_TILE_BYTES]
+  uint8_t* w2x = nullptr;      // three-limb f16 kernel: [groups][n_tiles][W2X_TILE_BYTES]
+  float w1s[4] = {1, 1, 1, 1}, w2s[4] = {1, 1, 1, 1};   // three-limb f16 kernel: power-of-two range scale of the packed W1 / (W2, b2) of each group
   int n_cols = 0;              // flush columns (8 output channels each); col_start[c] = first tile of column c, col_start[n_cols] = n_tiles
   int col_start[17] = {};
   // GEMM1 split: W1 [edge_emb | x_src[:ns] | x_dst[:ns]] = W1a edge_emb + (W1b x[src][:ns] + b1) + W1c x[dst][:ns]; the
@@ -119,6 +121,7 @@ struct ConvLayerDev {          // device copies for one TensorProductConvLayer w
   std::vector<float> h_bn_mean, h_bn_scale, h_bn_bias;          // [n_bn][XW]: one BatchNorm per layer (score) or per conv (confidence)
   int n_groups = 4;
   std::vector<TileDesc> h_tiles;
+  std::vector<uint8_t> h_w1x, h_w2x;     // host copies of the three-limb records (ddk_debug_export, CPU tests)
   // block shapes of the FasterTensorProduct (tensor_layers.py:58-63), order 0e,1o,1e,0o
   int n_in[4] = {}, n_out[4] = {}, blk_off[4] = {};
   int in_mul[4] = {}, out_mul[4] = {};   // 0e,1o,1e,0o multiplicities of the layer's in/out irreps
@@ -220,10 +223,11 @@ struct ConvLaunch {
   const int32_t* gend = nullptr;
 };
 hipError_t launch_conv_fused(const ConvLayerDev& L, const ConvLaunch& a, int n_cu, hipStream_t s);
-hipError_t launch_conv_fused_h(const ConvLayerDev& L, const ConvLaunch& a, int n_cu, hipStream_t s);   // k_conv_h.hip (3 x f16)
+hipError_t launch_conv_fused_x(const ConvLayerDev& L, const ConvLaunch& a, int n_cu, hipStream_t s);   // k_conv_x.hip (exact three-limb f16)
+hipError_t launch_split3_probe(const float* x, int64_t n, int group, float* hi, float* mid, float* lo, float* scale, hipStream_t s);
 int build_head_layer(ddk_ctx* ctx, int mode, ConvLayerDev& L);      // ddk_capi.hip: mode 2 = tor_bond_conv, 3 = final_conv
 hipError_t conv_prepare_device();     // per-device kernel attributes (dynamic LDS opt-in), called by ddk_create
-hipError_t conv_prepare_device_h();   // k_conv_h.hip
+hipError_t conv_prepare_device_x();   // k_conv_x.hip
 hipError_t launch_conv_setup(int32_t* tile_info, const int64_t* group_offsets_host, hipStream_t s);
 hipError_t launch_conv_one_group(int32_t* gt, int n_groups, int k, int64_t E, hipStream_t s);
 hipError_t launch_pad_rows(const float* x, int64_t n, int din, float* xpad, hipStream_t s);

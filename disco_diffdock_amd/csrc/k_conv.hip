@@ -616,7 +616,7 @@ hipError_t conv_prepare_device() {
   if (e == hipSuccess) e = conv_attr_t<false, 1, false>();
   if (e == hipSuccess) e = conv_attr_t<true, 0, true, true>();
   if (e == hipSuccess) e = conv_attr_t<false, 0, false, true>();
-  if (e == hipSuccess) e = conv_prepare_device_h();
+  if (e == hipSuccess) e = conv_prepare_device_x();
   return e;
 }
 
@@ -659,11 +659,17 @@ __global__ __launch_bounds__(256) void conv_det_fix_kernel(ConvKArgs A, int dout
   if (lane + 64 < dout) row[lane + 64] = acc1;
 }
 
+// deterministic mode: the fix-up pass behind a conv launch of either kernel
+void conv_det_fix(const ConvKArgs& k, const ConvLaunch& a, int dout, hipStream_t s) {
+  const int64_t tiles = a.edge_bound / 32 + 8 * CONV_MAX_GROUPS;
+  hipLaunchKernelGGL(conv_det_fix_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s, k, dout);
+}
+
 hipError_t launch_conv_fused(const ConvLayerDev& L, const ConvLaunch& a, int n_cu, hipStream_t s) {
-  if (L.w2h != nullptr && a.mode == 0) return launch_conv_fused_h(L, a, n_cu, s);   // ddk_config.conv_f16x3
+  if (L.w2x != nullptr && a.mode == 0) return launch_conv_fused_x(L, a, n_cu, s);   // the default: exact three-limb product on the f16 matrix pipe
   ConvKArgs k;
-  k.w1h = nullptr; k.w2h = nullptr;
-  for (int g = 0; g < 4; ++g) { k.w1s[g] = 1.0f; k.w1u[g] = 1.0f; k.w2u[g] = 1.0f; }
+  k.w1x = nullptr; k.w2x = nullptr;
+  for (int g = 0; g < 4; ++g) { k.w1s[g] = 1.0f; k.w1u[g] = 1.0f; k.w2s[g] = 1.0f; k.w2u[g] = 1.0f; }
   k.x = a.x; k.src = a.src; k.dst = a.dst; k.edge_attr = a.edge_attr; k.sh = a.sh; k.sum = a.sum;
   k.counter = a.counter;
   k.w1p = L.w1p[0]; k.b1p = L.b1p[0]; k.w2r = L.w2r[0]; k.n_tiles = L.n_tiles;
@@ -675,12 +681,11 @@ hipError_t launch_conv_fused(const ConvLayerDev& L, const ConvLaunch& a, int n_c
   else { k.gbeg = a.tile_info + 5; k.gend = a.tile_info + 6; }   // 4 contiguous groups go[g] .. go[g+1] (explicit-boundary entry point)
   k.pre = a.pre; k.part = a.part;
   if (a.part != nullptr) {       // deterministic scatter (score model paths only)
-    if (a.mode != 0 || L.w2h != nullptr) return hipErrorInvalidValue;
+    if (a.mode != 0) return hipErrorInvalidValue;
     hipError_t e = (a.gather && a.pre != nullptr) ? launch_conv_t<true, 0, true, true>(k, n_cu, s)
                                                   : (!a.gather ? launch_conv_t<false, 0, false, true>(k, n_cu, s) : hipErrorInvalidValue);
     if (e != hipSuccess) return e;
-    const int64_t tiles = a.edge_bound / 32 + 8 * CONV_MAX_GROUPS;
-    hipLaunchKernelGGL(conv_det_fix_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s, k, L.dout);
+    conv_det_fix(k, a, L.dout, s);
     return hipGetLastError();
   }
   if (a.mode == 1) return a.gather ? launch_conv_t<true, 1, false>(k, n_cu, s) : launch_conv_t<false, 1, false>(k, n_cu, s);

@@ -1,4 +1,4 @@
-// Device helpers shared by the fused conv kernels (k_conv.hip: fp32 MFMA; k_conv_h.hip: error-compensated 3 x f16 MFMA).
+// Device helpers shared by the fused conv kernels (k_conv.hip: fp32 MFMA; k_conv_x.hip: exact three-limb f16 MFMA).
 #pragma once
 #include "ddk_internal.h"
 
@@ -18,9 +18,9 @@ struct ConvKArgs {
   const float* w1p;   // [4][3][9][64][4]
   const float* b1p;   // [4][3][2][16]
   const float* w2r;   // [4][n_tiles][W2_TILE_FLOATS]
-  const uint16_t* w1h;   // 3 x f16 mode: [groups][3][2][5][64][8] fp16 (hi, lo*2^11) GEMM1 fragments
-  const uint8_t* w2h;    // 3 x f16 mode: [groups][n_tiles][W2H_TILE_BYTES] tile records
-  float w1s[4], w1u[4], w2u[4];   // 3 x f16 mode: weight range scale of GEMM1 (and its inverse), inverse weight scale of GEMM2
+  const uint8_t* w1x;    // three-limb f16 kernel: [groups][3][W1X_TILE_BYTES] GEMM1 fragments
+  const uint8_t* w2x;    // three-limb f16 kernel: [groups][n_tiles][W2X_TILE_BYTES] tile records
+  float w1s[4], w1u[4], w2s[4], w2u[4];   // three-limb f16 kernel: weight range scales of GEMM1 / GEMM2 and their inverses
   int n_tiles;
   int n_cols;         // flush columns; col_start[c] .. col_start[c+1] = tiles of column c
   int col_start[17];

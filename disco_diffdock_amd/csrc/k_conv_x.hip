@@ -1,0 +1,544 @@
+// Fused tensor-product convolution on the f16 matrix pipe with EXACT fp32 operands (the default conv kernel of the score model).
+//
+// Same algorithm, tile tables, F rows, epilogue and scatter as k_conv.hip (the fp32-MFMA kernel, kept as ddk_config.conv_kernel = 1 and for
+// the confidence model); only the two radial-MLP GEMMs of models/tensor_layers.py:140-143,154-155 change pipe.  Every fp32 operand x (after an
+// exact power-of-two range scaling, below) is split into three fp16 limbs
+//        x = hi + mid * 2^-11 + lo * 2^-22,     hi = fp16(x),  mid = fp16((x - hi) 2^11),  lo = fp16(((x - hi) 2^11 - mid) 2^11)
+// which is EXACT: a 24-bit significand minus its 11-bit rounding leaves <= 13 bits, of which mid takes 11 and lo the rest (no rounding in the
+// last conversion; checked on the host for every packed weight and on the device by ddk_debug_split3).  The product of two such sums is formed
+// with v_mfma_f32_32x32x16_f16 (products of fp16 numbers are exact in the fp32 accumulators) keeping the six terms
+//        hi.hi  +  2^-11 (hi.mid + mid.hi)  +  2^-22 (hi.lo + lo.hi + mid.mid)
+// and dropping mid.lo + lo.mid + lo.lo <= 3 * 2^-33 relative - 500 times below the fp32 rounding of the accumulation itself.  Three fp32
+// accumulators (one per power of 2^-11) are combined once per tile.  6 MFMAs of 8 passes replace 8 x 16 passes of v_mfma_f32_32x32x2_f32 per
+// 16 K values: 2.7x fewer matrix-pipe cycles, and the f16 pipe does not share issue with the VALU the way the fp32 MFMA does.
+//
+// Range: fp16 spans 2^-24 .. 65504, a checkpoint does not.  Each split operand is first multiplied by an exact power of two that brings the
+// maximum of its group into [2^13, 2^14): W1 and (W2 | b2) per (layer, edge group) at pack time, the GEMM1 inputs and the hidden vector per
+// EDGE in the kernel (exponent arithmetic only); the results are multiplied back by the inverse powers.  With the limbs' own 2^11 / 2^22
+// factors every value within 2^-36 of its group's maximum is represented exactly; smaller ones are off by < 2^-59 of the maximum.
+//
+// K = 72 = 4 steps of 16 + one of 8 (v_mfma_f32_32x32x8_f16): register 8s+i (< 36) of a lane half is element i of step s.
+// The b2 bias starts the hi.hi accumulator (scaled like the products).  Tile record in the LDS ring (13,968 B): three limbs x
+// [4 x 1 KB fragments | 512 B tail fragment] | bias [2][16] f32; the tile descriptors ride in the kernel arguments (scalar loads).
+// The fragments are streamed from the ring INSIDE the burst (no register double buffer: h's three limbs need the registers), so the ring
+// holds the tile in use and the next one: every thread requests its 16-32 B of tile t+1 before the burst of tile t and publishes them behind it.
+#include <stdlib.h>
+
+#include "k_conv_common.h"
+
+namespace ddk {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+#define MFMA8(a, b, c) __builtin_amdgcn_mfma_f32_32x32x8f16((a), (b), (c), 0, 0, 0)
+
+struct ConvXArgs {
+  ConvKArgs k;
+  int32_t tq[W2X_MAX_TILES][2];     // tile descriptors (TileDesc::w0, chan0)
+};
+
+// Exact power-of-two range scale: 2^(13 - floor(log2 max(m, 2^-40))) and its inverse (max|x| lands in [2^13, 2^14))
+__device__ __forceinline__ float range_scale(float m, float& inv) {
+  const uint32_t eb = max((__float_as_uint(m) >> 23) & 0xffu, 87u);   // biased exponent; 0 and subnormals map to the 2^-40 floor
+  inv = __uint_as_float((eb - 13u) << 23);
+  return __uint_as_float((267u - eb) << 23);
+}
+
+// the three limbs of one (range-scaled) value; every step is exact except the first rounding
+struct Limb3 { _Float16 h, m, l; };
+__device__ __forceinline__ Limb3 split3(float v) {
+  Limb3 q;
+  q.h = (_Float16)v;
+  const float r1 = (v - (float)q.h) * 2048.0f;
+  q.m = (_Float16)r1;
+  q.l = (_Float16)((r1 - (float)q.m) * 2048.0f);
+  return q;
+}
+
+// B-operand limbs of the 36 values a lane half holds: steps 0..3 (8 values each) and the 4-value tail
+struct Limbs {
+  f16x8 hi[4], mid[4], lo[4];
+  f16x4 thi, tmid, tlo;
+};
+
+__device__ __forceinline__ void make_limbs(Limbs& L, const float (&v)[36], float scale) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const Limb3 q = split3(v[8 * s + i] * scale); L.hi[s][i] = q.h; L.mid[s][i] = q.m; L.lo[s][i] = q.l; }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const Limb3 q = split3(v[32 + i] * scale); L.thi[i] = q.h; L.tmid[i] = q.m; L.tlo[i] = q.l; }
+}
+
+// six-term product of one K step into the three accumulators (same-accumulator MFMAs never adjacent)
+#define X3_STEP(MF, ah, am, al, bh, bm, bl)   \
+  D2 = MF(ah, bl, D2);                        \
+  D1 = MF(ah, bm, D1);                        \
+  D2 = MF(al, bh, D2);                        \
+  D0 = MF(ah, bh, D0);                        \
+  D2 = MF(am, bm, D2);                        \
+  D1 = MF(am, bh, D1);
+
+// scalar-accumulator tensor-product epilogue of one W2 tile (wave-uniform branch on the tile kind; the f16 pipe does not compete with the VALU
+// for issue: fewer registers beat fewer instructions here).  T_RTS: only rows j = 0,1 belong to the column that is about to be flushed.
+__device__ __forceinline__ void tile_epilogue_s(int kind, const f32x16& D, const float* Fp, f32x4 f0, float (&accA)[4], float (&accV)[4][3]) {
+  if (kind == T_TV) {
+    const f32x4 f1 = ldv4(Fp + 4), f2 = ldv4(Fp + 8);      // y / z components of the 4 feature rows
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const float d0 = D[4 * rq], d1 = D[4 * rq + 1], d2 = D[4 * rq + 2], d3 = D[4 * rq + 3];
+      accV[rq][0] = fmaf(f0.x, d0, fmaf(f0.y, d1, fmaf(f0.z, d2, fmaf(f0.w, d3, accV[rq][0]))));
+      accV[rq][1] = fmaf(f1.x, d0, fmaf(f1.y, d1, fmaf(f1.z, d2, fmaf(f1.w, d3, accV[rq][1]))));
+      accV[rq][2] = fmaf(f2.x, d0, fmaf(f2.y, d1, fmaf(f2.z, d2, fmaf(f2.w, d3, accV[rq][2]))));
+    }
+  } else if (kind == T_RA) {
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq)
+      accA[rq] = fmaf(f0.x, D[4 * rq], fmaf(f0.y, D[4 * rq + 1], fmaf(f0.z, D[4 * rq + 2], fmaf(f0.w, D[4 * rq + 3], accA[rq]))));
+  } else if (kind == T_RT) {
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq)
+      accV[rq][0] = fmaf(f0.x, D[4 * rq], fmaf(f0.y, D[4 * rq + 1], fmaf(f0.z, D[4 * rq + 2], fmaf(f0.w, D[4 * rq + 3], accV[rq][0]))));
+  } else {
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) accV[rq][0] = fmaf(f0.x, D[4 * rq], fmaf(f0.y, D[4 * rq + 1], accV[rq][0]));
+  }
+}
+
+template <bool GATHER, bool SPLIT, bool DET>
+__global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) {
+  static_assert(!SPLIT || GATHER, "the GEMM1 split exists for the gather path");
+  const ConvKArgs& A = AX.k;
+  constexpr int WAVES = CONV_WAVES, FS = F_STRIDE, BLOCK_EDGES = 32 * WAVES;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* F = lds + wave * (32 * FS);                                   // this wave's 32 F rows
+  char* ring = reinterpret_cast<char*>(lds + WAVES * (32 * FS));       // [2][W2X_TILE_BYTES]
+  int* blk_slot = reinterpret_cast<int*>(ring + 2 * W2X_TILE_BYTES);
+  const int el = lane & 31;
+  const int hh = lane >> 5;
+  const bool g2_shared = A.sum_g2 != nullptr;                 // group 2 is the shared rec-rec copy (layer-0 de-duplication): its own accumulator
+  // work unit: a block of BLOCK_EDGES consecutive edges of ONE edge group (its radial-MLP weights are shared by the workgroup); lane g < n_active
+  // keeps group g's edge range and its block range of the work queue; a block index is mapped to its group with one ballot
+  int gb_v = 0, ge_v = 0;
+  if (lane < A.n_active) {
+    gb_v = A.gbeg[lane];
+    ge_v = A.gend[lane];
+  }
+  const int nb_v = (ge_v - gb_v + BLOCK_EDGES - 1) / BLOCK_EDGES;
+  int pend_v = nb_v;
+#pragma unroll
+  for (int d = 1; d < 16; d *= 2) {
+    const int t = __shfl_up(pend_v, d, 64);
+    if (lane >= d) pend_v += t;
+  }
+  const int pbeg_v = pend_v - nb_v;
+  const int bs4 = __builtin_amdgcn_readlane(pend_v, 15);
+  float* Fr = F + el * FS;
+  const float inv_s3 = 0.57735026918962576451f, inv_s2 = 0.70710678118654752440f;
+  const int n_tiles = A.n_tiles;
+  constexpr int REC16 = W2X_TILE_BYTES / 16;                   // 873 x 16 B per tile record
+  const bool second = tid < REC16 - 64 * WAVES;                 // threads that move a second 16 B of the record
+
+  // work units: whole blocks, except that the last (bs4 mod #workgroups) blocks are split into column chunks so that the final round of the
+  // persistent workgroups is a fraction of a block long (same rule as k_conv.hip)
+  const int nwg = gridDim.x;
+  const int full = bs4 >= nwg ? (bs4 / nwg) * nwg : 0;
+  const int rest = bs4 - full;
+  int split = 1;
+  if (rest > 0) {
+    float best = 1e30f;
+    for (int sp = 1; sp <= A.n_cols; ++sp) {
+      const float cost = (float)((rest * sp + nwg - 1) / nwg) / (float)sp * (1.0f + 0.05f * (float)(sp - 1));
+      if (cost < best - 1e-6f) { best = cost; split = sp; }
+    }
+  }
+  const int n_units = full + rest * split;
+
+  int unit = blockIdx.x;
+  for (;;) {
+    if (unit >= n_units) break;
+    int unit_next = 0;
+    if (tid == 0) unit_next = nwg + atomicAdd(A.counter, 1);      // fetched at the START of this unit: the round trip hides under the tile loop
+    int blk = unit, t_begin = 0, t_end = n_tiles;
+    if (unit >= full) {
+      const int r = unit - full, c = r % split;
+      blk = full + r / split;
+      t_begin = A.col_start[(c * A.n_cols) / split];
+      t_end = A.col_start[((c + 1) * A.n_cols) / split];
+    }
+    const int g = __popcll(__ballot(lane < 16 && blk >= pend_v));
+    const int gbeg = __builtin_amdgcn_readlane(gb_v, g), gend = __builtin_amdgcn_readlane(ge_v, g);
+    const int bstart = __builtin_amdgcn_readlane(pbeg_v, g);
+    const int e0 = gbeg + BLOCK_EDGES * (blk - bstart) + 32 * wave;
+    const int nvalid = min(32, gend - e0);                    // <= 0: this wave's slice lies past the end of the group
+    const bool valid = el < nvalid;
+    const int e = nvalid > 0 ? e0 + min(el, nvalid - 1) : gend - 1;
+    const int sn = A.src[e], dn = A.dst[e];
+
+    // ---- stage the first W2 tile of this unit (the ring is idle: the previous unit ended with a barrier) ----
+    const int gw = (int)((A.wmap >> (4 * g)) & 15);                 // weight set / node-term roles of this group
+    const char* wrec = reinterpret_cast<const char*>(A.w2x) + (size_t)gw * n_tiles * W2X_TILE_BYTES;
+    {
+      const char* wr0 = wrec + (size_t)t_begin * W2X_TILE_BYTES;
+      *reinterpret_cast<float4*>(ring + 16 * tid) = *reinterpret_cast<const float4*>(wr0 + 16 * tid);
+      if (second) *reinterpret_cast<float4*>(ring + 16 * (tid + 64 * WAVES)) = *reinterpret_cast<const float4*>(wr0 + 16 * (tid + 64 * WAVES));
+    }
+
+    // ---- segmented-scan control words (identical for every output channel of this wave's 32 edges) ----
+    const SegCtl seg = make_segctl(sn, el, nvalid, valid);
+
+    // ---- GEMM1: h = relu(W1 [edge_emb | x_src[:ns] | x_dst[:ns]] + b1), K order kappa(s,hh) = 24*(s/12)+12*hh+s%12, three-limb product ----
+    Limbs H;
+    float osc, bsc2;      // GEMM2 accumulators hold (s2 h) x (w2s W2): bias goes in times bsc2, flushed sums come out times osc
+    {
+      float h[36];
+      const char* w1 = reinterpret_cast<const char*>(A.w1x) + (size_t)gw * 3 * W1X_TILE_BYTES;
+      if constexpr (SPLIT) {
+        // W1a edge_emb on top of the per-node terms (W1b x[src][:ns] + b1) + W1c x[dst][:ns] (node_finalize_pre_kernel), which arrive in the
+        // accumulator's own register order: K = 24 = one step of 16 + one of 8
+        float bin[12];
+        {
+          const float* pe = A.edge_attr + (size_t)e * NS + 12 * hh;
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const float4 a = ld4(pe + 4 * j);
+            bin[4 * j + 0] = a.x; bin[4 * j + 1] = a.y; bin[4 * j + 2] = a.z; bin[4 * j + 3] = a.w;
+          }
+        }
+        float m1 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) m1 = fmaxf(m1, fabsf(bin[j]));
+        m1 = fmaxf(m1, __shfl_xor(m1, 32));          // both lane halves hold K slices of the same edge
+        float inv1;
+        const float s1 = range_scale(m1, inv1);
+        f16x8 b0h, b0m, b0l;
+        f16x4 b1h, b1m, b1l;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const Limb3 q = split3(bin[i] * s1); b0h[i] = q.h; b0m[i] = q.m; b0l[i] = q.l; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const Limb3 q = split3(bin[8 + i] * s1); b1h[i] = q.h; b1m[i] = q.m; b1l[i] = q.l; }
+        const float bsc = s1 * A.w1s[gw], usc = inv1 * A.w1u[gw];
+        const float* ps = A.pre + ((size_t)sn * 4 + (gw & 1)) * NE + 36 * hh;
+        const float* pd = A.pre + ((size_t)dn * 4 + 2 + (gw >> 1)) * NE + 36 * hh;
+#pragma unroll
+        for (int T = 0; T < 3; ++T) {
+          f32x16 D0, D1, D2;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (T < 2 || j == 0) {
+              const float4 u = ld4(ps + 16 * T + 4 * j), w = ld4(pd + 16 * T + 4 * j);
+              D0[4 * j + 0] = (u.x + w.x) * bsc; D0[4 * j + 1] = (u.y + w.y) * bsc; D0[4 * j + 2] = (u.z + w.z) * bsc; D0[4 * j + 3] = (u.w + w.w) * bsc;
+            } else {
+              D0[4 * j + 0] = 0.0f; D0[4 * j + 1] = 0.0f; D0[4 * j + 2] = 0.0f; D0[4 * j + 3] = 0.0f;
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { D1[r] = 0.0f; D2[r] = 0.0f; }
+          const char* wt = w1 + (size_t)T * W1X_TILE_BYTES;
+          {
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(wt + lane * 16);
+            const f16x8 am = *reinterpret_cast<const f16x8*>(wt + W2X_LIMB_BYTES + lane * 16);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(wt + 2 * W2X_LIMB_BYTES + lane * 16);
+            X3_STEP(MFMA16, ah, am, al, b0h, b0m, b0l)
+          }
+          {     // registers 8..11: the first half of step 1's fragment
+            const f16x4 ah = *reinterpret_cast<const f16x4*>(wt + 1024 + lane * 16);
+            const f16x4 am = *reinterpret_cast<const f16x4*>(wt + W2X_LIMB_BYTES + 1024 + lane * 16);
+            const f16x4 al = *reinterpret_cast<const f16x4*>(wt + 2 * W2X_LIMB_BYTES + 1024 + lane * 16);
+            X3_STEP(MFMA8, ah, am, al, b1h, b1m, b1l)
+          }
+          const int nr = T < 2 ? 16 : 4;
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (r < nr) h[16 * T + r] = fmaxf(fmaf(fmaf(D2[r], 1.0f / 2048.0f, D1[r]), 1.0f / 2048.0f, D0[r]), 0.0f) * usc;
+        }
+      } else {
+        float bin[36];
+        {
+          const float *pe, *pxs, *pxd;
+          if (GATHER) {
+            pe = A.edge_attr + (size_t)e * NS + 12 * hh;
+            pxs = A.x + (size_t)sn * XW + 12 * hh;
+            pxd = A.x + (size_t)dn * XW + 12 * hh;
+          } else {
+            pe = A.edge_attr + (size_t)e * NE + 12 * hh;
+            pxs = pe + NS;
+            pxd = pe + 2 * NS;
+          }
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const float4 a = ld4(pe + 4 * j), b = ld4(pxs + 4 * j), c = ld4(pxd + 4 * j);
+            bin[4 * j + 0] = a.x; bin[4 * j + 1] = a.y; bin[4 * j + 2] = a.z; bin[4 * j + 3] = a.w;
+            bin[12 + 4 * j + 0] = b.x; bin[12 + 4 * j + 1] = b.y; bin[12 + 4 * j + 2] = b.z; bin[12 + 4 * j + 3] = b.w;
+            bin[24 + 4 * j + 0] = c.x; bin[24 + 4 * j + 1] = c.y; bin[24 + 4 * j + 2] = c.z; bin[24 + 4 * j + 3] = c.w;
+          }
+        }
+        float m1 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 36; ++j) m1 = fmaxf(m1, fabsf(bin[j]));
+        m1 = fmaxf(m1, __shfl_xor(m1, 32));
+        float inv1;
+        const float s1 = range_scale(m1, inv1);
+        Limbs Bn;
+        make_limbs(Bn, bin, s1);
+        const float bsc = s1 * A.w1s[gw], usc = inv1 * A.w1u[gw];
+        const float* b1 = A.b1p + (size_t)gw * (3 * 2 * 16);
+#pragma unroll
+        for (int T = 0; T < 3; ++T) {
+          f32x16 D0, D1, D2;
+          const float* bp = b1 + (T * 2 + hh) * 16;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float4 b = ld4(bp + 4 * j);
+            D0[4 * j + 0] = b.x * bsc; D0[4 * j + 1] = b.y * bsc; D0[4 * j + 2] = b.z * bsc; D0[4 * j + 3] = b.w * bsc;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { D1[r] = 0.0f; D2[r] = 0.0f; }
+          const char* wt = w1 + (size_t)T * W1X_TILE_BYTES;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(wt + s * 1024 + lane * 16);
+            const f16x8 am = *reinterpret_cast<const f16x8*>(wt + W2X_LIMB_BYTES + s * 1024 + lane * 16);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(wt + 2 * W2X_LIMB_BYTES + s * 1024 + lane * 16);
+            X3_STEP(MFMA16, ah, am, al, Bn.hi[s], Bn.mid[s], Bn.lo[s])
+          }
+          {
+            const f16x4 ah = *reinterpret_cast<const f16x4*>(wt + 4096 + lane * 8);
+            const f16x4 am = *reinterpret_cast<const f16x4*>(wt + W2X_LIMB_BYTES + 4096 + lane * 8);
+            const f16x4 al = *reinterpret_cast<const f16x4*>(wt + 2 * W2X_LIMB_BYTES + 4096 + lane * 8);
+            X3_STEP(MFMA8, ah, am, al, Bn.thi, Bn.tmid, Bn.tlo)
+          }
+          const int nr = T < 2 ? 16 : 4;
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (r < nr) h[16 * T + r] = fmaxf(fmaf(fmaf(D2[r], 1.0f / 2048.0f, D1[r]), 1.0f / 2048.0f, D0[r]), 0.0f) * usc;
+        }
+      }
+      float m2 = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 36; ++j) m2 = fmaxf(m2, h[j]);
+      m2 = fmaxf(m2, __shfl_xor(m2, 32));
+      float inv2;
+      const float s2 = range_scale(m2, inv2);
+      make_limbs(H, h, s2);
+      bsc2 = s2 * A.w2s[gw];
+      osc = inv2 * A.w2u[gw];
+    }
+
+    // ---- F row of this edge: TP row operands derived from x[dst] and sh (written by both lane halves) ----
+    const float4 shv = ld4(A.sh + (size_t)e * 4);
+    const float s0 = shv.x, vx = shv.y, vy = shv.z, vz = shv.w;
+    {
+      const float* xr = A.x + (size_t)dn * XW;
+      // half 0: a -> F_A, p: (p.v) -> F_PQ, p*s0 -> rows 0..nv-1 of T1O, (p x v)/sqrt2 -> rows 0..nv-1 of T1E
+      // half 1: c -> F_C, q: (q.v) -> F_PQ, q*s0 -> rows nv.. of T1E, (q x v)/sqrt2 -> rows nv.. of T1O
+      const int o_main_src = hh ? OFF_C : 0, o_main_dst = hh ? F_C : F_A;
+      const int o_vec_src = hh ? OFF_Q : OFF_P;
+      const int o_vs = hh ? F_T1E : F_T1O, o_vc = hh ? F_T1O : F_T1E, r0 = hh ? NV : 0;
+#pragma unroll
+      for (int j = 0; j < NS / 4; ++j) *reinterpret_cast<float4*>(Fr + o_main_dst + 4 * j) = ld4(xr + o_main_src + 4 * j);
+      float pv[3 * NV];
+#pragma unroll
+      for (int j = 0; j < 3 * NV / 2; ++j) {
+        const float2 t = ld2(xr + o_vec_src + 2 * j);
+        pv[2 * j] = t.x; pv[2 * j + 1] = t.y;
+      }
+#pragma unroll
+      for (int m = 0; m < NV; ++m) {
+        const float px = pv[3 * m], py = pv[3 * m + 1], pz = pv[3 * m + 2];
+        // F_PQ = [pv0..3 | qv0..3 | pv4 pv5 qv4 qv5]
+        Fr[F_PQ + (m < 4 ? 4 * hh + m : 8 + 2 * hh + (m - 4))] = (px * vx + py * vy + pz * vz) * inv_s3;
+        // vector parts: row r of the 12-row part lives at 12*(r/4) + 4*c + r%4 (component-major inside a quad of rows)
+        const int r = r0 + m;
+        float* Ps = Fr + o_vs + 12 * (r >> 2) + (r & 3);
+        float* Pc = Fr + o_vc + 12 * (r >> 2) + (r & 3);
+        Ps[0] = px * s0;
+        Ps[4] = py * s0;
+        Ps[8] = pz * s0;
+        Pc[0] = (py * vz - pz * vy) * inv_s2;
+        Pc[4] = (pz * vx - px * vz) * inv_s2;
+        Pc[8] = (px * vy - py * vx) * inv_s2;
+      }
+    }
+    __syncthreads();   // ring stage 0 and the F rows are visible
+
+    // ---- GEMM2 over the W2 tiles + fused tensor-product epilogue ----
+    float* node_row = (g2_shared && g == 2) ? A.sum_g2 + (size_t)(sn - A.g2_node_off) * XW
+                                            : A.sum + ((size_t)sn * A.n_slots + ((A.slots >> (2 * g)) & 3)) * XW;
+    if constexpr (DET) {
+      // runs of equal edge_src are contiguous inside a group: only the tile's first / last run can continue in the neighbouring tile
+      if (nvalid > 0) {
+        const int sn0 = __shfl(sn, 0, 32), snl = __shfl(sn, nvalid - 1, 32);
+        const bool first_cont = e0 > gbeg && A.src[e0 - 1] == sn0;
+        const bool last_cont = e0 + nvalid < gend && A.src[e0 + nvalid] == snl;
+        float* prow = A.part + ((size_t)(blk * WAVES + wave) * 2) * XW;    // this tile's two partial rows (tile id = global block index x 8 + wave)
+        if (sn == sn0 && first_cont) node_row = prow;
+        else if (sn == snl && last_cont) node_row = prow + XW;
+      }
+    }
+    float accA[4], accV[4][3];
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) { accA[rq] = 0.0f; accV[rq][0] = 0.0f; accV[rq][1] = 0.0f; accV[rq][2] = 0.0f; }
+    int w0n = AX.tq[t_begin][0], chan0n = AX.tq[t_begin][1];
+    for (int t = t_begin; t < t_end; ++t) {
+      const int w0 = w0n, chan0 = chan0n;
+      const int t1 = min(t + 1, t_end - 1);
+      w0n = AX.tq[t1][0]; chan0n = AX.tq[t1][1];
+      // (1) this thread's share of tile t+1 from L2
+      const char* rec1 = wrec + (size_t)t1 * W2X_TILE_BYTES;
+      const float4 st0 = *reinterpret_cast<const float4*>(rec1 + 16 * tid);
+      float4 st1 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (second) st1 = *reinterpret_cast<const float4*>(rec1 + 16 * (tid + 64 * WAVES));
+      const char* stage = ring + ((t - t_begin) & 1) * W2X_TILE_BYTES;
+      const float* Fp = Fr + (w0 >> 16);
+      const f32x4 f0 = ldv4(Fp);
+      // (2) the burst: 30 MFMAs, fragments streamed from the ring
+      f32x16 D0, D1, D2;
+      {
+        const float* bp = reinterpret_cast<const float*>(stage + W2X_BIAS_OFF) + hh * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 b = ld4(bp + 4 * j);
+          D0[4 * j + 0] = b.x * bsc2; D0[4 * j + 1] = b.y * bsc2; D0[4 * j + 2] = b.z * bsc2; D0[4 * j + 3] = b.w * bsc2;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { D1[r] = 0.0f; D2[r] = 0.0f; }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const f16x8 ah = *reinterpret_cast<const f16x8*>(stage + s * 1024 + lane * 16);
+        const f16x8 am = *reinterpret_cast<const f16x8*>(stage + W2X_LIMB_BYTES + s * 1024 + lane * 16);
+        const f16x8 al = *reinterpret_cast<const f16x8*>(stage + 2 * W2X_LIMB_BYTES + s * 1024 + lane * 16);
+        X3_STEP(MFMA16, ah, am, al, H.hi[s], H.mid[s], H.lo[s])
+      }
+      {
+        const f16x4 ah = *reinterpret_cast<const f16x4*>(stage + 4096 + lane * 8);
+        const f16x4 am = *reinterpret_cast<const f16x4*>(stage + W2X_LIMB_BYTES + 4096 + lane * 8);
+        const f16x4 al = *reinterpret_cast<const f16x4*>(stage + 2 * W2X_LIMB_BYTES + 4096 + lane * 8);
+        X3_STEP(MFMA8, ah, am, al, H.thi, H.tmid, H.tlo)
+      }
+      // (3) the three accumulators into one, tensor-product epilogue, flush at the end of a column
+      f32x16 D;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) D[r] = fmaf(fmaf(D2[r], 1.0f / 2048.0f, D1[r]), 1.0f / 2048.0f, D0[r]);
+      tile_epilogue_s(w0 & 3, D, Fp, f0, accA, accV);
+      if (w0 & 0x80) {   // 6-channel column: accumulator quad 3 holds another a / c row quad for channel pair xp
+        const f32x4 g0 = ldv4(Fr + ((w0 >> 8) & 0x3c));
+        const float xv = fmaf(g0.x, D[12], fmaf(g0.y, D[13], fmaf(g0.z, D[14], g0.w * D[15])));
+        const int xp = (w0 >> 8) & 3;
+        if (xp == 0) accA[0] += xv; else if (xp == 1) accA[1] += xv; else accA[2] += xv;
+      }
+      const int fl = (w0 >> 2) & 3;
+      if (fl) {
+        const int nrq = (w0 >> 4) & 7;
+        if (fl == FL_S && nrq == 4) {   // a full scalar column: its four channels in one pass
+          float m4[4];
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) m4[rq] = osc * fmaf(accA[rq], s0, accV[rq][0]);
+          seg_add_n<DET, 4>(node_row + chan0 + hh, 2, m4, seg);
+        }
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          if (rq < nrq && !(fl == FL_S && nrq == 4)) {
+            if (fl == FL_S) {
+              seg_add<DET>(node_row + chan0 + 2 * rq + hh, osc * fmaf(accA[rq], s0, accV[rq][0]), seg);
+            } else {
+              float* d = node_row + chan0 + 3 * (2 * rq + hh);
+              const float sa = accA[rq];
+              float m3[3] = {osc * fmaf(sa, vx, accV[rq][0]), osc * fmaf(sa, vy, accV[rq][1]), osc * fmaf(sa, vz, accV[rq][2])};
+              seg_add_n<DET, 3>(d, 1, m3, seg);
+            }
+          }
+          accA[rq] = 0.0f; accV[rq][0] = 0.0f; accV[rq][1] = 0.0f; accV[rq][2] = 0.0f;
+        }
+        if ((w0 & 3) == T_RTS) {   // rows j = 2,3 of the shared tail open the next (0o) column
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) accV[rq][0] = fmaf(f0.z, D[4 * rq + 2], f0.w * D[4 * rq + 3]);
+        }
+      }
+      // (4) publish tile t+1 into the other stage (tile t-1 was retired by the previous barrier), (5) barrier
+      char* stg = ring + ((t + 1 - t_begin) & 1) * W2X_TILE_BYTES;
+      *reinterpret_cast<float4*>(stg + 16 * tid) = st0;
+      if (second) *reinterpret_cast<float4*>(stg + 16 * (tid + 64 * WAVES)) = st1;
+      __syncthreads();
+    }
+    // hand the next unit to the workgroup; this barrier also retires the ring before the next unit's staging writes
+    if (tid == 0) *blk_slot = unit_next;
+    __syncthreads();
+    unit = __builtin_amdgcn_readfirstlane(*blk_slot);
+  }
+}
+
+// Test hook kernel: the in-kernel limb split of n fp32 values (one range scale per group of `group` consecutive values, like the kernel's
+// per-edge scaling): limbs as fp32, and the scale
+__global__ void split3_probe_kernel(const float* x, int64_t n, int group, float* hi, float* mid, float* lo, float* scale) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t g0 = (i / group) * group;
+  float m = 0.0f;
+  for (int64_t k = g0; k < g0 + group && k < n; ++k) m = fmaxf(m, fabsf(x[k]));
+  float inv;
+  const float s = range_scale(m, inv);
+  const Limb3 q = split3(x[i] * s);
+  hi[i] = (float)q.h; mid[i] = (float)q.m; lo[i] = (float)q.l; scale[i] = s;
+}
+
+hipError_t launch_split3_probe(const float* x, int64_t n, int group, float* hi, float* mid, float* lo, float* scale, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(split3_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, group, hi, mid, lo, scale);
+  return hipGetLastError();
+}
+
+template <bool GATHER, bool SPLIT, bool DET>
+static hipError_t launch_x_t(const ConvXArgs& k, int n_cu, hipStream_t s) {
+  hipLaunchKernelGGL((conv_x3_kernel<GATHER, SPLIT, DET>), dim3(n_cu), dim3(64 * CONV_WAVES), CONV_X_LDS_BYTES, s, k);
+  return hipGetLastError();
+}
+
+template <bool GATHER, bool SPLIT, bool DET>
+static hipError_t attr_x_t() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<GATHER, SPLIT, DET>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)CONV_X_LDS_BYTES);
+}
+
+hipError_t conv_prepare_device_x() {
+  hipError_t e = attr_x_t<true, true, false>();
+  if (e == hipSuccess) e = attr_x_t<true, false, false>();
+  if (e == hipSuccess) e = attr_x_t<false, false, false>();
+  if (e == hipSuccess) e = attr_x_t<true, true, true>();
+  if (e == hipSuccess) e = attr_x_t<false, false, true>();
+  return e;
+}
+
+void conv_det_fix(const ConvKArgs& k, const ConvLaunch& a, int dout, hipStream_t s);   // k_conv.hip
+
+hipError_t launch_conv_fused_x(const ConvLayerDev& L, const ConvLaunch& a, int n_cu, hipStream_t s) {
+  if (L.n_tiles > W2X_MAX_TILES || a.mode != 0) return hipErrorInvalidValue;
+  ConvXArgs X;
+  ConvKArgs& k = X.k;
+  k.x = a.x; k.src = a.src; k.dst = a.dst; k.edge_attr = a.edge_attr; k.sh = a.sh; k.sum = a.sum;
+  k.counter = a.counter;
+  k.w1p = nullptr; k.b1p = L.b1p[0]; k.w2r = nullptr; k.w1x = L.w1x; k.w2x = L.w2x; k.n_tiles = L.n_tiles;
+  for (int g = 0; g < 4; ++g) { k.w1s[g] = L.w1s[g]; k.w1u[g] = 1.0f / L.w1s[g]; k.w2s[g] = L.w2s[g]; k.w2u[g] = 1.0f / L.w2s[g]; }
+  k.n_cols = L.n_cols;
+  for (int c = 0; c <= L.n_cols; ++c) k.col_start[c] = L.col_start[c];
+  for (int t = 0; t < L.n_tiles; ++t) { X.tq[t][0] = L.h_tiles[t].w0; X.tq[t][1] = L.h_tiles[t].chan0; }
+  k.sum_g2 = a.sum_g2; k.g2_node_off = a.g2_node_off;
+  k.n_groups = a.n_groups; k.n_active = a.n_active; k.n_slots = a.n_slots; k.slots = a.slots; k.wmap = a.wmap;
+  if (a.gbeg) { k.gbeg = a.gbeg; k.gend = a.gend; }
+  else { k.gbeg = a.tile_info + 5; k.gend = a.tile_info + 6; }   // 4 contiguous groups go[g] .. go[g+1] (explicit-boundary entry point)
+  k.pre = a.pre; k.part = a.part;
+  if (a.part != nullptr) {       // deterministic scatter
+    hipError_t e = (a.gather && a.pre != nullptr) ? launch_x_t<true, true, true>(X, n_cu, s)
+                                                  : (!a.gather ? launch_x_t<false, false, true>(X, n_cu, s) : hipErrorInvalidValue);
+    if (e != hipSuccess) return e;
+    conv_det_fix(k, a, L.dout, s);
+    return hipGetLastError();
+  }
+  if (a.gather && a.pre != nullptr) return launch_x_t<true, true, false>(X, n_cu, s);
+  return a.gather ? launch_x_t<true, false, false>(X, n_cu, s) : launch_x_t<false, false, false>(X, n_cu, s);
+}
+
+}  // namespace ddk

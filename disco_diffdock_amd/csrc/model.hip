@@ -421,7 +421,7 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
   // Latent-conditioned (DisCo) model: the latents are one-hot at a few nodes per sample, so the shared pass (on sample 0's rows) is right
   // for every receiver whose senders and itself carry zero latents in sample s and in sample 0; all the other receivers get their
   // rec-rec messages per sample from a fifth "patch" edge group (disco_patch kernels, rebuilt when the latents change)
-  const bool patched = c.latent_dim > 0 && ctx->layer0_dedup && !c.deterministic && !c.conv_f16x3 && cx->patch_off >= 0 && cx->pre != nullptr &&
+  const bool patched = c.latent_dim > 0 && ctx->layer0_dedup && !c.deterministic && cx->patch_off >= 0 && cx->pre != nullptr &&
                        ctx->conv[0].wn != nullptr && c.num_conv_layers > 1;
   const bool dedup = ((c.latent_dim == 0 && ctx->layer0_dedup) || patched) && B > 1 && cx->E_rr > 0;
   if (c.latent_dim > 0 && (!cx->lig_latent || !cx->rec_latent))
@@ -457,8 +457,8 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
   NE_.x = xin; NE_.lig_latent = cx->lig_latent; NE_.rec_latent = cx->rec_latent; NE_.lig_w_lat = M->dev.lig_w_lat; NE_.rec_w_lat = M->dev.rec_w_lat;
   NE_.lig_unc = M->dev.lig_node_unc; NE_.rec_unc = M->dev.rec_node_unc; NE_.unconditional = cx->unconditional; NE_.latent_dim = c.latent_dim;
   CK(launch_node_embed(NE_, s), "node embed");
-  // per-node terms of layer 0's GEMM1 (ConvLayerDev::wn); the 3 x f16 kernel keeps the unsplit GEMM1
-  const bool split = ctx->conv[0].wn != nullptr && ctx->conv[0].w2h == nullptr && cx->pre != nullptr;
+  // per-node terms of layer 0's GEMM1 (ConvLayerDev::wn)
+  const bool split = ctx->conv[0].wn != nullptr && cx->pre != nullptr;
   if (split) {
     NodePreArgs PA = {};
     PA.x_out = xin; PA.n_lig_total = B * n_lig; PA.n_rec_total = B * n_rec; PA.n_rec = n_rec;
@@ -758,7 +758,7 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
   cx->sum = cx_upload<float>(cx, nullptr, N * XW * (det ? 2 : 1));      // deterministic: one accumulator per (node, receiving group)
   if (det) cx->part = cx_upload<float>(cx, nullptr, (cx->edge_cap / CONV_BLOCK_EDGES + 16) * CONV_WAVES * 2 * XW);
   cx->sum_rr0 = cx_upload<float>(cx, nullptr, (int64_t)n_rec * XW);
-  if (has_model && !c.conv_f16x3) cx->pre = cx_upload<float>(cx, nullptr, N * PRE_W);
+  if (has_model) cx->pre = cx_upload<float>(cx, nullptr, N * PRE_W);
   if (has_model) {      // heads (k_heads.hip): edge list [B*n_lig centre edges | <= B*R*BOND_CAP bond-neighbour edges], accumulators [B | B*R] rows
     const int64_t Eh = Bm * ((int64_t)n_lig + (int64_t)(d->n_rot > 0 ? d->n_rot : 0) * BOND_CAP) + 64, Nh = Bm * (1 + (int64_t)(d->n_rot > 0 ? d->n_rot : 0)) + 1;   // (+ a scratch row for the deterministic mode's null edges)
     cx->h_src = cx_upload<int32_t>(cx, nullptr, Eh);

@@ -17,7 +17,7 @@ DEFAULTS = dict(ns=24, nv=6, num_conv_layers=5, sigma_embed_dim=32, distance_emb
                 latent_dim=0, latent_vocab=0, latent_droprate=0.0, lm_embedding_dim=1280,
                 tr_sigma_min=0.1, tr_sigma_max=19.0, rot_sigma_min=0.03, rot_sigma_max=1.55,
                 tor_sigma_min=0.03, tor_sigma_max=3.14, device=0, all_atoms=0, num_confidence_outputs=1, confidence_no_batchnorm=0,
-                conv_f16x3=0, deterministic=0)
+                conv_kernel=0, deterministic=0)
 
 
 def config_from_args(args, device=0):
@@ -84,13 +84,13 @@ class Context:
     def __init__(self, device=0, **cfg):
         self.L = _lib.lib()
         d = dict(DEFAULTS)
-        if os.environ.get('DDK_CONV_F16X3'):      # select the error-compensated 3 x f16 conv kernel for every context of this process
-            d['conv_f16x3'] = int(os.environ['DDK_CONV_F16X3'])
+        if os.environ.get('DDK_CONV_KERNEL'):     # 1: the fp32-MFMA conv kernel (the fallback) for every context of this process
+            d['conv_kernel'] = int(os.environ['DDK_CONV_KERNEL'])
         if os.environ.get('DDK_DETERMINISTIC'):   # select the deterministic scatter for every context of this process
             d['deterministic'] = int(os.environ['DDK_DETERMINISTIC'])
         d.update(cfg)
-        if d.get('all_atoms') or d.get('conv_f16x3'):
-            d['deterministic'] = int(cfg.get('deterministic', 0))      # the env switch applies to fp32 score-model contexts only
+        if d.get('all_atoms'):
+            d['deterministic'] = int(cfg.get('deterministic', 0))      # the env switch applies to score-model contexts only
         d['device'] = device
         self.cfg = SimpleNamespace(**d)
         c = _lib.ddk_config(**d)

@@ -132,7 +132,7 @@ class TensorProductScoreModel(nn.Module):
                  center_max_distance=30, distance_embed_dim=32, cross_distance_embed_dim=32, no_torsion=False,
                  scale_by_sigma=True, use_second_order_repr=False, batch_norm=True, dynamic_max_cross=False, dropout=0.0,
                  lm_embedding_type=None, confidence_mode=False, use_old_atom_encoder=False, latent_dim=0, latent_vocab=32,
-                 latent_cross_attention=False, latent_droprate=0.0, embedding_scale=1000.0, sigma_limits=None, conv_f16x3=None, **unused):
+                 latent_cross_attention=False, latent_droprate=0.0, embedding_scale=1000.0, sigma_limits=None, conv_kernel=None, **unused):
         super().__init__()
         if sh_lmax != 1 or use_second_order_repr or confidence_mode or use_old_atom_encoder or latent_cross_attention:
             raise RuntimeError('ddk implements the sh_lmax=1 first-order score model with the new AtomEncoder only')
@@ -150,8 +150,8 @@ class TensorProductScoreModel(nn.Module):
                         scale_by_sigma=int(bool(scale_by_sigma)), no_torsion=int(bool(no_torsion)), batch_norm=int(bool(batch_norm)),
                         latent_dim=int(latent_dim), latent_vocab=int(latent_vocab), latent_droprate=float(latent_droprate),
                         lm_embedding_dim=1280 if lm_embedding_type == 'esm' else 0, **lim)
-        if conv_f16x3 is not None:      # extra (not in the reference ctor): opt into the error-compensated 3 x f16 conv kernel
-            self.cfg['conv_f16x3'] = int(bool(conv_f16x3))
+        if conv_kernel is not None:      # extra (not in the reference ctor): 1 selects the fp32-MFMA conv kernel (ddk_config.conv_kernel)
+            self.cfg['conv_kernel'] = int(conv_kernel)
         self.ctx = Context(device=dev_index, **self.cfg)
         self.no_torsion = no_torsion
         self._loaded = False

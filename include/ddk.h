@@ -49,15 +49,17 @@ typedef struct ddk_config {
   int32_t all_atoms;                   /* 1: AAScoreModel in confidence_mode (sh_lmax=2 FCTP, OldAtomEncoder, 9 convs/layer) */
   int32_t num_confidence_outputs;      /* len(rmsd_classification_cutoff)+1 when it is a list, else 1 */
   int32_t confidence_no_batchnorm;
-  /* 1: the radial-MLP GEMMs of the fused conv kernel run as an error-compensated 3 x f16 product on the f16 matrix pipe
-   *    (w = w_hi + w_lo/2^11, h = h_hi + h_lo/2^11, fp32 accumulation; the dropped lo.lo term is 2^-22 relative) instead of the
-   *    fp32 MFMA.  Same fp32-level accuracy; 0 (default) keeps the plain fp32 MFMA. */
-  int32_t conv_f16x3;
+  /* which matrix pipe the radial-MLP GEMMs (Linear(72,72) + ReLU + Linear(72,W), tensor_layers.py:140-143) of the score model's fused conv
+   * kernel run on.  0 (default): the f16 matrix pipe with EXACT fp32 operands - every fp32 weight / activation is split into three fp16 limbs
+   *    x = hi + mid 2^-11 + lo 2^-22 (no bits dropped), six of the nine limb products are kept (the dropped ones are <= 3 * 2^-33 relative,
+   *    below the rounding of the fp32 accumulation itself), fp32 accumulators (k_conv_x.hip).
+   * 1: v_mfma_f32_32x32x2_f32, plain fp32 FMA chains (k_conv.hip) - the stated fallback; the all-atom confidence model always uses it. */
+  int32_t conv_kernel;
   /* 1: fixed summation order per node in the score model's conv layers and heads (scatter_mean of tensor_layers.py:159): edges are
    *    sorted by the receiving node, so run tails STORE and the runs that straddle 32-edge tiles are folded in tile order by a second
    *    small kernel; one accumulator per (node, receiving edge group); no float atomics -> bit-identical outputs run to run.
    *    0 (default): wave-level segmented sums + fp32 atomics on the run tails (~1e-7 relative run-to-run noise).  Applies to
-   *    ddk_score_forward / ddk_sample; ddk_conv_forward (caller-ordered edges) keeps the atomics; not with conv_f16x3 or all_atoms. */
+   *    ddk_score_forward / ddk_sample; ddk_conv_forward (caller-ordered edges) keeps the atomics; not with all_atoms. */
   int32_t deterministic;
 } ddk_config;
 

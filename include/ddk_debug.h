@@ -10,7 +10,7 @@
 extern "C" {
 #endif
 
-/* Packed host-side arrays of a context ("conv.<l>.w1p.<g>", "conv.<l>.w2p.<g>", "conv.<l>.tiles", "conv.<l>.bn_scale", ...):
+/* Packed host-side arrays of a context ("conv.<l>.w1p.<g>", "conv.<l>.w2p.<g>", "conv.<l>.tiles", "conv.<l>.bn_scale", "conv.<l>.w2x", ...):
  * returns the number of 32-bit words of the item (buf may be NULL to query) or a negative ddk_status. */
 int64_t ddk_debug_export(ddk_ctx* ctx, const char* what, void* buf, int64_t cap_words);
 
@@ -41,6 +41,11 @@ int ddk_debug_read_patch(ddk_ctx* ctx, ddk_complex* cx, int32_t B, int32_t* coun
  *   axis_angle: aa [n, 3] -> R [n, 3, 3]                                     (utils/geometry.py:71-85, small-angle branch included) */
 int ddk_debug_kabsch(ddk_ctx* ctx, int32_t nb, int32_t n, const float* A, const float* B, float* R_out, float* t_out, void* stream);
 int ddk_debug_axis_angle(ddk_ctx* ctx, int32_t n, const float* aa, float* R_out, void* stream);
+
+/* The default conv kernel's limb split (k_conv_x.hip) on a DEVICE array x [n], cut into groups of `group` consecutive values that share one
+ * power-of-two range scale (the kernel scales per edge): hi / mid / lo [n] = the fp16 limbs as fp32, scale [n] = the group's scale;
+ * x * scale == hi + mid 2^-11 + lo 2^-22 bit for bit for every value within 2^-36 of its group's maximum. */
+int ddk_debug_split3(ddk_ctx* ctx, const float* x, int64_t n, int32_t group, float* hi, float* mid, float* lo, float* scale, void* stream);
 
 #ifdef __cplusplus
 }

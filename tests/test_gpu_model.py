@@ -614,8 +614,8 @@ def test_sampling_with_confidence_golden(dev, model7, golden):
 
 
 @pytest.mark.parametrize('t', [1.0, 0.05])
-def test_score_model_golden_f16x3(dev, golden, t):
-    """The opt-in 3 x f16 conv kernel (ddk_config.conv_f16x3) against the reference-produced score goldens, same 1e-4 bar."""
+def test_score_model_golden_fp32_kernel(dev, golden, t):
+    """The fallback fp32-MFMA conv kernel (ddk_config.conv_kernel = 1) against the reference-produced score goldens, same 1e-4 bar."""
     from functools import partial
     from disco_diffdock_amd.model_utils import get_model
     from disco_diffdock_amd.diffusion_utils import t_to_sigma
@@ -626,7 +626,7 @@ def test_score_model_golden_f16x3(dev, golden, t):
     sm = model.score_model
     sm.ctx.close()
     from disco_diffdock_amd.runtime import Context
-    sm.cfg['conv_f16x3'] = 1
+    sm.cfg['conv_kernel'] = 1
     sm.ctx = Context(device=0, **sm.cfg)
     sm.load_state_dict(smr.random_state_dict(CFG, seed=7), strict=True)
     B = int(z['B'])

@@ -146,14 +146,14 @@ def test_confidence_conv_layer_vs_oracle(dev, l):
     (3, 400, [0, 1500, 6000, 9000, 12345], True),
     (4, 400, [0, 33, 64, 4000, 4031], False),
 ])
-def test_conv_layer_f16x3_vs_oracle(dev, l, N, splits, sort_src):
-    """Opt-in mode ddk_config.conv_f16x3: the radial-MLP GEMMs as an error-compensated 3 x f16 product (f32 accumulation) must meet
-    the SAME bar as the fp32 MFMA path against the fp64 oracle, and repeated launches must agree (no timing dependence)."""
+def test_conv_layer_fp32_kernel_vs_oracle(dev, l, N, splits, sort_src):
+    """The fallback ddk_config.conv_kernel = 1 (radial-MLP GEMMs as fp32 MFMA chains; the default is the exact three-limb f16 product, which
+    every other test of this file runs) must meet the SAME bar against the fp64 oracle, and repeated launches must agree."""
     from disco_diffdock_amd.runtime import Context
     i_irr, o_irr = CFG.conv_irreps(l)
     Pl = smr.random_conv_layer_params(CFG, l, 40 + l, True)
     node, ei, ea, sh = _random_case(l, N, splits, 7 + l, sort_src)
-    ctx = Context(device=0, conv_f16x3=1)
+    ctx = Context(device=0, conv_kernel=1)
     ctx.load_state_dict({f'conv_layers.{l}.{k}': v for k, v in Pl.items()})
     dout = smr.irreps_dim(o_irr)
     P = {'L.' + k: v.double() for k, v in Pl.items()}
@@ -170,9 +170,10 @@ def test_conv_layer_f16x3_vs_oracle(dev, l, N, splits, sort_src):
     (1e-4, 1e-2, 1e6),      # tiny inputs, W1 and hidden units (~1e-6); W2 above the fp16 maximum
     (1.0, 1e6, 1e-6),       # W1 above, W2 below
 ])
-def test_conv_layer_f16x3_range(dev, in_scale, w1_scale, w2_scale):
-    """The 3 x f16 split must not depend on the SCALE of a checkpoint or of the features: operands are range-scaled by exact powers of
-    two (weights per group at pack time, activations per edge in the kernel), so operands far outside the fp16 range meet the same bar.
+def test_conv_layer_x3_range(dev, in_scale, w1_scale, w2_scale):
+    """The three-limb f16 product must not depend on the SCALE of a checkpoint or of the features: operands are range-scaled by exact powers
+    of two (weights per group at pack time, activations per edge in the kernel), so operands far outside the fp16 range meet the same bar,
+    and its error against the fp64 oracle is not larger than the fp32-MFMA kernel's (VERDICT r02 #3 ii).
     (The three scales multiply to 1, so the messages stay O(1) next to the residual and the batch-norm statistics.)"""
     from disco_diffdock_amd.runtime import Context
     l, N, splits = 3, 300, [0, 700, 2500, 4000, 5555]
@@ -193,10 +194,11 @@ def test_conv_layer_f16x3_range(dev, in_scale, w1_scale, w2_scale):
     assert 0.05 < float(ref.abs().max()) < 1e3
     args = (l, node.to(dev), ei[0].to(dev), ei[1].to(dev), splits, ea.to(dev), sh.to(dev), smr.irreps_dim(o_irr))
     err = {}
-    for mode in (1, 0):
-        ctx = Context(device=0, conv_f16x3=mode)
+    for kernel in (0, 1):          # 0: three-limb f16 (default), 1: fp32 MFMA
+        ctx = Context(device=0, conv_kernel=kernel)
         ctx.load_state_dict({f'conv_layers.{l}.{k}': v for k, v in Pl.items()})
         out = ctx.conv_forward(*args).cpu()
         assert torch.isfinite(out).all()
-        err[mode] = rel_err(out, ref)
-    assert err[1] < 1e-5 and err[1] < 4 * err[0] + 1e-6, err
+        err[kernel] = rel_err(out, ref)
+    print(f'range test {in_scale:g}/{w1_scale:g}/{w2_scale:g}: three-limb f16 {err[0]:.2e}, fp32 MFMA {err[1]:.2e}')
+    assert err[0] < 1e-5 and err[0] < 1.5 * err[1] + 2e-7, err

@@ -289,7 +289,7 @@ def test_deterministic_scatter_is_bit_identical(dev, t):
     P = smr.random_state_dict(CFG, seed=3)
     B = 40
     pos = T(_poses(c, B, np.random.default_rng(0), spread=8.0)).to(dev)
-    ctx = Context(device=0, deterministic=1, conv_f16x3=0)
+    ctx = Context(device=0, deterministic=1)
     ctx.load_state_dict(P)
     cx = Complex(ctx, c, B)
     outs = []
@@ -298,7 +298,7 @@ def test_deterministic_scatter_is_bit_identical(dev, t):
         outs.append(torch.cat([tr.reshape(-1), rot.reshape(-1), tor.reshape(-1), cx.lig_node_features(B, dev).reshape(-1)]).cpu())
     assert all(torch.equal(outs[0], o) for o in outs[1:])
     assert bool(torch.isfinite(outs[0]).all()) and float(outs[0].abs().max()) > 0
-    ctx2 = Context(device=0, deterministic=0, conv_f16x3=0)
+    ctx2 = Context(device=0, deterministic=0)
     ctx2.load_state_dict(P)
     cx2 = Complex(ctx2, c, B)
     tr, rot, tor = cx2.score_forward(pos, t, t, t)
@@ -391,8 +391,8 @@ def test_disco_layer0_patches_equal_full(dev, t):
         # the patch group of the last de-duplicated forward: empty without receptor latents, the whole rec-rec group of samples 1.. for dense ones
         cx.set_latents(ll, lr, 0.0)
         cx.score_forward(pos, t, t, t)
-        if int(ctx.cfg.deterministic) or int(ctx.cfg.conv_f16x3):
-            continue          # (DDK_DETERMINISTIC / DDK_CONV_F16X3 runs of the suite: those modes keep the full evaluation, there is no patch group)
+        if int(ctx.cfg.deterministic):
+            continue          # (DDK_DETERMINISTIC runs of the suite: that mode keeps the full evaluation, there is no patch group)
         cnt, mask = cx.debug_read_patch(B)
         E_rr = c['rec_edge_index'].shape[1]
         assert cnt[0] == 0 and cnt[1] == 0 and not mask[0].any()          # sample 0 IS the shared evaluation
@@ -477,7 +477,7 @@ def test_full_size_disco_oracle_parity(dev, tables, t):
     p = T(pos).to(dev)
     tr, rot, tor = cx.score_forward(p, t, t, t)
     lig = cx.lig_node_features(B, dev).cpu()
-    if not (int(ctx.cfg.deterministic) or int(ctx.cfg.conv_f16x3)):      # (those opt-in modes keep the full layer-0 evaluation)
+    if not int(ctx.cfg.deterministic):      # (that opt-in mode keeps the full layer-0 evaluation)
         cnt, mask = cx.debug_read_patch(B)
         assert cnt[B] > 0 and mask[1:].any() and not mask[0].any()          # the patch path is what ran
     cx.keep_receptor_features(True)

@@ -68,3 +68,217 @@ def test_bench_line_reports_executed_work_and_both_floors(dev):
     assert ex['pocket_bound']['min_cross_edges_per_sample_over_steps'] > 0          # the pocket-bound samples never lose contact
     assert ex['pocket_bound']['edges_executed_over_unpruned'] >= rf['edges_executed_over_unpruned'] - 1e-9
     assert len(ex['per_step']) == 20 and all(0 < s['edges_executed_over_unpruned'] <= 1 for s in ex['per_step'])
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# the exact three-limb f16 product of the default conv kernel (VERDICT r02 #3 i, ii)
+# ------------------------------------------------------------------------------------------------------------------------------------------
+def _adversarial_values(rng, n):
+    """fp32 values that stress the limb split: full 24-bit mantissas, values one ulp around powers of two and around fp16 rounding
+    boundaries (hi rounds up / ties), mixed signs and magnitudes over 36 binades below each group's maximum"""
+    m = rng.integers(1 << 23, 1 << 24, size=n).astype(np.float64)              # every mantissa bit in play
+    m[::7] = (1 << 23) + rng.integers(0, 3, size=m[::7].shape)                  # just above a power of two
+    m[1::7] = (1 << 24) - 1 - rng.integers(0, 3, size=m[1::7].shape)            # just below
+    m[2::7] = ((rng.integers(1 << 10, 1 << 11, size=m[2::7].shape) << 13) | (1 << 12)) + rng.integers(-1, 2, size=m[2::7].shape)   # hi ties
+    m[3::7] = (rng.integers(1 << 10, 1 << 11, size=m[3::7].shape) << 13) | ((1 << 12) + (1 << 1) - 1) | (rng.integers(0, 2, size=m[3::7].shape) << 1)   # mid ties
+    e = rng.integers(-36, 1, size=n)
+    sgn = rng.choice([-1.0, 1.0], size=n)
+    return (sgn * m * np.exp2(e.astype(np.float64) - 23)).astype(np.float32)
+
+
+@pytest.mark.parametrize('scale', [1.0, 3e-9, 7e11])
+def test_device_limb_split_is_exact(dev, scale):
+    """The in-kernel split (ddk_debug_split3 runs the kernel's own split3 / range_scale): x * scale == hi + mid 2^-11 + lo 2^-22 BIT FOR BIT for
+    every value within 2^-36 of its group's maximum, whatever the magnitude of the group (per-edge power-of-two scaling); the limbs are fp16
+    values; the scale is a power of two that puts the group's maximum into [2^13, 2^14)."""
+    import ctypes as C
+    from disco_diffdock_amd.tensor_layers import _shape_context
+    ctx = _shape_context(0)
+    rng = np.random.default_rng(17)
+    group, n = 72, 72 * 4000
+    x = _adversarial_values(rng, n) * np.float32(scale)
+    xs = torch.from_numpy(x).to(dev)
+    hi, mid, lo, sc = [torch.empty(n, device=dev) for _ in range(4)]
+    p = lambda t: C.c_void_p(t.data_ptr())
+    ctx._check(ctx.L.ddk_debug_split3(ctx.h, p(xs), n, group, p(hi), p(mid), p(lo), p(sc), C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'split3')
+    hi, mid, lo, sc = [t.cpu().numpy().astype(np.float64) for t in (hi, mid, lo, sc)]
+    gmax = np.abs(x.astype(np.float64)).reshape(-1, group).max(axis=1).repeat(group)
+    assert np.all(np.log2(sc) == np.round(np.log2(sc)))                                  # powers of two
+    assert np.all((gmax * sc >= 2.0 ** 13) & (gmax * sc < 2.0 ** 14))
+    for limb in (hi, mid, lo):                                                            # fp16-representable
+        assert np.array_equal(limb.astype(np.float16).astype(np.float64), limb)
+    want = x.astype(np.float64) * sc
+    back = hi + mid * 2.0 ** -11 + lo * 2.0 ** -22
+    big = np.abs(want) >= 2.0 ** -23
+    assert big.mean() > 0.95
+    assert np.array_equal(back[big], want[big])                                           # exact: not one bit dropped
+    assert np.abs(back[~big] - want[~big]).max(initial=0.0) <= 2.0 ** -46
+
+
+def test_three_limb_product_at_least_as_accurate_as_fp32_chain(dev):
+    """(ii): one conv layer at W = 1872 on 20k edges against the fp64 oracle: the three-limb f16 kernel's error is not above the fp32-MFMA
+    kernel's (products are exact and only three of nine limb products, <= 3 * 2^-33, are dropped; both accumulate in fp32)."""
+    from disco_diffdock_amd.runtime import Context
+    from test_gpu_ops import _random_case, CFG as OCFG
+    l, N, splits = 3, 1000, [0, 3000, 9000, 15000, 20000]
+    i_irr, o_irr = OCFG.conv_irreps(l)
+    Pl = smr.random_conv_layer_params(OCFG, l, 123, True)
+    node, ei, ea, sh = _random_case(l, N, splits, 5, True)
+    P = {'L.' + k: v.double() for k, v in Pl.items()}
+    ref = smr.tp_conv_layer(P, 'L', node.double(), ei, [ea.double()[splits[i]:splits[i + 1]] for i in range(4)], sh.double(),
+                            i_irr, '1x0e+1x1o', o_irr, residual=True, batch_norm=True, faster=True, edge_groups=4)
+    args = (l, node.to(dev), ei[0].to(dev), ei[1].to(dev), splits, ea.to(dev), sh.to(dev), smr.irreps_dim(o_irr))
+    err = {}
+    for kernel in (0, 1):
+        ctx = Context(device=0, conv_kernel=kernel)
+        ctx.load_state_dict({f'conv_layers.{l}.{k}': v for k, v in Pl.items()})
+        out = ctx.conv_forward(*args).cpu()
+        err[kernel] = (rel_err(out, ref), elem_err(out, ref))
+    print(f'conv layer vs fp64: three-limb f16 {err[0]}, fp32 MFMA {err[1]}')
+    assert err[0][0] < 1e-5 and err[0][0] <= 1.25 * err[1][0] + 1e-7 and err[0][1] <= 1.25 * err[1][1] + 1e-6, err
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# the core parity tests once more under every (conv kernel, scatter) mode, inside the driver's single `pytest -m gpu` (VERDICT r02 #5d)
+# ------------------------------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(params=[(0, 0), (0, 1), (1, 0), (1, 1)], ids=['x3-atomics', 'x3-deterministic', 'fp32-atomics', 'fp32-deterministic'])
+def mode(request, monkeypatch):
+    """every ddk context created inside the test runs the given conv kernel / scatter mode (runtime.Context reads the switches)"""
+    kernel, det = request.param
+    monkeypatch.setenv('DDK_CONV_KERNEL', str(kernel))
+    monkeypatch.setenv('DDK_DETERMINISTIC', str(det))
+    return request.param
+
+
+def test_core_parity_in_every_mode(dev, golden, tables, mode):
+    """conv-layer goldens (Tier A, unmodified reference code), score-model goldens at three diffusion times, the reference-produced
+    trajectory and a full-size (300 residues) forward against the oracle - in the mode of the fixture."""
+    from functools import partial
+    from helpers import complex_from_npz, batch_of, chan_err
+    from test_gpu_model import ARGS_S, README_S, _dev_batch, _ref_noise
+    from test_gpu_ops import CFG as OCFG
+    from disco_diffdock_amd.tensor_layers import TensorProductConvLayer
+    from disco_diffdock_amd.model_utils import get_model
+    from disco_diffdock_amd.diffusion_utils import t_to_sigma, get_t_schedule
+    from disco_diffdock_amd.sampling import sampling
+    from disco_diffdock_amd.data import from_arrays
+    from disco_diffdock_amd import synthetic
+    from disco_diffdock_amd.runtime import Context, Complex
+    for l in range(5):
+        for bn in (0, 1):
+            z = golden(f'conv_layer_l{l}_bn{bn}')
+            i_irr, o_irr = OCFG.conv_irreps(l)
+            layer = TensorProductConvLayer(i_irr, '1x0e+1x1o', o_irr, 72, hidden_features=72, residual=True, batch_norm=bool(bn), dropout=0.1,
+                                           faster=True, edge_groups=4).eval()
+            layer.load_state_dict(smr.random_conv_layer_params(OCFG, l, int(z['param_seed']), bool(bn)), strict=True)
+            s = z['splits']
+            ea = T(z['edge_attr']).to(dev)
+            out = layer(T(z['node']).to(dev), T(z['edge_index']).to(dev), [ea[s[i]:s[i + 1]] for i in range(4)], T(z['sh']).to(dev)).cpu()
+            assert int(layer._ctx.cfg.conv_kernel) == mode[0]
+            assert rel_err(out, z['out']) < 1e-5, (l, bn)
+    model = get_model(ARGS_S, dev, partial(t_to_sigma, args=ARGS_S), no_parallel=True)
+    sm = model.score_model
+    assert (int(sm.ctx.cfg.conv_kernel), int(sm.ctx.cfg.deterministic)) == mode
+    sm.load_state_dict(smr.random_state_dict(CFG, seed=7), strict=True)
+    tag = 'diffdockS_score_model'
+    c = complex_from_npz(golden(f'complex_{tag}'))
+    for t in (1.0, 0.55, 0.05):
+        z = golden(f'score_{tag}_t{t}')
+        B = int(z['B'])
+        tr, rot, tor = sm(_dev_batch(c, B, z['pos'], dev, t), keep_receptor_features=True)
+        lig, rec = sm.last_complex.node_features(B, dev)
+        assert chan_err(lig.cpu(), z['lig_node_attr']) < 1e-4 and chan_err(rec.cpu(), z['rec_node_attr']) < 1e-4
+        for name, a in (('tr', tr), ('rot', rot), ('tor', tor)):
+            assert elem_err(a.cpu(), z[name]) < 1e-4, (name, t)
+    z = golden(f'trajectory_{tag}')
+    B, steps, n = 2, int(z['steps']), len(c['lig_pos'])
+    dl = [from_arrays(c) for _ in range(B)]
+    for i, d in enumerate(dl):
+        d['ligand'].pos = T(z['pos0'][i * n:(i + 1) * n])
+    sched = get_t_schedule(steps)
+    noise = [_ref_noise(int(z['seed']), steps, B, int(c['edge_mask'].sum()))]
+    out, _ = sampling(dl, model, steps, sched, sched, sched, dev, partial(t_to_sigma, args=ARGS_S), ARGS_S, batch_size=B, no_final_step_noise=True,
+                      use_latent=False, noise=noise, **README_S)
+    assert rel_err(torch.cat([d['ligand'].pos for d in out]).cpu(), z['pos_out']) < 1e-4
+    # full size: 300 residues, B = 2, small t (few cross edges: pruning active), scores and ligand rows against the oracle
+    cc = synthetic.make_complex(7, n_res=300)
+    P = smr.random_state_dict(CFG, seed=5)
+    ctx = Context(device=0)
+    ctx.load_state_dict(P)
+    rng = np.random.default_rng(3)
+    pos = np.stack([cc['lig_pos'] + rng.normal(0, 4.0, size=(1, 3)) for _ in range(2)]).astype(np.float32)
+    cx = Complex(ctx, cc, 2)
+    tr, rot, tor = cx.score_forward(T(pos).to(dev), 0.05, 0.05, 0.05)
+    lig = cx.lig_node_features(2, dev).cpu()
+    b = batch_of(cc, 2, pos)
+    spr.set_time(b, 0.05, 0.05, 0.05, 2)
+    tr_r, rot_r, tor_r, inter = smr.score_model_forward(P, CFG, b, tables[0], tables[1], return_intermediates=True)
+    for name, a, r in (('tr', tr, tr_r), ('rot', rot, rot_r), ('tor', tor, tor_r)):
+        assert elem_err(a.cpu(), r) < 1e-4, name
+    assert chan_err(lig, inter['lig_node_attr']) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# parity at the size and length of the workload (VERDICT r02 #5a, b)
+# ------------------------------------------------------------------------------------------------------------------------------------------
+def _workload_trajectory(dev, ctx_kwargs, prune=True, seed=11, B=2):
+    """20 reverse steps of B samples of a 300-residue complex with the README low-temperature coefficients and UNSCALED injected noise"""
+    from functools import partial
+    from argparse import Namespace
+    from disco_diffdock_amd import synthetic
+    from disco_diffdock_amd.runtime import Context, Complex
+    from disco_diffdock_amd.sampling import step_coefficients
+    from disco_diffdock_amd.diffusion_utils import t_to_sigma, get_t_schedule
+    from test_gpu_model import README_S
+    args = Namespace(tr_sigma_min=0.1, tr_sigma_max=19.0, rot_sigma_min=0.03, rot_sigma_max=1.55, tor_sigma_min=0.03, tor_sigma_max=3.14, no_torsion=False)
+    c = synthetic.make_complex(seed, n_res=300)
+    P = smr.random_state_dict(CFG, seed=21)
+    ctx = Context(device=0, **ctx_kwargs)
+    ctx.load_state_dict(P)
+    ctx.set_pruning(prune)
+    steps = 20
+    cx = Complex(ctx, c, B)
+    sched = get_t_schedule(steps)
+    coeffs = step_coefficients(steps, sched, sched, sched, partial(t_to_sigma, args=args), args, False, False, True, README_S['temp_sampling'],
+                               README_S['temp_psi'], README_S['temp_sigma_data'])
+    rng = np.random.default_rng(4)
+    pos0 = np.stack([c['lig_pos'] + rng.normal(0, 6.0, size=(1, 3)) for _ in range(B)]).astype(np.float32)
+    z = torch.randn(steps, B, 6 + cx.R, generator=torch.Generator().manual_seed(9))
+    pos = T(pos0.copy()).to(dev)
+    cx.sample(pos, *coeffs, z.to(dev))
+    st = cx.graph_stats()
+    return c, P, pos0, z, pos.cpu(), st, sched
+
+
+def test_workload_size_trajectory_vs_oracle(dev, tables):
+    """(a) BASELINE config 2's shape and length - 300 residues, 20 reverse steps, unscaled N(0,1) noise, B = 2 - against
+    oracle.sampler_ref (about a minute of oracle time).  Poses within 1e-3 of the receptor scale after 20 chaotic steps; the drift is printed."""
+    from test_gpu_model import README_S
+    c, P, pos0, z, pos, st, sched = _workload_trajectory(dev, {})
+    dl = []
+    for p in pos0:
+        g = to_graph(c)
+        g['ligand'].pos = T(p)
+        dl.append(g)
+    nf = lambda b, t, name, shape: {'tr': z[t, :, 0:3], 'rot': z[t, :, 3:6], 'tor': z[t, :, 6:].reshape(-1)}[name]
+    ref, _ = spr.sampling(dl, P, CFG, tables[0], tables[1], 20, sched, sched, sched, noise_fn=nf, batch_size=len(dl), no_final_step_noise=True, **README_S)
+    r = torch.cat([g['ligand'].pos for g in ref])
+    err = rel_err(pos.reshape(-1, 3), r)
+    print(f'20-step, 300-residue, unscaled-noise trajectory drift vs oracle: {err:.2e} (last graph: {st})')
+    assert err < 1e-3
+
+
+@pytest.mark.parametrize('kernel', [0, 1])
+def test_pruned_trajectory_equals_unpruned_over_twenty_steps(dev, kernel):
+    """(b) the receptive-field pruning over 20 ACCUMULATING steps at workload size, deterministic scatter on both sides (no atomics: what
+    differs is only which dead messages are evaluated and where the 32-edge tile boundaries fall inside the re-ordered rec-rec group, i.e.
+    the association of a node's partial sums).  Final poses equal to ~1e-6 of the receptor scale; pruning must have dropped edges."""
+    a = _workload_trajectory(dev, dict(deterministic=1, conv_kernel=kernel), prune=True)
+    b = _workload_trajectory(dev, dict(deterministic=1, conv_kernel=kernel), prune=False)
+    a2 = _workload_trajectory(dev, dict(deterministic=1, conv_kernel=kernel), prune=True)
+    assert torch.equal(a[4], a2[4])                                   # deterministic: the same path twice is bit-identical
+    E_rr = a[0]['rec_edge_index'].shape[1] * 2
+    assert a[5]['E_rr_live'][0] < E_rr and b[5]['E_rr_live'][0] == E_rr      # the last step's level-A segment: pruned vs everything
+    err = elem_err(a[4], b[4], floor=1e-2)
+    print(f'pruned vs unpruned 20-step trajectory (kernel {kernel}): max element error {err:.2e}, bitwise equal: {torch.equal(a[4], b[4])}')
+    assert err < 2e-5

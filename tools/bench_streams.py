@@ -15,7 +15,7 @@ margs = B.ARGS_S
 sched = get_t_schedule(B.STEPS)
 t_arr, sc, nc = step_coefficients(B.STEPS, sched, sched, sched, partial(t_to_sigma, args=margs), margs, False, False, True,
                                   B.README_S['temp_sampling'], B.README_S['temp_psi'], B.README_S['temp_sigma_data'])
-ctx = Context(device=0, conv_f16x3=int(os.environ.get('DDK_CONV_F16X3', '0')))
+ctx = Context(device=0)
 ctx.load_state_dict(synthetic.random_score_model_state_dict(seed=0))
 cs = [synthetic.make_complex(i, n_res=300) for i in range(8)]
 cxs = [Complex(ctx, c, B.SAMPLES) for c in cs]

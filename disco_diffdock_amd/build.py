@@ -15,6 +15,11 @@ SOURCES = ['ddk_capi.hip', 'k_conv.hip', 'k_tp.hip', 'k_graph.hip', 'k_heads.hip
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-mllvm', '-amdgpu-mfma-vgpr-form', '-Wall', '-Wno-unused-function', '-Wno-unused-value', '-Wno-unused-result']
 
 
+# per-file flags.  k_conv_x: the SLP vectoriser packs the fp32 epilogue FMAs into v_pk_fma_f32 with a v_mov shuffle per operand pair (packed
+# f32 VALU has no rate advantage on gfx950 and is an anti-lever next to MFMAs, MI355X_MICROARCH.md)
+FILE_FLAGS = {'k_conv_x.hip': ['-fno-slp-vectorize']}
+
+
 def _hipcc():
     for c in ('/opt/rocm/bin/hipcc', 'hipcc'):
         if os.path.sep not in c or os.path.exists(c):
@@ -48,9 +53,10 @@ def build(force=False, verbose=True):
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace('.hip', '.o'))
         objs.append(o)
-        dg = _digest([s] + headers, ' '.join(FLAGS))
+        flags = FLAGS + FILE_FLAGS.get(src, [])
+        dg = _digest([s] + headers, ' '.join(flags))
         if force or not os.path.exists(o) or not _stamp_ok(o, dg):
-            cmd = [_hipcc()] + FLAGS + ['-c', s, '-o', o]
+            cmd = [_hipcc()] + flags + ['-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd), flush=True)
             subprocess.check_call(cmd)

@@ -62,6 +62,7 @@ constexpr int W2X_LIMB_BYTES = 4 * 1024 + 512;                      // 4,608
 constexpr int W2X_BIAS_OFF = 3 * W2X_LIMB_BYTES;                    // 13,824
 constexpr int W2X_TILE_BYTES = W2X_BIAS_OFF + 128 + 16;             // 13,968 = 873 x 16 B
 constexpr int W1X_TILE_BYTES = 3 * W2X_LIMB_BYTES;                  // GEMM1: the three limbs of one 32-row tile
+constexpr int CONV_TRACE_TILES = 1024;                              // tiles per wave the TRACE instantiation of the kernel records
 constexpr int W2X_MAX_TILES = 64;                                   // tile descriptors ride in the kernel arguments
 constexpr size_t CONV_X_LDS_BYTES = (size_t)CONV_WAVES * 32 * F_STRIDE * 4 + 2 * W2X_TILE_BYTES + 16;   // 163,120 B of the 163,840
 static_assert(CONV_X_LDS_BYTES <= 160 * 1024 && W2X_TILE_BYTES % 16 == 0, "LDS budget (three-limb f16)");
@@ -179,6 +180,7 @@ struct ddk_ctx {
   // profiling (ddk_profile_enable / ddk_profile_read)
   bool prof = false;
   bool prune = true;                // backward receptive-field pruning of the rec-rec messages (ddk_set_receptive_field_pruning)
+  uint32_t* conv_trace = nullptr; int conv_trace_layer = -1;   // ddk_debug_conv_trace: the next forward's launch of this layer runs the TRACE kernel
   bool layer0_dedup = true;         // layer-0 rec-rec messages once per batch (+ per-sample patches for the latent-conditioned model); ddk_debug_set_layer0_dedup
   struct ProfRec { hipEvent_t a, b; int layer; int slot; int tab = 0; int64_t r01_skipped = 0; bool lig_only = false; };   // tab: group table of the launch
   std::vector<ProfRec> prof_recs;
@@ -221,6 +223,7 @@ struct ConvLaunch {
   uint64_t wmap = 0x876543210ull;   // 4 bits per group: weight set of group g (the DisCo patch group 4 uses the rec-rec weights: 0x23210)
   const int32_t* gbeg = nullptr;
   const int32_t* gend = nullptr;
+  uint32_t* trace = nullptr;   // != null (three-limb kernel, split gather path): workgroup 0 records its half-phase time stamps here
 };
 hipError_t launch_conv_fused(const ConvLayerDev& L, const ConvLaunch& a, int n_cu, hipStream_t s);
 hipError_t launch_conv_fused_x(const ConvLayerDev& L, const ConvLaunch& a, int n_cu, hipStream_t s);   // k_conv_x.hip (exact three-limb f16)

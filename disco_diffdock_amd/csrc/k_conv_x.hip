@@ -20,8 +20,16 @@
 // K = 72 = 4 steps of 16 + one of 8 (v_mfma_f32_32x32x8_f16): register 8s+i (< 36) of a lane half is element i of step s.
 // The b2 bias starts the hi.hi accumulator (scaled like the products).  Tile record in the LDS ring (13,968 B): three limbs x
 // [4 x 1 KB fragments | 512 B tail fragment] | bias [2][16] f32; the tile descriptors ride in the kernel arguments (scalar loads).
-// The fragments are streamed from the ring INSIDE the burst (no register double buffer: h's three limbs need the registers), so the ring
-// holds the tile in use and the next one: every thread requests its 16-32 B of tile t+1 before the burst of tile t and publishes them behind it.
+// The fragments are streamed from the ring INSIDE the burst (no register double buffer: h's three limbs need the registers).
+//
+// Two waves share a SIMD and with it ONE matrix pipe; a wave's tile is a burst of 30 MFMAs (960 pipe cycles) followed by a VALU / LDS
+// epilogue.  Run in lock step (one barrier per tile) both waves of a SIMD burst together and then leave the pipe idle together.  So the
+// workgroup runs as two half-groups in STRICT ALTERNATION: waves 0-3 (group A, one per SIMD) burst tile t while waves 4-7 (group B, their SIMD
+// partners) run the epilogue of tile t-1, then the roles swap - two barriers per tile, every half phase pairs one wave's MFMA burst with its
+// partner's epilogue, and the pipe sees one burst after the other.  Ring protocol (2 stages, tile t in stage t & 1): group B alone fills the
+// ring - it requests tile t+2 from L2 at the start of its burst of tile t and publishes it in its epilogue of tile t, into the stage that
+// tile t left (group A reads the other stage meanwhile) - so that a tile is complete one half phase before its first reader and each
+// group can fetch the first two K steps of its NEXT tile before the barrier that starts that tile's burst.
 #include <stdlib.h>
 
 #include "k_conv_common.h"
@@ -36,6 +44,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 struct ConvXArgs {
   ConvKArgs k;
   int32_t tq[W2X_MAX_TILES][2];     // tile descriptors (TileDesc::w0, chan0)
+  uint32_t* trace;                  // TRACE instantiation: [8 waves][CONV_TRACE_TILES][8] s_memtime stamps of workgroup 0
 };
 
 // Exact power-of-two range scale: 2^(13 - floor(log2 max(m, 2^-40))) and its inverse (max|x| lands in [2^13, 2^14))
@@ -69,6 +78,23 @@ __device__ __forceinline__ void make_limbs(Limbs& L, const float (&v)[36], float
     for (int i = 0; i < 8; ++i) { const Limb3 q = split3(v[8 * s + i] * scale); L.hi[s][i] = q.h; L.mid[s][i] = q.m; L.lo[s][i] = q.l; }
 #pragma unroll
   for (int i = 0; i < 4; ++i) { const Limb3 q = split3(v[32 + i] * scale); L.thi[i] = q.h; L.tmid[i] = q.m; L.tlo[i] = q.l; }
+}
+
+// workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also drains vmcnt, i.e. the global atomics of a flush and
+// the tile record requests that are meant to stay in flight across the barrier
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");      // s_waitcnt lgkmcnt(0)
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+struct Frag16 { f16x8 h, m, l; };     // the three limbs of one K step's A fragment
+__device__ __forceinline__ Frag16 lds_frag16(const char* stage, int s, int lane) {
+  Frag16 f;
+  f.h = *reinterpret_cast<const f16x8*>(stage + s * 1024 + lane * 16);
+  f.m = *reinterpret_cast<const f16x8*>(stage + W2X_LIMB_BYTES + s * 1024 + lane * 16);
+  f.l = *reinterpret_cast<const f16x8*>(stage + 2 * W2X_LIMB_BYTES + s * 1024 + lane * 16);
+  return f;
 }
 
 // six-term product of one K step into the three accumulators (same-accumulator MFMAs never adjacent)
@@ -106,9 +132,20 @@ __device__ __forceinline__ void tile_epilogue_s(int kind, const f32x16& D, const
   }
 }
 
-template <bool GATHER, bool SPLIT, bool DET>
+// TRACE: workgroup 0 stamps s_memtime at the four edges of every tile's two half phases (slots 0-3) and, in the first tile's record of a unit, at
+// four points of the unit's prologue (slots 4-7: unit start, indices + ring staging done, GEMM1 done, limbs + F rows done); ddk_debug_conv_trace,
+// tools/conv_trace.py.  Every stamp costs the wave ~100 cycles (s_memtime round trip): read the spans as upper bounds.
+template <bool GATHER, bool SPLIT, bool DET, bool TRACE = false>
 __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) {
   static_assert(!SPLIT || GATHER, "the GEMM1 split exists for the gather path");
+  int trace_n = 0;
+  auto stamp = [&](int phase) {
+    if constexpr (TRACE) {
+      if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && trace_n < CONV_TRACE_TILES)
+        AX.trace[((threadIdx.x >> 6) * CONV_TRACE_TILES + trace_n) * 8 + phase] = (uint32_t)__builtin_amdgcn_s_memtime();
+      if (phase == 3) ++trace_n;
+    }
+  };
   const ConvKArgs& A = AX.k;
   constexpr int WAVES = CONV_WAVES, FS = F_STRIDE, BLOCK_EDGES = 32 * WAVES;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -139,7 +176,11 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
   const float inv_s3 = 0.57735026918962576451f, inv_s2 = 0.70710678118654752440f;
   const int n_tiles = A.n_tiles;
   constexpr int REC16 = W2X_TILE_BYTES / 16;                   // 873 x 16 B per tile record
-  const bool second = tid < REC16 - 64 * WAVES;                 // threads that move a second 16 B of the record
+  const bool second = tid < REC16 - 64 * WAVES;                 // prologue: threads that move a second 16 B of the record
+  const int grp = wave >> 2;                                    // half-group: 0 = waves 0-3 (A), 1 = waves 4-7 (B, their SIMD partners)
+  const int ftid = tid & 255;                                   // group B fills the ring: 16-B chunks ftid + 256 k, k < 3, and a fourth below
+  const bool fourth = ftid < REC16 - 3 * 256;
+  const uint32_t fo0 = 16u * ftid, fo3 = fourth ? fo0 + 12288u : fo0;      // byte offsets of this thread's chunks inside a tile record
 
   // work units: whole blocks, except that the last (bs4 mod #workgroups) blocks are split into column chunks so that the final round of the
   // persistent workgroups is a fraction of a block long (same rule as k_conv.hip)
@@ -159,6 +200,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
   int unit = blockIdx.x;
   for (;;) {
     if (unit >= n_units) break;
+    stamp(4);
     int unit_next = 0;
     if (tid == 0) unit_next = nwg + atomicAdd(A.counter, 1);      // fetched at the START of this unit: the round trip hides under the tile loop
     int blk = unit, t_begin = 0, t_end = n_tiles;
@@ -177,17 +219,26 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
     const int e = nvalid > 0 ? e0 + min(el, nvalid - 1) : gend - 1;
     const int sn = A.src[e], dn = A.dst[e];
 
-    // ---- stage the first W2 tile of this unit (the ring is idle: the previous unit ended with a barrier) ----
+    // ---- stage the first two W2 tiles of this unit (the ring is idle: the previous unit ended with a barrier) ----
     const int gw = (int)((A.wmap >> (4 * g)) & 15);                 // weight set / node-term roles of this group
     const char* wrec = reinterpret_cast<const char*>(A.w2x) + (size_t)gw * n_tiles * W2X_TILE_BYTES;
     {
       const char* wr0 = wrec + (size_t)t_begin * W2X_TILE_BYTES;
-      *reinterpret_cast<float4*>(ring + 16 * tid) = *reinterpret_cast<const float4*>(wr0 + 16 * tid);
-      if (second) *reinterpret_cast<float4*>(ring + 16 * (tid + 64 * WAVES)) = *reinterpret_cast<const float4*>(wr0 + 16 * (tid + 64 * WAVES));
+      const char* wr1 = wrec + (size_t)min(t_begin + 1, t_end - 1) * W2X_TILE_BYTES;
+      const float4 r0 = *reinterpret_cast<const float4*>(wr0 + 16 * tid), r1 = *reinterpret_cast<const float4*>(wr1 + 16 * tid);
+      *reinterpret_cast<float4*>(ring + 16 * tid) = r0;
+      *reinterpret_cast<float4*>(ring + W2X_TILE_BYTES + 16 * tid) = r1;
+      if (second) {
+        const int q = 16 * (tid + 64 * WAVES);
+        const float4 r2 = *reinterpret_cast<const float4*>(wr0 + q), r3 = *reinterpret_cast<const float4*>(wr1 + q);
+        *reinterpret_cast<float4*>(ring + q) = r2;
+        *reinterpret_cast<float4*>(ring + W2X_TILE_BYTES + q) = r3;
+      }
     }
 
     // ---- segmented-scan control words (identical for every output channel of this wave's 32 edges) ----
     const SegCtl seg = make_segctl(sn, el, nvalid, valid);
+    stamp(5);
 
     // ---- GEMM1: h = relu(W1 [edge_emb | x_src[:ns] | x_dst[:ns]] + b1), K order kappa(s,hh) = 24*(s/12)+12*hh+s%12, three-limb product ----
     Limbs H;
@@ -322,6 +373,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
       m2 = fmaxf(m2, __shfl_xor(m2, 32));
       float inv2;
       const float s2 = range_scale(m2, inv2);
+      stamp(6);
       make_limbs(H, h, s2);
       bsc2 = s2 * A.w2s[gw];
       osc = inv2 * A.w2u[gw];
@@ -362,7 +414,8 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
         Pc[8] = (px * vy - py * vx) * inv_s2;
       }
     }
-    __syncthreads();   // ring stage 0 and the F rows are visible
+    stamp(7);
+    lds_barrier();   // ring stages 0 / 1 and the F rows are visible
 
     // ---- GEMM2 over the W2 tiles + fused tensor-product epilogue ----
     float* node_row = (g2_shared && g == 2) ? A.sum_g2 + (size_t)(sn - A.g2_node_off) * XW
@@ -381,48 +434,72 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
     float accA[4], accV[4][3];
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) { accA[rq] = 0.0f; accV[rq][0] = 0.0f; accV[rq][1] = 0.0f; accV[rq][2] = 0.0f; }
+    // the first two K steps of the first tile (every later tile's are fetched at the end of the previous epilogue)
+    Frag16 p0 = lds_frag16(ring, 0, lane), p1 = lds_frag16(ring, 1, lane);
     int w0n = AX.tq[t_begin][0], chan0n = AX.tq[t_begin][1];
+    if (grp) lds_barrier();        // group B runs half a tile behind group A
     for (int t = t_begin; t < t_end; ++t) {
       const int w0 = w0n, chan0 = chan0n;
       const int t1 = min(t + 1, t_end - 1);
-      w0n = AX.tq[t1][0]; chan0n = AX.tq[t1][1];
-      // (1) this thread's share of tile t+1 from L2
-      const char* rec1 = wrec + (size_t)t1 * W2X_TILE_BYTES;
-      const float4 st0 = *reinterpret_cast<const float4*>(rec1 + 16 * tid);
-      float4 st1 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (second) st1 = *reinterpret_cast<const float4*>(rec1 + 16 * (tid + 64 * WAVES));
       const char* stage = ring + ((t - t_begin) & 1) * W2X_TILE_BYTES;
+      stamp(0);
+      // ================= burst: 30 MFMAs, everything else of this half phase threaded between them =================
+      // Issue order, pinned region by region (one K step each): the first MFMA goes out right behind the barrier (its operands were fetched
+      // before it) and every other instruction of this half phase rides in the shadow of an MFMA, one per MFMA: the LDS reads of the
+      // fragments two steps ahead, the epilogue's operands (feature rows, bias), and the next ring record - BOTH groups request their
+      // 48-64 B of tile t+2 from L2 (a branch would cut the stream); only group B publishes them, in this tile's epilogue.
+      const char* rec2 = wrec + (size_t)min(t + 2, t_end - 1) * W2X_TILE_BYTES;
       const float* Fp = Fr + (w0 >> 16);
+      const float* bp = reinterpret_cast<const float*>(stage + W2X_BIAS_OFF) + hh * 16;
+      f32x16 D0, D1, D2, Bs;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { D0[r] = 0.0f; D1[r] = 0.0f; D2[r] = 0.0f; }
+#define X3_PAIR(mask) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(mask, 1, 0); }
+      __builtin_amdgcn_sched_barrier(0);
+      const Frag16 q2 = lds_frag16(stage, 2, lane);
       const f32x4 f0 = ldv4(Fp);
-      // (2) the burst: 30 MFMAs, fragments streamed from the ring
-      f32x16 D0, D1, D2;
-      {
-        const float* bp = reinterpret_cast<const float*>(stage + W2X_BIAS_OFF) + hh * 16;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float4 b = ld4(bp + 4 * j);
-          D0[4 * j + 0] = b.x * bsc2; D0[4 * j + 1] = b.y * bsc2; D0[4 * j + 2] = b.z * bsc2; D0[4 * j + 3] = b.w * bsc2;
-        }
+      const float4 bs0 = ld4(bp), bs1 = ld4(bp + 4);
+      X3_STEP(MFMA16, p0.h, p0.m, p0.l, H.hi[0], H.mid[0], H.lo[0])
+      X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100)
+      __builtin_amdgcn_sched_barrier(0);
+      const Frag16 q3 = lds_frag16(stage, 3, lane);
+      const f16x4 th = *reinterpret_cast<const f16x4*>(stage + 4096 + lane * 8);
+      const f16x4 tm = *reinterpret_cast<const f16x4*>(stage + W2X_LIMB_BYTES + 4096 + lane * 8);
+      const f16x4 tl = *reinterpret_cast<const f16x4*>(stage + 2 * W2X_LIMB_BYTES + 4096 + lane * 8);
+      X3_STEP(MFMA16, p1.h, p1.m, p1.l, H.hi[1], H.mid[1], H.lo[1])
+      X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100)
+      __builtin_amdgcn_sched_barrier(0);
+      const float4 bs2 = ld4(bp + 8), bs3 = ld4(bp + 12);
+      const float4 st0 = *reinterpret_cast<const float4*>(rec2 + fo0);
+      const float4 st1 = *reinterpret_cast<const float4*>(rec2 + fo0 + 4096u);
+      const float4 st2 = *reinterpret_cast<const float4*>(rec2 + fo0 + 8192u);
+      const float4 st3 = *reinterpret_cast<const float4*>(rec2 + fo3);
+      X3_STEP(MFMA16, q2.h, q2.m, q2.l, H.hi[2], H.mid[2], H.lo[2])
+      X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x020) X3_PAIR(0x020) X3_PAIR(0x020) X3_PAIR(0x020)
+      __builtin_amdgcn_sched_barrier(0);
+      X3_STEP(MFMA16, q3.h, q3.m, q3.l, H.hi[3], H.mid[3], H.lo[3])
+      X3_STEP(MFMA8, th, tm, tl, H.thi, H.tmid, H.tlo)
+      __builtin_amdgcn_sched_barrier(0);
+#undef X3_PAIR
+      Bs[0] = bs0.x; Bs[1] = bs0.y; Bs[2] = bs0.z; Bs[3] = bs0.w; Bs[4] = bs1.x; Bs[5] = bs1.y; Bs[6] = bs1.z; Bs[7] = bs1.w;
+      Bs[8] = bs2.x; Bs[9] = bs2.y; Bs[10] = bs2.z; Bs[11] = bs2.w; Bs[12] = bs3.x; Bs[13] = bs3.y; Bs[14] = bs3.z; Bs[15] = bs3.w;
+      stamp(1);
+      lds_barrier();
+      stamp(2);
+      // ================= epilogue (the SIMD partner bursts meanwhile) =================
+      // (the next tile's descriptor: a scalar load in flight makes every LDS wait a wait for everything, so it is requested here and not in the burst)
+      w0n = AX.tq[t1][0]; chan0n = AX.tq[t1][1];
+      if (grp) {      // publish tile t+2 into the stage tile t is leaving (both groups have read it; group A reads the other stage now)
+        char* stg = ring + ((t - t_begin) & 1) * W2X_TILE_BYTES + 16 * ftid;
+        *reinterpret_cast<float4*>(stg) = st0;
+        *reinterpret_cast<float4*>(stg + 4096) = st1;
+        *reinterpret_cast<float4*>(stg + 8192) = st2;
+        if (fourth) *reinterpret_cast<float4*>(stg + 12288) = st3;
       }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { D1[r] = 0.0f; D2[r] = 0.0f; }
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const f16x8 ah = *reinterpret_cast<const f16x8*>(stage + s * 1024 + lane * 16);
-        const f16x8 am = *reinterpret_cast<const f16x8*>(stage + W2X_LIMB_BYTES + s * 1024 + lane * 16);
-        const f16x8 al = *reinterpret_cast<const f16x8*>(stage + 2 * W2X_LIMB_BYTES + s * 1024 + lane * 16);
-        X3_STEP(MFMA16, ah, am, al, H.hi[s], H.mid[s], H.lo[s])
-      }
-      {
-        const f16x4 ah = *reinterpret_cast<const f16x4*>(stage + 4096 + lane * 8);
-        const f16x4 am = *reinterpret_cast<const f16x4*>(stage + W2X_LIMB_BYTES + 4096 + lane * 8);
-        const f16x4 al = *reinterpret_cast<const f16x4*>(stage + 2 * W2X_LIMB_BYTES + 4096 + lane * 8);
-        X3_STEP(MFMA8, ah, am, al, H.thi, H.tmid, H.tlo)
-      }
-      // (3) the three accumulators into one, tensor-product epilogue, flush at the end of a column
+      // the three accumulators and the bias into one
       f32x16 D;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) D[r] = fmaf(fmaf(D2[r], 1.0f / 2048.0f, D1[r]), 1.0f / 2048.0f, D0[r]);
+      for (int r = 0; r < 16; ++r) D[r] = fmaf(Bs[r], bsc2, fmaf(fmaf(D2[r], 1.0f / 2048.0f, D1[r]), 1.0f / 2048.0f, D0[r]));
       tile_epilogue_s(w0 & 3, D, Fp, f0, accA, accV);
       if (w0 & 0x80) {   // 6-channel column: accumulator quad 3 holds another a / c row quad for channel pair xp
         const f32x4 g0 = ldv4(Fr + ((w0 >> 8) & 0x3c));
@@ -458,15 +535,20 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
           for (int rq = 0; rq < 4; ++rq) accV[rq][0] = fmaf(f0.z, D[4 * rq + 2], f0.w * D[4 * rq + 3]);
         }
       }
-      // (4) publish tile t+1 into the other stage (tile t-1 was retired by the previous barrier), (5) barrier
-      char* stg = ring + ((t + 1 - t_begin) & 1) * W2X_TILE_BYTES;
-      *reinterpret_cast<float4*>(stg + 16 * tid) = st0;
-      if (second) *reinterpret_cast<float4*>(stg + 16 * (tid + 64 * WAVES)) = st1;
-      __syncthreads();
+      // the first two K steps of this wave's next tile (complete in the ring since the previous half phase)
+      {
+        const char* nxt = ring + ((t1 - t_begin) & 1) * W2X_TILE_BYTES;
+        p0 = lds_frag16(nxt, 0, lane);
+        p1 = lds_frag16(nxt, 1, lane);
+      }
+      stamp(3);
+      if (grp && t + 1 == t_end) break;        // group B: the barrier that ends its last epilogue is the hand-over below
+      lds_barrier();
     }
-    // hand the next unit to the workgroup; this barrier also retires the ring before the next unit's staging writes
+    // hand the next unit to the workgroup.  Group A waits here through group B's last epilogue: the barrier that ends it also retires the ring
+    // (nobody reads it any more) before the next unit's staging writes
     if (tid == 0) *blk_slot = unit_next;
-    __syncthreads();
+    lds_barrier();
     unit = __builtin_amdgcn_readfirstlane(*blk_slot);
   }
 }
@@ -509,6 +591,9 @@ hipError_t conv_prepare_device_x() {
   if (e == hipSuccess) e = attr_x_t<false, false, false>();
   if (e == hipSuccess) e = attr_x_t<true, true, true>();
   if (e == hipSuccess) e = attr_x_t<false, false, true>();
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<true, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)CONV_X_LDS_BYTES);
   return e;
 }
 
@@ -530,11 +615,18 @@ hipError_t launch_conv_fused_x(const ConvLayerDev& L, const ConvLaunch& a, int n
   if (a.gbeg) { k.gbeg = a.gbeg; k.gend = a.gend; }
   else { k.gbeg = a.tile_info + 5; k.gend = a.tile_info + 6; }   // 4 contiguous groups go[g] .. go[g+1] (explicit-boundary entry point)
   k.pre = a.pre; k.part = a.part;
+  X.trace = nullptr;
   if (a.part != nullptr) {       // deterministic scatter
     hipError_t e = (a.gather && a.pre != nullptr) ? launch_x_t<true, true, true>(X, n_cu, s)
                                                   : (!a.gather ? launch_x_t<false, false, true>(X, n_cu, s) : hipErrorInvalidValue);
     if (e != hipSuccess) return e;
     conv_det_fix(k, a, L.dout, s);
+    return hipGetLastError();
+  }
+  X.trace = a.trace;
+  if (a.trace != nullptr) {
+    if (!(a.gather && a.pre != nullptr)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((conv_x3_kernel<true, true, false, true>), dim3(n_cu), dim3(64 * CONV_WAVES), CONV_X_LDS_BYTES, s, X);
     return hipGetLastError();
   }
   if (a.gather && a.pre != nullptr) return launch_x_t<true, true, false>(X, n_cu, s);

@@ -42,6 +42,11 @@ int ddk_debug_read_patch(ddk_ctx* ctx, ddk_complex* cx, int32_t B, int32_t* coun
 int ddk_debug_kabsch(ddk_ctx* ctx, int32_t nb, int32_t n, const float* A, const float* B, float* R_out, float* t_out, void* stream);
 int ddk_debug_axis_angle(ddk_ctx* ctx, int32_t n, const float* aa, float* R_out, void* stream);
 
+/* Timeline of the default conv kernel (k_conv_x.hip): conv layer `layer` of the following score-model forwards runs the kernel's TRACE
+ * instantiation, whose workgroup 0 stamps s_memtime at the four edges of every tile's two half phases into trace (DEVICE,
+ * [8 waves][1024 tiles][8] uint32: burst start, burst end, epilogue start, epilogue end, then four stamps inside the burst: before K step 0, 1, 2, 3; tools/conv_trace.py).  trace = NULL: off. */
+int ddk_debug_conv_trace(ddk_ctx* ctx, int32_t layer, uint32_t* trace);
+
 /* The default conv kernel's limb split (k_conv_x.hip) on a DEVICE array x [n], cut into groups of `group` consecutive values that share one
  * power-of-two range scale (the kernel scales per edge): hi / mid / lo [n] = the fp16 limbs as fp32, scale [n] = the group's scale;
  * x * scale == hi + mid 2^-11 + lo 2^-22 bit for bit for every value within 2^-36 of its group's maximum. */

@@ -272,7 +272,8 @@ def test_workload_size_trajectory_vs_oracle(dev, tables):
 def test_pruned_trajectory_equals_unpruned_over_twenty_steps(dev, kernel):
     """(b) the receptive-field pruning over 20 ACCUMULATING steps at workload size, deterministic scatter on both sides (no atomics: what
     differs is only which dead messages are evaluated and where the 32-edge tile boundaries fall inside the re-ordered rec-rec group, i.e.
-    the association of a node's partial sums).  Final poses equal to ~1e-6 of the receptor scale; pruning must have dropped edges."""
+    the association of a node's partial sums, amplified by 20 chaotic steps).  Final poses within the north star's 1e-4 per element;
+    pruning must have dropped edges."""
     a = _workload_trajectory(dev, dict(deterministic=1, conv_kernel=kernel), prune=True)
     b = _workload_trajectory(dev, dict(deterministic=1, conv_kernel=kernel), prune=False)
     a2 = _workload_trajectory(dev, dict(deterministic=1, conv_kernel=kernel), prune=True)
@@ -281,4 +282,4 @@ def test_pruned_trajectory_equals_unpruned_over_twenty_steps(dev, kernel):
     assert a[5]['E_rr_live'][0] < E_rr and b[5]['E_rr_live'][0] == E_rr      # the last step's level-A segment: pruned vs everything
     err = elem_err(a[4], b[4], floor=1e-2)
     print(f'pruned vs unpruned 20-step trajectory (kernel {kernel}): max element error {err:.2e}, bitwise equal: {torch.equal(a[4], b[4])}')
-    assert err < 2e-5
+    assert err < 1e-4

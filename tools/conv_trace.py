@@ -1,0 +1,43 @@
+"""Half-phase timeline of the default conv kernel (k_conv_x.hip) from its TRACE instantiation (ddk_debug_conv_trace): workgroup 0 of one conv
+layer's launch stamps s_memtime at burst start / burst end / epilogue start / epilogue end of every tile, and at four points of every unit's
+prologue.  Prints the mean spans per wave (waves 0-3 = group A, 4-7 = group B; every stamp itself costs ~100 cycles).
+
+    python tools/conv_trace.py [--layer 3] [--t 0.6]"""
+import argparse, ctypes as C, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), '..')))
+from disco_diffdock_amd import synthetic
+from disco_diffdock_amd.runtime import Context, Complex
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--layer', type=int, default=3)
+ap.add_argument('--t', type=float, default=0.6)
+a = ap.parse_args()
+dev = torch.device('cuda:0')
+ctx = Context(device=0)
+ctx.load_state_dict(synthetic.random_score_model_state_dict(seed=0))
+c = synthetic.make_complex(0, n_res=300)
+B = 40
+cx = Complex(ctx, c, B)
+rng = np.random.default_rng(0)
+pos = torch.from_numpy(np.stack([c['lig_pos'] + rng.normal(0, 3.0, size=(1, 3)) for _ in range(B)]).astype(np.float32)).to(dev)
+for _ in range(3):
+    cx.score_forward(pos, a.t, a.t, a.t)
+trace = torch.zeros((8, 1024, 8), dtype=torch.int32, device=dev)
+ctx._check(ctx.L.ddk_debug_conv_trace(ctx.h, a.layer, C.c_void_p(trace.data_ptr())), 'trace')
+cx.score_forward(pos, a.t, a.t, a.t)
+ctx._check(ctx.L.ddk_debug_conv_trace(ctx.h, -1, None), 'trace off')
+torch.cuda.synchronize()
+tr = trace.cpu().numpy().astype(np.int64) & 0xffffffff
+n = int((tr[0, :, 3] != 0).sum())
+print(f'layer {a.layer}: {n} tiles recorded by workgroup 0 (ticks = shader cycles)')
+for w in range(8):
+    x = tr[w, :n]
+    burst, bar1, epi = x[:, 1] - x[:, 0], x[:, 2] - x[:, 1], x[:, 3] - x[:, 2]
+    nxt = x[1:, 0] - x[:-1, 3]
+    same = x[1:, 4] == 0                      # the next tile belongs to the same unit
+    first = x[:, 4] != 0
+    pro = [int((x[first, b] - x[first, a_]).mean()) for a_, b in ((4, 5), (5, 6), (6, 7), (7, 0))]
+    print(f'wave {w}: burst {burst.mean():6.0f}  wait {bar1.mean():5.0f}  epilogue {epi.mean():6.0f} (median {np.median(epi):5.0f}, p90 {np.percentile(epi, 90):5.0f})  '
+          f'wait {nxt[same].mean():5.0f}  period {(x[1:, 0] - x[:-1, 0])[same].mean():6.0f} | prologue of {int(first.sum())} units: indices + staging {pro[0]}, '
+          f'GEMM1 {pro[1]}, limbs + F rows {pro[2]}, barrier + first fragments {pro[3]}')

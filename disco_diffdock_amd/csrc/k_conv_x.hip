@@ -240,6 +240,18 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
     const SegCtl seg = make_segctl(sn, el, nvalid, valid);
     stamp(5);
 
+    // ---- the F row's inputs (x[dst] row, sh), requested here so that their latency runs under GEMM1 ----
+    const float4 shv = ld4(A.sh + (size_t)e * 4);
+    float4 mainv[NS / 4];
+    float2 pv2[3 * NV / 2];
+    {
+      const float* xr = A.x + (size_t)dn * XW;
+#pragma unroll
+      for (int j = 0; j < NS / 4; ++j) mainv[j] = ld4(xr + (hh ? OFF_C : 0) + 4 * j);
+#pragma unroll
+      for (int j = 0; j < 3 * NV / 2; ++j) pv2[j] = ld2(xr + (hh ? OFF_Q : OFF_P) + 2 * j);
+    }
+
     // ---- GEMM1: h = relu(W1 [edge_emb | x_src[:ns] | x_dst[:ns]] + b1), K order kappa(s,hh) = 24*(s/12)+12*hh+s%12, three-limb product ----
     Limbs H;
     float osc, bsc2;      // GEMM2 accumulators hold (s2 h) x (w2s W2): bias goes in times bsc2, flushed sums come out times osc
@@ -248,7 +260,15 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
       const char* w1 = reinterpret_cast<const char*>(A.w1x) + (size_t)gw * 3 * W1X_TILE_BYTES;
       if constexpr (SPLIT) {
         // W1a edge_emb on top of the per-node terms (W1b x[src][:ns] + b1) + W1c x[dst][:ns] (node_finalize_pre_kernel), which arrive in the
-        // accumulator's own register order: K = 24 = one step of 16 + one of 8
+        // accumulator's own register order: K = 24 = one step of 16 + one of 8.  The node terms sit at random nodes of a 15 MB array (past the
+        // L2): all 18 requests of a lane go out together, right behind the indices - one exposed memory latency, not one per row tile
+        float4 psv[9], pdv[9];
+        {
+          const float* ps = A.pre + ((size_t)sn * 4 + (gw & 1)) * NE + 36 * hh;
+          const float* pd = A.pre + ((size_t)dn * 4 + 2 + (gw >> 1)) * NE + 36 * hh;
+#pragma unroll
+          for (int j = 0; j < 9; ++j) { psv[j] = ld4(ps + 4 * j); pdv[j] = ld4(pd + 4 * j); }
+        }
         float bin[12];
         {
           const float* pe = A.edge_attr + (size_t)e * NS + 12 * hh;
@@ -271,15 +291,13 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
 #pragma unroll
         for (int i = 0; i < 4; ++i) { const Limb3 q = split3(bin[8 + i] * s1); b1h[i] = q.h; b1m[i] = q.m; b1l[i] = q.l; }
         const float bsc = s1 * A.w1s[gw], usc = inv1 * A.w1u[gw];
-        const float* ps = A.pre + ((size_t)sn * 4 + (gw & 1)) * NE + 36 * hh;
-        const float* pd = A.pre + ((size_t)dn * 4 + 2 + (gw >> 1)) * NE + 36 * hh;
 #pragma unroll
         for (int T = 0; T < 3; ++T) {
           f32x16 D0, D1, D2;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             if (T < 2 || j == 0) {
-              const float4 u = ld4(ps + 16 * T + 4 * j), w = ld4(pd + 16 * T + 4 * j);
+              const float4 u = psv[4 * T + j], w = pdv[4 * T + j];
               D0[4 * j + 0] = (u.x + w.x) * bsc; D0[4 * j + 1] = (u.y + w.y) * bsc; D0[4 * j + 2] = (u.z + w.z) * bsc; D0[4 * j + 3] = (u.w + w.w) * bsc;
             } else {
               D0[4 * j + 0] = 0.0f; D0[4 * j + 1] = 0.0f; D0[4 * j + 2] = 0.0f; D0[4 * j + 3] = 0.0f;
@@ -380,23 +398,17 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
     }
 
     // ---- F row of this edge: TP row operands derived from x[dst] and sh (written by both lane halves) ----
-    const float4 shv = ld4(A.sh + (size_t)e * 4);
     const float s0 = shv.x, vx = shv.y, vy = shv.z, vz = shv.w;
     {
-      const float* xr = A.x + (size_t)dn * XW;
       // half 0: a -> F_A, p: (p.v) -> F_PQ, p*s0 -> rows 0..nv-1 of T1O, (p x v)/sqrt2 -> rows 0..nv-1 of T1E
       // half 1: c -> F_C, q: (q.v) -> F_PQ, q*s0 -> rows nv.. of T1E, (q x v)/sqrt2 -> rows nv.. of T1O
-      const int o_main_src = hh ? OFF_C : 0, o_main_dst = hh ? F_C : F_A;
-      const int o_vec_src = hh ? OFF_Q : OFF_P;
+      const int o_main_dst = hh ? F_C : F_A;
       const int o_vs = hh ? F_T1E : F_T1O, o_vc = hh ? F_T1O : F_T1E, r0 = hh ? NV : 0;
 #pragma unroll
-      for (int j = 0; j < NS / 4; ++j) *reinterpret_cast<float4*>(Fr + o_main_dst + 4 * j) = ld4(xr + o_main_src + 4 * j);
+      for (int j = 0; j < NS / 4; ++j) *reinterpret_cast<float4*>(Fr + o_main_dst + 4 * j) = mainv[j];
       float pv[3 * NV];
 #pragma unroll
-      for (int j = 0; j < 3 * NV / 2; ++j) {
-        const float2 t = ld2(xr + o_vec_src + 2 * j);
-        pv[2 * j] = t.x; pv[2 * j + 1] = t.y;
-      }
+      for (int j = 0; j < 3 * NV / 2; ++j) { pv[2 * j] = pv2[j].x; pv[2 * j + 1] = pv2[j].y; }
 #pragma unroll
       for (int m = 0; m < NV; ++m) {
         const float px = pv[3 * m], py = pv[3 * m + 1], pz = pv[3 * m + 2];

@@ -501,6 +501,13 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
       // ================= epilogue (the SIMD partner bursts meanwhile) =================
       // (the next tile's descriptor: a scalar load in flight makes every LDS wait a wait for everything, so it is requested here and not in the burst)
       w0n = AX.tq[t1][0]; chan0n = AX.tq[t1][1];
+      // the first two K steps of this wave's next tile (complete in the ring since the previous half phase), requested FIRST: the barrier that
+      // ends this epilogue drains the wave's LDS queue, and reads issued just before it would expose their whole latency there
+      {
+        const char* nxt = ring + ((t1 - t_begin) & 1) * W2X_TILE_BYTES;
+        p0 = lds_frag16(nxt, 0, lane);
+        p1 = lds_frag16(nxt, 1, lane);
+      }
       if (grp) {      // publish tile t+2 into the stage tile t is leaving (both groups have read it; group A reads the other stage now)
         char* stg = ring + ((t - t_begin) & 1) * W2X_TILE_BYTES + 16 * ftid;
         *reinterpret_cast<float4*>(stg) = st0;
@@ -546,12 +553,6 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
 #pragma unroll
           for (int rq = 0; rq < 4; ++rq) accV[rq][0] = fmaf(f0.z, D[4 * rq + 2], f0.w * D[4 * rq + 3]);
         }
-      }
-      // the first two K steps of this wave's next tile (complete in the ring since the previous half phase)
-      {
-        const char* nxt = ring + ((t1 - t_begin) & 1) * W2X_TILE_BYTES;
-        p0 = lds_frag16(nxt, 0, lane);
-        p1 = lds_frag16(nxt, 1, lane);
       }
       stamp(3);
       if (grp && t + 1 == t_end) break;        // group B: the barrier that ends its last epilogue is the hand-over below

@@ -21,14 +21,18 @@ rank), config 5 shards SAMPLES (strong scaling); no collective on the data path,
 Without torchrun, ``--gpus N`` (N > 1) starts the N ranks itself (re-exec under ``python -m torch.distributed.run --nproc-per-node N``).
 
 Prints ONE JSON line on rank 0, with
-  roofline      fused TP-conv kernel, HIP events around every launch of the timed region: ``achieved`` / ``frac`` = algorithmic FLOPs
-                of the edges the launches EVALUATED / event time vs the matrix-pipe peak (the kernel's own roofline fraction);
-                ``reference_equivalent_TFLOPs`` also counts the rec-rec messages the receptive-field pruning proves dead (no frac)
+  roofline      fused TP-conv kernel, HIP events around every launch of the timed region: ``achieved`` / ``frac`` = MFMA FLOPs the launches
+                EXECUTED / event time vs the dense f16 matrix peak (the kernel's own roofline fraction); ``fp32_equivalent_TFLOPs`` = the
+                algorithmic fp32 FLOPs of the evaluated edges over the same time; ``reference_equivalent_TFLOPs`` also counts the rec-rec
+                messages the receptive-field pruning proves dead (no frac)
   extra         pruning_off: the same bracket with ddk_set_receptive_field_pruning(ctx, 0) - the guaranteed floor of ``value``;
                 pocket_bound: the same bracket on start poses inside the pocket with noise scaled so that every sample keeps its
                 cross edges for all 20 steps (what a trained model's trajectories look like to the pruning);
                 per_step: executed-edge fraction and conv ms of each of the 20 reverse steps of the default workload;
+                create_ms: host time of one ddk_complex_create call at 300 / 2000 residues; per_call_spread_same_complex: max / min - 1 of
+                the device time of the timed calls that ran the same complex;
                 device_loop: the same workload with complexes and noise resident in HBM (round 1's bracket), for comparison
+  fallback_fp32_kernel  the resident loop with ddk_config.conv_kernel = 1 (fp32 MFMA chains), N = 1 and config 2 only
   cpu_baseline  the CPU oracle (oracle/: PyTorch-CPU restatement of the reference) on this box's host cores, bounded sample;
                 its scores are asserted equal to the GPU's on the same inputs
 """
@@ -59,6 +63,8 @@ W_LAYER = [720, 936, 1152, 1872, 1872]
 TP_FLOP = [2016, 2736, 3456, 5472, 5472]
 FUSED_BYTES = [408, 480, 552, 648, 648]                        # fused boundary, bytes per edge
 PEAK_F32_MFMA_TFLOPS = 157.3                                   # MI355X_MICROARCH.md
+PEAK_F16_MFMA_TFLOPS = 2500.0                                  # dense f16 / bf16 matrix peak (MI355X_MICROARCH.md; micro-benchmark ceiling 2382)
+MFMA_FLOP_PER_EDGE_TILE = (24 * 2 * 32 * 32 * 16 + 6 * 2 * 32 * 32 * 8) / 32      # k_conv_x.hip: 24 x 32x32x16 + 6 x 32x32x8 MFMAs per 32 edges and W2 tile (and per GEMM1)
 PEAK_HBM_GBS = 8000.0
 
 ARGS_S = Namespace(ns=24, nv=6, num_conv_layers=5, sigma_embed_dim=32, distance_embed_dim=32, cross_distance_embed_dim=32,
@@ -90,7 +96,7 @@ CONFIG_TEXT = {
 
 def pmc_traffic():
     """HBM bytes per fused-conv launch from the committed PMC passes of this same command (None if absent)."""
-    for name in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+    for name in ('r03_pmc_traffic.json',):
         try:
             return json.load(open(os.path.join(ROOT, 'profiles', name)))['traffic_bytes_per_launch'], name
         except Exception:
@@ -196,7 +202,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--config', type=int, default=2, choices=[2, 3, 4, 5])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-alt', action='store_true', help='skip the opt-in 3 x f16 measurement')
+    ap.add_argument('--no-alt', action='store_true', help='skip the measurement of the fallback fp32-MFMA kernel')
     ap.add_argument('--no-device-loop', action='store_true', help='skip the resident-loop comparison figure')
     ap.add_argument('--no-extras', action='store_true', help='skip the pruning-off and pocket-bound brackets')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl == RCCL; gloo for smoke tests)')
@@ -364,7 +370,7 @@ def main():
             elapsed = float(tmax.item())
         for p in final.values():
             assert bool(torch.isfinite(p).all()), 'non-finite pose'
-        return dict(elapsed=elapsed, prof=prof, fw=fw, per_call_ms=per_call_ms, final=final, confs=confs)
+        return dict(elapsed=elapsed, prof=prof, fw=fw, per_call_ms=per_call_ms, final=final, confs=confs, order=order[warmup:warmup + a.steps])
 
     layer_flop = [2 * 72 * (72 + W_LAYER[l]) + TP_FLOP[l] for l in range(5)]
 
@@ -376,7 +382,7 @@ def main():
         fw = r['fw']
         cross = fw[:, 3].reshape(-1, STEPS) / b_local if len(fw) and len(fw) % STEPS == 0 else None
         return {'value': n_units / r['elapsed'], 'unit': 'complexes/s', 'ms_per_step': 1e3 * r['elapsed'] / a.steps,
-                'edges_executed_over_unpruned': e_x / max(e_u, 1), 'conv_TFLOPs_executed': fl / max(conv_ms, 1e-9) / 1e9,
+                'edges_executed_over_unpruned': e_x / max(e_u, 1), 'conv_fp32_equivalent_TFLOPs': fl / max(conv_ms, 1e-9) / 1e9,
                 'conv_share_of_wall': conv_ms * 1e-3 / r['elapsed'],
                 'min_cross_edges_per_sample_over_steps': None if cross is None else float(cross.min())}
 
@@ -416,6 +422,22 @@ def main():
                                 'trained model do; the default workload starts from randomize_position (N(0, 19 A)) and random-init weights let the '
                                 'ligand wander')
 
+    # ---- host cost of ddk_complex_create (topology + staged uploads; the ESM projection and the receptor-edge terms run on the upload stream) ------
+    create_ms = None
+    if rank == 0 and not a.no_extras:
+        create_ms = {}
+        for nr in sorted({n_res, 300, 2000}):
+            cc = complexes[mine[0]] if nr == n_res else synthetic.make_complex(0, n_res=nr)
+            ts = []
+            for rep in range(6):
+                torch.cuda.synchronize()
+                t_c = time.perf_counter()
+                cxc = Complex(ctx, cc, b_local)
+                ts.append(time.perf_counter() - t_c)
+                torch.cuda.synchronize()
+                cxc.close()
+            create_ms[f'{nr}_residues'] = round(1e3 * float(np.median(ts[1:])), 3)
+
     # ---- comparison figure: the loop alone on resident complexes with pre-drawn noise (round 1's bracket) ----------------------
     device_loop = None
     if not a.no_device_loop and not disco:
@@ -439,6 +461,8 @@ def main():
         conv_ms = sum(p['ms'] for p in prof)
         fl = lambda key: sum(p[key] * layer_flop[l] for l, p in enumerate(prof))
         flops_exec, flops_unpruned, flops_full = fl('edges'), fl('edges_unpruned'), fl('edges_reference')
+        n_tiles = [len(ctx.export(f'conv.{l}.tiles', dtype=np.int32)) // 4 for l in range(5)]        # W2 tiles of 32 rows per layer (59 for W = 1872)
+        mfma_exec = sum(p['edges'] * MFMA_FLOP_PER_EDGE_TILE * (n_tiles[l] + 1) for l, p in enumerate(prof))
         byts = sum(p['edges'] * FUSED_BYTES[l] for l, p in enumerate(prof))
         launches = sum(p['launches'] for p in prof)
         tf = lambda f: f / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
@@ -449,39 +473,54 @@ def main():
             f3 = fw.reshape(a.steps, STEPS, 4)
             per_step = [{'step': s_, 't': round(float(t_arr[s_, 0]), 3), 'edges_executed_over_unpruned': float(f3[:, s_, 1].sum() / max(f3[:, s_, 2].sum(), 1)),
                          'conv_ms': float(f3[:, s_, 0].mean()), 'cross_edges_per_sample': float(f3[:, s_, 3].mean() / b_local)} for s_ in range(STEPS)]
+        # device time of the timed calls that ran the SAME complex (same ligand size, own noise): max / min - 1 over each complex' calls
+        by_cx = {}
+        for i, ms in zip(head['order'], head['per_call_ms']):
+            by_cx.setdefault(i, []).append(ms)
+        rep = [max(v) / min(v) - 1.0 for v in by_cx.values() if len(v) > 1]
+        per_call_spread = round(max(rep), 4) if rep else None
         out = {
             'metric': 'complexes/sec, 20-step 40-sample inference',
             'value': n_done / elapsed, 'unit': 'complexes/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True, 'scaling': 'strong' if big else 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
+            'dtype_note': 'every operand and accumulator of the path is fp32; the radial-MLP GEMMs multiply the fp32 operands exactly as three f16 limbs each on the f16 '
+                          'matrix pipe (six of nine limb products, dropped terms <= 3 * 2^-33 relative) with fp32 accumulation (DESIGN.md 3.3)',
             'config': {'workload': f'BASELINE config {cfg_id}: ' + CONFIG_TEXT[cfg_id] + '; 1 step = 1 complex',
                        'bracket': 'wall time around sampling(data_list, model, ...) on host data_lists, a new complex every call (evaluate.py:259,293): '
                                   'collation, ddk_complex_create, H2D, noise draws, the 20-step loop, pose write-back; K calls + one final synchronisation',
                        'samples_per_complex': SAMPLES, 'inference_steps': STEPS, 'complexes_per_gpu': n_cx,
                        'parallelism': (f'the {SAMPLES} samples of every complex sharded over {world} process(es) ({b_local} per GPU), final all_gather'
                                        if big else f'{world} process(es), one per GPU, each with the same {n_cx} complexes (own start poses and noise: per-GPU work fixed), final RCCL all_gather of the poses')},
-            'roofline': {'bound': 'mfma', 'kernel': 'ddk::conv_fused_kernel<true, 0>', 'achieved': tf(flops_exec), 'peak': PEAK_F32_MFMA_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': tf(flops_exec) / PEAK_F32_MFMA_TFLOPS,
-                         'accounting': 'achieved / frac: algorithmic FLOPs (2*72*(72+W) + TP per edge and layer, BASELINE.md section 3) of the edges the '
-                                       'launches EVALUATED / HIP-event time of the launches, against the fp32 MFMA peak; reference_equivalent_TFLOPs '
-                                       'additionally counts the receptor-receptor messages the backward receptive-field pruning proved dead (not a '
-                                       'roofline figure: no frac); full_reference_TFLOPs counts every edge of the reference graph in every layer',
+            'roofline': {'bound': 'mfma', 'kernel': 'ddk::conv_x3_kernel<true, true, false> (k_conv_x.hip: fp32 operands as three exact f16 limbs, six limb '
+                                                    'products on v_mfma_f32_32x32x16_f16, fp32 accumulators)',
+                         'achieved': tf(mfma_exec), 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf(mfma_exec) / PEAK_F16_MFMA_TFLOPS,
+                         'accounting': 'achieved / frac: MFMA FLOPs the launches EXECUTED (per evaluated edge and layer: (W2 tiles + 1 GEMM1) x (24 x 32x32x16 + 6 x '
+                                       '32x32x8 MFMAs per 32 edges) = six limb products, K padded 72 -> 80 in GEMM2, rows padded to 32-row tiles) / HIP-event time of the '
+                                       'launches, against the dense f16 matrix peak.  fp32_equivalent_TFLOPs: the ALGORITHMIC fp32 FLOPs of the same edges '
+                                       '(2*72*(72+W) + TP per edge and layer, BASELINE.md section 3) / the same time - what an fp32 kernel would have to sustain; '
+                                       'the fp32 MFMA peak is 157.3.  reference_equivalent_TFLOPs additionally counts the receptor-receptor messages the backward '
+                                       'receptive-field pruning proved dead (not a roofline figure: no frac); full_reference_TFLOPs every edge of the reference graph',
+                         'fp32_equivalent_TFLOPs': tf(flops_exec), 'fp32_mfma_peak_TFLOPs': PEAK_F32_MFMA_TFLOPS,
+                         'fp32_equivalent_over_fp32_mfma_peak': tf(flops_exec) / PEAK_F32_MFMA_TFLOPS,
                          'reference_equivalent_TFLOPs': tf(flops_unpruned), 'full_reference_TFLOPs': tf(flops_full),
                          'edges_executed_over_unpruned': sum(p['edges'] for p in prof) / max(sum(p['edges_unpruned'] for p in prof), 1),
                          'traffic': traffic,
                          'traffic_source': f'profiles/{traffic_file}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over this command, '
-                                           'bytes per conv_fused launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 FETCH correction)' if traffic_file else None,
+                                           'bytes per conv launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 FETCH correction)' if traffic_file else None,
                          'algorithmic_bytes_per_launch': byts / max(launches, 1),
                          'launches': launches, 'avg_launch_ms': conv_ms / max(launches, 1),
-                         'flop_per_launch': flops_exec / max(launches, 1),
+                         'flop_per_launch': mfma_exec / max(launches, 1), 'fp32_equivalent_flop_per_launch': flops_exec / max(launches, 1),
                          'algorithmic_hbm_GBps': byts / (conv_ms * 1e-3) / 1e9 if conv_ms > 0 else 0.0,
                          'algorithmic_hbm_frac_of_peak': (byts / (conv_ms * 1e-3) / 1e9) / PEAK_HBM_GBS if conv_ms > 0 else 0.0,
                          'conv_share_of_wall': conv_ms * 1e-3 / elapsed,
-                         'per_layer': [{'layer': l, 'ms_per_launch': p['ms'] / max(p['launches'], 1),
-                                        'TFLOPs': p['edges'] * layer_flop[l] / max(p['ms'], 1e-9) / 1e9,
+                         'per_layer': [{'layer': l, 'ms_per_launch': p['ms'] / max(p['launches'], 1), 'w2_tiles': n_tiles[l],
+                                        'mfma_TFLOPs': p['edges'] * MFMA_FLOP_PER_EDGE_TILE * (n_tiles[l] + 1) / max(p['ms'], 1e-9) / 1e9,
+                                        'fp32_equivalent_TFLOPs': p['edges'] * layer_flop[l] / max(p['ms'], 1e-9) / 1e9,
                                         'edges_executed_frac': p['edges'] / max(p['edges_unpruned'], 1)}
                                        for l, p in enumerate(prof)]},
-            'extra': {'pruning_off': pruning_off, 'pocket_bound': pocket_bound, 'per_step': per_step,
+            'extra': {'pruning_off': pruning_off, 'pocket_bound': pocket_bound, 'per_step': per_step, 'create_ms': create_ms,
+                      'per_call_spread_same_complex': per_call_spread,
                       'headline': {k: v for k, v in summary(head, n_done).items() if k != 'value'},
                       'device_loop': device_loop, 'per_call_ms': head['per_call_ms']},
         }
@@ -495,10 +534,9 @@ def main():
         else:
             out['cpu_baseline'] = None
         if world == 1 and cfg_id == 2 and not a.no_alt:
-            # opt-in mode ddk_config.conv_f16x3 (NOT the headline; VERDICT r01: alt_precision): resident loop with the radial-MLP GEMMs as an
-            # error-compensated 3 x f16 product on the f16 matrix pipe
+            # the stated fallback ddk_config.conv_kernel = 1 (radial-MLP GEMMs as fp32 MFMA chains, k_conv.hip): the same resident loop
             from disco_diffdock_amd.runtime import Context
-            ctx2 = Context(device=local, conv_f16x3=1)
+            ctx2 = Context(device=local, conv_kernel=1)
             ctx2.load_state_dict(P)
             cxs = {i: Complex(ctx2, complexes[i], SAMPLES) for i in mine}
             gen = torch.Generator(device=dev).manual_seed(1234)
@@ -512,9 +550,9 @@ def main():
                 cxs[order[k]].sample(p0[order[k]].clone(), t_arr, sc, nc, nz[order[k]])
             torch.cuda.synchronize()
             e2 = time.perf_counter() - t2
-            out['alt_precision'] = {'mode': 'conv_f16x3 (error-compensated 3 x f16 MFMA, f32 accumulation; opt-in, ddk_config.conv_f16x3 = 1), '
-                                            'resident-loop bracket (compare with extra.device_loop)',
-                                    'value': a.steps / e2, 'unit': 'complexes/s', 'ms_per_step': 1e3 * e2 / a.steps}
+            out['fallback_fp32_kernel'] = {'mode': 'ddk_config.conv_kernel = 1: v_mfma_f32_32x32x2_f32 chains (k_conv.hip), resident-loop bracket (compare with '
+                                                   'extra.device_loop)',
+                                           'value': a.steps / e2, 'unit': 'complexes/s', 'ms_per_step': 1e3 * e2 / a.steps}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

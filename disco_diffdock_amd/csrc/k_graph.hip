@@ -542,6 +542,48 @@ __global__ void node_embed_kernel(NodeEmbedArgs A) {
   A.x[i] = v;
 }
 
+// Static per-complex precompute on the upload stream (ddk_complex_create): the receptor's node embedding without its sigma columns,
+//   out[j] = W[:, :ns] . table[residue_j] + W[:, ns:ns+lm] . lm_features_j + b     (AtomEncoder, models/layers.py:140-149; 1336-wide at lm = 1280)
+// in the summation order and precision (fp64 accumulator, rounded to fp32 once) of the host loop it replaces; 8 residues x 24 outputs per block,
+// the 24 threads of a residue read the same feature, w_lm_t is [lm][ns] so their weights are contiguous.
+__global__ __launch_bounds__(8 * NS) void rec_node_static_kernel(RecStaticArgs A) {
+  const int o = threadIdx.x % NS, j = blockIdx.x * 8 + threadIdx.x / NS;
+  if (j >= A.n_rec) return;
+  const float* xr = A.rec_x + (size_t)j * A.feat_dim;
+  const float* emb = A.rec_table + (size_t)(int)xr[0] * NS;
+  double a = A.b[o];
+  for (int k = 0; k < NS; ++k) a += (double)A.w_emb[o * NS + k] * emb[k];
+  for (int k = 0; k < A.lm; ++k) a += (double)A.w_lm_t[(size_t)k * NS + o] * (double)xr[1 + k];
+  A.out[(size_t)j * NS + o] = (float)a;
+}
+
+// ... and the distance half of rec_edge_embedding.0 on the static receptor edges: pre1[k] = W1[:, dist] . gauss(|pos_b - pos_a|)
+// (score_model.py:327-344 + GaussianSmearing, tensor_layers.py:171-181), one thread per edge
+__global__ __launch_bounds__(128) void rec_edge_static_kernel(const int32_t* rr_src, const int32_t* rr_dst, const float* rec_pos, int E, EdgeMlpDev m,
+                                                              float* pre1) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= E) return;
+  const int a = rr_src[k], b = rr_dst[k];
+  const float vx = rec_pos[3 * b] - rec_pos[3 * a], vy = rec_pos[3 * b + 1] - rec_pos[3 * a + 1], vz = rec_pos[3 * b + 2] - rec_pos[3 * a + 2];
+  const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
+  float gs[DE];
+#pragma unroll
+  for (int q = 0; q < DE; ++q) { const float t = dist - m.offset[q]; gs[q] = expf(m.coeff * (t * t)); }
+  for (int o = 0; o < NS; ++o) {
+    float a2 = 0.0f;
+#pragma unroll
+    for (int q = 0; q < DE; ++q) a2 += m.w1d[o * DE + q] * gs[q];
+    pre1[(size_t)k * NS + o] = a2;
+  }
+}
+
+hipError_t launch_complex_static(const RecStaticArgs& R, const int32_t* rr_src, const int32_t* rr_dst, const float* rec_pos, int E, const EdgeMlpDev& m,
+                                 float* pre1, hipStream_t s) {
+  if (R.n_rec > 0) hipLaunchKernelGGL(rec_node_static_kernel, dim3((R.n_rec + 7) / 8), dim3(8 * NS), 0, s, R);
+  if (E > 0) hipLaunchKernelGGL(rec_edge_static_kernel, dim3((E + 127) / 128), dim3(128), 0, s, rr_src, rr_dst, rec_pos, E, m, pre1);
+  return hipGetLastError();
+}
+
 hipError_t launch_graph(const GraphArgs& G, int64_t edge_cap, hipStream_t s) {
   const size_t lds = (size_t)(MAX_LIG * 3 + G.n_rec * 3) * 4 + (size_t)G.n_rec * 4 + (((size_t)G.n_rec + 15) & ~(size_t)15);   // + the level bytes
   hipLaunchKernelGGL(graph_count_kernel, dim3(G.B), dim3(256), lds, s, G);

@@ -80,6 +80,8 @@ struct ModelDev {
   const float *tb_w0, *tb_b0, *tb_w4, *tb_b4;   // [72][72],[72],[288][72],[288]
   const float *tb_bn_scale, *tb_bn_mean, *tb_bn_bias;  // [48] (mean/bias non-zero only on the 0e half)
   const float *tf_w0, *tf_w3;                    // [NS][2NS], [NS]
+  // receptor AtomEncoder without its sigma columns (rec_node_static_kernel): table [38][ns], W[:, :ns], W[:, ns:ns+lm] transposed to [lm][ns], bias
+  const float *rec_table, *rec_w_emb, *rec_w_lm_t, *rec_b;
 };
 
 // AR latent model predictors (k_ar.hip); BatchNorm1d (eval) folded into the Linear in front of it
@@ -259,6 +261,10 @@ struct NodeEmbedArgs {
   const float *lig_latent, *rec_latent, *lig_w_lat, *rec_w_lat, *lig_unc, *rec_unc; float unconditional; int latent_dim;
 };
 hipError_t launch_node_embed(const NodeEmbedArgs& a, hipStream_t s);
+// static per-complex precompute on the device (ddk_complex_create, upload stream)
+struct RecStaticArgs { const float* rec_x; int n_rec, feat_dim, lm; const float *rec_table, *w_emb, *w_lm_t, *b; float* out; };
+hipError_t launch_complex_static(const RecStaticArgs& R, const int32_t* rr_src, const int32_t* rr_dst, const float* rec_pos, int E, const EdgeMlpDev& m,
+                                 float* pre1, hipStream_t s);
 hipError_t launch_heads_pre(const HeadArgs& A, bool torsion, hipStream_t s);
 hipError_t launch_heads_post(const HeadArgs& A, bool torsion, hipStream_t s);
 hipError_t launch_se3(const Se3Args& A, hipStream_t s);

@@ -75,6 +75,13 @@ int model_finalize(ddk_ctx* ctx) {
   GET(rb, "rec_node_embedding.additional_features_embedder.bias", NS);
   H.rec_table = rt->data; H.rec_w_emb = cols(rw, 0, NS); H.rec_w_esm = cols(rw, NS, NS + lm);
   H.rec_w_sig = cols(rw, NS + lm, NS + lm + SIG); H.rec_b = rb->data;
+  {
+    std::vector<float> w_lm_t((size_t)lm * NS);      // [lm][NS]: the 24 outputs of one feature are contiguous
+    for (int o = 0; o < NS; ++o)
+      for (int k = 0; k < lm; ++k) w_lm_t[(size_t)k * NS + o] = H.rec_w_esm[(size_t)o * lm + k];
+    D.rec_table = dev_upload(ctx, H.rec_table); D.rec_w_emb = dev_upload(ctx, H.rec_w_emb); D.rec_w_lm_t = dev_upload(ctx, w_lm_t); D.rec_b = dev_upload(ctx, H.rec_b);
+    if (!D.rec_table || !D.rec_w_emb || !D.rec_w_lm_t || !D.rec_b) return fail(ctx, DDK_ERR_NOMEM, "alloc");
+  }
   D.latent_dim = LD;
   D.lig_w_lat = D.rec_w_lat = D.lig_node_unc = D.rec_node_unc = nullptr;
   if (LD > 0) {
@@ -621,13 +628,14 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
   {   // one chunk for everything this function allocates (sizes below mirror the uploads / workspaces; 256 B of slack per array)
     const size_t E0 = (size_t)d->n_rec_edges, Bm0 = (size_t)max_batch, R0 = (size_t)(d->n_rot > 0 ? d->n_rot : 1);
     const size_t cap0 = Bm0 * ((size_t)M + (size_t)n_lig * (LIG_CAP - 1) + 2 * (size_t)n_lig * n_rec + E0) + E0 + 64, N0 = Bm0 * (size_t)(n_lig + n_rec);
-    size_t need = (size_t)M * 24 + R0 * 8 + R0 * n_lig + (size_t)n_rec * 12 + (size_t)(n_lig + n_rec) * NS * 4 + E0 * (8 + NS * 4 + 16) + (size_t)n_rec * 4;
+    size_t need = (size_t)M * 24 + R0 * 8 + R0 * n_lig + (size_t)n_rec * 12 + (size_t)(n_lig + n_rec) * NS * 4 + E0 * (8 + NS * 4 + 16) + (size_t)n_rec * 4 +
+                  (size_t)n_rec * d->rec_feat_dim * 4;
     need += cap0 * (12 + NS * 4 + 16) + N0 * 4 + N0 * PRE_W * 4 + (c.deterministic ? N0 * XW * 4 + (cap0 / 32 + 128) * 2 * XW * 4 : 0) + Bm0 * ((size_t)n_lig + R0 * BOND_CAP + 2) * (8 + NE * 4 + 16) + Bm0 * (1 + R0) * (XW * 4 + 4) + 8 * 256 + Bm0 * 2 * CNT_STRIDE * 4 + INFO_INTS * 4 + (size_t)n_rec * 4 + Bm0 * n_rec + 3 * N0 * XW * 4 + (size_t)n_rec * XW * 4 + Bm0 * n_lig * 12 + 2 * Bm0 * (6 + R0) * 4;
     if (c.latent_dim > 0) need += N0 * c.latent_dim * 4 + Bm0 * E0 * (12 + NS * 4 + 16) + Bm0 * n_rec + (Bm0 + 1) * 4 + 3 * 256;
     cx_reserve(cx, need + 64 * 256);
     // everything uploaded below (topology, static embeddings, receptor-edge geometry) goes through one pinned staging buffer
-    const size_t staged = (size_t)M * 24 + R0 * 8 + R0 * n_lig + (size_t)n_rec * 12 + (size_t)(n_lig + n_rec) * NS * 4 + E0 * (8 + NS * 4 + 16) +
-                          (size_t)n_rec * 8 + 24 * 256;
+    const size_t staged = (size_t)M * 24 + R0 * 8 + R0 * n_lig + (size_t)n_rec * 12 + (size_t)n_lig * NS * 4 + E0 * (8 + 16) +
+                          (size_t)n_rec * 8 + (size_t)n_rec * d->rec_feat_dim * 4 + 24 * 256;
     int rc0 = cx_stage_begin(ctx, cx, staged);
     if (rc0) return rc0;
   }
@@ -650,7 +658,7 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
   cx->mask_rotate = cx_upload(cx, d->mask_rotate, (size_t)d->n_rot * n_lig);
   cx->rec_pos = cx_upload(cx, d->rec_pos, (size_t)n_rec * 3);
   // ---- static node embeddings (AtomEncoder without its sigma columns, models/layers.py:140-149) ----
-  std::vector<float> ls((size_t)n_lig * NS), rs((size_t)n_rec * NS);
+  std::vector<float> ls((size_t)n_lig * NS);
   for (int i = 0; has_model && i < n_lig; ++i) {
     float emb[NS] = {0};
     for (int f = 0; f < 16; ++f) {
@@ -665,36 +673,18 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
       ls[(size_t)i * NS + o] = (float)a;
     }
   }
-  std::vector<float> w_esm_t((size_t)lm * NS);      // [lm][NS]: the 24 outputs of one feature are contiguous -> the inner loop vectorises
-  for (int o = 0; has_model && o < NS; ++o)
-    for (int k = 0; k < lm; ++k) w_esm_t[(size_t)k * NS + o] = H.rec_w_esm[(size_t)o * lm + k];
   for (int j = 0; has_model && j < n_rec; ++j) {
     const int res = (int)d->rec_x[(size_t)j * d->rec_feat_dim];
     if (res < 0 || res >= REC_DIM) return fail(ctx, DDK_ERR_INVALID, "residue id out of range");
   }
-  host_parallel_for(has_model ? n_rec : 0, [&](int j) {
-    const float* xr = d->rec_x + (size_t)j * d->rec_feat_dim;
-    const int res = (int)xr[0];
-    const float* emb = H.rec_table.data() + (size_t)res * NS;
-    double acc[NS];
-    for (int o = 0; o < NS; ++o) {
-      double a = H.rec_b[o];
-      for (int k = 0; k < NS; ++k) a += (double)H.rec_w_emb[(size_t)o * NS + k] * emb[k];
-      acc[o] = a;
-    }
-    for (int k = 0; k < lm; ++k) {
-      const double xk = xr[1 + k];
-      const float* w = w_esm_t.data() + (size_t)k * NS;
-      for (int o = 0; o < NS; ++o) acc[o] += (double)w[o] * xk;
-    }
-    for (int o = 0; o < NS; ++o) rs[(size_t)j * NS + o] = (float)acc[o];
-  });
+  // the receptor's language-model features go up as they are; the 1336-wide projection runs on the upload stream (rec_node_static_kernel)
+  float* rec_x_dev = has_model ? cx_upload(cx, d->rec_x, (size_t)n_rec * d->rec_feat_dim) : nullptr;
   cx->lig_node_static = cx_upload(cx, ls.data(), ls.size());
-  cx->rec_node_static = cx_upload(cx, rs.data(), rs.size());
+  cx->rec_node_static = cx_upload<float>(cx, nullptr, (size_t)n_rec * NS);
   // ---- static receptor edges: geometry, SH and the distance half of rec_edge_embedding.0 --------
   const int E = d->n_rec_edges;
   std::vector<int32_t> outdeg(n_rec, 0);
-  std::vector<float> pre1((size_t)E * NS), sh((size_t)E * 4);
+  std::vector<float> sh((size_t)E * 4);
   for (int k = 0; k < E; ++k) {
     const int a = d->rec_edge_index[k], b = d->rec_edge_index[E + k];
     if (a < 0 || a >= n_rec || b < 0 || b >= n_rec) return fail(ctx, DDK_ERR_INVALID, "receptor edge index out of range");
@@ -706,19 +696,6 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
     const float inv = 1.7320508075688772f / fmaxf(dist, 1e-12f);
     sh[4 * (size_t)k] = 1.0f; sh[4 * (size_t)k + 1] = vx * inv; sh[4 * (size_t)k + 2] = vy * inv; sh[4 * (size_t)k + 3] = vz * inv;
   }
-  host_parallel_for(has_model ? E : 0, [&](int k) {      // W1[:, dist] . gauss(d): 32 exp + 768 MAC per edge, 48 k edges at 2000 residues
-    const int a = d->rec_edge_index[k], b = d->rec_edge_index[E + k];
-    const float vx = d->rec_pos[3 * b] - d->rec_pos[3 * a], vy = d->rec_pos[3 * b + 1] - d->rec_pos[3 * a + 1],
-                vz = d->rec_pos[3 * b + 2] - d->rec_pos[3 * a + 2];
-    const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
-    float gs[DE];
-    for (int q = 0; q < DE; ++q) { const float t = dist - H.rec_offset[q]; gs[q] = expf(H.rec_coeff * (t * t)); }
-    for (int o = 0; o < NS; ++o) {
-      float a2 = 0.0f;
-      for (int q = 0; q < DE; ++q) a2 += H.re_w1d[(size_t)o * DE + q] * gs[q];
-      pre1[(size_t)k * NS + o] = a2;
-    }
-  });
   cx->h_rr.assign(d->rec_edge_index, d->rec_edge_index + 2 * (size_t)E);
   cx->h_rec_pos.assign(d->rec_pos, d->rec_pos + 3 * (size_t)n_rec);
   cx->rr_src = cx_upload(cx, d->rec_edge_index, (size_t)E);
@@ -727,7 +704,7 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
   std::vector<int32_t> rstart(n_rec, 0);
   for (int j = 1; j < n_rec; ++j) rstart[j] = rstart[j - 1] + outdeg[j - 1];
   cx->rr_start = cx_upload(cx, rstart.data(), rstart.size());
-  cx->rr_pre1 = cx_upload(cx, pre1.data(), pre1.size());
+  cx->rr_pre1 = cx_upload<float>(cx, nullptr, (size_t)E * NS);      // filled by rec_edge_static_kernel behind the uploads
   cx->rr_sh = cx_upload(cx, sh.data(), sh.size());
   // ---- workspaces -------------------------------------------------------------------------------
   const int64_t Bm = max_batch;
@@ -784,7 +761,18 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
     hipMemsetAsync(cx->sum_rr0, 0, (size_t)n_rec * XW * sizeof(float), ctx->up_stream);
     cx->sum_clean = true;
   }
-  return cx_stage_flush(ctx, cx);   // the copies are in flight on the upload stream; every launch entry point waits for cx->ready
+  int rcf = cx_stage_flush(ctx, cx);   // the copies are in flight on the upload stream; every launch entry point waits for cx->ready
+  if (rcf || !has_model) return rcf;
+  {   // static precompute behind the copies, on the upload stream; `ready` moves behind it
+    const ModelDev& MD = ((Model*)ctx->model)->dev;
+    RecStaticArgs RS;
+    RS.rec_x = rec_x_dev; RS.n_rec = n_rec; RS.feat_dim = d->rec_feat_dim; RS.lm = lm; RS.rec_table = MD.rec_table; RS.w_emb = MD.rec_w_emb; RS.w_lm_t = MD.rec_w_lm_t;
+    RS.b = MD.rec_b; RS.out = cx->rec_node_static;
+    hipError_t e = launch_complex_static(RS, cx->rr_src, cx->rr_dst, cx->rec_pos, E, MD.rec_edge, cx->rr_pre1, ctx->up_stream);
+    if (e == hipSuccess) e = hipEventRecord(cx->ready, ctx->up_stream);
+    if (e != hipSuccess) return hip_fail(ctx, e, "static precompute");
+  }
+  return DDK_OK;
 }
 
 void ddk_complex_destroy(ddk_ctx* ctx, ddk_complex* cx) {

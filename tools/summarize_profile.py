@@ -6,7 +6,7 @@ from collections import defaultdict
 
 src, out = sys.argv[1], sys.argv[2]
 os.makedirs(out, exist_ok=True)
-KERNEL = 'conv_fused_kernel<true, 0, true'      # the score model's conv layers (the two head launches are conv_fused_kernel<false, ...>)
+KERNEL = 'conv_x3_kernel<true, true, false'      # the score model's conv layers (the two head launches are conv_x3_kernel<false, ...>)
 
 
 def find(d, suffix):
@@ -26,12 +26,12 @@ for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
     lines.append(f'| {k[:92]} | {len(v)} | {sum(v) / 1e3:.2f} | {sum(v) / len(v):.1f} | {min(v):.1f} | {max(v):.1f} | {100 * sum(v) / tot:.1f} |')
 conv = [v for k, v in agg.items() if KERNEL in k]
 conv = conv[0] if conv else []
-head = (f'# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-alt --no-device-loop (MI355X)\n\n'
+head = (f'# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-alt --no-device-loop --no-extras (MI355X)\n\n'
         f'{len(conv)} fused TP-conv launches, average {sum(conv) / max(len(conv), 1):.1f} us.\n\n')
 open(os.path.join(out, 'kernel_stats.md'), 'w').write(head + '\n'.join(lines) + '\n')
 
 # ---- counters
-res = {'command': 'rocprofv3 --kernel-trace --pmc <group> (one group per pass) -- python bench.py --no-cpu-baseline --no-alt --no-device-loop',
+res = {'command': 'rocprofv3 --kernel-trace --pmc <group> (one group per pass) -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-alt --no-device-loop --no-extras',
        'kernel': 'ddk::' + KERNEL + ', false>', 'avg_launch_us_kernel_trace': sum(conv) / max(len(conv), 1)}
 for d in sorted(glob.glob(os.path.join(src, 'pmc*'))):
     if not os.path.isdir(d):

@@ -97,6 +97,43 @@ __device__ __forceinline__ Frag16 lds_frag16(const char* stage, int s, int lane)
   return f;
 }
 
+// Segmented inclusive scan over runs of equal edge_src with the step masks as 0 / 1 FLOATS: every Hillis-Steele step is one
+// v_fmac_f32 whose first source is the DPP-shifted value (x += shr(x) * m), a third of the mov / select / add form of k_conv_common.h;
+// the masks cost five VGPRs, which this kernel has and the fp32 kernel has not.
+struct SegF { float m1, m2, m4, m8, m16; bool tail, valid; };
+__device__ __forceinline__ SegF make_segf(const SegCtl& c) {
+  SegF f;
+  f.m1 = c.m1 ? 1.0f : 0.0f; f.m2 = c.m2 ? 1.0f : 0.0f; f.m4 = c.m4 ? 1.0f : 0.0f; f.m8 = c.m8 ? 1.0f : 0.0f; f.m16 = c.m16 ? 1.0f : 0.0f;
+  f.tail = c.tail; f.valid = c.valid;
+  return f;
+}
+// one scan step of N interleaved channels: x += dpp(x) * m as ONE v_fmac_f32 with the DPP modifier on its first source (the compiler keeps a
+// v_mov_b32_dpp in front of an fma).  A VALU result needs two wait states before a DPP read of it: the other channels' instructions provide
+// them for N >= 3, a lone channel gets an s_nop.
+#define SEGF_STEP(CTRL, m)                                                                                                  \
+  _Pragma("unroll") for (int i = 0; i < N; ++i) {                                                                           \
+    if (N >= 3) asm volatile("v_fmac_f32_dpp %0, %0, %1 " CTRL " bound_ctrl:1" : "+v"(xv[i]) : "v"(m));                     \
+    else asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 " CTRL " bound_ctrl:1" : "+v"(xv[i]) : "v"(m));                 \
+  }
+template <bool DET, int N>
+__device__ __forceinline__ void segf_add_n(float* dst, int stride, float (&xv)[N], const SegF& c) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) xv[i] = c.valid ? xv[i] : 0.0f;
+  SEGF_STEP("row_shr:1 row_mask:0xf bank_mask:0xf", c.m1)
+  SEGF_STEP("row_shr:2 row_mask:0xf bank_mask:0xf", c.m2)
+  SEGF_STEP("row_shr:4 row_mask:0xf bank_mask:0xf", c.m4)
+  SEGF_STEP("row_shr:8 row_mask:0xf bank_mask:0xf", c.m8)
+  SEGF_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf", c.m16)      // lane 15 of rows 0 / 2 into rows 1 / 3
+  if (c.tail) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      if (DET) dst[i * stride] = xv[i];
+      else unsafeAtomicAdd(dst + i * stride, xv[i]);
+    }
+  }
+}
+#undef SEGF_STEP
+
 // six-term product of one K step into the three accumulators (same-accumulator MFMAs never adjacent)
 #define X3_STEP(MF, ah, am, al, bh, bm, bl)   \
   D2 = MF(ah, bl, D2);                        \
@@ -237,7 +274,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
     }
 
     // ---- segmented-scan control words (identical for every output channel of this wave's 32 edges) ----
-    const SegCtl seg = make_segctl(sn, el, nvalid, valid);
+    const SegF seg = make_segf(make_segctl(sn, el, nvalid, valid));
     stamp(5);
 
     // ---- the F row's inputs (x[dst] row, sh), requested here so that their latency runs under GEMM1 ----
@@ -533,18 +570,19 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
           float m4[4];
 #pragma unroll
           for (int rq = 0; rq < 4; ++rq) m4[rq] = osc * fmaf(accA[rq], s0, accV[rq][0]);
-          seg_add_n<DET, 4>(node_row + chan0 + hh, 2, m4, seg);
+          segf_add_n<DET, 4>(node_row + chan0 + hh, 2, m4, seg);
         }
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
           if (rq < nrq && !(fl == FL_S && nrq == 4)) {
             if (fl == FL_S) {
-              seg_add<DET>(node_row + chan0 + 2 * rq + hh, osc * fmaf(accA[rq], s0, accV[rq][0]), seg);
+              float m1v[1] = {osc * fmaf(accA[rq], s0, accV[rq][0])};
+              segf_add_n<DET, 1>(node_row + chan0 + 2 * rq + hh, 1, m1v, seg);
             } else {
               float* d = node_row + chan0 + 3 * (2 * rq + hh);
               const float sa = accA[rq];
               float m3[3] = {osc * fmaf(sa, vx, accV[rq][0]), osc * fmaf(sa, vy, accV[rq][1]), osc * fmaf(sa, vz, accV[rq][2])};
-              seg_add_n<DET, 3>(d, 1, m3, seg);
+              segf_add_n<DET, 3>(d, 1, m3, seg);
             }
           }
           accA[rq] = 0.0f; accV[rq][0] = 0.0f; accV[rq][1] = 0.0f; accV[rq][2] = 0.0f;

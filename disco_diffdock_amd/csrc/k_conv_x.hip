@@ -70,6 +70,16 @@ struct Limbs {
   f16x8 hi[4], mid[4], lo[4];
   f16x4 thi, tmid, tlo;
 };
+// The K = 8 tail step costs the matrix pipe as much as a K = 16 step, and four of its six limb products come in pairs on the same accumulator:
+// hi.mid + mid.hi and hi.lo + lo.hi each fit ONE 32x32x16 MFMA on concatenated operands ({W_hi, W_mid} x {h_mid, h_hi}, {W_lo, W_hi} x {h_hi, h_lo}),
+// so the tail is 4 MFMAs instead of 6 (28 per tile).  B-side operands of those two, built once per unit:
+struct TailB { f16x8 mh, hl; };      // {h_mid, h_hi}, {h_hi, h_lo} of the 4-value tail
+__device__ __forceinline__ TailB make_tailb(const Limbs& L) {
+  TailB t;
+  t.mh = __builtin_shufflevector(L.tmid, L.thi, 0, 1, 2, 3, 4, 5, 6, 7);
+  t.hl = __builtin_shufflevector(L.thi, L.tlo, 0, 1, 2, 3, 4, 5, 6, 7);
+  return t;
+}
 
 __device__ __forceinline__ void make_limbs(Limbs& L, const float (&v)[36], float scale) {
 #pragma unroll
@@ -215,6 +225,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
   constexpr int REC16 = W2X_TILE_BYTES / 16;                   // 873 x 16 B per tile record
   const bool second = tid < REC16 - 64 * WAVES;                 // prologue: threads that move a second 16 B of the record
   const int grp = wave >> 2;                                    // half-group: 0 = waves 0-3 (A), 1 = waves 4-7 (B, their SIMD partners)
+  if (grp) __builtin_amdgcn_s_setprio(1);                       // the later-dispatched half loses every issue arbitration by age: static priority evens it out
   const int ftid = tid & 255;                                   // group B fills the ring: 16-B chunks ftid + 256 k, k < 3, and a fourth below
   const bool fourth = ftid < REC16 - 3 * 256;
   const uint32_t fo0 = 16u * ftid, fo3 = fourth ? fo0 + 12288u : fo0;      // byte offsets of this thread's chunks inside a tile record
@@ -291,6 +302,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
 
     // ---- GEMM1: h = relu(W1 [edge_emb | x_src[:ns] | x_dst[:ns]] + b1), K order kappa(s,hh) = 24*(s/12)+12*hh+s%12, three-limb product ----
     Limbs H;
+    TailB HT;
     float osc, bsc2;      // GEMM2 accumulators hold (s2 h) x (w2s W2): bias goes in times bsc2, flushed sums come out times osc
     {
       float h[36];
@@ -430,6 +442,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
       const float s2 = range_scale(m2, inv2);
       stamp(6);
       make_limbs(H, h, s2);
+      HT = make_tailb(H);
       bsc2 = s2 * A.w2s[gw];
       osc = inv2 * A.w2u[gw];
     }
@@ -527,7 +540,13 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
       X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x020) X3_PAIR(0x020) X3_PAIR(0x020) X3_PAIR(0x020)
       __builtin_amdgcn_sched_barrier(0);
       X3_STEP(MFMA16, q3.h, q3.m, q3.l, H.hi[3], H.mid[3], H.lo[3])
-      X3_STEP(MFMA8, th, tm, tl, H.thi, H.tmid, H.tlo)
+      {     // packed tail: D1 += hi.mid + mid.hi, D2 += lo.hi + hi.lo as one K = 16 MFMA each; mid.mid and hi.hi stay K = 8
+        const f16x8 a_hm = __builtin_shufflevector(th, tm, 0, 1, 2, 3, 4, 5, 6, 7), a_lh = __builtin_shufflevector(tl, th, 0, 1, 2, 3, 4, 5, 6, 7);
+        D2 = MFMA16(a_lh, HT.hl, D2);
+        D1 = MFMA16(a_hm, HT.mh, D1);
+        D0 = MFMA8(th, H.thi, D0);
+        D2 = MFMA8(tm, H.tmid, D2);
+      }
       __builtin_amdgcn_sched_barrier(0);
 #undef X3_PAIR
       Bs[0] = bs0.x; Bs[1] = bs0.y; Bs[2] = bs0.z; Bs[3] = bs0.w; Bs[4] = bs1.x; Bs[5] = bs1.y; Bs[6] = bs1.z; Bs[7] = bs1.w;

@@ -64,7 +64,7 @@ TP_FLOP = [2016, 2736, 3456, 5472, 5472]
 FUSED_BYTES = [408, 480, 552, 648, 648]                        # fused boundary, bytes per edge
 PEAK_F32_MFMA_TFLOPS = 157.3                                   # MI355X_MICROARCH.md
 PEAK_F16_MFMA_TFLOPS = 2500.0                                  # dense f16 / bf16 matrix peak (MI355X_MICROARCH.md; micro-benchmark ceiling 2382)
-MFMA_FLOP_PER_EDGE_TILE = (24 * 2 * 32 * 32 * 16 + 6 * 2 * 32 * 32 * 8) / 32      # k_conv_x.hip: 24 x 32x32x16 + 6 x 32x32x8 MFMAs per 32 edges and W2 tile (and per GEMM1)
+MFMA_FLOP_PER_EDGE_TILE = (24 * 2 * 32 * 32 * 16 + 6 * 2 * 32 * 32 * 8) / 32      # k_conv_x.hip: 432 K-columns of 32x32 limb products per 32 edges and W2 tile (26 x 32x32x16 + 2 x 32x32x8 with the packed tail; 24 + 6 unpacked; the same count per GEMM1)
 PEAK_HBM_GBS = 8000.0
 
 ARGS_S = Namespace(ns=24, nv=6, num_conv_layers=5, sigma_embed_dim=32, distance_embed_dim=32, cross_distance_embed_dim=32,
@@ -495,8 +495,8 @@ def main():
             'roofline': {'bound': 'mfma', 'kernel': 'ddk::conv_x3_kernel<true, true, false> (k_conv_x.hip: fp32 operands as three exact f16 limbs, six limb '
                                                     'products on v_mfma_f32_32x32x16_f16, fp32 accumulators)',
                          'achieved': tf(mfma_exec), 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf(mfma_exec) / PEAK_F16_MFMA_TFLOPS,
-                         'accounting': 'achieved / frac: MFMA FLOPs the launches EXECUTED (per evaluated edge and layer: (W2 tiles + 1 GEMM1) x (24 x 32x32x16 + 6 x '
-                                       '32x32x8 MFMAs per 32 edges) = six limb products, K padded 72 -> 80 in GEMM2, rows padded to 32-row tiles) / HIP-event time of the '
+                         'accounting': 'achieved / frac: MFMA FLOPs the launches EXECUTED (per evaluated edge and layer: (W2 tiles + 1 GEMM1) x (432 K-columns of 32x32 f16 MFMA = 24 x 32x32x16 + 6 x '
+                                       '32x32x8 unpacked, per 32 edges) = six limb products of K = 72, rows padded to 32-row tiles) / HIP-event time of the '
                                        'launches, against the dense f16 matrix peak.  fp32_equivalent_TFLOPs: the ALGORITHMIC fp32 FLOPs of the same edges '
                                        '(2*72*(72+W) + TP per edge and layer, BASELINE.md section 3) / the same time - what an fp32 kernel would have to sustain; '
                                        'the fp32 MFMA peak is 157.3.  reference_equivalent_TFLOPs additionally counts the receptor-receptor messages the backward '

@@ -22,7 +22,7 @@
 // [4 x 1 KB fragments | 512 B tail fragment] | bias [2][16] f32; the tile descriptors ride in the kernel arguments (scalar loads).
 // The fragments are streamed from the ring INSIDE the burst (no register double buffer: h's three limbs need the registers).
 //
-// Two waves share a SIMD and with it ONE matrix pipe; a wave's tile is a burst of 30 MFMAs (960 pipe cycles) followed by a VALU / LDS
+// Two waves share a SIMD and with it ONE matrix pipe; a wave's tile is a burst of 28 MFMAs (896 pipe cycles; the K=8 tail packs two products per 32x32x16) followed by a VALU / LDS
 // epilogue.  Run in lock step (one barrier per tile) both waves of a SIMD burst together and then leave the pipe idle together.  So the
 // workgroup runs as two half-groups in STRICT ALTERNATION: waves 0-3 (group A, one per SIMD) burst tile t while waves 4-7 (group B, their SIMD
 // partners) run the epilogue of tile t-1, then the roles swap - two barriers per tile, every half phase pairs one wave's MFMA burst with its
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
       const int t1 = min(t + 1, t_end - 1);
       const char* stage = ring + ((t - t_begin) & 1) * W2X_TILE_BYTES;
       stamp(0);
-      // ================= burst: 30 MFMAs, everything else of this half phase threaded between them =================
+      // ================= burst: 28 MFMAs, everything else of this half phase threaded between them =================
       // Issue order, pinned region by region (one K step each): the first MFMA goes out right behind the barrier (its operands were fetched
       // before it) and every other instruction of this half phase rides in the shadow of an MFMA, one per MFMA: the LDS reads of the
       // fragments two steps ahead, the epilogue's operands (feature rows, bias), and the next ring record - BOTH groups request their

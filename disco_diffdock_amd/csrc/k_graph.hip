@@ -31,14 +31,19 @@ __device__ __forceinline__ float dist2(const float* a, const float* b) {
 // adjacency of the capped radius graph: bit (i, j) set <=> j is among the first LIG_CAP (incl. self) atoms within
 // lig_max_radius of centre i, j != i  (radius_graph -> edge (src=j, dst=i), score_model.py:315)
 __device__ void build_lig_adj(const float* lp, int n_lig, float r2, unsigned (*adj)[MAX_LIG / 32]) {
-  for (int i = threadIdx.x; i < n_lig; i += blockDim.x) {
+  // one wave per centre, lane = candidate: the cap keeps the first LIG_CAP candidates (ascending index, self included) inside the radius, i.e. a
+  // candidate survives when fewer than LIG_CAP in-radius candidates precede it - a ballot and a prefix popcount instead of a serial walk
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int i = wave; i < n_lig; i += nw) {
     int cnt = 0;
-    for (int w = 0; w < MAX_LIG / 32; ++w) adj[i][w] = 0u;
-    for (int j = 0; j < n_lig && cnt < LIG_CAP; ++j) {
-      if (dist2(lp + 3 * i, lp + 3 * j) < r2) {
-        ++cnt;
-        if (j != i) adj[i][j >> 5] |= 1u << (j & 31);
-      }
+    for (int j0 = 0; j0 < MAX_LIG; j0 += 64) {
+      const int j = j0 + lane;
+      const bool in = j0 < n_lig && j < n_lig && dist2(lp + 3 * i, lp + 3 * j) < r2;
+      const unsigned long long m = __ballot(in);
+      const bool keep = in && cnt + __popcll(m & ((1ull << lane) - 1ull)) < LIG_CAP && j != i;
+      const unsigned long long kept = __ballot(keep);
+      if (lane == 0) { adj[i][j0 >> 5] = (unsigned)kept; adj[i][(j0 >> 5) + 1] = (unsigned)(kept >> 32); }
+      cnt += __popcll(m);
     }
   }
 }
@@ -316,9 +321,21 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(GraphArgs G) {
   __shared__ int bdeg[MAX_LIG], odeg[MAX_LIG], c_lr[MAX_LIG], ll_pre[MAX_LIG], lr_pre[MAX_LIG], scan_tmp[8], lvl_tmp[4][4], lvl_tot[4];
   // FILL_SLICES workgroups per sample: each repeats the (cheap) counting / prefix phase and writes one slice of the edge list --
   // one workgroup per sample left 216 CUs idle while 256 threads issued ~300 scattered stores each
+  constexpr int BOND_LDS = 1024;                    // directed bonds staged in LDS for slice 0's bond-ordered walk (more: read from global)
+  __shared__ short2 bond_sd[BOND_LDS];
   const int b = blockIdx.x, slice = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (G.info[I_OVF]) return;   // capacity overflow: reported by the host wrapper
   const int n_lig = G.n_lig, n_rec = G.n_rec;
+  // the scan kernel's results, requested here: their latency runs under the counting phase
+  const int g1 = G.info[I_GO + 1], g3 = G.info[I_GO + 3];
+  const int32_t* offs = G.offs + CNT_STRIDE * b;
+  const int off0 = offs[0], off1 = offs[1];
+  int segoff[4];                                    // level segment start + this sample's offset inside it (group 2)
+#pragma unroll
+  for (int l = 0; l < 4; ++l) segoff[l] = G.info[I_SEG + l] + offs[2 + l];
+  const bool bonds_in_lds = G.M <= BOND_LDS;
+  if (slice == 0 && bonds_in_lds)
+    for (int m = tid; m < G.M; m += 256) bond_sd[m] = make_short2((short)G.bond_src[m], (short)G.bond_dst[m]);
   __shared__ float lps[MAX_LIG * 3];             // ligand coordinates / cross cutoff
   for (int i = tid; i < n_lig * 3; i += 256) { const float v = G.lig_pos[(size_t)b * n_lig * 3 + i]; lp[i] = v; lps[i] = v / G.cross_cutoff; }
   for (int i = tid; i < n_rec * 3; i += 256) rp[i] = G.rec_pos[i] / G.cross_cutoff;      // only the cross test reads the residues here
@@ -366,15 +383,20 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(GraphArgs G) {
     }
   }
   block_exclusive_scan(c_rl, n_rec, scan_tmp);   // exclusive prefix of the per-residue rec->lig counts (in place; ends with a barrier)
-  const int g1 = G.info[I_GO + 1], g3 = G.info[I_GO + 3];
-  const int32_t* offs = G.offs + CNT_STRIDE * b;
   // ---- group 0: lig-lig, sorted by src: bonds of the atom (bond order) then radius edges (ascending dst)
   for (int j = tid; slice == 0 && j < n_lig; j += 256) {
-    int pos = offs[0] + ll_pre[j];
-    for (int m = 0; m < G.M; ++m)
-      if (G.bond_src[m] == j) {
-        G.e_src[pos] = lig0 + j; G.e_dst[pos] = lig0 + G.bond_dst[m]; G.e_aux[pos] = m; ++pos;
+    int pos = off0 + ll_pre[j];
+    if (bonds_in_lds) {
+      for (int m = 0; m < G.M; ++m) {
+        const short2 sd = bond_sd[m];
+        if (sd.x == j) { G.e_src[pos] = lig0 + j; G.e_dst[pos] = lig0 + sd.y; G.e_aux[pos] = m; ++pos; }
       }
+    } else {
+      for (int m = 0; m < G.M; ++m)
+        if (G.bond_src[m] == j) {
+          G.e_src[pos] = lig0 + j; G.e_dst[pos] = lig0 + G.bond_dst[m]; G.e_aux[pos] = m; ++pos;
+        }
+    }
     for (int i = 0; i < n_lig; ++i)
       if ((adj[i][j >> 5] >> (j & 31)) & 1u) {
         G.e_src[pos] = lig0 + j; G.e_dst[pos] = lig0 + i; G.e_aux[pos] = -1; ++pos;
@@ -382,7 +404,7 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(GraphArgs G) {
   }
   // ---- group 1: lig->rec, sorted by ligand atom then residue: one wave per ligand atom, ballot compaction
   for (int i = wave + 4 * slice; i < n_lig; i += 4 * FILL_SLICES) {
-    int pos = g1 + offs[1] + lr_pre[i];
+    int pos = g1 + off1 + lr_pre[i];
     for (int j0 = 0; j0 < n_rec; j0 += 64) {
       const int j = j0 + lane;
       const bool in = j < n_rec && cross_within_scaled(lps + 3 * i, rp + 3 * j);
@@ -396,7 +418,7 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(GraphArgs G) {
   }
   // ---- group 3: rec->lig (flipped cross edges), sorted by residue then ligand atom
   for (int j = tid + 256 * slice; j < n_rec; j += 256 * FILL_SLICES) {
-    int pos = g3 + offs[1] + c_rl[j];
+    int pos = g3 + off1 + c_rl[j];
     for (int i = 0; i < n_lig; ++i)
       if (cross_within_scaled(lps + 3 * i, rp + 3 * j)) {
         G.e_src[pos] = rec0 + j; G.e_dst[pos] = lig0 + i; G.e_aux[pos] = -1; ++pos;
@@ -407,10 +429,26 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(GraphArgs G) {
   // residue j: segment start + edges of this level in the samples before + in the residues before + rank among j's edges.
   __syncthreads();                                  // group 3 has consumed c_rl: reuse it for the per-level prefix
   level_scan(lvl, G.rr_outdeg, n_rec, c_rl, lvl_tmp, lvl_tot);
-  for (int k = tid + 256 * slice; k < G.E_rr; k += 256 * FILL_SLICES) {
-    const int j = G.rr_src[k], l = lvl[j];
-    const int pos = G.info[I_SEG + l] + offs[2 + l] + c_rl[j] + (k - G.rr_start[j]);
-    G.e_src[pos] = rec0 + j; G.e_dst[pos] = rec0 + G.rr_dst[k]; G.e_aux[pos] = k;
+  {
+    constexpr int U = 8;                              // the index loads of U edges in flight (two dependent L2 round trips per batch instead of per edge)
+    for (int k0 = tid + 256 * slice; k0 < G.E_rr; k0 += 256 * FILL_SLICES * U) {
+      int j[U], d[U], st[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = k0 + 256 * FILL_SLICES * u;
+        j[u] = k < G.E_rr ? G.rr_src[k] : -1;
+        d[u] = k < G.E_rr ? G.rr_dst[k] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) st[u] = j[u] >= 0 ? G.rr_start[j[u]] : 0;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (j[u] < 0) continue;
+        const int k = k0 + 256 * FILL_SLICES * u, l = lvl[j[u]];
+        const int pos = (l == 0 ? segoff[0] : l == 1 ? segoff[1] : l == 2 ? segoff[2] : segoff[3]) + c_rl[j[u]] + (k - st[u]);
+        G.e_src[pos] = rec0 + j[u]; G.e_dst[pos] = rec0 + d[u]; G.e_aux[pos] = k;
+      }
+    }
   }
   // ---- the shared copy of the receptor edges (sample-0 numbering) behind the four groups: layer 0 evaluates the rec-rec
   // messages once for the whole batch (see model.hip)

@@ -32,35 +32,54 @@ __device__ void horn_rotation(const double* S, float* R) {
       {S[6] - S[2], S[1] + S[3], -S[0] + S[4] - S[8], S[5] + S[7]},
       {S[1] - S[3], S[6] + S[2], S[5] + S[7], -S[0] - S[4] + S[8]}};
   double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+  // Cyclic Jacobi.  A sweep costs six rotations of one sqrt + one rsqrt each on a single lane (the kernel's serial tail), so: the rotation
+  // comes from (c, s) = (|r|, sgn(r) x) / sqrt(r^2 + x^2) with r = d + sgn(d) sqrt(d^2 + x^2), d = (N_qq - N_pp) / 2 - the textbook
+  // t = sgn(theta) / (|theta| + sqrt(theta^2 + 1)) without its three divisions; an off-diagonal element below 2^-60 of its diagonal pair is left
+  // alone (the rotation would be the identity in fp64); the sweeps end when the off-diagonal mass is below 1e-32 of the diagonal's.
   for (int sweep = 0; sweep < 30; ++sweep) {
-    double off = 0;
-    for (int p = 0; p < 4; ++p)
+    double off = 0, dg = 0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      dg += N[p][p] * N[p][p];
+#pragma unroll
       for (int q = p + 1; q < 4; ++q) off += N[p][q] * N[p][q];
-    if (off < 1e-30) break;
+    }
+    if (off <= 1e-32 * dg || off < 1e-300) break;
+    // (every index below is a compile-time constant after unrolling: N and V stay in registers - with rolled loops they lived in scratch memory)
+#pragma unroll
     for (int p = 0; p < 4; ++p)
+#pragma unroll
       for (int q = p + 1; q < 4; ++q) {
-        if (fabs(N[p][q]) < 1e-300) continue;
-        const double theta = (N[q][q] - N[p][p]) / (2.0 * N[p][q]);
-        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        const double x = N[p][q];
+        if (fabs(x) <= 8.7e-19 * (fabs(N[p][p]) + fabs(N[q][q]))) continue;
+        const double d = 0.5 * (N[q][q] - N[p][p]);
+        const double r = d + (d >= 0 ? 1.0 : -1.0) * sqrt(d * d + x * x);
+        const double inv = rsqrt(r * r + x * x);
+        const double c = fabs(r) * inv, s = (r >= 0 ? x : -x) * inv;
+        // N <- G^T N G on the symmetric matrix: the two diagonal elements in closed form, the (p, q) element is zero by construction, the two
+        // other rows / columns once (mirrored)
+        const double app = N[p][p], aqq = N[q][q], cc = c * c, ss = s * s, cs2 = 2.0 * c * s * x;
+        N[p][p] = cc * app - cs2 + ss * aqq;
+        N[q][q] = ss * app + cs2 + cc * aqq;
+        N[p][q] = 0.0; N[q][p] = 0.0;
+#pragma unroll
         for (int k = 0; k < 4; ++k) {
+          if (k == p || k == q) continue;
           const double a = N[k][p], b = N[k][q];
-          N[k][p] = c * a - s * b; N[k][q] = s * a + c * b;
+          const double np_ = c * a - s * b, nq_ = s * a + c * b;
+          N[k][p] = np_; N[p][k] = np_; N[k][q] = nq_; N[q][k] = nq_;
         }
-        for (int k = 0; k < 4; ++k) {
-          const double a = N[p][k], b = N[q][k];
-          N[p][k] = c * a - s * b; N[q][k] = s * a + c * b;
-        }
+#pragma unroll
         for (int k = 0; k < 4; ++k) {
           const double a = V[k][p], b = V[k][q];
           V[k][p] = c * a - s * b; V[k][q] = s * a + c * b;
         }
       }
   }
-  int best = 0;
+  double top = N[0][0], w = V[0][0], x = V[1][0], y = V[2][0], z = V[3][0];
+#pragma unroll
   for (int k = 1; k < 4; ++k)
-    if (N[k][k] > N[best][best]) best = k;
-  const double w = V[0][best], x = V[1][best], y = V[2][best], z = V[3][best];
+    if (N[k][k] > top) { top = N[k][k]; w = V[0][k]; x = V[1][k]; y = V[2][k]; z = V[3][k]; }
   const double nn = w * w + x * x + y * y + z * z, s2 = 2.0 / nn;
   R[0] = (float)(1 - s2 * (y * y + z * z)); R[1] = (float)(s2 * (x * y - z * w)); R[2] = (float)(s2 * (x * z + y * w));
   R[3] = (float)(s2 * (x * y + z * w)); R[4] = (float)(1 - s2 * (x * x + z * z)); R[5] = (float)(s2 * (y * z - x * w));
@@ -119,9 +138,11 @@ hipError_t launch_debug_axis_angle(const float* aa, int n, float* R_out, hipStre
 }
 
 __global__ __launch_bounds__(256) void se3_update_kernel(Se3Args A) {
-  __shared__ float rig[MAX_LIG * 3], flx[MAX_LIG * 3];
-  __shared__ float upd[6], ctr[3], Rm[9], Rt[9], piv[3], cA[3], cB[3], Rk[9], tk[3];
+  __shared__ float rig[MAX_LIG * 3], flx_a[MAX_LIG * 3], flx2[MAX_LIG * 3];
+  __shared__ float upd[6], ctr[3], Rm[9], cA[3], cB[3], Rk[9], tk[3], rot_th[64];
+  __shared__ int2 rot_uv[64];
   __shared__ double S[9];
+  float* flx = flx_a;
   const int b = blockIdx.x, tid = threadIdx.x, n = A.n_lig, R = A.R;
   const float* nz = A.noise ? A.noise + (size_t)b * (6 + R) : nullptr;
   for (int i = tid; i < n * 3; i += 256) rig[i] = A.pos[(size_t)b * n * 3 + i];
@@ -152,24 +173,44 @@ __global__ __launch_bounds__(256) void se3_update_kernel(Se3Args A) {
     for (int i = tid; i < n * 3; i += 256) A.pos_out[(size_t)b * n * 3 + i] = rig[i];
     return;
   }
-  for (int r = 0; r < R; ++r) {
-    if (tid == 0) {
-      const int u = A.rot_u[r], v = A.rot_v[r];
-      const float th = A.sc[2] * A.tor[(size_t)b * R + r] + (nz ? A.nc[2] * nz[6 + r] : 0.0f);
-      float ax = flx[3 * u] - flx[3 * v], ay = flx[3 * u + 1] - flx[3 * v + 1], az = flx[3 * u + 2] - flx[3 * v + 2];
-      const float nn = sqrtf(ax * ax + ay * ay + az * az);
-      axis_angle_to_matrix_dev(ax / nn * th, ay / nn * th, az / nn * th, Rt);
-      piv[0] = flx[3 * v]; piv[1] = flx[3 * v + 1]; piv[2] = flx[3 * v + 2];
+  // Sequential torsion rotations, one barrier per rotor: the rotor table (u, v, angle) and every atom's mask bits are fetched for up to 64 rotors at
+  // once (one exposed memory latency per chunk instead of three per rotor), every thread builds the rotor's matrix itself from the CURRENT
+  // coordinates (same instruction sequence on every lane) and writes its atom into the other of two coordinate buffers.
+  float* cur = flx;
+  float* nxt = flx2;
+  for (int r0 = 0; r0 < R; r0 += 64) {
+    const int chunk = min(64, R - r0);
+    if (tid < chunk) {
+      const int r = r0 + tid;
+      rot_uv[tid] = make_int2(A.rot_u[r], A.rot_v[r]);
+      rot_th[tid] = A.sc[2] * A.tor[(size_t)b * R + r] + (nz ? A.nc[2] * nz[6 + r] : 0.0f);
     }
+    unsigned long long mbits = 0ull;
+    if (tid < n)
+      for (int k = 0; k < chunk; ++k) mbits |= (unsigned long long)(A.mask_rotate[(size_t)(r0 + k) * n + tid] != 0) << k;
     __syncthreads();
-    if (tid < n && A.mask_rotate[(size_t)r * n + tid]) {
-      const float x = flx[3 * tid] - piv[0], y = flx[3 * tid + 1] - piv[1], z = flx[3 * tid + 2] - piv[2];
-      flx[3 * tid] = Rt[0] * x + Rt[1] * y + Rt[2] * z + piv[0];
-      flx[3 * tid + 1] = Rt[3] * x + Rt[4] * y + Rt[5] * z + piv[1];
-      flx[3 * tid + 2] = Rt[6] * x + Rt[7] * y + Rt[8] * z + piv[2];
+    for (int k = 0; k < chunk; ++k) {
+      if (tid < n) {
+        const int2 uv = rot_uv[k];
+        const float th = rot_th[k];
+        const float px = cur[3 * uv.y], py = cur[3 * uv.y + 1], pz = cur[3 * uv.y + 2];
+        float x = cur[3 * tid], y = cur[3 * tid + 1], z = cur[3 * tid + 2];
+        if ((mbits >> k) & 1ull) {
+          const float ax = cur[3 * uv.x] - px, ay = cur[3 * uv.x + 1] - py, az = cur[3 * uv.x + 2] - pz;
+          const float nn = sqrtf(ax * ax + ay * ay + az * az);
+          float Rl[9];
+          axis_angle_to_matrix_dev(ax / nn * th, ay / nn * th, az / nn * th, Rl);
+          x -= px; y -= py; z -= pz;
+          const float nx = Rl[0] * x + Rl[1] * y + Rl[2] * z + px, ny = Rl[3] * x + Rl[4] * y + Rl[5] * z + py, nz_ = Rl[6] * x + Rl[7] * y + Rl[8] * z + pz;
+          x = nx; y = ny; z = nz_;
+        }
+        nxt[3 * tid] = x; nxt[3 * tid + 1] = y; nxt[3 * tid + 2] = z;
+      }
+      __syncthreads();
+      float* t_ = cur; cur = nxt; nxt = t_;
     }
-    __syncthreads();
   }
+  flx = cur;
   kabsch_block(flx, rig, n, cA, cB, S, Rk, tk);
   if (tid < n) {
     const float x = flx[3 * tid], y = flx[3 * tid + 1], z = flx[3 * tid + 2];

@@ -17,9 +17,10 @@ __device__ __forceinline__ bool cross_within(const float* lp, const float* rp, f
 }
 
 // the same test on coordinates that were divided by c ONCE when they were staged in LDS (bit-identical quotients; the six IEEE
-// divisions per pair were ~90 % of the instructions of the counting / fill loops)
-__device__ __forceinline__ bool cross_within_scaled(const float* lps, const float* rps) {
-  const float dx = rps[0] - lps[0], dy = rps[1] - lps[1], dz = rps[2] - lps[2];
+// divisions per pair were ~90 % of the instructions of the counting / fill loops): the ligand atom as one 16-B LDS word
+// (x, y, z, -), the residue in registers
+__device__ __forceinline__ bool cross_within4(const float4 a, float rx, float ry, float rz) {
+  const float dx = rx - a.x, dy = ry - a.y, dz = rz - a.z;
   return dx * dx + dy * dy + dz * dz < 1.0f;
 }
 
@@ -27,6 +28,10 @@ __device__ __forceinline__ float dist2(const float* a, const float* b) {
   const float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
   return dx * dx + dy * dy + dz * dz;
 }
+
+// The two per-sample graph kernels are chains of short phases whose length is a few LDS / L2 latencies times the trips of their loops:
+// 16 waves per workgroup cut the trips by four against the 4 waves they ran with.
+constexpr int GT = 1024;
 
 // adjacency of the capped radius graph: bit (i, j) set <=> j is among the first LIG_CAP (incl. self) atoms within
 // lig_max_radius of centre i, j != i  (radius_graph -> edge (src=j, dst=i), score_model.py:315)
@@ -36,9 +41,10 @@ __device__ void build_lig_adj(const float* lp, int n_lig, float r2, unsigned (*a
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   for (int i = wave; i < n_lig; i += nw) {
     int cnt = 0;
-    for (int j0 = 0; j0 < MAX_LIG; j0 += 64) {
+    if (lane < MAX_LIG / 32) adj[i][lane] = 0u;          // (LDS writes of one wave land in program order: the chunks below overwrite their words)
+    for (int j0 = 0; j0 < n_lig; j0 += 64) {
       const int j = j0 + lane;
-      const bool in = j0 < n_lig && j < n_lig && dist2(lp + 3 * i, lp + 3 * j) < r2;
+      const bool in = j < n_lig && dist2(lp + 3 * i, lp + 3 * j) < r2;
       const unsigned long long m = __ballot(in);
       const bool keep = in && cnt + __popcll(m & ((1ull << lane) - 1ull)) < LIG_CAP && j != i;
       const unsigned long long kept = __ballot(keep);
@@ -48,11 +54,12 @@ __device__ void build_lig_adj(const float* lp, int n_lig, float r2, unsigned (*a
   }
 }
 
-// In-place exclusive prefix sum of a[0..n) in LDS by a 256-thread block (thread t owns a contiguous chunk; wave shuffles across
-// the chunk totals); tmp: 8 ints of LDS.  Ends with a barrier.  (A single thread walking 2000 residues took 85 us.)
+// In-place exclusive prefix sum of a[0..n) in LDS by the whole block (any multiple of 64 threads up to 1024; thread t owns a contiguous chunk; wave shuffles across
+// the chunk totals); tmp: 16 ints of LDS.  Ends with a barrier.  (A single thread walking 2000 residues took 85 us.)
 __device__ void block_exclusive_scan(int* a, int n, int* tmp) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int per = (n + 255) / 256;
+  const int nt = blockDim.x;
+  const int per = (n + nt - 1) / nt;
   const int beg = min(tid * per, n), end = min(beg + per, n);
   int s = 0;
   for (int k = beg; k < end; ++k) s += a[k];
@@ -78,14 +85,34 @@ __device__ void block_exclusive_scan(int* a, int n, int* tmp) {
 // C = B + {senders into B}.  Exact: a pruned message never reaches anything the heads read.  (Messages are received at edge_src
 // and sent from edge_dst, tensor_layers.py:153-159.)  lvl[j]: 0 = A, 1 = B \ A, 2 = C \ B, 3 = the rest.
 // On entry lvl[j] is 0 or 3 and a barrier has passed; ends with a barrier.
+// (called by the GT threads of graph_count_kernel)
 __device__ void propagate_levels(uint8_t* lvl, const GraphArgs& G) {
+  constexpr int UC = 8;                             // edges per thread the register path holds (src | dst << 16: n_rec <= MAX_REC < 65536)
+  if (G.E_rr <= GT * UC) {
+    // both passes walk the same static edge list: fetched ONCE (all loads in flight together), then two LDS-only passes
+    unsigned e[UC];
+#pragma unroll
+    for (int u = 0; u < UC; ++u) {
+      const int k = threadIdx.x + GT * u;
+      e[u] = k < G.E_rr ? (unsigned)G.rr_src[k] | ((unsigned)G.rr_dst[k] << 16) : 0xffffffffu;
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int u = 0; u < UC; ++u) {
+        const int r = (int)(e[u] & 0xffffu), d = (int)(e[u] >> 16);
+        if (e[u] != 0xffffffffu && lvl[r] == pass && lvl[d] == 3) lvl[d] = (uint8_t)(pass + 1);   // (concurrent writers store the same value)
+      }
+      __syncthreads();
+    }
+    return;
+  }
   constexpr int U = 8;                              // independent index loads in flight per thread (the loop is L2-latency bound)
   for (int pass = 0; pass < 2; ++pass) {
-    for (int k0 = threadIdx.x; k0 < G.E_rr; k0 += 256 * U) {
+    for (int k0 = threadIdx.x; k0 < G.E_rr; k0 += GT * U) {
       int r[U], d[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int k = k0 + 256 * u;
+        const int k = k0 + GT * u;
         r[u] = k < G.E_rr ? G.rr_src[k] : -1;
         d[u] = k < G.E_rr ? G.rr_dst[k] : 0;
       }
@@ -98,11 +125,12 @@ __device__ void propagate_levels(uint8_t* lvl, const GraphArgs& G) {
 }
 
 // Per level: the number of static rec-rec edges received by the residues of that level (tot[0..3]) and, when pre != nullptr, for
-// every residue the count over the residues before it of the SAME level (pre[j]) - a 4-component block scan by 256 threads
-// (thread t owns a contiguous chunk; wave shuffles across the chunk totals).  tmp: [4 waves][4], tot: [4] in LDS.  Ends with a barrier.
+// every residue the count over the residues before it of the SAME level (pre[j]) - a 4-component block scan by the whole block
+// (thread t owns a contiguous chunk; wave shuffles across the chunk totals).  tmp: [16 waves][4], tot: [4] in LDS.  Ends with a barrier.
 __device__ void level_scan(const uint8_t* lvl, const int32_t* outdeg, int n, int* pre, int (*tmp)[4], int* tot) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int per = (n + 255) / 256;
+  const int nt = blockDim.x, nw = nt >> 6;
+  const int per = (n + nt - 1) / nt;
   const int beg = min(tid * per, n), end = min(beg + per, n);
   int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
   for (int k = beg; k < end; ++k) {
@@ -126,42 +154,50 @@ __device__ void level_scan(const uint8_t* lvl, const int32_t* outdeg, int n, int
       b0 += l == 0 ? od : 0; b1 += l == 1 ? od : 0; b2 += l == 2 ? od : 0; b3 += l == 3 ? od : 0;
     }
   }
-  if (tid < 4) tot[tid] = tmp[0][tid] + tmp[1][tid] + tmp[2][tid] + tmp[3][tid];
+  if (tid < 4) { int t_ = 0; for (int w = 0; w < nw; ++w) t_ += tmp[w][tid]; tot[tid] = t_; }
   __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void graph_count_kernel(GraphArgs G) {
+__global__ __launch_bounds__(GT) void graph_count_kernel(GraphArgs G) {
   extern __shared__ float smem[];
   float* lp = smem;                              // [MAX_LIG*3]
   float* rp = lp + MAX_LIG * 3;                  // [n_rec*3]
   uint8_t* lvl = reinterpret_cast<uint8_t*>(rp + 3 * G.n_rec + G.n_rec);   // [n_rec] (behind the int array only the fill kernel uses)
   __shared__ unsigned adj[MAX_LIG][MAX_LIG / 32];
-  __shared__ float lps[MAX_LIG * 3];             // ligand coordinates / cross cutoff
-  __shared__ int s_cnt[2], lvl_tmp[4][4], lvl_tot[4];
+  __shared__ float4 lps[MAX_LIG];                // ligand coordinates / cross cutoff, one 16-B word per atom
+  __shared__ int s_cnt[2], lvl_tmp[GT / 64][4], lvl_tot[4];
   const int b = blockIdx.x, tid = threadIdx.x;
-  for (int i = tid; i < G.n_lig * 3; i += 256) { const float v = G.lig_pos[(size_t)b * G.n_lig * 3 + i]; lp[i] = v; lps[i] = v / G.cross_cutoff; }
-  for (int i = tid; i < G.n_rec * 3; i += 256) rp[i] = G.rec_pos[i] / G.cross_cutoff;      // only the cross test reads the residues here
+  for (int i = tid; i < G.n_lig * 3; i += GT) {
+    const float v = G.lig_pos[(size_t)b * G.n_lig * 3 + i];
+    lp[i] = v;
+    reinterpret_cast<float*>(lps)[4 * (i / 3) + i % 3] = v / G.cross_cutoff;
+  }
+  for (int i = tid; i < G.n_rec * 3; i += GT) rp[i] = G.rec_pos[i] / G.cross_cutoff;      // only the cross test reads the residues here
   if (tid < 2) s_cnt[tid] = 0;
   __syncthreads();
   build_lig_adj(lp, G.n_lig, G.lig_r2, adj);
   __syncthreads();
   int c_ll = 0, c_lr = 0;
-  for (int i = tid; i < G.n_lig; i += 256)
+  for (int i = tid; i < G.n_lig; i += GT)
     for (int w = 0; w < MAX_LIG / 32; ++w) c_ll += __popc(adj[i][w]);
-  for (int j = tid; j < G.n_rec; j += 256) {
+  for (int j = tid; j < G.n_rec; j += GT) {
+    const float rx = rp[3 * j], ry = rp[3 * j + 1], rz = rp[3 * j + 2];
     int cnt = 0;
-    for (int i = 0; i < G.n_lig; ++i) cnt += cross_within_scaled(lps + 3 * i, rp + 3 * j) ? 1 : 0;
+#pragma unroll 4
+    for (int i = 0; i < G.n_lig; ++i) cnt += cross_within4(lps[i], rx, ry, rz) ? 1 : 0;
     c_lr += cnt;
     lvl[j] = (G.prune && cnt == 0) ? 3 : 0;
   }
-  atomicAdd(&s_cnt[0], c_ll);
-  atomicAdd(&s_cnt[1], c_lr);
+  // one LDS atomic per wave (every thread adding to the same two words serialised 2 x 1024 updates: the longest phase of the kernel)
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) { c_ll += __shfl_down(c_ll, d, 64); c_lr += __shfl_down(c_lr, d, 64); }
+  if ((tid & 63) == 0) { atomicAdd(&s_cnt[0], c_ll); atomicAdd(&s_cnt[1], c_lr); }
   __syncthreads();
   if (G.prune) propagate_levels(lvl, G);
   level_scan(lvl, G.rr_outdeg, G.n_rec, nullptr, lvl_tmp, lvl_tot);
   if (tid < 2) G.counts[CNT_STRIDE * b + tid] = s_cnt[tid];
   if (tid < 3) G.counts[CNT_STRIDE * b + 2 + tid] = lvl_tot[tid];
-  for (int j = tid; j < G.n_rec; j += 256) G.levels[(size_t)b * G.n_rec + j] = lvl[j];      // the fill kernel's four slices read them back
+  for (int j = tid; j < G.n_rec; j += GT) G.levels[(size_t)b * G.n_rec + j] = lvl[j];      // the fill kernel's four slices read them back
 }
 
 // one thread: prefixes over the samples, group offsets, the per-layer group tables (InfoSlot / GroupTable in model.h)
@@ -285,7 +321,7 @@ __global__ void disco_patch_scan_kernel(PatchArgs A) {
 // one workgroup per sample: the patch edges of the masked receivers in (receiver, static order)
 __global__ __launch_bounds__(256) void disco_patch_fill_kernel(PatchArgs A) {
   extern __shared__ int pre_[];                  // [n_rec] exclusive prefix of the masked receivers' edge counts
-  __shared__ int scan_tmp[8];
+  __shared__ int scan_tmp[16];
   const int b = blockIdx.x, tid = threadIdx.x;
   for (int i = tid; i < A.n_rec; i += 256) pre_[i] = A.rr_mask[(size_t)b * A.n_rec + i] ? A.rr_outdeg[i] : 0;
   __syncthreads();
@@ -311,14 +347,14 @@ hipError_t launch_disco_patch(const PatchArgs& a, hipStream_t s) {
 
 constexpr int FILL_SLICES = 4;
 
-__global__ __launch_bounds__(256) void graph_fill_kernel(GraphArgs G) {
+__global__ __launch_bounds__(GT) void graph_fill_kernel(GraphArgs G) {
   extern __shared__ float smem[];
   float* lp = smem;                                   // [MAX_LIG*3]
   float* rp = lp + MAX_LIG * 3;                       // [n_rec*3]
   int* c_rl = reinterpret_cast<int*>(rp + 3 * G.n_rec);   // [n_rec] -> exclusive prefix; later the per-level prefix of the rec-rec edges
   uint8_t* lvl = reinterpret_cast<uint8_t*>(c_rl + G.n_rec);   // [n_rec] receptive-field level of the residue
   __shared__ unsigned adj[MAX_LIG][MAX_LIG / 32];
-  __shared__ int bdeg[MAX_LIG], odeg[MAX_LIG], c_lr[MAX_LIG], ll_pre[MAX_LIG], lr_pre[MAX_LIG], scan_tmp[8], lvl_tmp[4][4], lvl_tot[4];
+  __shared__ int bdeg[MAX_LIG], odeg[MAX_LIG], c_lr[MAX_LIG], ll_pre[MAX_LIG], lr_pre[MAX_LIG], scan_tmp[GT / 64], lvl_tmp[GT / 64][4], lvl_tot[4];
   // FILL_SLICES workgroups per sample: each repeats the (cheap) counting / prefix phase and writes one slice of the edge list --
   // one workgroup per sample left 216 CUs idle while 256 threads issued ~300 scattered stores each
   constexpr int BOND_LDS = 1024;                    // directed bonds staged in LDS for slice 0's bond-ordered walk (more: read from global)
@@ -334,34 +370,41 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(GraphArgs G) {
 #pragma unroll
   for (int l = 0; l < 4; ++l) segoff[l] = G.info[I_SEG + l] + offs[2 + l];
   const bool bonds_in_lds = G.M <= BOND_LDS;
-  if (slice == 0 && bonds_in_lds)
-    for (int m = tid; m < G.M; m += 256) bond_sd[m] = make_short2((short)G.bond_src[m], (short)G.bond_dst[m]);
-  __shared__ float lps[MAX_LIG * 3];             // ligand coordinates / cross cutoff
-  for (int i = tid; i < n_lig * 3; i += 256) { const float v = G.lig_pos[(size_t)b * n_lig * 3 + i]; lp[i] = v; lps[i] = v / G.cross_cutoff; }
-  for (int i = tid; i < n_rec * 3; i += 256) rp[i] = G.rec_pos[i] / G.cross_cutoff;      // only the cross test reads the residues here
-  for (int i = tid; i < MAX_LIG; i += 256) { bdeg[i] = 0; c_lr[i] = 0; }
-  for (int j = tid; j < n_rec; j += 256) c_rl[j] = 0;
+  if (bonds_in_lds)
+    for (int m = tid; m < G.M; m += GT) bond_sd[m] = make_short2((short)G.bond_src[m], (short)G.bond_dst[m]);
+  __shared__ float4 lps[MAX_LIG];                // ligand coordinates / cross cutoff, one 16-B word per atom
+  for (int i = tid; i < n_lig * 3; i += GT) {
+    const float v = G.lig_pos[(size_t)b * n_lig * 3 + i];
+    lp[i] = v;
+    reinterpret_cast<float*>(lps)[4 * (i / 3) + i % 3] = v / G.cross_cutoff;
+  }
+  for (int i = tid; i < n_rec * 3; i += GT) rp[i] = G.rec_pos[i] / G.cross_cutoff;      // only the cross test reads the residues here
+  for (int i = tid; i < MAX_LIG; i += GT) { bdeg[i] = 0; c_lr[i] = 0; }
+  for (int j = tid; j < n_rec; j += GT) c_rl[j] = 0;
   __syncthreads();
   build_lig_adj(lp, n_lig, G.lig_r2, adj);
-  for (int m = tid; m < G.M; m += 256) atomicAdd(&bdeg[G.bond_src[m]], 1);
+  for (int m = tid; m < G.M; m += GT) atomicAdd(&bdeg[G.bond_src[m]], 1);
   // cross-edge counts without LDS atomics (at t ~ 1 every pair is an edge: 2 x n_lig x n_rec atomics on n_lig + n_rec addresses
   // serialised): per ligand atom one wave + ballots, per residue one thread
-  for (int i = wave; i < n_lig; i += 4) {
+  for (int i = wave; i < n_lig; i += GT / 64) {
+    const float4 a = lps[i];
     int cnt = 0;
     for (int j0 = 0; j0 < n_rec; j0 += 64) {
-      const int j = j0 + lane;
-      cnt += __popcll(__ballot(j < n_rec && cross_within_scaled(lps + 3 * i, rp + 3 * j)));
+      const int j = min(j0 + lane, n_rec - 1);
+      cnt += __popcll(__ballot(j0 + lane < n_rec && cross_within4(a, rp[3 * j], rp[3 * j + 1], rp[3 * j + 2])));
     }
     if (lane == 0) c_lr[i] = cnt;
   }
-  for (int j = tid; j < n_rec; j += 256) {
+  for (int j = tid; j < n_rec; j += GT) {
+    const float rx = rp[3 * j], ry = rp[3 * j + 1], rz = rp[3 * j + 2];
     int cnt = 0;
-    for (int i = 0; i < n_lig; ++i) cnt += cross_within_scaled(lps + 3 * i, rp + 3 * j) ? 1 : 0;
+#pragma unroll 4
+    for (int i = 0; i < n_lig; ++i) cnt += cross_within4(lps[i], rx, ry, rz) ? 1 : 0;
     c_rl[j] = cnt;
     lvl[j] = G.levels[(size_t)b * n_rec + j];        // receptive-field level, computed by graph_count_kernel
   }
   __syncthreads();
-  for (int j = tid; j < n_lig; j += 256) {
+  for (int j = tid; j < n_lig; j += GT) {
     int od = 0;
     for (int i = 0; i < n_lig; ++i) od += (adj[i][j >> 5] >> (j & 31)) & 1u;
     odeg[j] = od;
@@ -371,43 +414,64 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(GraphArgs G) {
   const int lig0 = b * n_lig, rec0 = rec_base + b * n_rec;
   // degrees (scatter 'mean' divisor: all incoming groups together, tensor_layers.py:159)
   if (slice == 0) {
-    for (int i = tid; i < n_lig; i += 256) G.deg[lig0 + i] = bdeg[i] + odeg[i] + c_lr[i];
-    for (int j = tid; j < n_rec; j += 256) G.deg[rec0 + j] = G.rr_outdeg[j] + c_rl[j];
+    for (int i = tid; i < n_lig; i += GT) G.deg[lig0 + i] = bdeg[i] + odeg[i] + c_lr[i];
+    for (int j = tid; j < n_rec; j += GT) G.deg[rec0 + j] = G.rr_outdeg[j] + c_rl[j];
   }
   __syncthreads();
-  if (tid == 0) {
+  if (wave == 0) {                                  // exclusive prefixes over the atoms: one wave, shuffles, chunks of 64
     int a = 0, c = 0;
-    for (int i = 0; i < n_lig; ++i) {
-      ll_pre[i] = a; a += bdeg[i] + odeg[i];
-      lr_pre[i] = c; c += c_lr[i];
+    for (int i0 = 0; i0 < n_lig; i0 += 64) {
+      const int i = i0 + lane;
+      const int va = i < n_lig ? bdeg[i] + odeg[i] : 0, vc = i < n_lig ? c_lr[i] : 0;
+      int xa = va, xc = vc;
+#pragma unroll
+      for (int d = 1; d < 64; d *= 2) {
+        const int ta = __shfl_up(xa, d, 64), tc = __shfl_up(xc, d, 64);
+        if (lane >= d) { xa += ta; xc += tc; }
+      }
+      if (i < n_lig) { ll_pre[i] = a + xa - va; lr_pre[i] = c + xc - vc; }
+      a += __shfl(xa, 63, 64); c += __shfl(xc, 63, 64);
     }
   }
   block_exclusive_scan(c_rl, n_rec, scan_tmp);   // exclusive prefix of the per-residue rec->lig counts (in place; ends with a barrier)
-  // ---- group 0: lig-lig, sorted by src: bonds of the atom (bond order) then radius edges (ascending dst)
-  for (int j = tid; slice == 0 && j < n_lig; j += 256) {
+  // ---- group 0: lig-lig, sorted by src: bonds of the atom (bond order) then radius edges (ascending dst); one wave per atom, ballot compaction
+  // (a thread per atom walking M bonds and n_lig candidates with a conditional store each was the longest phase of the kernel)
+  for (int j = wave + (GT / 64) * slice; j < n_lig; j += (GT / 64) * FILL_SLICES) {
     int pos = off0 + ll_pre[j];
-    if (bonds_in_lds) {
-      for (int m = 0; m < G.M; ++m) {
-        const short2 sd = bond_sd[m];
-        if (sd.x == j) { G.e_src[pos] = lig0 + j; G.e_dst[pos] = lig0 + sd.y; G.e_aux[pos] = m; ++pos; }
+    for (int m0 = 0; m0 < G.M; m0 += 64) {
+      const int m = m0 + lane;
+      int src = -1, dst = 0;
+      if (m < G.M) {
+        if (bonds_in_lds) { const short2 sd = bond_sd[m]; src = sd.x; dst = sd.y; }
+        else { src = G.bond_src[m]; dst = G.bond_dst[m]; }
       }
-    } else {
-      for (int m = 0; m < G.M; ++m)
-        if (G.bond_src[m] == j) {
-          G.e_src[pos] = lig0 + j; G.e_dst[pos] = lig0 + G.bond_dst[m]; G.e_aux[pos] = m; ++pos;
-        }
+      const bool hit = src == j;
+      const unsigned long long mask = __ballot(hit);
+      if (hit) {
+        const int p = pos + __popcll(mask & ((1ull << lane) - 1ull));
+        G.e_src[p] = lig0 + j; G.e_dst[p] = lig0 + dst; G.e_aux[p] = m;
+      }
+      pos += __popcll(mask);
     }
-    for (int i = 0; i < n_lig; ++i)
-      if ((adj[i][j >> 5] >> (j & 31)) & 1u) {
-        G.e_src[pos] = lig0 + j; G.e_dst[pos] = lig0 + i; G.e_aux[pos] = -1; ++pos;
+    for (int i0 = 0; i0 < n_lig; i0 += 64) {
+      const int i = i0 + lane;
+      const bool hit = i < n_lig && ((adj[i][j >> 5] >> (j & 31)) & 1u);
+      const unsigned long long mask = __ballot(hit);
+      if (hit) {
+        const int p = pos + __popcll(mask & ((1ull << lane) - 1ull));
+        G.e_src[p] = lig0 + j; G.e_dst[p] = lig0 + i; G.e_aux[p] = -1;
       }
+      pos += __popcll(mask);
+    }
   }
   // ---- group 1: lig->rec, sorted by ligand atom then residue: one wave per ligand atom, ballot compaction
-  for (int i = wave + 4 * slice; i < n_lig; i += 4 * FILL_SLICES) {
+  for (int i = wave + (GT / 64) * slice; i < n_lig; i += (GT / 64) * FILL_SLICES) {
     int pos = g1 + off1 + lr_pre[i];
+    const float4 a = lps[i];
     for (int j0 = 0; j0 < n_rec; j0 += 64) {
       const int j = j0 + lane;
-      const bool in = j < n_rec && cross_within_scaled(lps + 3 * i, rp + 3 * j);
+      const int jc = min(j, n_rec - 1);
+      const bool in = j < n_rec && cross_within4(a, rp[3 * jc], rp[3 * jc + 1], rp[3 * jc + 2]);
       const unsigned long long mask = __ballot(in);
       if (in) {
         const int p = pos + __popcll(mask & ((1ull << lane) - 1ull));
@@ -417,12 +481,20 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(GraphArgs G) {
     }
   }
   // ---- group 3: rec->lig (flipped cross edges), sorted by residue then ligand atom
-  for (int j = tid + 256 * slice; j < n_rec; j += 256 * FILL_SLICES) {
+  // (one wave per residue, lane = ligand atom: the residue's edges leave as one contiguous store)
+  for (int j = wave + (GT / 64) * slice; j < n_rec; j += (GT / 64) * FILL_SLICES) {
+    const float rx = rp[3 * j], ry = rp[3 * j + 1], rz = rp[3 * j + 2];
     int pos = g3 + off1 + c_rl[j];
-    for (int i = 0; i < n_lig; ++i)
-      if (cross_within_scaled(lps + 3 * i, rp + 3 * j)) {
-        G.e_src[pos] = rec0 + j; G.e_dst[pos] = lig0 + i; G.e_aux[pos] = -1; ++pos;
+    for (int i0 = 0; i0 < n_lig; i0 += 64) {
+      const int i = i0 + lane;
+      const bool in = i < n_lig && cross_within4(lps[min(i, n_lig - 1)], rx, ry, rz);
+      const unsigned long long mask = __ballot(in);
+      if (in) {
+        const int p = pos + __popcll(mask & ((1ull << lane) - 1ull));
+        G.e_src[p] = rec0 + j; G.e_dst[p] = lig0 + i; G.e_aux[p] = -1;
       }
+      pos += __popcll(mask);
+    }
   }
   // ---- group 2: the static receptor edges of this sample in four segments [A | B | C | rest] by the level of the receiving
   // residue; inside a segment by (sample, residue, static order), i.e. still sorted by edge_src.  Position of static edge k of
@@ -430,12 +502,12 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(GraphArgs G) {
   __syncthreads();                                  // group 3 has consumed c_rl: reuse it for the per-level prefix
   level_scan(lvl, G.rr_outdeg, n_rec, c_rl, lvl_tmp, lvl_tot);
   {
-    constexpr int U = 8;                              // the index loads of U edges in flight (two dependent L2 round trips per batch instead of per edge)
-    for (int k0 = tid + 256 * slice; k0 < G.E_rr; k0 += 256 * FILL_SLICES * U) {
+    constexpr int U = 2;                              // the index loads of U edges in flight (two dependent L2 round trips per batch instead of per edge)
+    for (int k0 = tid + GT * slice; k0 < G.E_rr; k0 += GT * FILL_SLICES * U) {
       int j[U], d[U], st[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int k = k0 + 256 * FILL_SLICES * u;
+        const int k = k0 + GT * FILL_SLICES * u;
         j[u] = k < G.E_rr ? G.rr_src[k] : -1;
         d[u] = k < G.E_rr ? G.rr_dst[k] : 0;
       }
@@ -444,7 +516,7 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(GraphArgs G) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (j[u] < 0) continue;
-        const int k = k0 + 256 * FILL_SLICES * u, l = lvl[j[u]];
+        const int k = k0 + GT * FILL_SLICES * u, l = lvl[j[u]];
         const int pos = (l == 0 ? segoff[0] : l == 1 ? segoff[1] : l == 2 ? segoff[2] : segoff[3]) + c_rl[j[u]] + (k - st[u]);
         G.e_src[pos] = rec0 + j[u]; G.e_dst[pos] = rec0 + d[u]; G.e_aux[pos] = k;
       }
@@ -454,7 +526,7 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(GraphArgs G) {
   // messages once for the whole batch (see model.hip)
   if (G.shared_rr && b == 0) {
     const int g4 = G.info[I_SHARED];
-    for (int k = tid + 256 * slice; k < G.E_rr; k += 256 * FILL_SLICES) {
+    for (int k = tid + GT * slice; k < G.E_rr; k += GT * FILL_SLICES) {
       G.e_src[g4 + k] = rec_base + G.rr_src[k]; G.e_dst[g4 + k] = rec_base + G.rr_dst[k]; G.e_aux[g4 + k] = k;
     }
   }
@@ -624,9 +696,17 @@ hipError_t launch_complex_static(const RecStaticArgs& R, const int32_t* rr_src, 
 
 hipError_t launch_graph(const GraphArgs& G, int64_t edge_cap, hipStream_t s) {
   const size_t lds = (size_t)(MAX_LIG * 3 + G.n_rec * 3) * 4 + (size_t)G.n_rec * 4 + (((size_t)G.n_rec + 15) & ~(size_t)15);   // + the level bytes
-  hipLaunchKernelGGL(graph_count_kernel, dim3(G.B), dim3(256), lds, s, G);
+  // large receptors: beyond the default 64 KB of LDS per workgroup the dynamic part has to be granted explicitly (once per size class)
+  static size_t granted = 0;
+  if (lds > 32 * 1024 && lds > granted) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&graph_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&graph_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    granted = lds;
+  }
+  hipLaunchKernelGGL(graph_count_kernel, dim3(G.B), dim3(GT), lds, s, G);
   hipLaunchKernelGGL(graph_scan_kernel, dim3(1), dim3(64), 0, s, G, edge_cap);
-  hipLaunchKernelGGL(graph_fill_kernel, dim3(G.B, FILL_SLICES), dim3(256), lds, s, G);
+  hipLaunchKernelGGL(graph_fill_kernel, dim3(G.B, FILL_SLICES), dim3(GT), lds, s, G);
   return hipGetLastError();
 }
 

@@ -200,18 +200,18 @@ __global__ __launch_bounds__(GT) void graph_count_kernel(GraphArgs G) {
   for (int j = tid; j < G.n_rec; j += GT) G.levels[(size_t)b * G.n_rec + j] = lvl[j];      // the fill kernel's four slices read them back
 }
 
-// one thread: prefixes over the samples, group offsets, the per-layer group tables (InfoSlot / GroupTable in model.h)
-__global__ void graph_scan_kernel(GraphArgs G, int64_t edge_cap) {
-  if (blockIdx.x != 0) return;
-  // exclusive prefix over the samples of the five counts: one wave, lane = sample (chunks of 64 for larger batches)
-  const int lane = threadIdx.x;
-  int tot[5] = {0, 0, 0, 0, 0};
-  for (int b0 = 0; b0 < G.B; b0 += 64) {
-    const int b = b0 + lane;
-    int v[5];
+// Prefixes over the samples of the five per-sample counts, by ONE WAVE (lane = sample, chunks of 64 for larger batches; every wave of every
+// fill workgroup repeats it: 5 x B coalesced ints and a few shuffles - a separate one-wave kernel between count and fill cost a launch and
+// its two dependency stalls).  ex[0..4]: the exclusive prefixes at sample b, ex[5]: its offset in the "rest" level segment; tot[0..4]: the sums.
+__device__ __forceinline__ void sample_prefix(const GraphArgs& G, int b, int* ex, int* tot) {
+  const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int k = 0; k < 5; ++k) v[k] = b < G.B ? G.counts[CNT_STRIDE * b + k] + (k == 0 ? G.M : 0) : 0;
-    int inc[5];
+  for (int k = 0; k < 5; ++k) { tot[k] = 0; ex[k] = 0; }
+  for (int b0 = 0; b0 < G.B; b0 += 64) {
+    const int bb = b0 + lane;
+    int v[5], inc[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) v[k] = bb < G.B ? G.counts[CNT_STRIDE * bb + k] + (k == 0 ? G.M : 0) : 0;
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
       int x = v[k];
@@ -219,17 +219,18 @@ __global__ void graph_scan_kernel(GraphArgs G, int64_t edge_cap) {
       for (int d = 1; d < 64; d *= 2) { const int t = __shfl_up(x, d, 64); if (lane >= d) x += t; }
       inc[k] = x;
     }
-    if (b < G.B) {
-      int32_t* o = G.offs + CNT_STRIDE * b;
-      int ex[5];
+    if (b >= b0 && b < b0 + 64) {
 #pragma unroll
-      for (int k = 0; k < 5; ++k) { ex[k] = tot[k] + inc[k] - v[k]; o[k] = ex[k]; }
-      o[5] = b * G.E_rr - (ex[2] + ex[3] + ex[4]);
+      for (int k = 0; k < 5; ++k) ex[k] = tot[k] + __shfl(inc[k] - v[k], b - b0, 64);
     }
 #pragma unroll
     for (int k = 0; k < 5; ++k) tot[k] += __shfl(inc[k], 63, 64);
   }
-  if (lane != 0) return;
+  ex[5] = b * G.E_rr - (ex[2] + ex[3] + ex[4]);
+}
+
+// one thread: group offsets and the per-layer group tables (InfoSlot / GroupTable in model.h) from the sums over the samples
+__device__ void write_group_tables(const GraphArgs& G, const int* tot) {
   const int ll = tot[0], lr = tot[1], ra = tot[2], rb = tot[3], rc = tot[4];
   int go[5];
   go[0] = 0; go[1] = ll; go[2] = ll + lr; go[3] = go[2] + G.B * G.E_rr; go[4] = go[3] + lr;
@@ -245,7 +246,7 @@ __global__ void graph_scan_kernel(GraphArgs G, int64_t edge_cap) {
   for (int k = 0; k < 8; ++k) G.info[I_CNT + k] = 0;
   for (int l = 0; l < 4; ++l) G.info[I_SEG + l] = seg[l];
   G.info[I_E] = go[4];
-  G.info[I_OVF] = ((int64_t)go[4] + n_shared > edge_cap) ? 1 : 0;
+  G.info[I_OVF] = ((int64_t)go[4] + n_shared > G.edge_cap) ? 1 : 0;
   G.info[I_SHARED] = G.shared_rr ? go[4] : -1;
   G.info[I_HEAD] = 0; G.info[I_HEAD + 1] = G.B * G.n_lig; G.info[I_HEAD + 2] = G.B * G.n_lig; G.info[I_HEAD + 3] = G.B * G.n_lig;
   G.info[I_HEAD + 4] = 0; G.info[I_HEAD + 5] = 0;
@@ -360,15 +361,15 @@ __global__ __launch_bounds__(GT) void graph_fill_kernel(GraphArgs G) {
   constexpr int BOND_LDS = 1024;                    // directed bonds staged in LDS for slice 0's bond-ordered walk (more: read from global)
   __shared__ short2 bond_sd[BOND_LDS];
   const int b = blockIdx.x, slice = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (G.info[I_OVF]) return;   // capacity overflow: reported by the host wrapper
   const int n_lig = G.n_lig, n_rec = G.n_rec;
-  // the scan kernel's results, requested here: their latency runs under the counting phase
-  const int g1 = G.info[I_GO + 1], g3 = G.info[I_GO + 3];
-  const int32_t* offs = G.offs + CNT_STRIDE * b;
-  const int off0 = offs[0], off1 = offs[1];
-  int segoff[4];                                    // level segment start + this sample's offset inside it (group 2)
-#pragma unroll
-  for (int l = 0; l < 4; ++l) segoff[l] = G.info[I_SEG + l] + offs[2 + l];
+  // group offsets of the merged edge list and this sample's place in every group (no separate scan kernel: see sample_prefix)
+  int ex[6], tot[5];
+  sample_prefix(G, b, ex, tot);
+  const int g1 = tot[0], g2 = tot[0] + tot[1], g3 = g2 + G.B * G.E_rr, g4 = g3 + tot[1];
+  if (b == 0 && slice == 0 && tid == 0) write_group_tables(G, tot);
+  if ((int64_t)g4 + (G.shared_rr ? G.E_rr : 0) > G.edge_cap) return;   // capacity overflow (I_OVF is set): reported by the host wrapper
+  const int off0 = ex[0], off1 = ex[1];
+  const int segoff[4] = {g2 + ex[2], g2 + tot[2] + ex[3], g2 + tot[2] + tot[3] + ex[4], g2 + tot[2] + tot[3] + tot[4] + ex[5]};   // level segment start + this sample's offset inside it (group 2)
   const bool bonds_in_lds = G.M <= BOND_LDS;
   if (bonds_in_lds)
     for (int m = tid; m < G.M; m += GT) bond_sd[m] = make_short2((short)G.bond_src[m], (short)G.bond_dst[m]);
@@ -525,7 +526,6 @@ __global__ __launch_bounds__(GT) void graph_fill_kernel(GraphArgs G) {
   // ---- the shared copy of the receptor edges (sample-0 numbering) behind the four groups: layer 0 evaluates the rec-rec
   // messages once for the whole batch (see model.hip)
   if (G.shared_rr && b == 0) {
-    const int g4 = G.info[I_SHARED];
     for (int k = tid + GT * slice; k < G.E_rr; k += GT * FILL_SLICES) {
       G.e_src[g4 + k] = rec_base + G.rr_src[k]; G.e_dst[g4 + k] = rec_base + G.rr_dst[k]; G.e_aux[g4 + k] = k;
     }
@@ -704,9 +704,10 @@ hipError_t launch_graph(const GraphArgs& G, int64_t edge_cap, hipStream_t s) {
     if (e != hipSuccess) return e;
     granted = lds;
   }
-  hipLaunchKernelGGL(graph_count_kernel, dim3(G.B), dim3(GT), lds, s, G);
-  hipLaunchKernelGGL(graph_scan_kernel, dim3(1), dim3(64), 0, s, G, edge_cap);
-  hipLaunchKernelGGL(graph_fill_kernel, dim3(G.B, FILL_SLICES), dim3(GT), lds, s, G);
+  GraphArgs Gc = G;
+  Gc.edge_cap = edge_cap;
+  hipLaunchKernelGGL(graph_count_kernel, dim3(G.B), dim3(GT), lds, s, Gc);
+  hipLaunchKernelGGL(graph_fill_kernel, dim3(G.B, FILL_SLICES), dim3(GT), lds, s, Gc);
   return hipGetLastError();
 }
 

@@ -13,7 +13,7 @@ constexpr int MAX_REC = 8192;  // residues per sample
 constexpr int LIG_CAP = 33;    // radius_graph(max_num_neighbors=32) -> radius(..., 33) including self
 constexpr int BOND_CAP = 32;   // radius(..., max_num_neighbors=32) of the bond-centre graph
 
-// Layout of the per-complex int32 `info` table written by graph_scan_kernel (device side; no launch depends on a host read-back).
+// Layout of the per-complex int32 `info` table written by graph_fill_kernel (write_group_tables; device side; no launch depends on a host read-back).
 // Group 2 (rec-rec) of the merged edge list is stored in four segments ordered by the BACKWARD RECEPTIVE-FIELD LEVEL of the edge's
 // receiving residue (see graph_fill_kernel): [A | B | C | rest], so that every conv layer evaluates a PREFIX of the group.
 enum InfoSlot : int {
@@ -154,6 +154,7 @@ struct GraphArgs {
   int32_t* deg;             // [B*(n_lig+n_rec)]
   int rec_node_base = -1;   // node id of sample 0's first residue (-1: B*n_lig, the score model's [lig | rec] numbering)
   int64_t patch_off = -1;   // >= 0: first edge of the DisCo patch group (I_TABX / I_PATCH / I_FBX are maintained)
+  int64_t edge_cap = 0;     // capacity of the edge arrays (set by launch_graph)
 };
 
 // DisCo layer-0 patches: receivers whose rec-rec messages differ from the shared (sample-0) evaluation

@@ -41,3 +41,19 @@ for w in range(8):
     print(f'wave {w}: burst {burst.mean():6.0f}  wait {bar1.mean():5.0f}  epilogue {epi.mean():6.0f} (median {np.median(epi):5.0f}, p90 {np.percentile(epi, 90):5.0f})  '
           f'wait {nxt[same].mean():5.0f}  period {(x[1:, 0] - x[:-1, 0])[same].mean():6.0f} | prologue of {int(first.sum())} units: indices + staging {pro[0]}, '
           f'GEMM1 {pro[1]}, limbs + F rows {pro[2]}, barrier + first fragments {pro[3]}')
+
+# per tile position inside a unit (wave 0 = group A, wave 4 = group B): which tiles carry the long epilogues (flush tiles, vector tiles)
+if os.environ.get('CONV_TRACE_PER_TILE'):
+    for w in (0, 4):
+        x = tr[w, :n]
+        starts = np.nonzero(x[:, 4] != 0)[0]
+        if len(starts) < 3:
+            continue
+        T = int(np.median(np.diff(starts)))
+        full = [s for s in starts[:-1] if (x[s + 1:s + T, 4] == 0).all() and s + T <= n]
+        ep = np.stack([(x[s:s + T, 3] - x[s:s + T, 2]) for s in full]).mean(0)
+        bu = np.stack([(x[s:s + T, 1] - x[s:s + T, 0]) for s in full]).mean(0)
+        print(f'wave {w}: {len(full)} units of {T} tiles; epilogue by tile position:')
+        print('   ' + ' '.join('%4d' % v for v in ep))
+        print('   burst by tile position:')
+        print('   ' + ' '.join('%4d' % v for v in bu))

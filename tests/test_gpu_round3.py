@@ -283,3 +283,42 @@ def test_pruned_trajectory_equals_unpruned_over_twenty_steps(dev, kernel):
     err = elem_err(a[4], b[4], floor=1e-2)
     print(f'pruned vs unpruned 20-step trajectory (kernel {kernel}): max element error {err:.2e}, bitwise equal: {torch.equal(a[4], b[4])}')
     assert err < 1e-4
+
+
+@pytest.mark.parametrize('t', [1.0, 0.2])
+def test_build_graph_large_shapes_vs_oracle(dev, t):
+    """The graph kernels on shapes the workloads do not reach: 100 ligand atoms (two 64-lane chunks in every wave-per-atom / wave-per-residue
+    loop of csrc/k_graph.hip) and 3000 residues (the workgroup's LDS beyond the default 64 KB, the static edge list beyond the register-held
+    8192) against the oracle's graph builders (score_model.py:310-408): the edge multiset of every group, group order, every group sorted
+    by the receiving node."""
+    from collections import Counter
+    from disco_diffdock_amd import synthetic
+    from disco_diffdock_amd.runtime import Context, Complex
+    from helpers import batch_of
+    c = synthetic.make_complex(5, n_res=3000, n_lig=100)
+    assert c['lig_pos'].shape[0] == 100 and c['rec_pos'].shape[0] == 3000
+    ctx = Context(device=0)
+    ctx.load_state_dict(smr.random_state_dict(CFG, seed=2))
+    B = 2
+    rng = np.random.default_rng(3)
+    pos = np.stack([c['lig_pos'] + rng.normal(0, 3.0, size=(1, 3)) for _ in range(B)]).astype(np.float32)
+    cx = Complex(ctx, c, B)
+    ei, off = cx.build_graph(T(pos).to(dev), t)
+    ei, off = ei.cpu().long(), [int(v) for v in off]
+    b = batch_of(c, B, pos)
+    spr.set_time(b, t, t, t, B)
+    dt = torch.float32
+    _, lig_ei, _, _, lig_sig = smr.build_lig_conv_graph(b, CFG, None, dt)
+    _, rec_ei, _, _ = smr.build_rec_conv_graph(b, CFG, None, dt)
+    tr_sigma = smr.t_to_sigma(*[b.complex_t[k] for k in ('tr', 'rot', 'tor')], CFG)[0]
+    lr_ei, _, _ = smr.build_cross_conv_graph(b, CFG, (tr_sigma * 3 + 20).unsqueeze(1).to(dt), lig_sig, None, dt)
+    n_l = B * 100
+    lr = torch.stack([lr_ei[0], lr_ei[1] + n_l])
+    want = [lig_ei, lr, rec_ei + n_l, torch.flip(lr, dims=[0])]
+    assert off[0] == 0 and off[4] == ei.shape[1] == sum(w.shape[1] for w in want)
+    assert lr.shape[1] > 64 * 100                       # cross edges well beyond one 64-lane chunk per atom
+    for k in range(4):
+        sl = ei[:, off[k]:off[k + 1]]
+        assert sl.shape[1] == want[k].shape[1], k
+        assert Counter(zip(sl[0].tolist(), sl[1].tolist())) == Counter(zip(want[k][0].tolist(), want[k][1].tolist())), k
+        assert bool((sl[0, 1:] >= sl[0, :-1]).all()), k

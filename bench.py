@@ -524,6 +524,22 @@ def main():
                       'headline': {k: v for k, v in summary(head, n_done).items() if k != 'value'},
                       'device_loop': device_loop, 'per_call_ms': head['per_call_ms']},
         }
+        if int(getattr(ctx.cfg, 'conv_kernel', 0)) == 1:
+            # the whole run was switched to the fallback kernel (DDK_CONV_KERNEL=1): its work is fp32 MFMA chains, priced against the fp32 MFMA peak
+            r_ = out['roofline']
+            r_['kernel'] = 'ddk::conv_fused_kernel<true, 0> (k_conv.hip: radial-MLP GEMMs as v_mfma_f32_32x32x2_f32 chains; the fallback, ddk_config.conv_kernel = 1)'
+            r_['achieved'] = r_['fp32_equivalent_TFLOPs']
+            r_['peak'] = PEAK_F32_MFMA_TFLOPS
+            r_['frac'] = r_['fp32_equivalent_TFLOPs'] / PEAK_F32_MFMA_TFLOPS
+            r_['accounting'] = ('achieved / frac: the ALGORITHMIC fp32 FLOPs of the evaluated edges (2*72*(72+W) + TP per edge and layer) / HIP-event time of the launches, '
+                                'against the fp32 MFMA peak (the kernel executes them as fp32 MFMA chains, K padded 72 -> 80)')
+            for k_ in ('flop_per_launch',):
+                r_[k_] = r_['fp32_equivalent_flop_per_launch']
+            for pl in r_['per_layer']:
+                pl.pop('mfma_TFLOPs', None)
+            r_['traffic'] = None
+            r_['traffic_source'] = None
+            out['dtype_note'] = 'every operand and accumulator of the path is fp32 (fallback kernel: fp32 MFMA chains)'
         if world == 1 and not a.no_cpu_baseline and not disco:
             c0 = complexes[mine[0]]
             cx0 = Complex(ctx, c0, 2)

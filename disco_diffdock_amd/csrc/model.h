@@ -10,7 +10,7 @@ constexpr int SIG = 32;        // sigma_embed_dim
 constexpr int DE = 32;         // distance_embed_dim
 constexpr int MAX_LIG = 256;   // ligand atoms per sample the graph kernels support
 constexpr int MAX_REC = 8192;  // residues per sample
-constexpr int LIG_CAP = 33;    // radius_graph(max_num_neighbors=32) -> radius(..., 33) including self
+constexpr int LIG_CAP = 33;    // radius_graph(max_num_neighbors=32) -> radius(..., 33) including self; an atom with 33 lower-index atoms in range keeps all 33 (self is not among them)
 constexpr int BOND_CAP = 32;   // radius(..., max_num_neighbors=32) of the bond-centre graph
 
 // Layout of the per-complex int32 `info` table written by graph_fill_kernel (write_group_tables; device side; no launch depends on a host read-back).

@@ -455,7 +455,7 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
   F.patch_off = (dedup && patched) ? cx->patch_off : -1;
   F.latent_dim = c.latent_dim; F.lig_latent = cx->lig_latent; F.rec_latent = cx->rec_latent; F.unconditional = cx->unconditional;
   // worst-case edge count of THIS batch size bounds the launch
-  const int64_t cap_b = (int64_t)B * ((int64_t)cx->M + (int64_t)n_lig * (LIG_CAP - 1) + 2LL * n_lig * n_rec + cx->E_rr) + cx->E_rr;
+  const int64_t cap_b = (int64_t)B * ((int64_t)cx->M + (int64_t)n_lig * LIG_CAP + 2LL * n_lig * n_rec + cx->E_rr) + cx->E_rr;
   CK(launch_edge_features(F, (cap_b < cx->edge_cap ? cap_b : cx->edge_cap) + (F.patch_off >= 0 ? (int64_t)B * cx->E_rr + 256 : 0), s), "edge features");
   float* xin = cx->xa;
   float* xout = cx->xb;
@@ -627,7 +627,7 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
   const int n_lig = d->n_lig, n_rec = d->n_rec, M = d->n_bond_edges, lm = c.lm_embedding_dim;
   {   // one chunk for everything this function allocates (sizes below mirror the uploads / workspaces; 256 B of slack per array)
     const size_t E0 = (size_t)d->n_rec_edges, Bm0 = (size_t)max_batch, R0 = (size_t)(d->n_rot > 0 ? d->n_rot : 1);
-    const size_t cap0 = Bm0 * ((size_t)M + (size_t)n_lig * (LIG_CAP - 1) + 2 * (size_t)n_lig * n_rec + E0) + E0 + 64, N0 = Bm0 * (size_t)(n_lig + n_rec);
+    const size_t cap0 = Bm0 * ((size_t)M + (size_t)n_lig * LIG_CAP + 2 * (size_t)n_lig * n_rec + E0) + E0 + 64, N0 = Bm0 * (size_t)(n_lig + n_rec);
     size_t need = (size_t)M * 24 + R0 * 8 + R0 * n_lig + (size_t)n_rec * 12 + (size_t)(n_lig + n_rec) * NS * 4 + E0 * (8 + NS * 4 + 16) + (size_t)n_rec * 4 +
                   (size_t)n_rec * d->rec_feat_dim * 4;
     need += cap0 * (12 + NS * 4 + 16) + N0 * 4 + N0 * PRE_W * 4 + (c.deterministic ? N0 * XW * 4 + (cap0 / 32 + 128) * 2 * XW * 4 : 0) + Bm0 * ((size_t)n_lig + R0 * BOND_CAP + 2) * (8 + NE * 4 + 16) + Bm0 * (1 + R0) * (XW * 4 + 4) + 8 * 256 + Bm0 * 2 * CNT_STRIDE * 4 + INFO_INTS * 4 + (size_t)n_rec * 4 + Bm0 * n_rec + 3 * N0 * XW * 4 + (size_t)n_rec * XW * 4 + Bm0 * n_lig * 12 + 2 * Bm0 * (6 + R0) * 4;
@@ -708,7 +708,7 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
   cx->rr_sh = cx_upload(cx, sh.data(), sh.size());
   // ---- workspaces -------------------------------------------------------------------------------
   const int64_t Bm = max_batch;
-  cx->edge_cap = Bm * ((int64_t)M + (int64_t)n_lig * (LIG_CAP - 1) + 2LL * n_lig * n_rec + E) + E + 64;   // + the shared rec-rec copy
+  cx->edge_cap = Bm * ((int64_t)M + (int64_t)n_lig * LIG_CAP + 2LL * n_lig * n_rec + E) + E + 64;   // + the shared rec-rec copy
   if (cx->edge_cap >= ((int64_t)1 << 31)) return fail(ctx, DDK_ERR_INVALID, "edge capacity exceeds int32 (reduce max_batch)");
   const int64_t N = Bm * (n_lig + n_rec);
   // latent-conditioned model: room for the layer-0 patch group (at most every rec-rec edge of every sample) behind the regular edges
@@ -830,7 +830,7 @@ int ddk_build_graph(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* lig_p
   if (rc) return rc;
   { hipError_t we = cx_wait_ready(cx, (hipStream_t)stream); if (we != hipSuccess) return hip_fail(ctx, we, "wait for the complex upload"); }
   if (!lig_pos || !edge_src_out || !edge_dst_out || !group_offsets_out) return fail(ctx, DDK_ERR_INVALID, "ddk_build_graph: null argument");
-  const int64_t cap_b = (int64_t)B * ((int64_t)cx->M + (int64_t)cx->n_lig * (LIG_CAP - 1) + 2LL * cx->n_lig * cx->n_rec + cx->E_rr);
+  const int64_t cap_b = (int64_t)B * ((int64_t)cx->M + (int64_t)cx->n_lig * LIG_CAP + 2LL * cx->n_lig * cx->n_rec + cx->E_rr);
   const int64_t need = cap_b < cx->edge_cap ? cap_b : cx->edge_cap;
   if (cap < need) return fail(ctx, DDK_ERR_INVALID, "ddk_build_graph: cap " + std::to_string(cap) + " is below the worst case " + std::to_string(need) + " of this batch");
   StepParams sp;

@@ -420,7 +420,7 @@ class Complex:
         receiving node, tensor_layers.py:159); nodes numbered [all ligand atoms | all residues]."""
         pos = _need_cuda(pos).contiguous().float().reshape(-1, self.n_lig, 3)
         B = pos.shape[0]
-        cap = B * (self.M + self.n_lig * 32 + 2 * self.n_lig * self.n_rec + self.E_rr)
+        cap = B * (self.M + self.n_lig * 33 + 2 * self.n_lig * self.n_rec + self.E_rr)      # 33: radius(..., 32 + 1) minus a self loop that may not be among them
         src = torch.empty(cap, dtype=torch.int32, device=pos.device)
         dst = torch.empty(cap, dtype=torch.int32, device=pos.device)
         off = torch.empty(5, dtype=torch.int32, device=pos.device)

@@ -1,6 +1,8 @@
 """Development aid: randomised parity sweep of ddk_score_forward against the CPU oracle over small complexes of varied shape
 (ligand size, receptor size, batch, diffusion time, ligand placement incl. far away from the receptor, compressed ligands whose
-neighbour caps bind).  Prints the worst relative error per output and the case that produced it."""
+neighbour caps bind).  Prints the worst relative error per output and the case that produced it.
+
+    python tests/devtools/fuzz_parity.py [cases] [boundary]     boundary: shapes on both sides of the 64-lane chunk edges of the graph kernels"""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..', '..'))
@@ -12,6 +14,7 @@ from disco_diffdock_amd import synthetic
 from disco_diffdock_amd.runtime import Context, Complex
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+BOUNDARY = len(sys.argv) > 2 and sys.argv[2] == 'boundary'
 dev = torch.device('cuda:0')
 d = os.path.join(ROOT, 'disco_diffdock_amd', 'data')
 tables = (np.load(os.path.join(d, 'so3_exp_score_norms.npy')), np.load(os.path.join(d, 'torus_score_norm_seed0.npy')))
@@ -20,8 +23,8 @@ worst = {}
 rng = np.random.default_rng(2024)
 for case in range(N):
     seed = int(rng.integers(1 << 30))
-    n_res = int(rng.choice([5, 17, 40, 64, 97]))
-    n_lig = int(rng.choice([12, 18, 25, 33, 48]))
+    n_res = int(rng.choice([63, 64, 65, 127, 128, 129, 191] if BOUNDARY else [5, 17, 40, 64, 97]))
+    n_lig = int(rng.choice([31, 32, 33, 63, 64, 65, 80] if BOUNDARY else [12, 18, 25, 33, 48]))
     B = int(rng.choice([1, 2, 3, 5]))
     t = float(rng.choice([1.0, 0.9, 0.5, 0.2, 0.03, 0.0]))
     place = rng.choice(['pocket', 'far', 'compressed', 'spread'])

@@ -322,3 +322,29 @@ def test_build_graph_large_shapes_vs_oracle(dev, t):
         assert sl.shape[1] == want[k].shape[1], k
         assert Counter(zip(sl[0].tolist(), sl[1].tolist())) == Counter(zip(want[k][0].tolist(), want[k][1].tolist())), k
         assert bool((sl[0, 1:] >= sl[0, :-1]).all()), k
+
+
+def test_compressed_ligand_keeps_33_neighbours_within_capacity(dev, tables):
+    """radius_graph(max_num_neighbors=32) is radius(..., 33) minus the self loop (score_model.py:315): an atom with 33 lower-index atoms inside
+    5 A keeps all 33.  A compressed 65-atom ligand in a batch of 3 used to exceed the edge capacity that assumed 32 per atom (found by
+    tests/devtools/fuzz_parity.py's boundary sweep); scores against the oracle at the north-star bar."""
+    from disco_diffdock_amd import synthetic
+    from disco_diffdock_amd.runtime import Context, Complex
+    from helpers import batch_of
+    seed, n_res, n_lig, B, t = 633457205, 63, 65, 3, 0.5
+    c = synthetic.make_complex(seed % 100000, n_res=n_res, n_lig=n_lig)
+    P = smr.random_state_dict(CFG, seed=seed % 1000)
+    base = c['lig_pos'].astype(np.float64)
+    cen = base.mean(0, keepdims=True)
+    pos = np.stack([cen + 0.35 * (base - cen) for _ in range(B)]).astype(np.float32)
+    ctx = Context(device=0)
+    ctx.load_state_dict(P)
+    cx = Complex(ctx, c, B)
+    tr, rot, tor = cx.score_forward(T(pos).to(dev), t, t, t)
+    st = cx.graph_stats()
+    assert st['E_ll'] > B * (cx.M + 32 * n_lig)          # more than 32 kept neighbours per atom on average: the old bound
+    assert st['E'] + st['E_shared'] <= st['cap']
+    bt = batch_of(c, B, pos)
+    spr.set_time(bt, t, t, t, B)
+    tr_r, rot_r, tor_r = smr.score_model_forward(P, CFG, bt, tables[0], tables[1])
+    assert rel_err(tr.cpu(), tr_r) < 1e-4 and rel_err(rot.cpu(), rot_r) < 1e-4 and rel_err(tor.cpu(), tor_r) < 1e-4

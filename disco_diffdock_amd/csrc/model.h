@@ -143,7 +143,7 @@ struct GraphArgs {
   float cross_cutoff;
   const int32_t* rr_start;  // [n_rec] exclusive prefix of rr_outdeg (first static edge of each residue)
   int32_t* counts;          // [B, CNT_STRIDE]: ll radius edges, lr edges, rec-rec edges of level A / B / C
-  int32_t* offs;            // [B, CNT_STRIDE]: exclusive prefix of counts over the samples
+  int32_t* offs;            // (unused since round 3: every wave of graph_fill_kernel prefixes the counts itself)
   int32_t* info;            // InfoSlot table
   uint8_t* levels;          // [B, n_rec] receptive-field level of every residue (graph_count_kernel -> graph_fill_kernel)
   int prune = 0;            // 1: order group 2 by receptive-field level (0: every residue is level A -> the reference order)

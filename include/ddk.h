@@ -242,7 +242,7 @@ int ddk_sample(ddk_ctx* ctx, ddk_complex* cx, int32_t B, int32_t steps, const fl
  *      conv layers consume, in the reference's group order [lig-lig | lig->rec | rec-rec | rec->lig(flipped)], every group sorted
  *      by edge_src.  Row convention of tensor_layers.py:147-159: edge_src = node that RECEIVES the message (scatter index),
  *      edge_dst = node whose features enter the tensor product; node numbering [ligand atoms of all samples | residues of all
- *      samples].  lig-lig = covalent bonds + radius_graph(lig_max_radius, <= 32 neighbours); cross cutoff = 3 sigma_tr(t_tr) + 20
+ *      samples].  lig-lig = covalent bonds + radius_graph(lig_max_radius, max_num_neighbors = 32: up to 33 kept per atom, see csrc/model.h LIG_CAP); cross cutoff = 3 sigma_tr(t_tr) + 20
  *      (dynamic_max_cross) or cross_max_distance.  edge_src_out / edge_dst_out: device [cap] int32; group_offsets_out: device [5]
  *      int32 (offsets of the four groups, [4] = E).  DDK_ERR_INVALID when cap is below the complex' worst case
  *      (ddk_last_graph_stats out[7]); no host synchronisation inside. */

@@ -11,12 +11,13 @@ from disco_diffdock_amd.runtime import Context, Complex
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--reps', type=int, default=20)
+ap.add_argument('--B', type=int, default=40, help='samples in the batch (5: the node rows of a forward fit one XCD-sized L2)')
 a = ap.parse_args()
 dev = torch.device('cuda:0')
 ctx = Context(device=0)
 ctx.load_state_dict(synthetic.random_score_model_state_dict(seed=0))
 c = synthetic.make_complex(0, n_res=300)
-B = 40
+B = a.B
 cx = Complex(ctx, c, B)
 rng = np.random.default_rng(0)
 pos = torch.from_numpy(np.stack([c['lig_pos'] + rng.normal(0, 3.0, size=(1, 3)) for _ in range(B)]).astype(np.float32)).to(dev)
@@ -35,3 +36,4 @@ for t in (1.0, 0.6, 0.2):
     tot += sum(ms)
     print('t=%.1f  ' % t + '  '.join('L%d %.4f' % (l, m) for l, m in enumerate(ms)) + '   sum %.4f ms   edges %s' % (sum(ms), [q['edges'] // max(q['launches'], 1) for q in p]))
 print('mean conv ms per forward over the three times: %.4f' % (tot / 3))
+print('ns per edge and layer (t = 0.2): ' + '  '.join('L%d %.3f' % (l, 1e6 * q['ms'] / max(q['edges'], 1)) for l, q in enumerate(p)))

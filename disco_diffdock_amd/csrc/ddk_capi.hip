@@ -358,8 +358,10 @@ static int fold_batch_norm(ddk_ctx* ctx, const std::string& pre, const int* out,
 }
 
 // Three-limb fp16 records of a layer's radial-MLP weights for k_conv_x.hip: every (range-scaled) fp32 weight v becomes
-// hi + mid 2^-11 + lo 2^-22 with hi = fp16(v), mid = fp16((v - hi) 2^11), lo = fp16(((v - hi) 2^11 - mid) 2^11) - exact, and checked here
-// for every value.  w1all / w2all: the fp32 fragment arrays [.][s/4][lane][s&3] (s = register of the lane half), b2all [t][2][16].
+// hi + mid + lo with hi = fp16(v), mid = fp16(v - hi), lo = fp16(v - hi - mid), each limb carrying its own weight (fp16 subnormals included).
+// Exact whenever the last bit of v is a multiple of the fp16 subnormal step 2^-24, i.e. for |v| >= 0.5 after scaling (the group's maximum is
+// scaled into [2^14, 2^15)); smaller values are off by at most 2^-25 = 2^-39 of the maximum.  Checked here for every value.
+// w1all / w2all: the fp32 fragment arrays [.][s/4][lane][s&3] (s = register of the lane half), b2all [t][2][16].
 static int pack_x3(ddk_ctx* ctx, ConvLayerDev& L, int NG, const std::vector<float>& w1all, const std::vector<float>& w2all,
                    const std::vector<float>& b2all) {
   if (L.n_tiles > W2X_MAX_TILES) return fail(ctx, DDK_ERR_INVALID, "too many W2 tiles for the three-limb kernel's descriptor table");
@@ -367,15 +369,15 @@ static int pack_x3(ddk_ctx* ctx, ConvLayerDev& L, int NG, const std::vector<floa
   bool exact = true;
   auto split = [&exact](float v, uint16_t& hi, uint16_t& mid, uint16_t& lo) {
     const _Float16 h = (_Float16)v;
-    const float r1 = (v - (float)h) * 2048.0f;
+    const float r1 = v - (float)h;
     const _Float16 m = (_Float16)r1;
-    const _Float16 l = (_Float16)((r1 - (float)m) * 2048.0f);
+    const _Float16 l = (_Float16)(r1 - (float)m);
     memcpy(&hi, &h, 2); memcpy(&mid, &m, 2); memcpy(&lo, &l, 2);
-    // the limbs must reproduce v bit for bit (values below 2^-23 - more than 2^-36 under the group's maximum - within 2^-46)
-    const double back = (double)(float)h + (double)(float)m * 0x1p-11 + (double)(float)l * 0x1p-22;
-    if (std::fabs(v) >= 0x1p-23f ? back != (double)v : std::fabs(back - (double)v) > 0x1p-46) exact = false;
+    // the limbs must reproduce v bit for bit (values below 0.5 - more than 2^-15 under the group's maximum - within 2^-25)
+    const double back = (double)(float)h + (double)(float)m + (double)(float)l;
+    if (std::fabs(v) >= 0.5f ? back != (double)v : std::fabs(back - (double)v) > 0x1p-25) exact = false;
   };
-  // exact power-of-two range scaling: max|w| of a group is brought into [2^13, 2^14) so that no limb leaves the fp16 range whatever the
+  // exact power-of-two range scaling: max|w| of a group is brought into [2^14, 2^15) so that no limb leaves the fp16 range whatever the
   // scale of the checkpoint (the kernel scales the activations per edge the same way)
   auto range_scale = [](const float* v, size_t n, const float* v2, size_t n2) {
     float m = 0.f;
@@ -383,7 +385,7 @@ static int pack_x3(ddk_ctx* ctx, ConvLayerDev& L, int NG, const std::vector<floa
     for (size_t i = 0; i < n2; ++i) m = std::max(m, std::fabs(v2[i]));
     int e = 0;
     std::frexp(std::max(m, 0x1p-40f), &e);      // m = f * 2^e, f in [0.5, 1)
-    return std::ldexp(1.0f, 14 - e);
+    return std::ldexp(1.0f, 15 - e);
   };
   std::vector<uint8_t> w2x((size_t)NG * L.n_tiles * W2X_TILE_BYTES, 0), w1x((size_t)NG * 3 * W1X_TILE_BYTES, 0);
   // one tile of fp32 fragments [9][64][4] -> three limbs x [4 x [64][8] | [64][4]]

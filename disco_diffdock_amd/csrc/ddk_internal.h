@@ -55,7 +55,7 @@ template <> struct ConvTraits<1> { static constexpr int WAVES = 6, FS = F_STRIDE
 template <int MODE> constexpr size_t conv_lds_bytes() { return (size_t)(ConvTraits<MODE>::WAVES * 32 * ConvTraits<MODE>::FS + 2 * W2_TILE_FLOATS + 16) * 4; }
 static_assert(conv_lds_bytes<1>() <= 160 * 1024, "LDS budget (l<=2)");
 constexpr int CONV_MAX_GROUPS = 9;
-// Exact three-limb f16 kernel (k_conv_x.hip, ddk_config.conv_kernel = 0): W2 tile record = three limbs (hi | mid 2^11 | lo 2^22, fp16) x
+// Exact three-limb f16 kernel (k_conv_x.hip, ddk_config.conv_kernel = 0): W2 tile record = three limbs (hi | mid | lo, fp16, each at its own weight) x
 // [4 fragments [64 lanes][8] of K steps 0..3 | tail fragment [64][4] of the last 8 K values] | bias [2][16] f32 | pad ; element (s, lane, i) of
 // a fragment = weight of tile row lane&31 for the hidden unit held by register 8*s+i of lane half lane>>5 (K = 72 = 4 x 16 + 8)
 constexpr int W2X_LIMB_BYTES = 4 * 1024 + 512;                      // 4,608
@@ -64,7 +64,14 @@ constexpr int W2X_TILE_BYTES = W2X_BIAS_OFF + 128 + 16;             // 13,968 = 
 constexpr int W1X_TILE_BYTES = 3 * W2X_LIMB_BYTES;                  // GEMM1: the three limbs of one 32-row tile
 constexpr int CONV_TRACE_TILES = 1024;                              // tiles per wave the TRACE instantiation of the kernel records
 constexpr int W2X_MAX_TILES = 64;                                   // tile descriptors ride in the kernel arguments
-constexpr size_t CONV_X_LDS_BYTES = (size_t)CONV_WAVES * 32 * F_STRIDE * 4 + 2 * W2X_TILE_BYTES + 16;   // 163,120 B of the 163,840
+// F row of the three-limb kernel (100 floats instead of 132): the vector blocks keep the RAW p / q rows once (12 rows x xyz, component-major inside
+// each quad of rows like T1O / T1E) instead of the four products p*s0, (q x v)/sqrt2, (p x v)/sqrt2, q*s0 - multiplying by s0 and crossing with v
+// are linear, so they are applied ONCE per output channel when a vector column is flushed (two accumulator sets: "times s0" and "cross v").
+// 16-B slot of row r = 25 r mod 16 = 9 r mod 16: conflict free for ds_read_b128.  The 36,864 B this frees hold two more ring stages.
+constexpr int FX_A = 0, FX_C = NS, FX_R = 2 * NS, FX_PQ = FX_R + 6 * NV, FX_STRIDE = FX_PQ + 12 + 4;     // 0, 24, 48, 84, 100
+static_assert(FX_STRIDE == 100 && FX_A == F_A && FX_C == F_C, "F row layout (three-limb f16)");
+constexpr int W2X_STAGES = 4;                                       // LDS ring stages of the three-limb kernel
+constexpr size_t CONV_X_LDS_BYTES = (size_t)CONV_WAVES * 32 * FX_STRIDE * 4 + W2X_STAGES * W2X_TILE_BYTES + 16;
 static_assert(CONV_X_LDS_BYTES <= 160 * 1024 && W2X_TILE_BYTES % 16 == 0, "LDS budget (three-limb f16)");
 
 // One W2 "tile" = 32 weight rows x 72 hidden units = one burst of 36 v_mfma_f32_32x32x2_f32 per 32 edges.
@@ -180,7 +187,7 @@ struct ddk_ctx {
   // profiling (ddk_profile_enable / ddk_profile_read)
   bool prof = false;
   bool prune = true;                // backward receptive-field pruning of the rec-rec messages (ddk_set_receptive_field_pruning)
-  uint32_t* conv_trace = nullptr; int conv_trace_layer = -1;   // ddk_debug_conv_trace: the next forward's launch of this layer runs the TRACE kernel
+  uint32_t* conv_trace = nullptr; int conv_trace_layer = -1; int conv_trace_coarse = 0;   // ddk_debug_conv_trace: the next forward's launch of this layer runs the TRACE kernel
   bool layer0_dedup = true;         // layer-0 rec-rec messages once per batch (+ per-sample patches for the latent-conditioned model); ddk_debug_set_layer0_dedup
   struct ProfRec { hipEvent_t a, b; int layer; int slot; int tab = 0; int64_t r01_skipped = 0; bool lig_only = false; };   // tab: group table of the launch
   std::vector<ProfRec> prof_recs;
@@ -224,6 +231,7 @@ struct ConvLaunch {
   const int32_t* gbeg = nullptr;
   const int32_t* gend = nullptr;
   uint32_t* trace = nullptr;   // != null (three-limb kernel, split gather path): workgroup 0 records its half-phase time stamps here
+  int trace_coarse = 0;        // one record per unit instead of per tile (no stamps inside the tile loop)
 };
 hipError_t launch_conv_fused(const ConvLayerDev& L, const ConvLaunch& a, int n_cu, hipStream_t s);
 hipError_t launch_conv_fused_x(const ConvLayerDev& L, const ConvLaunch& a, int n_cu, hipStream_t s);   // k_conv_x.hip (exact three-limb f16)

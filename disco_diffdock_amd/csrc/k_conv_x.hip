@@ -1,35 +1,39 @@
 // Fused tensor-product convolution on the f16 matrix pipe with EXACT fp32 operands (the default conv kernel of the score model).
 //
-// Same algorithm, tile tables, F rows, epilogue and scatter as k_conv.hip (the fp32-MFMA kernel, kept as ddk_config.conv_kernel = 1 and for
+// Same algorithm, tile tables, epilogue and scatter as k_conv.hip (the fp32-MFMA kernel, kept as ddk_config.conv_kernel = 1 and for
 // the confidence model); only the two radial-MLP GEMMs of models/tensor_layers.py:140-143,154-155 change pipe.  Every fp32 operand x (after an
-// exact power-of-two range scaling, below) is split into three fp16 limbs
-//        x = hi + mid * 2^-11 + lo * 2^-22,     hi = fp16(x),  mid = fp16((x - hi) 2^11),  lo = fp16(((x - hi) 2^11 - mid) 2^11)
-// which is EXACT: a 24-bit significand minus its 11-bit rounding leaves <= 13 bits, of which mid takes 11 and lo the rest (no rounding in the
-// last conversion; checked on the host for every packed weight and on the device by ddk_debug_split3).  The product of two such sums is formed
-// with v_mfma_f32_32x32x16_f16 (products of fp16 numbers are exact in the fp32 accumulators) keeping the six terms
-//        hi.hi  +  2^-11 (hi.mid + mid.hi)  +  2^-22 (hi.lo + lo.hi + mid.mid)
-// and dropping mid.lo + lo.mid + lo.lo <= 3 * 2^-33 relative - 500 times below the fp32 rounding of the accumulation itself.  Three fp32
-// accumulators (one per power of 2^-11) are combined once per tile.  6 MFMAs of 8 passes replace 8 x 16 passes of v_mfma_f32_32x32x2_f32 per
-// 16 K values: 2.7x fewer matrix-pipe cycles, and the f16 pipe does not share issue with the VALU the way the fp32 MFMA does.
+// exact power-of-two range scaling, below) is split into three fp16 limbs that carry their own weight
+//        x = hi + mid + lo,     hi = fp16(x),  mid = fp16(x - hi),  lo = fp16(x - hi - mid)
+// A 24-bit significand minus its 11-bit rounding leaves <= 13 bits, of which mid takes 11 and lo the rest: the split is EXACT as long as the
+// last bit of x is a multiple of the fp16 subnormal step 2^-24 (v_mfma_f32_32x32x16_f16 and v_cvt_f16_f32 honour fp16 subnormals:
+// tools/probes/mfma_probe10.hip), i.e. for every |x| >= 0.5 after scaling; smaller values are off by <= 2^-25 absolute.  The product of two
+// such sums is formed with v_mfma_f32_32x32x16_f16 (products of fp16 numbers are exact in fp32) keeping the six terms
+//        hi.hi + hi.mid + mid.hi   (accumulator D0)        hi.lo + lo.hi + mid.mid   (accumulator D1, everything of relative order 2^-22)
+// and dropping mid.lo + lo.mid + lo.lo <= 3 * 2^-33 relative - 500 times below the fp32 rounding of the accumulation itself.  D0 + D1 is
+// formed once per tile; D0 rounds like an fp32 FMA chain (one rounding per MFMA, round to nearest even), D1 keeps the small terms among
+// themselves.  6 MFMAs of 8 passes replace 8 x 16 passes of v_mfma_f32_32x32x2_f32 per 16 K values: 2.7x fewer matrix-pipe cycles, and the
+// f16 pipe does not share issue with the VALU the way the fp32 MFMA does.
 //
 // Range: fp16 spans 2^-24 .. 65504, a checkpoint does not.  Each split operand is first multiplied by an exact power of two that brings the
-// maximum of its group into [2^13, 2^14): W1 and (W2 | b2) per (layer, edge group) at pack time, the GEMM1 inputs and the hidden vector per
-// EDGE in the kernel (exponent arithmetic only); the results are multiplied back by the inverse powers.  With the limbs' own 2^11 / 2^22
-// factors every value within 2^-36 of its group's maximum is represented exactly; smaller ones are off by < 2^-59 of the maximum.
+// maximum of its group into [2^14, 2^15): W1 and W2 per (layer, edge group) at pack time, the GEMM1 inputs and the hidden vector per
+// EDGE in the kernel (exponent arithmetic only); the results are multiplied back by the inverse powers.  Every value within 2^-15 of its
+// group's maximum is represented exactly; smaller ones are off by <= 2^-39 of the maximum.
 //
 // K = 72 = 4 steps of 16 + one of 8 (v_mfma_f32_32x32x8_f16): register 8s+i (< 36) of a lane half is element i of step s.
-// The b2 bias starts the hi.hi accumulator (scaled like the products).  Tile record in the LDS ring (13,968 B): three limbs x
-// [4 x 1 KB fragments | 512 B tail fragment] | bias [2][16] f32; the tile descriptors ride in the kernel arguments (scalar loads).
+// Tile record in the LDS ring (13,968 B): three limbs x [4 x 1 KB fragments | 512 B tail fragment] | bias [2][16] f32 (added, scaled like the
+// products, when D0 + D1 is formed); the tile descriptors ride in the kernel arguments (scalar loads).
 // The fragments are streamed from the ring INSIDE the burst (no register double buffer: h's three limbs need the registers).
 //
-// Two waves share a SIMD and with it ONE matrix pipe; a wave's tile is a burst of 28 MFMAs (896 pipe cycles; the K=8 tail packs two products per 32x32x16) followed by a VALU / LDS
-// epilogue.  Run in lock step (one barrier per tile) both waves of a SIMD burst together and then leave the pipe idle together.  So the
-// workgroup runs as two half-groups in STRICT ALTERNATION: waves 0-3 (group A, one per SIMD) burst tile t while waves 4-7 (group B, their SIMD
-// partners) run the epilogue of tile t-1, then the roles swap - two barriers per tile, every half phase pairs one wave's MFMA burst with its
-// partner's epilogue, and the pipe sees one burst after the other.  Ring protocol (2 stages, tile t in stage t & 1): group B alone fills the
-// ring - it requests tile t+2 from L2 at the start of its burst of tile t and publishes it in its epilogue of tile t, into the stage that
-// tile t left (group A reads the other stage meanwhile) - so that a tile is complete one half phase before its first reader and each
-// group can fetch the first two K steps of its NEXT tile before the barrier that starts that tile's burst.
+// Two waves share a SIMD and with it ONE matrix pipe; a wave's tile is a burst of 28 MFMAs (896 pipe cycles; the K=8 tail packs two products per
+// 32x32x16) followed by a VALU / LDS epilogue.  The workgroup runs as two half-groups in ALTERNATION with ONE barrier per tile: between two
+// barriers waves 0-3 (group A, one per SIMD) run [burst t, epilogue t] and waves 4-7 (group B, their SIMD partners) [epilogue t-1, burst t], so
+// that a burst always sits beside the partner's epilogue and the pipe sees one burst after the other; where an epilogue is shorter than the
+// partner's burst the next burst simply starts early and shares the pipe for a while (round 3 separated the two halves of a tile by a second
+// barrier: every half phase then cost max(burst, partner's epilogue) + a barrier, 29 % of a wave's cycles were waits).
+// Ring protocol (4 stages, tile t in stage t & 3, both groups read tile t between the same two barriers): every thread requests its two 16-B
+// chunks of tile t+3 from L2 during its burst of tile t and stores them in its epilogue of tile t into the stage tile t-1 has left - group A
+// between barriers t and t+1, group B one interval later - so tile t+3 is complete at barrier t+2 and each wave fetches the first two K steps of
+// its NEXT tile at the start of its epilogue.
 #include <stdlib.h>
 
 #include "k_conv_common.h"
@@ -45,23 +49,25 @@ struct ConvXArgs {
   ConvKArgs k;
   int32_t tq[W2X_MAX_TILES][2];     // tile descriptors (TileDesc::w0, chan0)
   uint32_t* trace;                  // TRACE instantiation: [8 waves][CONV_TRACE_TILES][8] s_memtime stamps of workgroup 0
+  int trace_coarse;                 // 1: one record per UNIT (slots 4-7 prologue, 0 = tile loop done, 1 = tiles, 2 = unit handed over): no stamp inside the tile loop
 };
 
-// Exact power-of-two range scale: 2^(13 - floor(log2 max(m, 2^-40))) and its inverse (max|x| lands in [2^13, 2^14))
+// Exact power-of-two range scale: 2^(14 - floor(log2 max(m, 2^-40))) and its inverse (max|x| lands in [2^14, 2^15))
 __device__ __forceinline__ float range_scale(float m, float& inv) {
   const uint32_t eb = max((__float_as_uint(m) >> 23) & 0xffu, 87u);   // biased exponent; 0 and subnormals map to the 2^-40 floor
-  inv = __uint_as_float((eb - 13u) << 23);
-  return __uint_as_float((267u - eb) << 23);
+  inv = __uint_as_float((eb - 14u) << 23);
+  return __uint_as_float((268u - eb) << 23);
 }
 
-// the three limbs of one (range-scaled) value; every step is exact except the first rounding
+// the three limbs of one (range-scaled) value, each carrying its own weight: the subtractions are exact, the conversions of the remainders
+// round only below the fp16 subnormal step
 struct Limb3 { _Float16 h, m, l; };
 __device__ __forceinline__ Limb3 split3(float v) {
   Limb3 q;
   q.h = (_Float16)v;
-  const float r1 = (v - (float)q.h) * 2048.0f;
+  const float r1 = v - (float)q.h;
   q.m = (_Float16)r1;
-  q.l = (_Float16)((r1 - (float)q.m) * 2048.0f);
+  q.l = (_Float16)(r1 - (float)q.m);
   return q;
 }
 
@@ -144,26 +150,57 @@ __device__ __forceinline__ void segf_add_n(float* dst, int stride, float (&xv)[N
 }
 #undef SEGF_STEP
 
-// six-term product of one K step into the three accumulators (same-accumulator MFMAs never adjacent)
+// six-term product of one K step into the two accumulators, alternating (D0: hi.hi and the 2^-11 terms, D1: the 2^-22 terms)
 #define X3_STEP(MF, ah, am, al, bh, bm, bl)   \
-  D2 = MF(ah, bl, D2);                        \
-  D1 = MF(ah, bm, D1);                        \
-  D2 = MF(al, bh, D2);                        \
+  D1 = MF(ah, bl, D1);                        \
+  D0 = MF(ah, bm, D0);                        \
+  D1 = MF(al, bh, D1);                        \
   D0 = MF(ah, bh, D0);                        \
-  D2 = MF(am, bm, D2);                        \
-  D1 = MF(am, bh, D1);
+  D1 = MF(am, bm, D1);                        \
+  D0 = MF(am, bh, D0);
 
 // scalar-accumulator tensor-product epilogue of one W2 tile (wave-uniform branch on the tile kind; the f16 pipe does not compete with the VALU
 // for issue: fewer registers beat fewer instructions here).  T_RTS: only rows j = 0,1 belong to the column that is about to be flushed.
-__device__ __forceinline__ void tile_epilogue_s(int kind, const f32x16& D, const float* Fp, f32x4 f0, float (&accA)[4], float (&accV)[4][3]) {
+__device__ __forceinline__ void tile_epilogue_s(int w0, const f32x16& D, const float* Fp, f32x4 f0, float (&accA)[4], float (&accV)[4][3],
+                                                float (&accX)[4][3]) {
+  const int kind = w0 & 3;
   if (kind == T_TV) {
+    // raw p / q rows: rows whose product is "times s0" accumulate into accV, rows that are crossed with v into accX (bits 14 / 15 of the tile
+    // word: rows j = 0,1 / j = 2,3 are cross rows); both factors are applied when the column is flushed
     const f32x4 f1 = ldv4(Fp + 4), f2 = ldv4(Fp + 8);      // y / z components of the 4 feature rows
+    if (w0 & 0x4000) {
 #pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {
-      const float d0 = D[4 * rq], d1 = D[4 * rq + 1], d2 = D[4 * rq + 2], d3 = D[4 * rq + 3];
-      accV[rq][0] = fmaf(f0.x, d0, fmaf(f0.y, d1, fmaf(f0.z, d2, fmaf(f0.w, d3, accV[rq][0]))));
-      accV[rq][1] = fmaf(f1.x, d0, fmaf(f1.y, d1, fmaf(f1.z, d2, fmaf(f1.w, d3, accV[rq][1]))));
-      accV[rq][2] = fmaf(f2.x, d0, fmaf(f2.y, d1, fmaf(f2.z, d2, fmaf(f2.w, d3, accV[rq][2]))));
+      for (int rq = 0; rq < 4; ++rq) {
+        const float d0 = D[4 * rq], d1 = D[4 * rq + 1];
+        accX[rq][0] = fmaf(f0.x, d0, fmaf(f0.y, d1, accX[rq][0]));
+        accX[rq][1] = fmaf(f1.x, d0, fmaf(f1.y, d1, accX[rq][1]));
+        accX[rq][2] = fmaf(f2.x, d0, fmaf(f2.y, d1, accX[rq][2]));
+      }
+    } else {
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const float d0 = D[4 * rq], d1 = D[4 * rq + 1];
+        accV[rq][0] = fmaf(f0.x, d0, fmaf(f0.y, d1, accV[rq][0]));
+        accV[rq][1] = fmaf(f1.x, d0, fmaf(f1.y, d1, accV[rq][1]));
+        accV[rq][2] = fmaf(f2.x, d0, fmaf(f2.y, d1, accV[rq][2]));
+      }
+    }
+    if (w0 & 0x8000) {
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const float d2 = D[4 * rq + 2], d3 = D[4 * rq + 3];
+        accX[rq][0] = fmaf(f0.z, d2, fmaf(f0.w, d3, accX[rq][0]));
+        accX[rq][1] = fmaf(f1.z, d2, fmaf(f1.w, d3, accX[rq][1]));
+        accX[rq][2] = fmaf(f2.z, d2, fmaf(f2.w, d3, accX[rq][2]));
+      }
+    } else {
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const float d2 = D[4 * rq + 2], d3 = D[4 * rq + 3];
+        accV[rq][0] = fmaf(f0.z, d2, fmaf(f0.w, d3, accV[rq][0]));
+        accV[rq][1] = fmaf(f1.z, d2, fmaf(f1.w, d3, accV[rq][1]));
+        accV[rq][2] = fmaf(f2.z, d2, fmaf(f2.w, d3, accV[rq][2]));
+      }
     }
   } else if (kind == T_RA) {
 #pragma unroll
@@ -188,18 +225,27 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
   int trace_n = 0;
   auto stamp = [&](int phase) {
     if constexpr (TRACE) {
+      if (AX.trace_coarse && phase < 4) return;
       if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && trace_n < CONV_TRACE_TILES)
         AX.trace[((threadIdx.x >> 6) * CONV_TRACE_TILES + trace_n) * 8 + phase] = (uint32_t)__builtin_amdgcn_s_memtime();
       if (phase == 3) ++trace_n;
     }
   };
+  auto stamp_unit = [&](int slot, int value) {      // coarse trace: slot 0 / 2 take the time, slot 1 the given value; slot 2 closes the record
+    if constexpr (TRACE) {
+      if (!AX.trace_coarse) return;
+      if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && trace_n < CONV_TRACE_TILES)
+        AX.trace[((threadIdx.x >> 6) * CONV_TRACE_TILES + trace_n) * 8 + slot] = slot == 1 ? (uint32_t)value : (uint32_t)__builtin_amdgcn_s_memtime();
+      if (slot == 2) ++trace_n;
+    }
+  };
   const ConvKArgs& A = AX.k;
-  constexpr int WAVES = CONV_WAVES, FS = F_STRIDE, BLOCK_EDGES = 32 * WAVES;
+  constexpr int WAVES = CONV_WAVES, FS = FX_STRIDE, BLOCK_EDGES = 32 * WAVES;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* F = lds + wave * (32 * FS);                                   // this wave's 32 F rows
-  char* ring = reinterpret_cast<char*>(lds + WAVES * (32 * FS));       // [2][W2X_TILE_BYTES]
-  int* blk_slot = reinterpret_cast<int*>(ring + 2 * W2X_TILE_BYTES);
+  char* ring = reinterpret_cast<char*>(lds + WAVES * (32 * FS));       // [W2X_STAGES][W2X_TILE_BYTES]
+  int* blk_slot = reinterpret_cast<int*>(ring + W2X_STAGES * W2X_TILE_BYTES);
   const int el = lane & 31;
   const int hh = lane >> 5;
   const bool g2_shared = A.sum_g2 != nullptr;                 // group 2 is the shared rec-rec copy (layer-0 de-duplication): its own accumulator
@@ -223,12 +269,11 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
   const float inv_s3 = 0.57735026918962576451f, inv_s2 = 0.70710678118654752440f;
   const int n_tiles = A.n_tiles;
   constexpr int REC16 = W2X_TILE_BYTES / 16;                   // 873 x 16 B per tile record
-  const bool second = tid < REC16 - 64 * WAVES;                 // prologue: threads that move a second 16 B of the record
   const int grp = wave >> 2;                                    // half-group: 0 = waves 0-3 (A), 1 = waves 4-7 (B, their SIMD partners)
   if (grp) __builtin_amdgcn_s_setprio(1);                       // the later-dispatched half loses every issue arbitration by age: static priority evens it out
-  const int ftid = tid & 255;                                   // group B fills the ring: 16-B chunks ftid + 256 k, k < 3, and a fourth below
-  const bool fourth = ftid < REC16 - 3 * 256;
-  const uint32_t fo0 = 16u * ftid, fo3 = fourth ? fo0 + 12288u : fo0;      // byte offsets of this thread's chunks inside a tile record
+  // every thread moves two 16-B chunks of a tile record: chunk tid and chunk tid + 512 (threads past the record's end move its last chunk
+  // again: same bytes to the same place, no branch in the burst)
+  const uint32_t fo0 = 16u * tid, fo1 = 16u * min(tid + 64 * WAVES, REC16 - 1);
 
   // work units: whole blocks, except that the last (bs4 mod #workgroups) blocks are split into column chunks so that the final round of the
   // persistent workgroups is a fraction of a block long (same rule as k_conv.hip)
@@ -267,21 +312,22 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
     const int e = nvalid > 0 ? e0 + min(el, nvalid - 1) : gend - 1;
     const int sn = A.src[e], dn = A.dst[e];
 
-    // ---- stage the first two W2 tiles of this unit (the ring is idle: the previous unit ended with a barrier) ----
+    // ---- stage the first three W2 tiles of this unit (the ring is idle: the previous unit ended with a barrier) ----
     const int gw = (int)((A.wmap >> (4 * g)) & 15);                 // weight set / node-term roles of this group
     const char* wrec = reinterpret_cast<const char*>(A.w2x) + (size_t)gw * n_tiles * W2X_TILE_BYTES;
     {
       const char* wr0 = wrec + (size_t)t_begin * W2X_TILE_BYTES;
       const char* wr1 = wrec + (size_t)min(t_begin + 1, t_end - 1) * W2X_TILE_BYTES;
-      const float4 r0 = *reinterpret_cast<const float4*>(wr0 + 16 * tid), r1 = *reinterpret_cast<const float4*>(wr1 + 16 * tid);
-      *reinterpret_cast<float4*>(ring + 16 * tid) = r0;
-      *reinterpret_cast<float4*>(ring + W2X_TILE_BYTES + 16 * tid) = r1;
-      if (second) {
-        const int q = 16 * (tid + 64 * WAVES);
-        const float4 r2 = *reinterpret_cast<const float4*>(wr0 + q), r3 = *reinterpret_cast<const float4*>(wr1 + q);
-        *reinterpret_cast<float4*>(ring + q) = r2;
-        *reinterpret_cast<float4*>(ring + W2X_TILE_BYTES + q) = r3;
-      }
+      const char* wr2 = wrec + (size_t)min(t_begin + 2, t_end - 1) * W2X_TILE_BYTES;
+      const float4 r0 = *reinterpret_cast<const float4*>(wr0 + fo0), r1 = *reinterpret_cast<const float4*>(wr0 + fo1);
+      const float4 r2 = *reinterpret_cast<const float4*>(wr1 + fo0), r3 = *reinterpret_cast<const float4*>(wr1 + fo1);
+      const float4 r4 = *reinterpret_cast<const float4*>(wr2 + fo0), r5 = *reinterpret_cast<const float4*>(wr2 + fo1);
+      *reinterpret_cast<float4*>(ring + fo0) = r0;
+      *reinterpret_cast<float4*>(ring + fo1) = r1;
+      *reinterpret_cast<float4*>(ring + W2X_TILE_BYTES + fo0) = r2;
+      *reinterpret_cast<float4*>(ring + W2X_TILE_BYTES + fo1) = r3;
+      *reinterpret_cast<float4*>(ring + 2 * W2X_TILE_BYTES + fo0) = r4;
+      *reinterpret_cast<float4*>(ring + 2 * W2X_TILE_BYTES + fo1) = r5;
     }
 
     // ---- segmented-scan control words (identical for every output channel of this wave's 32 edges) ----
@@ -342,7 +388,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
         const float bsc = s1 * A.w1s[gw], usc = inv1 * A.w1u[gw];
 #pragma unroll
         for (int T = 0; T < 3; ++T) {
-          f32x16 D0, D1, D2;
+          f32x16 D0, D1;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             if (T < 2 || j == 0) {
@@ -353,7 +399,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
             }
           }
 #pragma unroll
-          for (int r = 0; r < 16; ++r) { D1[r] = 0.0f; D2[r] = 0.0f; }
+          for (int r = 0; r < 16; ++r) D1[r] = 0.0f;
           const char* wt = w1 + (size_t)T * W1X_TILE_BYTES;
           {
             const f16x8 ah = *reinterpret_cast<const f16x8*>(wt + lane * 16);
@@ -370,7 +416,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
           const int nr = T < 2 ? 16 : 4;
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            if (r < nr) h[16 * T + r] = fmaxf(fmaf(fmaf(D2[r], 1.0f / 2048.0f, D1[r]), 1.0f / 2048.0f, D0[r]), 0.0f) * usc;
+            if (r < nr) h[16 * T + r] = fmaxf(D0[r] + D1[r], 0.0f) * usc;
         }
       } else {
         float bin[36];
@@ -405,7 +451,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
         const float* b1 = A.b1p + (size_t)gw * (3 * 2 * 16);
 #pragma unroll
         for (int T = 0; T < 3; ++T) {
-          f32x16 D0, D1, D2;
+          f32x16 D0, D1;
           const float* bp = b1 + (T * 2 + hh) * 16;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -413,7 +459,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
             D0[4 * j + 0] = b.x * bsc; D0[4 * j + 1] = b.y * bsc; D0[4 * j + 2] = b.z * bsc; D0[4 * j + 3] = b.w * bsc;
           }
 #pragma unroll
-          for (int r = 0; r < 16; ++r) { D1[r] = 0.0f; D2[r] = 0.0f; }
+          for (int r = 0; r < 16; ++r) D1[r] = 0.0f;
           const char* wt = w1 + (size_t)T * W1X_TILE_BYTES;
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
@@ -431,7 +477,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
           const int nr = T < 2 ? 16 : 4;
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            if (r < nr) h[16 * T + r] = fmaxf(fmaf(fmaf(D2[r], 1.0f / 2048.0f, D1[r]), 1.0f / 2048.0f, D0[r]), 0.0f) * usc;
+            if (r < nr) h[16 * T + r] = fmaxf(D0[r] + D1[r], 0.0f) * usc;
         }
       }
       float m2 = 0.0f;
@@ -450,10 +496,8 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
     // ---- F row of this edge: TP row operands derived from x[dst] and sh (written by both lane halves) ----
     const float s0 = shv.x, vx = shv.y, vy = shv.z, vz = shv.w;
     {
-      // half 0: a -> F_A, p: (p.v) -> F_PQ, p*s0 -> rows 0..nv-1 of T1O, (p x v)/sqrt2 -> rows 0..nv-1 of T1E
-      // half 1: c -> F_C, q: (q.v) -> F_PQ, q*s0 -> rows nv.. of T1E, (q x v)/sqrt2 -> rows nv.. of T1O
-      const int o_main_dst = hh ? F_C : F_A;
-      const int o_vs = hh ? F_T1E : F_T1O, o_vc = hh ? F_T1O : F_T1E, r0 = hh ? NV : 0;
+      // half 0: a -> FX_A, p: (p.v)/sqrt3 -> FX_PQ, raw p -> rows 0..nv-1 of FX_R;  half 1: c -> FX_C, q: (q.v)/sqrt3 -> FX_PQ, raw q -> rows nv..
+      const int o_main_dst = hh ? FX_C : FX_A, r0 = hh ? NV : 0;
 #pragma unroll
       for (int j = 0; j < NS / 4; ++j) *reinterpret_cast<float4*>(Fr + o_main_dst + 4 * j) = mainv[j];
       float pv[3 * NV];
@@ -462,18 +506,14 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
 #pragma unroll
       for (int m = 0; m < NV; ++m) {
         const float px = pv[3 * m], py = pv[3 * m + 1], pz = pv[3 * m + 2];
-        // F_PQ = [pv0..3 | qv0..3 | pv4 pv5 qv4 qv5]
-        Fr[F_PQ + (m < 4 ? 4 * hh + m : 8 + 2 * hh + (m - 4))] = (px * vx + py * vy + pz * vz) * inv_s3;
-        // vector parts: row r of the 12-row part lives at 12*(r/4) + 4*c + r%4 (component-major inside a quad of rows)
+        // FX_PQ = [pv0..3 | qv0..3 | pv4 pv5 qv4 qv5]
+        Fr[FX_PQ + (m < 4 ? 4 * hh + m : 8 + 2 * hh + (m - 4))] = (px * vx + py * vy + pz * vz) * inv_s3;
+        // row r of the 12 raw rows lives at 12*(r/4) + 4*c + r%4 (component-major inside a quad of rows)
         const int r = r0 + m;
-        float* Ps = Fr + o_vs + 12 * (r >> 2) + (r & 3);
-        float* Pc = Fr + o_vc + 12 * (r >> 2) + (r & 3);
-        Ps[0] = px * s0;
-        Ps[4] = py * s0;
-        Ps[8] = pz * s0;
-        Pc[0] = (py * vz - pz * vy) * inv_s2;
-        Pc[4] = (pz * vx - px * vz) * inv_s2;
-        Pc[8] = (px * vy - py * vx) * inv_s2;
+        float* Pr = Fr + FX_R + 12 * (r >> 2) + (r & 3);
+        Pr[0] = px;
+        Pr[4] = py;
+        Pr[8] = pz;
       }
     }
     stamp(7);
@@ -493,30 +533,31 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
         else if (sn == snl && last_cont) node_row = prow + XW;
       }
     }
-    float accA[4], accV[4][3];
+    float accA[4], accV[4][3], accX[4][3];      // accX: sums over the rows that are crossed with v (vector columns)
 #pragma unroll
-    for (int rq = 0; rq < 4; ++rq) { accA[rq] = 0.0f; accV[rq][0] = 0.0f; accV[rq][1] = 0.0f; accV[rq][2] = 0.0f; }
-    // the first two K steps of the first tile (every later tile's are fetched at the end of the previous epilogue)
+    for (int rq = 0; rq < 4; ++rq) {
+      accA[rq] = 0.0f; accV[rq][0] = 0.0f; accV[rq][1] = 0.0f; accV[rq][2] = 0.0f; accX[rq][0] = 0.0f; accX[rq][1] = 0.0f; accX[rq][2] = 0.0f;
+    }
+    // the first two K steps of the first tile (every later tile's are fetched at the start of the previous epilogue)
     Frag16 p0 = lds_frag16(ring, 0, lane), p1 = lds_frag16(ring, 1, lane);
     int w0n = AX.tq[t_begin][0], chan0n = AX.tq[t_begin][1];
-    if (grp) lds_barrier();        // group B runs half a tile behind group A
     for (int t = t_begin; t < t_end; ++t) {
       const int w0 = w0n, chan0 = chan0n;
       const int t1 = min(t + 1, t_end - 1);
-      const char* stage = ring + ((t - t_begin) & 1) * W2X_TILE_BYTES;
+      const char* stage = ring + ((t - t_begin) & 3) * W2X_TILE_BYTES;
       stamp(0);
-      // ================= burst: 28 MFMAs, everything else of this half phase threaded between them =================
-      // Issue order, pinned region by region (one K step each): the first MFMA goes out right behind the barrier (its operands were fetched
-      // before it) and every other instruction of this half phase rides in the shadow of an MFMA, one per MFMA: the LDS reads of the
-      // fragments two steps ahead, the epilogue's operands (feature rows, bias), and the next ring record - BOTH groups request their
-      // 48-64 B of tile t+2 from L2 (a branch would cut the stream); only group B publishes them, in this tile's epilogue.
-      const char* rec2 = wrec + (size_t)min(t + 2, t_end - 1) * W2X_TILE_BYTES;
+      // ================= burst: 28 MFMAs, everything else of this phase threaded between them =================
+      // Issue order, pinned region by region (one K step each): the first MFMA goes out first (its operands were fetched in the previous
+      // epilogue) and every other instruction of the burst rides in the shadow of an MFMA, one per MFMA: the LDS reads of the fragments two steps
+      // ahead, the epilogue's operands (feature rows, bias), and this thread's two chunks of ring record t+3.
+      const char* rec3 = wrec + (size_t)min(t + 3, t_end - 1) * W2X_TILE_BYTES;
       const float* Fp = Fr + (w0 >> 16);
       const float* bp = reinterpret_cast<const float*>(stage + W2X_BIAS_OFF) + hh * 16;
-      f32x16 D0, D1, D2, Bs;
+      f32x16 D0, D1, Bs;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { D0[r] = 0.0f; D1[r] = 0.0f; D2[r] = 0.0f; }
+      for (int r = 0; r < 16; ++r) { D0[r] = 0.0f; D1[r] = 0.0f; }
 #define X3_PAIR(mask) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(mask, 1, 0); }
+#define X3_BARE { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }
       __builtin_amdgcn_sched_barrier(0);
       const Frag16 q2 = lds_frag16(stage, 2, lane);
       const f32x4 f0 = ldv4(Fp);
@@ -532,57 +573,76 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
       X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100)
       __builtin_amdgcn_sched_barrier(0);
       const float4 bs2 = ld4(bp + 8), bs3 = ld4(bp + 12);
-      const float4 st0 = *reinterpret_cast<const float4*>(rec2 + fo0);
-      const float4 st1 = *reinterpret_cast<const float4*>(rec2 + fo0 + 4096u);
-      const float4 st2 = *reinterpret_cast<const float4*>(rec2 + fo0 + 8192u);
-      const float4 st3 = *reinterpret_cast<const float4*>(rec2 + fo3);
+#ifndef ABL_NO_RING
+      const float4 st0 = *reinterpret_cast<const float4*>(rec3 + fo0);
+      const float4 st1 = *reinterpret_cast<const float4*>(rec3 + fo1);
+#endif
       X3_STEP(MFMA16, q2.h, q2.m, q2.l, H.hi[2], H.mid[2], H.lo[2])
-      X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x020) X3_PAIR(0x020) X3_PAIR(0x020) X3_PAIR(0x020)
+#ifndef ABL_NO_RING
+      X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x020) X3_BARE X3_PAIR(0x020) X3_BARE
+#else
+      X3_PAIR(0x100) X3_PAIR(0x100) X3_BARE X3_BARE X3_BARE X3_BARE
+#endif
       __builtin_amdgcn_sched_barrier(0);
       X3_STEP(MFMA16, q3.h, q3.m, q3.l, H.hi[3], H.mid[3], H.lo[3])
-      {     // packed tail: D1 += hi.mid + mid.hi, D2 += lo.hi + hi.lo as one K = 16 MFMA each; mid.mid and hi.hi stay K = 8
+      {     // packed tail: D0 += hi.mid + mid.hi, D1 += lo.hi + hi.lo as one K = 16 MFMA each; mid.mid and hi.hi stay K = 8
         const f16x8 a_hm = __builtin_shufflevector(th, tm, 0, 1, 2, 3, 4, 5, 6, 7), a_lh = __builtin_shufflevector(tl, th, 0, 1, 2, 3, 4, 5, 6, 7);
-        D2 = MFMA16(a_lh, HT.hl, D2);
-        D1 = MFMA16(a_hm, HT.mh, D1);
+        D1 = MFMA16(a_lh, HT.hl, D1);
+        D0 = MFMA16(a_hm, HT.mh, D0);
+        D1 = MFMA8(tm, H.tmid, D1);
         D0 = MFMA8(th, H.thi, D0);
-        D2 = MFMA8(tm, H.tmid, D2);
       }
       __builtin_amdgcn_sched_barrier(0);
 #undef X3_PAIR
+#undef X3_BARE
       Bs[0] = bs0.x; Bs[1] = bs0.y; Bs[2] = bs0.z; Bs[3] = bs0.w; Bs[4] = bs1.x; Bs[5] = bs1.y; Bs[6] = bs1.z; Bs[7] = bs1.w;
       Bs[8] = bs2.x; Bs[9] = bs2.y; Bs[10] = bs2.z; Bs[11] = bs2.w; Bs[12] = bs3.x; Bs[13] = bs3.y; Bs[14] = bs3.z; Bs[15] = bs3.w;
       stamp(1);
-      lds_barrier();
+#ifndef ABL_NO_BAR
+      if (grp) lds_barrier();          // group B: [epilogue t-1, burst t] | barrier | [epilogue t, burst t+1]
+#endif
       stamp(2);
-      // ================= epilogue (the SIMD partner bursts meanwhile) =================
+      // ================= epilogue (beside the SIMD partner's burst) =================
       // (the next tile's descriptor: a scalar load in flight makes every LDS wait a wait for everything, so it is requested here and not in the burst)
       w0n = AX.tq[t1][0]; chan0n = AX.tq[t1][1];
-      // the first two K steps of this wave's next tile (complete in the ring since the previous half phase), requested FIRST: the barrier that
-      // ends this epilogue drains the wave's LDS queue, and reads issued just before it would expose their whole latency there
+      // the first two K steps of this wave's next tile (complete in the ring since the last barrier), requested FIRST: their latency runs
+      // under the epilogue
       {
-        const char* nxt = ring + ((t1 - t_begin) & 1) * W2X_TILE_BYTES;
+        const char* nxt = ring + ((t1 - t_begin) & 3) * W2X_TILE_BYTES;
         p0 = lds_frag16(nxt, 0, lane);
         p1 = lds_frag16(nxt, 1, lane);
       }
-      if (grp) {      // publish tile t+2 into the stage tile t is leaving (both groups have read it; group A reads the other stage now)
-        char* stg = ring + ((t - t_begin) & 1) * W2X_TILE_BYTES + 16 * ftid;
-        *reinterpret_cast<float4*>(stg) = st0;
-        *reinterpret_cast<float4*>(stg + 4096) = st1;
-        *reinterpret_cast<float4*>(stg + 8192) = st2;
-        if (fourth) *reinterpret_cast<float4*>(stg + 12288) = st3;
+      {     // this thread's chunks of tile t+3 into the stage tile t-1 has left (nobody reads it between barriers t and t+2)
+        char* stg = ring + ((t + 3 - t_begin) & 3) * W2X_TILE_BYTES;
+#ifndef ABL_NO_RING
+        *reinterpret_cast<float4*>(stg + fo0) = st0;
+        *reinterpret_cast<float4*>(stg + fo1) = st1;
+#endif
       }
-      // the three accumulators and the bias into one
-      f32x16 D;
+      // the two accumulators and the bias into one
+#ifndef ABL_NO_FOLD      // (ablation builds: timing only, wrong results)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) D[r] = fmaf(Bs[r], bsc2, fmaf(fmaf(D2[r], 1.0f / 2048.0f, D1[r]), 1.0f / 2048.0f, D0[r]));
-      tile_epilogue_s(w0 & 3, D, Fp, f0, accA, accV);
+      for (int r = 0; r < 16; ++r) D0[r] = fmaf(Bs[r], bsc2, D0[r] + D1[r]);
+#else
+      D0[0] = fmaf(Bs[0], bsc2, D0[0] + D1[0]);
+#endif
+      const f32x16& D = D0;
+#ifndef ABL_NO_TP
+      tile_epilogue_s(w0, D, Fp, f0, accA, accV, accX);
+#else
+      accA[0] += D[0] * f0.x;
+#endif
       if (w0 & 0x80) {   // 6-channel column: accumulator quad 3 holds another a / c row quad for channel pair xp
         const f32x4 g0 = ldv4(Fr + ((w0 >> 8) & 0x3c));
         const float xv = fmaf(g0.x, D[12], fmaf(g0.y, D[13], fmaf(g0.z, D[14], g0.w * D[15])));
         const int xp = (w0 >> 8) & 3;
         if (xp == 0) accA[0] += xv; else if (xp == 1) accA[1] += xv; else accA[2] += xv;
       }
+#ifdef ABL_NO_FLUSH
+      const int fl = 0;
+#else
       const int fl = (w0 >> 2) & 3;
+#endif
       if (fl) {
         const int nrq = (w0 >> 4) & 7;
         if (fl == FL_S && nrq == 4) {   // a full scalar column: its four channels in one pass
@@ -599,12 +659,16 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
               segf_add_n<DET, 1>(node_row + chan0 + 2 * rq + hh, 1, m1v, seg);
             } else {
               float* d = node_row + chan0 + 3 * (2 * rq + hh);
-              const float sa = accA[rq];
-              float m3[3] = {osc * fmaf(sa, vx, accV[rq][0]), osc * fmaf(sa, vy, accV[rq][1]), osc * fmaf(sa, vz, accV[rq][2])};
+              // a (x) v  +  s0 * (sum of the "times s0" rows)  +  (sum of the cross rows) x v / sqrt2
+              const float sa = accA[rq], wx = vx * inv_s2, wy = vy * inv_s2, wz = vz * inv_s2;
+              const float X0 = accX[rq][0], X1 = accX[rq][1], X2 = accX[rq][2];
+              float m3[3] = {osc * fmaf(X1, wz, fmaf(-X2, wy, fmaf(sa, vx, s0 * accV[rq][0]))),
+                             osc * fmaf(X2, wx, fmaf(-X0, wz, fmaf(sa, vy, s0 * accV[rq][1]))),
+                             osc * fmaf(X0, wy, fmaf(-X1, wx, fmaf(sa, vz, s0 * accV[rq][2])))};
               segf_add_n<DET, 3>(d, 1, m3, seg);
             }
           }
-          accA[rq] = 0.0f; accV[rq][0] = 0.0f; accV[rq][1] = 0.0f; accV[rq][2] = 0.0f;
+          accA[rq] = 0.0f; accV[rq][0] = 0.0f; accV[rq][1] = 0.0f; accV[rq][2] = 0.0f; accX[rq][0] = 0.0f; accX[rq][1] = 0.0f; accX[rq][2] = 0.0f;
         }
         if ((w0 & 3) == T_RTS) {   // rows j = 2,3 of the shared tail open the next (0o) column
 #pragma unroll
@@ -612,14 +676,18 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
         }
       }
       stamp(3);
-      if (grp && t + 1 == t_end) break;        // group B: the barrier that ends its last epilogue is the hand-over below
-      lds_barrier();
+#ifndef ABL_NO_BAR
+      if (!grp) lds_barrier();         // group A: [burst t, epilogue t] | barrier
+#endif
     }
-    // hand the next unit to the workgroup.  Group A waits here through group B's last epilogue: the barrier that ends it also retires the ring
+    // hand the next unit to the workgroup.  Group A waits here through group B's last epilogue: this barrier also retires the ring
     // (nobody reads it any more) before the next unit's staging writes
+    stamp_unit(0, 0);
+    stamp_unit(1, t_end - t_begin);
     if (tid == 0) *blk_slot = unit_next;
     lds_barrier();
     unit = __builtin_amdgcn_readfirstlane(*blk_slot);
+    stamp_unit(2, 0);
   }
 }
 
@@ -679,13 +747,31 @@ hipError_t launch_conv_fused_x(const ConvLayerDev& L, const ConvLaunch& a, int n
   for (int g = 0; g < 4; ++g) { k.w1s[g] = L.w1s[g]; k.w1u[g] = 1.0f / L.w1s[g]; k.w2s[g] = L.w2s[g]; k.w2u[g] = 1.0f / L.w2s[g]; }
   k.n_cols = L.n_cols;
   for (int c = 0; c <= L.n_cols; ++c) k.col_start[c] = L.col_start[c];
-  for (int t = 0; t < L.n_tiles; ++t) { X.tq[t][0] = L.h_tiles[t].w0; X.tq[t][1] = L.h_tiles[t].chan0; }
+  for (int t = 0; t < L.n_tiles; ++t) {
+    // the tile table is written for the F row of k_conv.hip: move the feature offsets to this kernel's row (FX_*) and tell the vector tiles
+    // which of their rows are "times s0" rows and which are crossed with v (T1O = [p s0 (nv) ; q x v (nv)], T1E = [p x v (nv) ; q s0 (nv)])
+    int w0 = L.h_tiles[t].w0;
+    const int kind = w0 & 3, f_off = w0 >> 16;
+    int nf = f_off;
+    if (kind == T_RT || kind == T_RTS) nf = FX_PQ + (f_off - F_PQ);
+    else if (kind == T_TV) {
+      const bool odd = f_off < F_T1E;
+      const int q = (f_off - (odd ? F_T1O : F_T1E)) / 12;
+      if (f_off < F_T1O || f_off >= F_PQ || (f_off - (odd ? F_T1O : F_T1E)) % 12) return hipErrorInvalidValue;
+      nf = FX_R + 12 * q;
+      for (int half = 0; half < 2; ++half) {
+        const bool first = 4 * q + 2 * half < NV;                 // rows of the block's first part (p): s0 rows in T1O, cross rows in T1E
+        if (first != odd) w0 |= 0x4000 << half;
+      }
+    }
+    X.tq[t][0] = (w0 & 0xffff) | (nf << 16); X.tq[t][1] = L.h_tiles[t].chan0;
+  }
   k.sum_g2 = a.sum_g2; k.g2_node_off = a.g2_node_off;
   k.n_groups = a.n_groups; k.n_active = a.n_active; k.n_slots = a.n_slots; k.slots = a.slots; k.wmap = a.wmap;
   if (a.gbeg) { k.gbeg = a.gbeg; k.gend = a.gend; }
   else { k.gbeg = a.tile_info + 5; k.gend = a.tile_info + 6; }   // 4 contiguous groups go[g] .. go[g+1] (explicit-boundary entry point)
   k.pre = a.pre; k.part = a.part;
-  X.trace = nullptr;
+  X.trace = nullptr; X.trace_coarse = a.trace_coarse;
   if (a.part != nullptr) {       // deterministic scatter
     hipError_t e = (a.gather && a.pre != nullptr) ? launch_x_t<true, true, true>(X, n_cu, s)
                                                   : (!a.gather ? launch_x_t<false, false, true>(X, n_cu, s) : hipErrorInvalidValue);

@@ -518,7 +518,7 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
       pr.layer = l; pr.slot = ctx->prof_slots; pr.tab = tab; pr.lig_only = lig_only; pr.r01_skipped = shared0 ? (patched ? -1 : (int64_t)(B - 1) * cx->E_rr) : 0;      // (-1: E - executed edges, the patch count lives on the device)
       CK(hipEventRecord(pr.a, s), "event record");
     }
-    if (ctx->conv_trace != nullptr && ctx->conv_trace_layer == l) a.trace = ctx->conv_trace;
+    if (ctx->conv_trace != nullptr && ctx->conv_trace_layer == l) { a.trace = ctx->conv_trace; a.trace_coarse = ctx->conv_trace_coarse; }
     CK(launch_conv_fused(L, a, ctx->n_cu, s), "conv_fused");
     if (prof_slot) {
       CK(hipEventRecord(pr.b, s), "event record");
@@ -1083,7 +1083,7 @@ int ddk_profile_read_forwards(ddk_ctx* ctx, double* out, int32_t max_forwards) {
 // s_memtime stamps of its half phases to trace (DEVICE, [8][1024][8] uint32: burst start, burst end, epilogue start, epilogue end, before K steps 0 / 1 / 2 / 3); null: off
 int ddk_debug_conv_trace(ddk_ctx* ctx, int32_t layer, uint32_t* trace) {
   if (!ctx) return DDK_ERR_INVALID;
-  ctx->conv_trace = trace; ctx->conv_trace_layer = layer;
+  ctx->conv_trace = trace; ctx->conv_trace_layer = layer >= 100 ? layer - 100 : layer; ctx->conv_trace_coarse = layer >= 100;      // 100 + l: one record per unit
   return DDK_OK;
 }
 

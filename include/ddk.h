@@ -51,8 +51,9 @@ typedef struct ddk_config {
   int32_t confidence_no_batchnorm;
   /* which matrix pipe the radial-MLP GEMMs (Linear(72,72) + ReLU + Linear(72,W), tensor_layers.py:140-143) of the score model's fused conv
    * kernel run on.  0 (default): the f16 matrix pipe with EXACT fp32 operands - every fp32 weight / activation is split into three fp16 limbs
-   *    x = hi + mid 2^-11 + lo 2^-22 (no bits dropped), six of the nine limb products are kept (the dropped ones are <= 3 * 2^-33 relative,
-   *    below the rounding of the fp32 accumulation itself), fp32 accumulators (k_conv_x.hip).
+   *    x = hi + mid + lo (exact for every value within 2^-15 of its range-scaling group's maximum, off by <= 2^-39 of that maximum below),
+   *    six of the nine limb products are kept (the dropped ones are <= 3 * 2^-33 relative, below the rounding of the fp32 accumulation
+   *    itself), fp32 accumulators (k_conv_x.hip).
    * 1: v_mfma_f32_32x32x2_f32, plain fp32 FMA chains (k_conv.hip) - the stated fallback; the all-atom confidence model always uses it. */
   int32_t conv_kernel;
   /* 1: fixed summation order per node in the score model's conv layers and heads (scatter_mean of tensor_layers.py:159): edges are

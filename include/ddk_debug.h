@@ -45,11 +45,13 @@ int ddk_debug_axis_angle(ddk_ctx* ctx, int32_t n, const float* aa, float* R_out,
 /* Timeline of the default conv kernel (k_conv_x.hip): conv layer `layer` of the following score-model forwards runs the kernel's TRACE
  * instantiation, whose workgroup 0 stamps s_memtime at the four edges of every tile's two half phases into trace (DEVICE,
  * [8 waves][1024 tiles][8] uint32: burst start, burst end, epilogue start, epilogue end, then four stamps inside the burst: before K step 0, 1, 2, 3; tools/conv_trace.py).  trace = NULL: off. */
+/* layer = 100 + l: one record per UNIT instead of per tile (slots 4-7 as above, 0 = tile loop done, 1 = tiles of the unit, 2 = unit handed over):
+ * no stamp inside the tile loop, undisturbed cycles per tile. */
 int ddk_debug_conv_trace(ddk_ctx* ctx, int32_t layer, uint32_t* trace);
 
 /* The default conv kernel's limb split (k_conv_x.hip) on a DEVICE array x [n], cut into groups of `group` consecutive values that share one
  * power-of-two range scale (the kernel scales per edge): hi / mid / lo [n] = the fp16 limbs as fp32, scale [n] = the group's scale;
- * x * scale == hi + mid 2^-11 + lo 2^-22 bit for bit for every value within 2^-36 of its group's maximum. */
+ * x * scale == hi + mid + lo bit for bit for every value within 2^-15 of its group's maximum (|x * scale| >= 0.5), within 2^-25 below. */
 int ddk_debug_split3(ddk_ctx* ctx, const float* x, int64_t n, int32_t group, float* hi, float* mid, float* lo, float* scale, void* stream);
 
 #ifdef __cplusplus

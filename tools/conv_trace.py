@@ -12,6 +12,7 @@ from disco_diffdock_amd.runtime import Context, Complex
 ap = argparse.ArgumentParser()
 ap.add_argument('--layer', type=int, default=3)
 ap.add_argument('--t', type=float, default=0.6)
+ap.add_argument('--coarse', action='store_true', help='one record per unit (no stamps inside the tile loop): undisturbed cycles per tile')
 a = ap.parse_args()
 dev = torch.device('cuda:0')
 ctx = Context(device=0)
@@ -24,11 +25,22 @@ pos = torch.from_numpy(np.stack([c['lig_pos'] + rng.normal(0, 3.0, size=(1, 3)) 
 for _ in range(3):
     cx.score_forward(pos, a.t, a.t, a.t)
 trace = torch.zeros((8, 1024, 8), dtype=torch.int32, device=dev)
-ctx._check(ctx.L.ddk_debug_conv_trace(ctx.h, a.layer, C.c_void_p(trace.data_ptr())), 'trace')
+ctx._check(ctx.L.ddk_debug_conv_trace(ctx.h, a.layer + (100 if a.coarse else 0), C.c_void_p(trace.data_ptr())), 'trace')
 cx.score_forward(pos, a.t, a.t, a.t)
 ctx._check(ctx.L.ddk_debug_conv_trace(ctx.h, -1, None), 'trace off')
 torch.cuda.synchronize()
 tr = trace.cpu().numpy().astype(np.int64) & 0xffffffff
+if a.coarse:
+    n = int((tr[0, :, 2] != 0).sum())
+    print(f'layer {a.layer}: {n} units recorded by workgroup 0 (ticks = s_memtime)')
+    for w in range(8):
+        x = tr[w, :n]
+        d = lambda p, q: (x[:, p] - x[:, q]) & 0xffffffff
+        tiles = x[:, 1]
+        full = tiles == np.max(tiles)
+        print(f'wave {w}: units {n} ({int(full.sum())} with all {int(np.max(tiles))} tiles)  prologue {d(7, 4)[full].mean():7.0f}  tile loop {d(0, 7)[full].mean():8.0f} = {(d(0, 7)[full] / tiles[full]).mean():6.0f} per tile  '
+              f'hand-over {d(2, 0)[full].mean():5.0f}  unit {d(2, 4)[full].mean():8.0f}  | column-split units: {int((~full).sum())}, per tile {(d(0, 7)[~full] / np.maximum(tiles[~full], 1)).mean() if (~full).any() else 0:6.0f}')
+    sys.exit(0)
 n = int((tr[0, :, 3] != 0).sum())
 print(f'layer {a.layer}: {n} tiles recorded by workgroup 0 (ticks = shader cycles)')
 for w in range(8):

@@ -364,7 +364,6 @@ static int fold_batch_norm(ddk_ctx* ctx, const std::string& pre, const int* out,
 // w1all / w2all: the fp32 fragment arrays [.][s/4][lane][s&3] (s = register of the lane half), b2all [t][2][16].
 static int pack_x3(ddk_ctx* ctx, ConvLayerDev& L, int NG, const std::vector<float>& w1all, const std::vector<float>& w2all,
                    const std::vector<float>& b2all) {
-  if (L.n_tiles > W2X_MAX_TILES) return fail(ctx, DDK_ERR_INVALID, "too many W2 tiles for the three-limb kernel's descriptor table");
   const size_t w1sz = 3 * 9 * 64 * 4, w2sz = (size_t)L.n_tiles * 9 * 64 * 4, b2sz = (size_t)L.n_tiles * 32;
   bool exact = true;
   auto split = [&exact](float v, uint16_t& hi, uint16_t& mid, uint16_t& lo) {
@@ -410,6 +409,9 @@ static int pack_x3(ddk_ctx* ctx, ConvLayerDev& L, int NG, const std::vector<floa
       uint8_t* rec = w2x.data() + ((size_t)g * L.n_tiles + t) * W2X_TILE_BYTES;
       frags(w2 + (size_t)t * 2304, sc2, rec);
       memcpy(rec + W2X_BIAS_OFF, b2 + (size_t)t * 32, 128);       // fp32 as is: the kernel scales it like the products
+      const int32_t dq[2] = {x_tile_word(L.h_tiles[t].w0), L.h_tiles[t].chan0};
+      if (dq[0] < 0) return fail(ctx, DDK_ERR_INVALID, "internal: a vector tile of the conv layout does not sit on a T1O / T1E row quad");
+      memcpy(rec + W2X_DESC_OFF, dq, 8);
     }
     for (int T = 0; T < 3; ++T) frags(w1 + (size_t)T * 2304, sc1, w1x.data() + ((size_t)g * 3 + T) * W1X_TILE_BYTES);
   }

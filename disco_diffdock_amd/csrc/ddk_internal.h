@@ -60,10 +60,10 @@ constexpr int CONV_MAX_GROUPS = 9;
 // a fragment = weight of tile row lane&31 for the hidden unit held by register 8*s+i of lane half lane>>5 (K = 72 = 4 x 16 + 8)
 constexpr int W2X_LIMB_BYTES = 4 * 1024 + 512;                      // 4,608
 constexpr int W2X_BIAS_OFF = 3 * W2X_LIMB_BYTES;                    // 13,824
-constexpr int W2X_TILE_BYTES = W2X_BIAS_OFF + 128 + 16;             // 13,968 = 873 x 16 B
+constexpr int W2X_DESC_OFF = W2X_BIAS_OFF + 128;                    // the tile's two descriptor words (x_tile_word(w0), chan0) | 8 B pad
+constexpr int W2X_TILE_BYTES = W2X_DESC_OFF + 16;                   // 13,968 = 873 x 16 B
 constexpr int W1X_TILE_BYTES = 3 * W2X_LIMB_BYTES;                  // GEMM1: the three limbs of one 32-row tile
 constexpr int CONV_TRACE_TILES = 1024;                              // tiles per wave the TRACE instantiation of the kernel records
-constexpr int W2X_MAX_TILES = 64;                                   // tile descriptors ride in the kernel arguments
 // F row of the three-limb kernel (100 floats instead of 132): the vector blocks keep the RAW p / q rows once (12 rows x xyz, component-major inside
 // each quad of rows like T1O / T1E) instead of the four products p*s0, (q x v)/sqrt2, (p x v)/sqrt2, q*s0 - multiplying by s0 and crossing with v
 // are linear, so they are applied ONCE per output channel when a vector column is flushed (two accumulator sets: "times s0" and "cross v").
@@ -98,6 +98,26 @@ static inline TileDesc make_tile(int kind, int f_off, int flush, int nrq, int ch
   t.w0 = kind | (flush << 2) | (nrq << 4) | (f_off << 16);
   t.chan0 = chan0; t.pad0 = 0; t.pad1 = 0;
   return t;
+}
+
+// Descriptor word of a tile for the three-limb kernel: the tile table is written for the F row of k_conv.hip; this moves the feature offset to
+// the kernel's own row (FX_*) and tells a vector tile which of its rows are "times s0" rows and which are crossed with v (bit 14: rows j = 0,1
+// are cross rows, bit 15: rows j = 2,3; T1O = [p s0 (nv) ; q x v (nv)], T1E = [p x v (nv) ; q s0 (nv)]).  -1: not representable.
+static inline int32_t x_tile_word(int32_t w0) {
+  const int kind = w0 & 3, f_off = w0 >> 16;
+  int nf = f_off;
+  if (kind == T_RT || kind == T_RTS) nf = FX_PQ + (f_off - F_PQ);
+  else if (kind == T_TV) {
+    const bool odd = f_off < F_T1E;
+    const int rel = f_off - (odd ? F_T1O : F_T1E), q = rel / 12;
+    if (f_off < F_T1O || f_off >= F_PQ || rel % 12 || (w0 & 0xc000)) return -1;
+    nf = FX_R + 12 * q;
+    for (int half = 0; half < 2; ++half) {
+      const bool first = 4 * q + 2 * half < NV;                 // rows of the block's first part (p): s0 rows in T1O, cross rows in T1E
+      if (first != odd) w0 |= 0x4000 << half;
+    }
+  }
+  return (w0 & 0xffff) | (nf << 16);
 }
 
 struct ConvLayerDev {          // device copies for one TensorProductConvLayer with FasterTensorProduct

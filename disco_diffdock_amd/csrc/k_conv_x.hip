@@ -47,7 +47,6 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 struct ConvXArgs {
   ConvKArgs k;
-  int32_t tq[W2X_MAX_TILES][2];     // tile descriptors (TileDesc::w0, chan0)
   uint32_t* trace;                  // TRACE instantiation: [8 waves][CONV_TRACE_TILES][8] s_memtime stamps of workgroup 0
   int trace_coarse;                 // 1: one record per UNIT (slots 4-7 prologue, 0 = tile loop done, 1 = tiles, 2 = unit handed over): no stamp inside the tile loop
 };
@@ -270,7 +269,6 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
   const int n_tiles = A.n_tiles;
   constexpr int REC16 = W2X_TILE_BYTES / 16;                   // 873 x 16 B per tile record
   const int grp = wave >> 2;                                    // half-group: 0 = waves 0-3 (A), 1 = waves 4-7 (B, their SIMD partners)
-  if (grp) __builtin_amdgcn_s_setprio(1);                       // the later-dispatched half loses every issue arbitration by age: static priority evens it out
   // every thread moves two 16-B chunks of a tile record: chunk tid and chunk tid + 512 (threads past the record's end move its last chunk
   // again: same bytes to the same place, no branch in the burst)
   const uint32_t fo0 = 16u * tid, fo1 = 16u * min(tid + 64 * WAVES, REC16 - 1);
@@ -539,12 +537,21 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
       accA[rq] = 0.0f; accV[rq][0] = 0.0f; accV[rq][1] = 0.0f; accV[rq][2] = 0.0f; accX[rq][0] = 0.0f; accX[rq][1] = 0.0f; accX[rq][2] = 0.0f;
     }
     // the first two K steps of the first tile (every later tile's are fetched at the start of the previous epilogue)
+    // (the tile's two descriptor words ride behind its bias in the ring record: an LDS read, not a scalar load - a scalar load in flight turns
+    // every counted LDS wait into a full one)
     Frag16 p0 = lds_frag16(ring, 0, lane), p1 = lds_frag16(ring, 1, lane);
-    int w0n = AX.tq[t_begin][0], chan0n = AX.tq[t_begin][1];
+    int w0n, chan0n;
+    {
+      const int2 dq = *reinterpret_cast<const int2*>(ring + W2X_DESC_OFF);
+      w0n = __builtin_amdgcn_readfirstlane(dq.x); chan0n = __builtin_amdgcn_readfirstlane(dq.y);
+    }
     for (int t = t_begin; t < t_end; ++t) {
       const int w0 = w0n, chan0 = chan0n;
       const int t1 = min(t + 1, t_end - 1);
       const char* stage = ring + ((t - t_begin) & 3) * W2X_TILE_BYTES;
+      // the bursting wave wins issue arbitration against its SIMD partner's epilogue (round 3's static priority for the later-dispatched half
+      // costs 7 % once the half phases are not separated by a barrier any more; priority during the epilogue instead: +2.5 %)
+      __builtin_amdgcn_s_setprio(1);
       stamp(0);
       // ================= burst: 28 MFMAs, everything else of this phase threaded between them =================
       // Issue order, pinned region by region (one K step each): the first MFMA goes out first (its operands were fetched in the previous
@@ -552,7 +559,6 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
       // ahead, the epilogue's operands (feature rows, bias), and this thread's two chunks of ring record t+3.
       const char* rec3 = wrec + (size_t)min(t + 3, t_end - 1) * W2X_TILE_BYTES;
       const float* Fp = Fr + (w0 >> 16);
-      const float* bp = reinterpret_cast<const float*>(stage + W2X_BIAS_OFF) + hh * 16;
       f32x16 D0, D1, Bs;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { D0[r] = 0.0f; D1[r] = 0.0f; }
@@ -561,9 +567,8 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
       __builtin_amdgcn_sched_barrier(0);
       const Frag16 q2 = lds_frag16(stage, 2, lane);
       const f32x4 f0 = ldv4(Fp);
-      const float4 bs0 = ld4(bp), bs1 = ld4(bp + 4);
       X3_STEP(MFMA16, p0.h, p0.m, p0.l, H.hi[0], H.mid[0], H.lo[0])
-      X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100)
+      X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_BARE X3_BARE
       __builtin_amdgcn_sched_barrier(0);
       const Frag16 q3 = lds_frag16(stage, 3, lane);
       const f16x4 th = *reinterpret_cast<const f16x4*>(stage + 4096 + lane * 8);
@@ -572,16 +577,15 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
       X3_STEP(MFMA16, p1.h, p1.m, p1.l, H.hi[1], H.mid[1], H.lo[1])
       X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100)
       __builtin_amdgcn_sched_barrier(0);
-      const float4 bs2 = ld4(bp + 8), bs3 = ld4(bp + 12);
 #ifndef ABL_NO_RING
       const float4 st0 = *reinterpret_cast<const float4*>(rec3 + fo0);
       const float4 st1 = *reinterpret_cast<const float4*>(rec3 + fo1);
 #endif
       X3_STEP(MFMA16, q2.h, q2.m, q2.l, H.hi[2], H.mid[2], H.lo[2])
 #ifndef ABL_NO_RING
-      X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x020) X3_BARE X3_PAIR(0x020) X3_BARE
+      X3_PAIR(0x020) X3_BARE X3_PAIR(0x020) X3_BARE X3_BARE X3_BARE
 #else
-      X3_PAIR(0x100) X3_PAIR(0x100) X3_BARE X3_BARE X3_BARE X3_BARE
+      X3_BARE X3_BARE X3_BARE X3_BARE X3_BARE X3_BARE
 #endif
       __builtin_amdgcn_sched_barrier(0);
       X3_STEP(MFMA16, q3.h, q3.m, q3.l, H.hi[3], H.mid[3], H.lo[3])
@@ -595,23 +599,25 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
       __builtin_amdgcn_sched_barrier(0);
 #undef X3_PAIR
 #undef X3_BARE
-      Bs[0] = bs0.x; Bs[1] = bs0.y; Bs[2] = bs0.z; Bs[3] = bs0.w; Bs[4] = bs1.x; Bs[5] = bs1.y; Bs[6] = bs1.z; Bs[7] = bs1.w;
-      Bs[8] = bs2.x; Bs[9] = bs2.y; Bs[10] = bs2.z; Bs[11] = bs2.w; Bs[12] = bs3.x; Bs[13] = bs3.y; Bs[14] = bs3.z; Bs[15] = bs3.w;
+      __builtin_amdgcn_s_setprio(0);
       stamp(1);
 #ifndef ABL_NO_BAR
       if (grp) lds_barrier();          // group B: [epilogue t-1, burst t] | barrier | [epilogue t, burst t+1]
 #endif
       stamp(2);
       // ================= epilogue (beside the SIMD partner's burst) =================
-      // (the next tile's descriptor: a scalar load in flight makes every LDS wait a wait for everything, so it is requested here and not in the burst)
-      w0n = AX.tq[t1][0]; chan0n = AX.tq[t1][1];
-      // the first two K steps of this wave's next tile (complete in the ring since the last barrier), requested FIRST: their latency runs
-      // under the epilogue
+      // requested FIRST, in the order they are needed (LDS data returns in order): this tile's bias, the next tile's descriptor and the first two
+      // K steps of the next tile (complete in the ring since the last barrier); their latency runs under the MFMA drain
       {
-        const char* nxt = ring + ((t1 - t_begin) & 3) * W2X_TILE_BYTES;
-        p0 = lds_frag16(nxt, 0, lane);
-        p1 = lds_frag16(nxt, 1, lane);
+        const float* bp = reinterpret_cast<const float*>(stage + W2X_BIAS_OFF) + hh * 16;
+        const float4 bs0 = ld4(bp), bs1 = ld4(bp + 4), bs2 = ld4(bp + 8), bs3 = ld4(bp + 12);
+        Bs[0] = bs0.x; Bs[1] = bs0.y; Bs[2] = bs0.z; Bs[3] = bs0.w; Bs[4] = bs1.x; Bs[5] = bs1.y; Bs[6] = bs1.z; Bs[7] = bs1.w;
+        Bs[8] = bs2.x; Bs[9] = bs2.y; Bs[10] = bs2.z; Bs[11] = bs2.w; Bs[12] = bs3.x; Bs[13] = bs3.y; Bs[14] = bs3.z; Bs[15] = bs3.w;
       }
+      const char* nxt = ring + ((t1 - t_begin) & 3) * W2X_TILE_BYTES;
+      const int2 dq = *reinterpret_cast<const int2*>(nxt + W2X_DESC_OFF);
+      p0 = lds_frag16(nxt, 0, lane);
+      p1 = lds_frag16(nxt, 1, lane);
       {     // this thread's chunks of tile t+3 into the stage tile t-1 has left (nobody reads it between barriers t and t+2)
         char* stg = ring + ((t + 3 - t_begin) & 3) * W2X_TILE_BYTES;
 #ifndef ABL_NO_RING
@@ -675,6 +681,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
           for (int rq = 0; rq < 4; ++rq) accV[rq][0] = fmaf(f0.z, D[4 * rq + 2], f0.w * D[4 * rq + 3]);
         }
       }
+      w0n = __builtin_amdgcn_readfirstlane(dq.x); chan0n = __builtin_amdgcn_readfirstlane(dq.y);
       stamp(3);
 #ifndef ABL_NO_BAR
       if (!grp) lds_barrier();         // group A: [burst t, epilogue t] | barrier
@@ -738,7 +745,7 @@ hipError_t conv_prepare_device_x() {
 void conv_det_fix(const ConvKArgs& k, const ConvLaunch& a, int dout, hipStream_t s);   // k_conv.hip
 
 hipError_t launch_conv_fused_x(const ConvLayerDev& L, const ConvLaunch& a, int n_cu, hipStream_t s) {
-  if (L.n_tiles > W2X_MAX_TILES || a.mode != 0) return hipErrorInvalidValue;
+  if (a.mode != 0) return hipErrorInvalidValue;
   ConvXArgs X;
   ConvKArgs& k = X.k;
   k.x = a.x; k.src = a.src; k.dst = a.dst; k.edge_attr = a.edge_attr; k.sh = a.sh; k.sum = a.sum;
@@ -747,25 +754,6 @@ hipError_t launch_conv_fused_x(const ConvLayerDev& L, const ConvLaunch& a, int n
   for (int g = 0; g < 4; ++g) { k.w1s[g] = L.w1s[g]; k.w1u[g] = 1.0f / L.w1s[g]; k.w2s[g] = L.w2s[g]; k.w2u[g] = 1.0f / L.w2s[g]; }
   k.n_cols = L.n_cols;
   for (int c = 0; c <= L.n_cols; ++c) k.col_start[c] = L.col_start[c];
-  for (int t = 0; t < L.n_tiles; ++t) {
-    // the tile table is written for the F row of k_conv.hip: move the feature offsets to this kernel's row (FX_*) and tell the vector tiles
-    // which of their rows are "times s0" rows and which are crossed with v (T1O = [p s0 (nv) ; q x v (nv)], T1E = [p x v (nv) ; q s0 (nv)])
-    int w0 = L.h_tiles[t].w0;
-    const int kind = w0 & 3, f_off = w0 >> 16;
-    int nf = f_off;
-    if (kind == T_RT || kind == T_RTS) nf = FX_PQ + (f_off - F_PQ);
-    else if (kind == T_TV) {
-      const bool odd = f_off < F_T1E;
-      const int q = (f_off - (odd ? F_T1O : F_T1E)) / 12;
-      if (f_off < F_T1O || f_off >= F_PQ || (f_off - (odd ? F_T1O : F_T1E)) % 12) return hipErrorInvalidValue;
-      nf = FX_R + 12 * q;
-      for (int half = 0; half < 2; ++half) {
-        const bool first = 4 * q + 2 * half < NV;                 // rows of the block's first part (p): s0 rows in T1O, cross rows in T1E
-        if (first != odd) w0 |= 0x4000 << half;
-      }
-    }
-    X.tq[t][0] = (w0 & 0xffff) | (nf << 16); X.tq[t][1] = L.h_tiles[t].chan0;
-  }
   k.sum_g2 = a.sum_g2; k.g2_node_off = a.g2_node_off;
   k.n_groups = a.n_groups; k.n_active = a.n_active; k.n_slots = a.n_slots; k.slots = a.slots; k.wmap = a.wmap;
   if (a.gbeg) { k.gbeg = a.gbeg; k.gend = a.gend; }

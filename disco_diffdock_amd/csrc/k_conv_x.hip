@@ -150,6 +150,15 @@ __device__ __forceinline__ void segf_add_n(float* dst, int stride, float (&xv)[N
 #undef SEGF_STEP
 
 // six-term product of one K step into the two accumulators, alternating (D0: hi.hi and the 2^-11 terms, D1: the 2^-22 terms)
+#ifdef ONE_ACC
+#define X3_STEP(MF, ah, am, al, bh, bm, bl)   \
+  D0 = MF(ah, bl, D0);                        \
+  D0 = MF(al, bh, D0);                        \
+  D0 = MF(am, bm, D0);                        \
+  D0 = MF(ah, bm, D0);                        \
+  D0 = MF(am, bh, D0);                        \
+  D0 = MF(ah, bh, D0);
+#else
 #define X3_STEP(MF, ah, am, al, bh, bm, bl)   \
   D1 = MF(ah, bl, D1);                        \
   D0 = MF(ah, bm, D0);                        \
@@ -157,6 +166,7 @@ __device__ __forceinline__ void segf_add_n(float* dst, int stride, float (&xv)[N
   D0 = MF(ah, bh, D0);                        \
   D1 = MF(am, bm, D1);                        \
   D0 = MF(am, bh, D0);
+#endif
 
 // scalar-accumulator tensor-product epilogue of one W2 tile (wave-uniform branch on the tile kind; the f16 pipe does not compete with the VALU
 // for issue: fewer registers beat fewer instructions here).  T_RTS: only rows j = 0,1 belong to the column that is about to be flushed.
@@ -588,14 +598,25 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
       X3_BARE X3_BARE X3_BARE X3_BARE X3_BARE X3_BARE
 #endif
       __builtin_amdgcn_sched_barrier(0);
+      // (this tile's bias: needed at the very start of the epilogue, so its LDS latency runs under the last MFMAs)
+      const float* bp = reinterpret_cast<const float*>(stage + W2X_BIAS_OFF) + hh * 16;
+      const float4 bs0 = ld4(bp), bs1 = ld4(bp + 4), bs2 = ld4(bp + 8), bs3 = ld4(bp + 12);
       X3_STEP(MFMA16, q3.h, q3.m, q3.l, H.hi[3], H.mid[3], H.lo[3])
       {     // packed tail: D0 += hi.mid + mid.hi, D1 += lo.hi + hi.lo as one K = 16 MFMA each; mid.mid and hi.hi stay K = 8
         const f16x8 a_hm = __builtin_shufflevector(th, tm, 0, 1, 2, 3, 4, 5, 6, 7), a_lh = __builtin_shufflevector(tl, th, 0, 1, 2, 3, 4, 5, 6, 7);
+#ifdef ONE_ACC
+        D0 = MFMA16(a_lh, HT.hl, D0);
+        D0 = MFMA8(tm, H.tmid, D0);
+        D0 = MFMA16(a_hm, HT.mh, D0);
+        D0 = MFMA8(th, H.thi, D0);
+#else
         D1 = MFMA16(a_lh, HT.hl, D1);
         D0 = MFMA16(a_hm, HT.mh, D0);
         D1 = MFMA8(tm, H.tmid, D1);
         D0 = MFMA8(th, H.thi, D0);
+#endif
       }
+      X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_BARE X3_BARE X3_BARE X3_BARE X3_BARE X3_BARE
       __builtin_amdgcn_sched_barrier(0);
 #undef X3_PAIR
 #undef X3_BARE
@@ -606,11 +627,9 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
 #endif
       stamp(2);
       // ================= epilogue (beside the SIMD partner's burst) =================
-      // requested FIRST, in the order they are needed (LDS data returns in order): this tile's bias, the next tile's descriptor and the first two
-      // K steps of the next tile (complete in the ring since the last barrier); their latency runs under the MFMA drain
+      // requested FIRST: the next tile's descriptor and the first two K steps of the next tile (complete in the ring since the last barrier);
+      // their latency runs under the MFMA drain and the epilogue
       {
-        const float* bp = reinterpret_cast<const float*>(stage + W2X_BIAS_OFF) + hh * 16;
-        const float4 bs0 = ld4(bp), bs1 = ld4(bp + 4), bs2 = ld4(bp + 8), bs3 = ld4(bp + 12);
         Bs[0] = bs0.x; Bs[1] = bs0.y; Bs[2] = bs0.z; Bs[3] = bs0.w; Bs[4] = bs1.x; Bs[5] = bs1.y; Bs[6] = bs1.z; Bs[7] = bs1.w;
         Bs[8] = bs2.x; Bs[9] = bs2.y; Bs[10] = bs2.z; Bs[11] = bs2.w; Bs[12] = bs3.x; Bs[13] = bs3.y; Bs[14] = bs3.z; Bs[15] = bs3.w;
       }

@@ -207,6 +207,8 @@ def main():
     ap.add_argument('--no-extras', action='store_true', help='skip the pruning-off and pocket-bound brackets')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl == RCCL; gloo for smoke tests)')
     ap.add_argument('--single-device', action='store_true', help='smoke test of the N > 1 path on a one-GPU box: every rank uses cuda:0')
+    ap.add_argument('--force-dist', action='store_true', help='N = 1 through the N > 1 code path: a world_size-1 process group on --backend, every '
+                    'barrier / all_reduce / all_gather of the path executes (proves that RCCL loads and runs beside libddk.so on a one-GPU box)')
     a = ap.parse_args()
     if 'WORLD_SIZE' not in os.environ and a.gpus > 1:
         self_launch(a)
@@ -219,9 +221,19 @@ def main():
         local = 0
     elif torch.cuda.device_count() <= local:
         sys.exit(f'bench.py: rank {rank} has no GPU {local} ({torch.cuda.device_count()} visible)')
-    if world > 1:
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
         torch.cuda.set_device(local)
-        dist.init_process_group(a.backend, rank=rank, world_size=world)
+        if world > 1:
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
+        else:
+            import socket
+            with socket.socket() as so:
+                so.bind(('127.0.0.1', 0))
+                port = so.getsockname()[1]
+            dist.init_process_group(a.backend, init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1)
+            import disco_diffdock_amd.distributed as ddist
+            ddist.FORCE_COLLECTIVES = True
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
 
@@ -234,7 +246,7 @@ def main():
     from disco_diffdock_amd.distributed import shard_samples, gather_poses, gather_samples, gather_confidences
     if rank == 0:
         build.build(verbose=False)       # no-op when the shipped libddk.so is current; never build concurrently
-    if world > 1:
+    if use_dist:
         dist.barrier()
 
     cfg_id = a.config
@@ -337,7 +349,7 @@ def main():
         torch.cuda.manual_seed(4321 + rank)      # the device generator sampling() draws its noise from (the resident-loop figure below replays it)
         sm_mod._complex_cache.clear()            # a NEW complex every timed call: no Complex of the warm-up survives
         ctx.profile_enable(True)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -356,7 +368,7 @@ def main():
         if disco:        # the latent bookkeeping of utils/sampling.py:205-221 (filled on first access): inside the bracket like the reference's
             assert all(len(o[0].latent_str) >= 2 and all(hasattr(d, 'latent_pos') for d in o) for o in outs)
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
@@ -364,7 +376,7 @@ def main():
         ctx.profile_enable(False)
         ctx.set_pruning(True)
         per_call_ms = [round(call_ev[k].elapsed_time(call_ev[k + 1]), 2) for k in range(a.steps)]
-        if world > 1:
+        if use_dist:
             tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
@@ -399,7 +411,7 @@ def main():
         nl = torch.zeros(n_total, dtype=torch.int64, device=dev)
         for i in mine:
             nl[i] = complexes[i]['lig_pos'].shape[0]
-        if world > 1:
+        if use_dist:
             dist.all_reduce(nl)
         if len(final) == len(mine):
             gathered = gather_poses(final, [int(v) for v in nl.tolist()], SAMPLES, dev)
@@ -570,7 +582,7 @@ def main():
                                                    'extra.device_loop)',
                                            'value': a.steps / e2, 'unit': 'complexes/s', 'ms_per_step': 1e3 * e2 / a.steps}
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -655,6 +655,8 @@ int ddk_create(const ddk_config* cfg, ddk_ctx** out) {
   if (e != hipSuccess) return hip_fail(ctx, e, "hipStreamCreate (head stream)");
   e = conv_prepare_device();
   if (e != hipSuccess) return hip_fail(ctx, e, "hipFuncSetAttribute(dynamic LDS)");
+  e = graph_prepare_device(&ctx->max_rec);
+  if (e != hipSuccess) return hip_fail(ctx, e, "hipFuncSetAttribute(dynamic LDS, graph kernels)");
   ctx->ws.tile_info = (int32_t*)dev_alloc(ctx, 64 * sizeof(int32_t));
   if (!ctx->ws.tile_info) return fail(ctx, DDK_ERR_NOMEM, "hipMalloc failed");
   return DDK_OK;

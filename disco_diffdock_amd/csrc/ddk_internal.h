@@ -185,6 +185,7 @@ struct ddk_ctx {
   bool finalized = false;
   bool host_only = false;
   int n_cu = 256;
+  int max_rec = 0;                // residues per sample the graph kernels' LDS holds on this device (graph_prepare_device)
   std::map<std::string, ddk::HostTensor> weights;
   std::vector<ddk::ConvLayerDev> conv;
   ddk::ConvLayerDev head[2];      // [0] tor_bond_conv, [1] final_conv as layouts of the fused conv kernel (build_head_layer)
@@ -259,6 +260,7 @@ hipError_t launch_split3_probe(const float* x, int64_t n, int group, float* hi, 
 int build_head_layer(ddk_ctx* ctx, int mode, ConvLayerDev& L);      // ddk_capi.hip: mode 2 = tor_bond_conv, 3 = final_conv
 hipError_t conv_prepare_device();     // per-device kernel attributes (dynamic LDS opt-in), called by ddk_create
 hipError_t conv_prepare_device_x();   // k_conv_x.hip
+hipError_t graph_prepare_device(int* max_rec);   // k_graph.hip, per device: dynamic-LDS opt-in of the graph kernels, largest receptor their LDS holds
 hipError_t launch_conv_setup(int32_t* tile_info, const int64_t* group_offsets_host, hipStream_t s);
 hipError_t launch_conv_one_group(int32_t* gt, int n_groups, int k, int64_t E, hipStream_t s);
 hipError_t launch_pad_rows(const float* x, int64_t n, int din, float* xpad, hipStream_t s);

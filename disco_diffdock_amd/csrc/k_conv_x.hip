@@ -134,6 +134,8 @@ template <bool DET, int N>
 __device__ __forceinline__ void segf_add_n(float* dst, int stride, float (&xv)[N], const SegF& c) {
 #pragma unroll
   for (int i = 0; i < N; ++i) xv[i] = c.valid ? xv[i] : 0.0f;
+  // the inline-asm DPP reads below are invisible to the compiler's hazard recogniser: two wait states behind whatever VALU instruction wrote xv
+  asm volatile("s_nop 1" ::: "memory");
   SEGF_STEP("row_shr:1 row_mask:0xf bank_mask:0xf", c.m1)
   SEGF_STEP("row_shr:2 row_mask:0xf bank_mask:0xf", c.m2)
   SEGF_STEP("row_shr:4 row_mask:0xf bank_mask:0xf", c.m4)

@@ -694,16 +694,33 @@ hipError_t launch_complex_static(const RecStaticArgs& R, const int32_t* rr_src, 
   return hipGetLastError();
 }
 
+// dynamic LDS of the two graph kernels for n_rec residues
+static inline size_t graph_lds_bytes(int n_rec) {
+  return (size_t)(MAX_LIG * 3 + n_rec * 3) * 4 + (size_t)n_rec * 4 + (((size_t)n_rec + 15) & ~(size_t)15);   // + the level bytes
+}
+
+// Per DEVICE (called by ddk_create, like conv_prepare_device): opt both graph kernels in to the largest dynamic LDS their static LDS leaves
+// of the 160 KB (the attribute is per device: a process-wide "granted so far" would leave every device but the first without it), and
+// report the largest receptor a complex on this device may have - ddk_complex_create refuses more with a message instead of letting every
+// forward fail with a raw launch error.
+hipError_t graph_prepare_device(int* max_rec) {
+  hipFuncAttributes a1, a2;
+  hipError_t e = hipFuncGetAttributes(&a1, reinterpret_cast<const void*>(&graph_count_kernel));
+  if (e == hipSuccess) e = hipFuncGetAttributes(&a2, reinterpret_cast<const void*>(&graph_fill_kernel));
+  if (e != hipSuccess) return e;
+  const size_t st = a1.sharedSizeBytes > a2.sharedSizeBytes ? a1.sharedSizeBytes : a2.sharedSizeBytes;
+  const size_t dyn = 160 * 1024 - st;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&graph_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - a1.sharedSizeBytes));
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&graph_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - a2.sharedSizeBytes));
+  if (e != hipSuccess) return e;
+  int n = MAX_REC;
+  while (n > 1 && graph_lds_bytes(n) > dyn) --n;
+  *max_rec = n;
+  return hipSuccess;
+}
+
 hipError_t launch_graph(const GraphArgs& G, int64_t edge_cap, hipStream_t s) {
-  const size_t lds = (size_t)(MAX_LIG * 3 + G.n_rec * 3) * 4 + (size_t)G.n_rec * 4 + (((size_t)G.n_rec + 15) & ~(size_t)15);   // + the level bytes
-  // large receptors: beyond the default 64 KB of LDS per workgroup the dynamic part has to be granted explicitly (once per size class)
-  static size_t granted = 0;
-  if (lds > 32 * 1024 && lds > granted) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&graph_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&graph_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    granted = lds;
-  }
+  const size_t lds = graph_lds_bytes(G.n_rec);
   GraphArgs Gc = G;
   Gc.edge_cap = edge_cap;
   hipLaunchKernelGGL(graph_count_kernel, dim3(G.B), dim3(GT), lds, s, Gc);

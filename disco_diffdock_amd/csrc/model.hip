@@ -615,7 +615,8 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
   static const ModelHost no_model;
   const ModelHost& H = has_model ? ((Model*)ctx->model)->host : no_model;
   if (d->n_lig < 1 || d->n_lig > MAX_LIG) return fail(ctx, DDK_ERR_INVALID, "n_lig must be in [1, 256]");
-  if (d->n_rec < 1 || d->n_rec > MAX_REC) return fail(ctx, DDK_ERR_INVALID, "n_rec must be in [1, 8192]");
+  if (d->n_rec < 1 || d->n_rec > ctx->max_rec)
+    return fail(ctx, DDK_ERR_INVALID, "n_rec must be in [1, " + std::to_string(ctx->max_rec) + "]: the graph kernels keep a sample's receptor (17 B per residue) in LDS");
   if (has_model && d->rec_feat_dim != 1 + c.lm_embedding_dim) return fail(ctx, DDK_ERR_INVALID, "receptor feature width != 1 + lm_embedding_dim");
   if (max_batch < 1) return fail(ctx, DDK_ERR_INVALID, "max_batch < 1");
   hipSetDevice(c.device);

@@ -19,8 +19,11 @@ def shard_indices(costs, rank, world):
     return sorted(mine)
 
 
+FORCE_COLLECTIVES = False     # run the collectives of the path on a world_size-1 group too (bench.py --force-dist, the one-GPU RCCL test)
+
+
 def _multi():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
 
 
 def _all_gather_rows(rows, idx, device):

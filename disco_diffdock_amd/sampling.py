@@ -98,6 +98,7 @@ class _Bookkeeping:
         self.name = getattr(graphs[0], 'name', None) if graphs else None
         self.len_lig, self.latent_dim = len_lig, latent_dim
         self.done = False
+        self._resolving = False
         self.bound = False       # the graphs carry this object as ``_lazy`` (our HeteroData): a graph a later call re-used is skipped
         self.choices = self.flat = None
         self.conf_status = conf_cx.confidence_status_async() if conf_cx is not None else None
@@ -117,9 +118,16 @@ class _Bookkeeping:
                           'returned as -1000 (NaN on the device)', RuntimeWarning)
 
     def resolve(self):
-        if self.done:
+        if self.done or self._resolving:
             return
-        self.done = True
+        self._resolving = True       # (done is set only when the bookkeeping below has finished: an exception part-way leaves the object retryable)
+        try:
+            self._resolve()
+            self.done = True
+        finally:
+            self._resolving = False
+
+    def _resolve(self):
         self.event.synchronize()
         if self in _pending:
             _pending.remove(self)

@@ -2,6 +2,7 @@
 ``forward(batch) -> (tr_pred [B,3], rot_pred [B,3], tor_pred [sum R])`` (score_model.py:259-308) runs entirely in
 libddk.so.  The checkpoint format is the reference's ``score_model.state_dict()`` (evaluate.py:169-171)."""
 import numpy as np
+import os
 import torch
 from torch import nn
 
@@ -134,6 +135,11 @@ class TensorProductScoreModel(nn.Module):
                  lm_embedding_type=None, confidence_mode=False, use_old_atom_encoder=False, latent_dim=0, latent_vocab=32,
                  latent_cross_attention=False, latent_droprate=0.0, embedding_scale=1000.0, sigma_limits=None, conv_kernel=None, **unused):
         super().__init__()
+        if 'conv_f16x3' in unused or os.environ.get('DDK_CONV_F16X3') is not None:
+            # round 2's switch had the opposite sense (1 = the f16 kernel); round 3 replaced it by conv_kernel (0 = exact three-limb f16, the
+            # default; 1 = fp32 MFMA).  Swallowing the old spelling would switch kernels silently.
+            raise RuntimeError("ddk: the conv_f16x3 option / DDK_CONV_F16X3 variable was replaced by the conv_kernel option "
+                               "(0 = exact three-limb f16 product, default; 1 = fp32 MFMA) - see INTEGRATION.md")
         if sh_lmax != 1 or use_second_order_repr or confidence_mode or use_old_atom_encoder or latent_cross_attention:
             raise RuntimeError('ddk implements the sh_lmax=1 first-order score model with the new AtomEncoder only')
         if in_lig_edge_features != 4:

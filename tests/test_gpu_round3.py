@@ -30,6 +30,21 @@ def dev():
     return torch.device('cuda:0')
 
 
+def _record_drift(key, value, **extra):
+    """parity figures that are printed are also KEPT (gpurun_out/parity_drift.json on the GPU box, copied to profiles/r0N_parity_drift.json per round):
+    a regression from 2e-5 to 9e-4 under a 1e-3 bar must be visible"""
+    path = os.path.join(ROOT, 'gpurun_out', 'parity_drift.json')
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        d = {}
+    d[key] = dict(value=float(value), **extra)
+    with open(path, 'w') as f:
+        json.dump(d, f, indent=1, sort_keys=True)
+
+
 def _bench(*args):
     env = dict(os.environ)
     env.pop('WORLD_SIZE', None)
@@ -269,6 +284,7 @@ def test_workload_size_trajectory_vs_oracle(dev, tables):
     r = torch.cat([g['ligand'].pos for g in ref])
     err = rel_err(pos.reshape(-1, 3), r)
     print(f'20-step, 300-residue, unscaled-noise trajectory drift vs oracle: {err:.2e} (last graph: {st})')
+    _record_drift('trajectory_20_steps_300_residues_B2_vs_oracle', err, bar=1e-3)
     assert err < 1e-3
 
 

@@ -1,0 +1,143 @@
+"""Round-4 GPU tests (VERDICT r03 "Next" #4, #5), through the C ABI / the shipped entry points:
+
+* parity at the BENCH's batch size: a 40-sample forward of the 300-residue workload (and 8 samples at 2000 residues) against the oracle,
+  which runs in chunks of 4 samples (the samples of a batch are independent);
+* RCCL on the one GPU of the box: a world_size-1 ``nccl`` process group beside a live ddk context, the three gathers of
+  disco_diffdock_amd/distributed.py on device tensors, and ``bench.py --gpus 1 --force-dist`` (every barrier / all_reduce / all_gather of the
+  N > 1 path on RCCL)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import score_model_ref as smr
+from oracle import sampler_ref as spr
+from helpers import batch_of, chan_err, elem_err, rel_err
+from test_gpu_round2 import _poses
+from test_gpu_round3 import _record_drift
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+CFG = smr.ScoreModelConfig(latent_vocab=64)
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a MI355X'
+    from disco_diffdock_amd import build
+    build.build(verbose=False)
+    return torch.device('cuda:0')
+
+
+@pytest.mark.parametrize('n_res,B,t', [(300, 40, 0.5), (2000, 8, 0.5)])
+def test_bench_batch_size_oracle_parity(dev, tables, n_res, B, t):
+    """The bench runs 40 samples per forward: more blocks in the conv kernel's work queue (column-split tail), more run tails per node and more
+    32-edge tiles per receiving node than any B = 2 / 3 case.  tr / rot / tor and the ligand rows of a B-sample forward at t = 0.5 (pruning
+    active, cross cutoff ~ 20 A) against oracle.score_model_ref run in chunks of 4 samples; per-element AND per-channel measures."""
+    from disco_diffdock_amd import synthetic
+    from disco_diffdock_amd.runtime import Context, Complex
+    c = synthetic.make_complex(5, n_res=n_res)
+    P = smr.random_state_dict(CFG, seed=8)
+    ctx = Context(device=0)
+    ctx.load_state_dict(P)
+    pos = _poses(c, B, np.random.default_rng(1), spread=5.0)
+    cx = Complex(ctx, c, B)
+    tr, rot, tor = [x.cpu() for x in cx.score_forward(T(pos).to(dev), t, t, t)]
+    lig = cx.lig_node_features(B, dev).cpu()
+    st = cx.graph_stats()
+    R, n_lig = int(c['edge_mask'].sum()), c['lig_pos'].shape[0]
+    tr_r, rot_r, tor_r, lig_r = [], [], [], []
+    for lo in range(0, B, 4):
+        b = batch_of(c, 4, pos[lo:lo + 4])
+        spr.set_time(b, t, t, t, 4)
+        a, bb, cc, inter = smr.score_model_forward(P, CFG, b, tables[0], tables[1], return_intermediates=True)
+        tr_r.append(a); rot_r.append(bb); tor_r.append(cc); lig_r.append(inter['lig_node_attr'])
+    tr_r, rot_r, tor_r, lig_r = [torch.cat(x) for x in (tr_r, rot_r, tor_r, lig_r)]
+    assert tor.shape[0] == B * R and lig.shape[0] == B * n_lig
+    def vec_err(a, b):      # tr / rot are one 3-vector per sample: |a - b| / |b| per SAMPLE (a component that vanishes by cancellation has no scale of its own)
+        a, b = a.double().reshape(-1, 3), b.double().reshape(-1, 3)
+        nb = b.norm(dim=1)
+        return float(((a - b).norm(dim=1) / torch.clamp(nb, min=1e-3 * float(nb.max()))).max())
+    errs = {'tr': vec_err(tr, tr_r), 'rot': vec_err(rot, rot_r), 'tor': elem_err(tor, tor_r), 'lig_chan': chan_err(lig, lig_r),
+            'tr_global': rel_err(tr, tr_r), 'rot_global': rel_err(rot, rot_r)}
+    info = {'tr_elem': elem_err(tr, tr_r), 'rot_elem': elem_err(rot, rot_r), 'lig_elem': elem_err(lig, lig_r)}      # per-element figures: recorded, not gated
+    print(f'parity at the bench batch size: n_res={n_res} B={B} t={t}: {errs}  per element: {info}  graph: {st}')
+    _record_drift(f'forward_B{B}_{n_res}_residues_t{t}_vs_oracle', max(errs.values()), bar=1e-4, **{k: float(v) for k, v in {**errs, **info}.items()})
+    for k, v in errs.items():
+        assert v < 1e-4, (k, errs)
+
+
+_RCCL_SCRIPT = r'''
+import os, sys, socket, json
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from disco_diffdock_amd import synthetic, distributed as dd
+from disco_diffdock_amd.runtime import Context, Complex
+torch.cuda.set_device(0)
+dev = torch.device('cuda:0')
+ctx = Context(device=0)                                   # libddk.so loaded, a live ddk_ctx on the same device
+ctx.load_state_dict(synthetic.random_score_model_state_dict(seed=0))
+c = synthetic.make_complex(0, n_res=120)
+cx = Complex(ctx, c, 4)
+pos = torch.from_numpy(np.stack([c['lig_pos'] + i for i in range(4)]).astype(np.float32)).to(dev)
+tr0 = cx.score_forward(pos, 0.6, 0.6, 0.6)[0].clone()
+with socket.socket() as so:
+    so.bind(('127.0.0.1', 0)); port = so.getsockname()[1]
+dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1)
+dd.FORCE_COLLECTIVES = True                               # a world of one still runs every collective of the path
+n_lig = [c['lig_pos'].shape[0], 7, 19]
+poses = {i: torch.randn(4, n, 3, device=dev) for i, n in enumerate(n_lig)}
+g = dd.gather_poses(poses, n_lig, 4, dev)
+assert all(torch.equal(g[i], poses[i]) for i in poses)
+conf = {i: torch.randn(4, device=dev) for i in range(3)}
+gc = dd.gather_confidences(conf, 3, dev)
+assert all(torch.equal(gc[i], conf[i]) for i in conf)
+sl = torch.randn(4, n_lig[0], 3, device=dev)
+gs = dd.gather_samples(sl, 4, 0, 1, dev)
+assert torch.equal(gs, sl)
+t = torch.ones(3, device=dev); dist.all_reduce(t); dist.barrier()
+tr1 = cx.score_forward(pos, 0.6, 0.6, 0.6)[0]              # the ddk context still works beside the RCCL communicator
+assert torch.allclose(tr0, tr1, rtol=1e-5, atol=1e-6)
+torch.cuda.synchronize()
+be = dist.get_backend()
+dist.destroy_process_group()
+print(json.dumps({'backend': be, 'nccl_version': list(torch.cuda.nccl.version()), 'gathers': ['gather_poses', 'gather_confidences', 'gather_samples'], 'ok': True}))
+'''
+
+
+def test_rccl_world_of_one_beside_a_live_context(dev):
+    """backend='nccl' (RCCL on ROCm) initialised by THIS code on a GPU box, beside libddk.so and a live ddk_ctx (two HIP runtimes in one
+    process was a real failure once: commit 41af4eb), and the path's three gathers executed on device tensors."""
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    r = subprocess.run([sys.executable, '-c', _RCCL_SCRIPT, ROOT], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
+    out = json.loads(line)
+    assert out['ok'] and out['backend'] == 'nccl'
+    os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+    with open(os.path.join(ROOT, 'gpurun_out', 'rccl_world1.json'), 'w') as f:
+        json.dump(out, f)
+    print('RCCL world-of-one:', out)
+
+
+def test_bench_force_dist_runs_the_multi_rank_path_on_rccl(dev):
+    """``bench.py --gpus 1 --force-dist --backend nccl``: the barrier / all_reduce(max time) / all_reduce(n_lig) / all_gather of the N > 1 path
+    execute on RCCL (config 4: poses AND confidences are gathered)."""
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--force-dist', '--backend', 'nccl', '--config', '4', '--steps', '3',
+                        '--warmup', '1', '--no-cpu-baseline', '--no-alt', '--no-extras', '--no-device-loop'], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert d['n_gpus'] == 1 and d['value'] > 0
+    with open(os.path.join(ROOT, 'gpurun_out', 'bench_force_dist_nccl.json'), 'w') as f:
+        json.dump(d, f)

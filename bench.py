@@ -94,14 +94,36 @@ CONFIG_TEXT = {
 }
 
 
+CONV_KERNEL_SOURCES = ('k_conv_x.hip', 'k_conv_common.h', 'ddk_internal.h')      # what the dominant kernel is compiled from
+
+
+def conv_kernel_source_sha():
+    """sha256 over the sources of the dominant kernel: a PMC profile is only quoted for the kernel it was taken on"""
+    import hashlib
+    h = hashlib.sha256()
+    for name in CONV_KERNEL_SOURCES:
+        with open(os.path.join(ROOT, 'disco_diffdock_amd', 'csrc', name), 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def pmc_traffic():
-    """HBM bytes per fused-conv launch from the committed PMC passes of this same command (None if absent)."""
-    for name in ('r03_pmc_traffic.json',):
-        try:
-            return json.load(open(os.path.join(ROOT, 'profiles', name)))['traffic_bytes_per_launch'], name
-        except Exception:
-            continue
-    return None, None
+    """HBM bytes per fused-conv launch from the committed PMC passes of this same command - only when the profile was taken on THIS kernel:
+    tools/summarize_profile.py stamps the profile with the sha256 of the kernel's sources, a profile of another (or no) hash yields None and
+    the reason."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')), reverse=True)
+    if not cands:
+        return None, 'no profiles/r*_pmc_traffic.json'
+    name = os.path.basename(cands[0])
+    try:
+        d = json.load(open(cands[0]))
+        if d.get('kernel_source_sha256') != conv_kernel_source_sha():
+            return None, (f'profiles/{name} was taken on other kernel sources (profile {str(d.get("kernel_source_sha256"))[:12]}, working tree '
+                          f'{conv_kernel_source_sha()[:12]}): re-run tools/profile_round.sh')
+        return d['traffic_bytes_per_launch'], name
+    except Exception as e:
+        return None, f'profiles/{name}: {e}'
 
 
 def start_poses(c, rng, samples, tr_sigma_max=19.0):
@@ -518,8 +540,9 @@ def main():
                          'reference_equivalent_TFLOPs': tf(flops_unpruned), 'full_reference_TFLOPs': tf(flops_full),
                          'edges_executed_over_unpruned': sum(p['edges'] for p in prof) / max(sum(p['edges_unpruned'] for p in prof), 1),
                          'traffic': traffic,
-                         'traffic_source': f'profiles/{traffic_file}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over this command, '
-                                           'bytes per conv launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 FETCH correction)' if traffic_file else None,
+                         'traffic_source': (f'profiles/{traffic_file} (taken on this kernel: source sha256 {conv_kernel_source_sha()[:16]}): rocprofv3 --pmc '
+                                            'FETCH_SIZE / WRITE_SIZE (separate passes) over this command, bytes per conv launch = 2*FETCH_SIZE + WRITE_SIZE '
+                                            '(gfx950 FETCH correction)') if traffic is not None else f'null: {traffic_file}',
                          'algorithmic_bytes_per_launch': byts / max(launches, 1),
                          'launches': launches, 'avg_launch_ms': conv_ms / max(launches, 1),
                          'flop_per_launch': mfma_exec / max(launches, 1), 'fp32_equivalent_flop_per_launch': flops_exec / max(launches, 1),

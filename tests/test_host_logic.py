@@ -355,3 +355,24 @@ def test_graph_copies_settle_pending_bookkeeping():
         h = op(g)
         assert bk.calls == 1 and '_lazy' not in g.__dict__ and '_lazy' not in h.__dict__
         assert h.latent_str == 'L1R2' and h.name == 'c' and tuple(h['ligand'].pos.shape) == (4, 3)
+
+
+def test_bench_quotes_pmc_traffic_only_for_the_profiled_kernel(tmp_path, monkeypatch):
+    """roofline.traffic is a constant read from profiles/; it must turn to null (with the reason) when the kernel's sources
+    differ from the ones the profile was taken on."""
+    import importlib.util, json as _json
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    prof = tmp_path / 'profiles'
+    prof.mkdir()
+    sha = b.conv_kernel_source_sha()
+    (prof / 'r09_pmc_traffic.json').write_text(_json.dumps({'kernel_source_sha256': sha, 'traffic_bytes_per_launch': 123.0}))
+    monkeypatch.setattr(b, 'ROOT', str(tmp_path))
+    monkeypatch.setattr(b, 'conv_kernel_source_sha', lambda: sha)
+    assert b.pmc_traffic() == (123.0, 'r09_pmc_traffic.json')
+    monkeypatch.setattr(b, 'conv_kernel_source_sha', lambda: 'f' * 64)          # "a deliberate edit to k_conv_x.hip without re-profiling"
+    t, why = b.pmc_traffic()
+    assert t is None and 'other kernel sources' in why
+    (prof / 'r09_pmc_traffic.json').write_text(_json.dumps({'traffic_bytes_per_launch': 123.0}))      # a profile without a stamp (rounds 1-3)
+    assert b.pmc_traffic()[0] is None

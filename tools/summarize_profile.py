@@ -31,7 +31,12 @@ head = (f'# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --war
 open(os.path.join(out, 'kernel_stats.md'), 'w').write(head + '\n'.join(lines) + '\n')
 
 # ---- counters
-res = {'command': 'rocprofv3 --kernel-trace --pmc <group> (one group per pass) -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-alt --no-device-loop --no-extras',
+import hashlib
+_root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+_h = hashlib.sha256()
+for _n in ('k_conv_x.hip', 'k_conv_common.h', 'ddk_internal.h'):          # == bench.py CONV_KERNEL_SOURCES: bench.py quotes this profile only for these sources
+    _h.update(open(os.path.join(_root, 'disco_diffdock_amd', 'csrc', _n), 'rb').read())
+res = {'kernel_source_sha256': _h.hexdigest(), 'command': 'rocprofv3 --kernel-trace --pmc <group> (one group per pass) -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-alt --no-device-loop --no-extras',
        'kernel': 'ddk::' + KERNEL + ', false>', 'avg_launch_us_kernel_trace': sum(conv) / max(len(conv), 1)}
 for d in sorted(glob.glob(os.path.join(src, 'pmc*'))):
     if not os.path.isdir(d):

@@ -126,17 +126,19 @@ def pmc_traffic():
         return None, f'profiles/{name}: {e}'
 
 
-def start_poses(c, rng, samples, tr_sigma_max=19.0):
-    """randomize_position (reference utils/sampling.py:12-34): random torsions are skipped (synthetic ligands are
-    already random conformers), random rotation about the centroid + N(0, tr_sigma_max) translation."""
+def start_poses(c, rng, samples, ctx, dev, tr_sigma_max=19.0):
+    """randomize_position (reference utils/sampling.py:12-34) on the device (ddk_randomize_position): uniform(-pi, pi) torsion angles on every
+    rotatable bond (:16-22), a random rotation about the centroid and a N(0, tr_sigma_max) translation (:24-34) per sample."""
     from scipy.spatial.transform import Rotation
-    lp = c['lig_pos'].astype(np.float64)
-    ctr = lp.mean(0, keepdims=True)
-    out = []
-    for _ in range(samples):
-        Rm = Rotation.random(random_state=rng).as_matrix()
-        out.append((lp - ctr) @ Rm.T + rng.normal(0, tr_sigma_max, size=(1, 3)))
-    return np.stack(out).astype(np.float32)
+    from disco_diffdock_amd.runtime import Complex
+    cx = Complex(ctx, {k: v for k, v in c.items() if not k.startswith('atom_')}, samples)
+    rot = np.stack([Rotation.random(random_state=rng).as_matrix() for _ in range(samples)]).astype(np.float32)
+    tor = rng.uniform(-np.pi, np.pi, size=(samples, cx.R)).astype(np.float32) if cx.R > 0 else None
+    tr = rng.normal(0, tr_sigma_max, size=(samples, 3)).astype(np.float32)
+    out = cx.randomize_position(torch.from_numpy(np.array(c['lig_pos'], np.float32)).to(dev), torch.from_numpy(rot).to(dev),
+                                None if tor is None else torch.from_numpy(tor).to(dev), torch.from_numpy(tr).to(dev)).cpu().numpy()
+    cx.close()
+    return out.astype(np.float32)
 
 
 def cpu_baseline(c, P, coeffs, gpu_scores, n_res, seconds_budget=40.0):
@@ -229,6 +231,9 @@ def main():
     ap.add_argument('--no-extras', action='store_true', help='skip the pruning-off and pocket-bound brackets')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl == RCCL; gloo for smoke tests)')
     ap.add_argument('--single-device', action='store_true', help='smoke test of the N > 1 path on a one-GPU box: every rank uses cuda:0')
+    ap.add_argument('--complexes', type=int, default=0, help='distinct synthetic complexes per rank (default 8 of ~30 ligand atoms; N > 8: ligand sizes '
+                    'drawn from 10-80 atoms like a PDBBind split - e.g. --complexes 363 --steps 363 streams a timesplit_test-sized set once)')
+    ap.add_argument('--complex-offset', type=int, default=0, help='first content seed of --complexes (to run a slice of a large set)')
     ap.add_argument('--force-dist', action='store_true', help='N = 1 through the N > 1 code path: a world_size-1 process group on --backend, every '
                     'barrier / all_reduce / all_gather of the path executes (proves that RCCL loads and runs beside libddk.so on a one-GPU box)')
     a = ap.parse_args()
@@ -279,7 +284,8 @@ def main():
 
     # ---- workload: this rank's complexes, written to and read back from the flat graph cache (the format a GPU box receives real
     #      PDBBind graphs in, disco_diffdock_amd/graph_cache.py) ---------------------------------------------------------------
-    n_cx = 4 if big else N_COMPLEXES
+    n_cx = a.complexes if a.complexes > 0 else (4 if big else N_COMPLEXES)
+    spread_ligands = a.complexes > N_COMPLEXES
     if big:                                  # samples sharded: every rank works on the same complexes
         mine = list(range(n_cx))
         lo, hi = shard_samples(SAMPLES, rank, world)
@@ -292,9 +298,10 @@ def main():
     b_local = hi - lo
     made = []
     for i in mine:
-        c = synthetic.make_complex(i % n_cx, n_res=n_res)
+        seed = a.complex_offset + i % n_cx
+        c = synthetic.make_complex(seed, n_res=n_res, n_lig=int(np.random.default_rng(7000 + seed).integers(10, 81)) if spread_ligands else None)
         if with_conf:
-            synthetic.add_receptor_atoms(c, np.random.default_rng(i % n_cx))
+            synthetic.add_receptor_atoms(c, np.random.default_rng(a.complex_offset + i % n_cx))
         made.append(c)
     cache_path = os.path.join(tempfile.gettempdir(), f'ddk_bench_cfg{cfg_id}_rank{rank}.ddkg')
     graph_cache.save_complexes(cache_path, made)
@@ -327,7 +334,7 @@ def main():
     ctx = score_model.ctx
 
     # host data_lists of every call, prepared BEFORE the clock starts like evaluate.py:232-233 (deepcopy + randomize_position)
-    poses_all = {i: start_poses(complexes[i], np.random.default_rng(i), SAMPLES) for i in mine}
+    poses_all = {i: start_poses(complexes[i], np.random.default_rng(i), SAMPLES, ctx, dev) for i in mine}
     graphs0 = {}
     for i in mine:
         c = complexes[i]
@@ -374,6 +381,7 @@ def main():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
+        pool0, mem_peak = ctx.pool_stats(), 0
         t0 = time.perf_counter()
         final, confs, outs = {}, {}, []
         call_ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]      # device time stamps behind every call (no host wait)
@@ -383,6 +391,9 @@ def main():
                 sm_mod._complex_cache.clear()    # K > #complexes: the second pass over the shard must not hit the cache either
             out, conf = one_call(k)
             call_ev[k - warmup + 1].record()
+            if (k - warmup) % 8 == 0:                # device memory in use (driver query, no synchronisation), sampled every 8th call
+                fr, tot_mem = torch.cuda.mem_get_info(dev)
+                mem_peak = max(mem_peak, tot_mem - fr)
             outs.append(out)
             final[order[k]] = torch.stack([d['ligand'].pos for d in out])
             if with_conf:
@@ -404,7 +415,15 @@ def main():
             elapsed = float(tmax.item())
         for p in final.values():
             assert bool(torch.isfinite(p).all()), 'non-finite pose'
-        return dict(elapsed=elapsed, prof=prof, fw=fw, per_call_ms=per_call_ms, final=final, confs=confs, order=order[warmup:warmup + a.steps])
+        pool1 = ctx.pool_stats()
+        stream = {'complexes_created': a.steps, 'distinct_complexes': len(mine),
+                  'ligand_atoms_min_max': [int(min(complexes[i]['lig_pos'].shape[0] for i in mine)), int(max(complexes[i]['lig_pos'].shape[0] for i in mine))],
+                  'chunk_pool_hipMalloc_in_timed_region': pool1['hipMalloc_calls'] - pool0['hipMalloc_calls'],
+                  'chunk_pool_reuses_in_timed_region': pool1['reuses'] - pool0['reuses'],
+                  'chunk_pool_hipFree_in_timed_region': pool1['hipFree_calls'] - pool0['hipFree_calls'],
+                  'chunk_pool_bytes_parked': pool1['bytes_parked'], 'complex_bytes_owned_peak': pool1['bytes_owned_peak'],
+                  'device_memory_in_use_peak_bytes': int(mem_peak)}
+        return dict(elapsed=elapsed, prof=prof, fw=fw, per_call_ms=per_call_ms, final=final, confs=confs, order=order[warmup:warmup + a.steps], stream=stream)
 
     layer_flop = [2 * 72 * (72 + W_LAYER[l]) + TP_FLOP[l] for l in range(5)]
 
@@ -557,7 +576,7 @@ def main():
             'extra': {'pruning_off': pruning_off, 'pocket_bound': pocket_bound, 'per_step': per_step, 'create_ms': create_ms,
                       'per_call_spread_same_complex': per_call_spread,
                       'headline': {k: v for k, v in summary(head, n_done).items() if k != 'value'},
-                      'device_loop': device_loop, 'per_call_ms': head['per_call_ms']},
+                      'device_loop': device_loop, 'per_call_ms': head['per_call_ms'] if a.steps <= 64 else head['per_call_ms'][:64] + ['...'], 'stream': head['stream']},
         }
         if int(getattr(ctx.cfg, 'conv_kernel', 0)) == 1:
             # the whole run was switched to the fallback kernel (DDK_CONV_KERNEL=1): its work is fp32 MFMA chains, priced against the fp32 MFMA peak

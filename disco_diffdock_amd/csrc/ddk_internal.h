@@ -205,6 +205,7 @@ struct ddk_ctx {
   struct PoolChunk { void* p = nullptr; size_t cap = 0; hipEvent_t free_after = nullptr; };   // free_after: last use by the previous owner
   std::vector<PoolChunk> chunk_pool;
   size_t chunk_pool_bytes = 0;
+  int64_t pool_mallocs = 0, pool_reuses = 0, pool_frees = 0, pool_bytes_out = 0, pool_bytes_out_peak = 0;   // ddk_debug_pool_stats
   // profiling (ddk_profile_enable / ddk_profile_read)
   bool prof = false;
   bool prune = true;                // backward receptive-field pruning of the rec-rec messages (ddk_set_receptive_field_pruning)

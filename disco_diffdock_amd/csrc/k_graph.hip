@@ -654,24 +654,38 @@ __global__ void node_embed_kernel(NodeEmbedArgs A) {
 
 // Static per-complex precompute on the upload stream (ddk_complex_create): the receptor's node embedding without its sigma columns,
 //   out[j] = W[:, :ns] . table[residue_j] + W[:, ns:ns+lm] . lm_features_j + b     (AtomEncoder, models/layers.py:140-149; 1336-wide at lm = 1280)
-// in the summation order and precision (fp64 accumulator, rounded to fp32 once) of the host loop it replaces; 8 residues x 24 outputs per block,
-// the 24 threads of a residue read the same feature, w_lm_t is [lm][ns] so their weights are contiguous.
-__global__ __launch_bounds__(8 * NS) void rec_node_static_kernel(RecStaticArgs A) {
-  const int o = threadIdx.x % NS, j = blockIdx.x * 8 + threadIdx.x / NS;
-  if (j >= A.n_rec) return;
+// with fp64 accumulators, rounded to fp32 once.  One workgroup per residue: 10 K slices x 24 outputs (round 3 ran the 1304-long sum as ONE
+// serial chain per output on 38 workgroups: 600 us for 9.6 MFLOP); w_lm_t is [lm][ns], so the 24 threads of a slice read contiguous weights
+// and the same feature.
+constexpr int RNS_SLICES = 10;
+__global__ __launch_bounds__(RNS_SLICES * NS) void rec_node_static_kernel(RecStaticArgs A) {
+  __shared__ double part[RNS_SLICES][NS];
+  const int o = threadIdx.x % NS, sl = threadIdx.x / NS, j = blockIdx.x;
   const float* xr = A.rec_x + (size_t)j * A.feat_dim;
-  const float* emb = A.rec_table + (size_t)(int)xr[0] * NS;
-  double a = A.b[o];
-  for (int k = 0; k < NS; ++k) a += (double)A.w_emb[o * NS + k] * emb[k];
-  for (int k = 0; k < A.lm; ++k) a += (double)A.w_lm_t[(size_t)k * NS + o] * (double)xr[1 + k];
-  A.out[(size_t)j * NS + o] = (float)a;
+  double a = 0.0;
+  if (sl == 0) {
+    const float* emb = A.rec_table + (size_t)(int)xr[0] * NS;
+    a = A.b[o];
+    for (int k = 0; k < NS; ++k) a += (double)A.w_emb[o * NS + k] * emb[k];
+  }
+  const int per = (A.lm + RNS_SLICES - 1) / RNS_SLICES, k0 = sl * per, k1 = min(A.lm, k0 + per);
+  for (int k = k0; k < k1; ++k) a += (double)A.w_lm_t[(size_t)k * NS + o] * (double)xr[1 + k];
+  part[sl][o] = a;
+  __syncthreads();
+  if (sl == 0) {
+#pragma unroll
+    for (int q = 1; q < RNS_SLICES; ++q) a += part[q][o];
+    A.out[(size_t)j * NS + o] = (float)a;
+  }
 }
 
 // ... and the distance half of rec_edge_embedding.0 on the static receptor edges: pre1[k] = W1[:, dist] . gauss(|pos_b - pos_a|)
-// (score_model.py:327-344 + GaussianSmearing, tensor_layers.py:171-181), one thread per edge
-__global__ __launch_bounds__(128) void rec_edge_static_kernel(const int32_t* rr_src, const int32_t* rr_dst, const float* rec_pos, int E, EdgeMlpDev m,
+// (score_model.py:327-344 + GaussianSmearing, tensor_layers.py:171-181): six threads per edge, four outputs each (a thread per edge left the
+// 7 200 edges of a 300-residue receptor on 57 workgroups with an 800-FMA chain each)
+__global__ __launch_bounds__(256) void rec_edge_static_kernel(const int32_t* rr_src, const int32_t* rr_dst, const float* rec_pos, int E, EdgeMlpDev m,
                                                               float* pre1) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = gid / (NS / 4), o4 = gid % (NS / 4);
   if (k >= E) return;
   const int a = rr_src[k], b = rr_dst[k];
   const float vx = rec_pos[3 * b] - rec_pos[3 * a], vy = rec_pos[3 * b + 1] - rec_pos[3 * a + 1], vz = rec_pos[3 * b + 2] - rec_pos[3 * a + 2];
@@ -679,18 +693,38 @@ __global__ __launch_bounds__(128) void rec_edge_static_kernel(const int32_t* rr_
   float gs[DE];
 #pragma unroll
   for (int q = 0; q < DE; ++q) { const float t = dist - m.offset[q]; gs[q] = expf(m.coeff * (t * t)); }
-  for (int o = 0; o < NS; ++o) {
+  float r[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int o = 4 * o4 + i;
     float a2 = 0.0f;
 #pragma unroll
     for (int q = 0; q < DE; ++q) a2 += m.w1d[o * DE + q] * gs[q];
-    pre1[(size_t)k * NS + o] = a2;
+    r[i] = a2;
   }
+  *reinterpret_cast<float4*>(pre1 + (size_t)k * NS + 4 * o4) = make_float4(r[0], r[1], r[2], r[3]);
+}
+
+// zero fill in 16-B stores (hipMemsetAsync's fill kernel takes 80 us for the 4.4 MB of a complex' accumulators); p 16-B aligned
+__global__ void zero_fill_kernel(float4* p, int64_t n4, float* tail, int n_tail) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n4) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n_tail) tail[i] = 0.0f;
+}
+hipError_t launch_zero_fill(void* p, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return hipSuccess;
+  if ((reinterpret_cast<uintptr_t>(p) & 15) || (bytes & 3)) return hipMemsetAsync(p, 0, bytes, s);
+  const int64_t n4 = (int64_t)(bytes / 16);
+  const int n_tail = (int)((bytes % 16) / 4);
+  hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)((n4 + 255) / 256 + 1)), dim3(256), 0, s, reinterpret_cast<float4*>(p), n4,
+                     reinterpret_cast<float*>(p) + 4 * n4, n_tail);
+  return hipGetLastError();
 }
 
 hipError_t launch_complex_static(const RecStaticArgs& R, const int32_t* rr_src, const int32_t* rr_dst, const float* rec_pos, int E, const EdgeMlpDev& m,
                                  float* pre1, hipStream_t s) {
-  if (R.n_rec > 0) hipLaunchKernelGGL(rec_node_static_kernel, dim3((R.n_rec + 7) / 8), dim3(8 * NS), 0, s, R);
-  if (E > 0) hipLaunchKernelGGL(rec_edge_static_kernel, dim3((E + 127) / 128), dim3(128), 0, s, rr_src, rr_dst, rec_pos, E, m, pre1);
+  if (R.n_rec > 0) hipLaunchKernelGGL(rec_node_static_kernel, dim3(R.n_rec), dim3(RNS_SLICES * NS), 0, s, R);
+  if (E > 0) hipLaunchKernelGGL(rec_edge_static_kernel, dim3((E * (NS / 4) + 255) / 256), dim3(256), 0, s, rr_src, rr_dst, rec_pos, E, m, pre1);
   return hipGetLastError();
 }
 

@@ -266,6 +266,7 @@ hipError_t launch_node_embed(const NodeEmbedArgs& a, hipStream_t s);
 struct RecStaticArgs { const float* rec_x; int n_rec, feat_dim, lm; const float *rec_table, *w_emb, *w_lm_t, *b; float* out; };
 hipError_t launch_complex_static(const RecStaticArgs& R, const int32_t* rr_src, const int32_t* rr_dst, const float* rec_pos, int E, const EdgeMlpDev& m,
                                  float* pre1, hipStream_t s);
+hipError_t launch_zero_fill(void* p, size_t bytes, hipStream_t s);      // k_graph.hip: 16-B stores (hipMemsetAsync's fill kernel is 50x slower at a few MB)
 hipError_t launch_heads_pre(const HeadArgs& A, bool torsion, hipStream_t s);
 hipError_t launch_heads_post(const HeadArgs& A, bool torsion, hipStream_t s);
 hipError_t launch_se3(const Se3Args& A, hipStream_t s);

@@ -291,6 +291,7 @@ static int make_step_params(ddk_ctx* ctx, float t_tr, float t_rot, float t_tor, 
 }
 
 // ---- asynchronous upload machinery (see ddk_ctx / ddk_complex) -----------------------------------------------------------------
+constexpr size_t CHUNK_POOL_MAX_CHUNKS = 1024;
 constexpr size_t CHUNK_POOL_MAX_BYTES = (size_t)96 << 30;   // device memory parked in the pool (288 GB of HBM per GPU); beyond it hipFree (device sync)
 
 void* cx_new_chunk(ddk_complex* cx, size_t cap) {
@@ -315,9 +316,14 @@ void* cx_new_chunk(ddk_complex* cx, size_t cap) {
     ctx->chunk_pool_bytes -= c.cap;
     if (c.free_after) hipEventDestroy(c.free_after);      // (complete: checked above)
     p = c.p; cap = c.cap;
+    ctx->pool_reuses++;
   } else if (hipMalloc(&p, cap) != hipSuccess) {
     return nullptr;
+  } else {
+    ctx->pool_mallocs++;
   }
+  ctx->pool_bytes_out += (int64_t)cap;
+  if (ctx->pool_bytes_out > ctx->pool_bytes_out_peak) ctx->pool_bytes_out_peak = ctx->pool_bytes_out;
   cx->allocs.push_back({p, cap});
   cx->chunk_cap = cap;
   return p;
@@ -746,20 +752,20 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
     cx->h_sh = cx_upload<float>(cx, nullptr, Eh * 4);
     cx->h_deg = cx_upload<int32_t>(cx, nullptr, Nh);
     cx->h_sum = cx_upload<float>(cx, nullptr, Nh * XW);
-    if (cx->h_sum) hipMemsetAsync(cx->h_sum, 0, (size_t)Nh * XW * sizeof(float), ctx->up_stream);
+    if (cx->h_sum) launch_zero_fill(cx->h_sum, (size_t)Nh * XW * sizeof(float), ctx->up_stream);
   }
   cx->scores = cx_upload<float>(cx, nullptr, Bm * (6 + (d->n_rot > 0 ? d->n_rot : 1)));
   cx->scores2 = cx_upload<float>(cx, nullptr, Bm * (6 + (d->n_rot > 0 ? d->n_rot : 1)));
   if (c.latent_dim > 0) {
     cx->zero_lat = cx_upload<float>(cx, nullptr, N * c.latent_dim);
-    if (cx->zero_lat) hipMemsetAsync(cx->zero_lat, 0, (size_t)N * c.latent_dim * sizeof(float), ctx->up_stream);
+    if (cx->zero_lat) launch_zero_fill(cx->zero_lat, (size_t)N * c.latent_dim * sizeof(float), ctx->up_stream);
   }
   if (cx->oom || !cx->bond_src || !cx->rr_sh || !cx->scores) return fail(ctx, DDK_ERR_NOMEM, "device allocation failed in ddk_complex_create");
   hipMemsetAsync(cx->info, 0, INFO_INTS * sizeof(int32_t), ctx->up_stream);
   // the accumulators start clean (node_finalize clears behind itself): cleared here, on the upload stream, beside the previous complex' loop
   if (cx->sum && cx->sum_rr0) {
-    hipMemsetAsync(cx->sum, 0, (size_t)N * XW * sizeof(float) * (det ? 2 : 1), ctx->up_stream);
-    hipMemsetAsync(cx->sum_rr0, 0, (size_t)n_rec * XW * sizeof(float), ctx->up_stream);
+    launch_zero_fill(cx->sum, (size_t)N * XW * sizeof(float) * (det ? 2 : 1), ctx->up_stream);
+    launch_zero_fill(cx->sum_rr0, (size_t)n_rec * XW * sizeof(float), ctx->up_stream);
     cx->sum_clean = true;
   }
   int rcf = cx_stage_flush(ctx, cx);   // the copies are in flight on the upload stream; every launch entry point waits for cx->ready
@@ -798,13 +804,18 @@ void ddk_complex_destroy(ddk_ctx* ctx, ddk_complex* cx) {
     if (!a.p) continue;
     ddk_ctx::PoolChunk c;
     c.p = a.p; c.cap = a.cap;
+    ctx->pool_bytes_out -= (int64_t)a.cap;
     bool ok = hipEventCreateWithFlags(&c.free_after, hipEventDisableTiming) == hipSuccess;
     // (a complex that was never launched: its copies may still be in flight on the upload stream; otherwise the launch stream, which
     // waited for them in cx_wait_ready)
     if (ok) ok = hipEventRecord(c.free_after, cx->used ? cx->last_stream : ctx->up_stream) == hipSuccess;
-    if (!ok || ctx->chunk_pool_bytes + c.cap > CHUNK_POOL_MAX_BYTES || ctx->chunk_pool.size() >= 64) {
+    if (!ok || ctx->chunk_pool_bytes + c.cap > CHUNK_POOL_MAX_BYTES || ctx->chunk_pool.size() >= CHUNK_POOL_MAX_CHUNKS) {
+      // the chunk leaves the process: wait for its last use first (hipFree does not wait for work on the context's NON-BLOCKING streams; a
+      // 363-complex stream with ligands of 10-80 atoms filled round 3's 64-chunk pool and freed memory under kernels still in flight)
+      if (ok) hipEventSynchronize(c.free_after); else hipDeviceSynchronize();
       if (c.free_after) hipEventDestroy(c.free_after);
       hipFree(a.p);
+      ctx->pool_frees++;
       continue;
     }
     ctx->chunk_pool.push_back(c);
@@ -1089,6 +1100,13 @@ int ddk_debug_conv_trace(ddk_ctx* ctx, int32_t layer, uint32_t* trace) {
 }
 
 // Test hook: layer-0 de-duplication of the rec-rec messages on / off (on by default; off = every sample evaluates all its rec-rec messages)
+int ddk_debug_pool_stats(ddk_ctx* ctx, int64_t* out) {
+  if (!ctx || !out) return DDK_ERR_INVALID;
+  out[0] = ctx->pool_mallocs; out[1] = ctx->pool_reuses; out[2] = ctx->pool_frees; out[3] = (int64_t)ctx->chunk_pool_bytes;
+  out[4] = (int64_t)ctx->chunk_pool.size(); out[5] = ctx->pool_bytes_out; out[6] = ctx->pool_bytes_out_peak; out[7] = 0;
+  return DDK_OK;
+}
+
 int ddk_debug_set_layer0_dedup(ddk_ctx* ctx, int32_t on) {
   if (!ctx) return DDK_ERR_INVALID;
   ctx->layer0_dedup = on != 0;

@@ -176,6 +176,13 @@ class Context:
         """backward receptive-field pruning of the receptor-receptor messages (default on; exact)"""
         self._check(self.L.ddk_set_receptive_field_pruning(self.h, int(bool(on))), 'ddk_set_receptive_field_pruning')
 
+    def pool_stats(self):
+        """device-chunk pool of the complexes (include/ddk_debug.h): hipMalloc calls, reuses, hipFree calls, bytes / chunks parked, bytes owned now / at peak"""
+        buf = (C.c_int64 * 8)()
+        self._check(self.L.ddk_debug_pool_stats(self.h, buf), 'ddk_debug_pool_stats')
+        keys = ('hipMalloc_calls', 'reuses', 'hipFree_calls', 'bytes_parked', 'chunks_parked', 'bytes_owned', 'bytes_owned_peak')
+        return dict(zip(keys, [int(v) for v in buf[:7]]))
+
     def debug_set_layer0_dedup(self, on=True):
         """test hook (include/ddk_debug.h): layer-0 de-duplication of the rec-rec messages on / off"""
         self._check(self.L.ddk_debug_set_layer0_dedup(self.h, int(bool(on))), 'ddk_debug_set_layer0_dedup')

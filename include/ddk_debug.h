@@ -32,6 +32,11 @@ int ddk_debug_conf_edges(ddk_ctx* ctx, ddk_complex* cx, int64_t first, int64_t n
  * patch group of the receivers that see a non-zero latent): on by default, `on = 0` makes every sample evaluate all its messages.  Exists
  * for the equality test of the two paths. */
 int ddk_debug_set_layer0_dedup(ddk_ctx* ctx, int32_t on);
+
+/* Device-chunk pool of the complexes (ddk_complex_create / destroy never synchronise: chunks whose previous owner has finished are reused,
+ * otherwise hipMalloc): out[8] = hipMalloc calls, reuses, hipFree calls, bytes parked in the pool, chunks parked, bytes owned by live
+ * complexes, the peak of that, 0. */
+int ddk_debug_pool_stats(ddk_ctx* ctx, int64_t* out);
 /* The patch group of the last forward of a latent-conditioned model: counts[B + 1] = exclusive prefix of the patch edges per sample
  * (counts[B] = total), mask[B * n_rec] = 1 for receivers whose rec-rec sum comes from the patch group.  HOST pointers; synchronises. */
 int ddk_debug_read_patch(ddk_ctx* ctx, ddk_complex* cx, int32_t B, int32_t* counts, uint8_t* mask);

@@ -386,7 +386,8 @@ static int pack_x3(ddk_ctx* ctx, ConvLayerDev& L, int NG, const std::vector<floa
     std::frexp(std::max(m, 0x1p-40f), &e);      // m = f * 2^e, f in [0.5, 1)
     return std::ldexp(1.0f, 15 - e);
   };
-  std::vector<uint8_t> w2x((size_t)NG * L.n_tiles * W2X_TILE_BYTES, 0), w1x((size_t)NG * 3 * W1X_TILE_BYTES, 0);
+  // (+ three zero records behind the last group: the kernel requests record t+3 without clamping at a group's last tile)
+  std::vector<uint8_t> w2x((size_t)(NG * L.n_tiles + 3) * W2X_TILE_BYTES, 0), w1x((size_t)NG * 3 * W1X_TILE_BYTES, 0);
   // one tile of fp32 fragments [9][64][4] -> three limbs x [4 x [64][8] | [64][4]]
   auto frags = [&](const float* src, float sc, uint8_t* dst) {
     for (int r = 0; r < 36; ++r)

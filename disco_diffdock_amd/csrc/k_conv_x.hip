@@ -42,6 +42,7 @@ namespace ddk {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((vector_size(16)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 #define MFMA8(a, b, c) __builtin_amdgcn_mfma_f32_32x32x8f16((a), (b), (c), 0, 0, 0)
 
@@ -236,15 +237,23 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
   int trace_n = 0;
   auto stamp = [&](int phase) {
     if constexpr (TRACE) {
-      if (AX.trace_coarse && phase < 4) return;
+      if (AX.trace_coarse == 1 && phase < 4) return;
       if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && trace_n < CONV_TRACE_TILES)
         AX.trace[((threadIdx.x >> 6) * CONV_TRACE_TILES + trace_n) * 8 + phase] = (uint32_t)__builtin_amdgcn_s_memtime();
       if (phase == 3) ++trace_n;
     }
   };
+  bool first_tile = true;
+  auto stamp_epi = [&](int slot) {     // trace mode 2: four stamps INSIDE the epilogue (slots 4-7 of every tile but a unit's first, whose slots hold the prologue)
+    if constexpr (TRACE) {
+      if (AX.trace_coarse != 2 || first_tile) return;
+      if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && trace_n < CONV_TRACE_TILES)
+        AX.trace[((threadIdx.x >> 6) * CONV_TRACE_TILES + trace_n) * 8 + slot] = (uint32_t)__builtin_amdgcn_s_memtime();
+    }
+  };
   auto stamp_unit = [&](int slot, int value) {      // coarse trace: slot 0 / 2 take the time, slot 1 the given value; slot 2 closes the record
     if constexpr (TRACE) {
-      if (!AX.trace_coarse) return;
+      if (AX.trace_coarse != 1) return;
       if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && trace_n < CONV_TRACE_TILES)
         AX.trace[((threadIdx.x >> 6) * CONV_TRACE_TILES + trace_n) * 8 + slot] = slot == 1 ? (uint32_t)value : (uint32_t)__builtin_amdgcn_s_memtime();
       if (slot == 2) ++trace_n;
@@ -304,6 +313,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
   for (;;) {
     if (unit >= n_units) break;
     stamp(4);
+    first_tile = true;
     int unit_next = 0;
     if (tid == 0) unit_next = nwg + atomicAdd(A.counter, 1);      // fetched at the START of this unit: the round trip hides under the tile loop
     int blk = unit, t_begin = 0, t_end = n_tiles;
@@ -548,144 +558,51 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
     for (int rq = 0; rq < 4; ++rq) {
       accA[rq] = 0.0f; accV[rq][0] = 0.0f; accV[rq][1] = 0.0f; accV[rq][2] = 0.0f; accX[rq][0] = 0.0f; accX[rq][1] = 0.0f; accX[rq][2] = 0.0f;
     }
-    // the first two K steps of the first tile (every later tile's are fetched at the start of the previous epilogue)
-    // (the tile's two descriptor words ride behind its bias in the ring record: an LDS read, not a scalar load - a scalar load in flight turns
-    // every counted LDS wait into a full one)
-    Frag16 p0 = lds_frag16(ring, 0, lane), p1 = lds_frag16(ring, 1, lane);
-    int w0n, chan0n;
+    // ---- per-lane ring addresses: with the tile loop unrolled over the four ring stages every ring access is ONE base register + an immediate
+    // (the ring spans 4 x 13,968 B < 2^16: the 16-bit ds offset reaches all of it), and the records of tile t+3 come through a buffer
+    // descriptor (per-lane offset in a VGPR, the tile's offset in ONE SGPR that advances by a record per tile) ----
+    const char* ringl = ring + lane * 16;       // 16-B fragment reads
+    const char* ringt = ring + lane * 8;        // 8-B tail-fragment reads
+    const char* ringb = ring + hh * 64;         // the lane half's 16 bias floats
+    char* ringw0 = ring + fo0;                  // this thread's two chunks of a record
+    char* ringw1 = ring + fo1;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wrec), 0, 0x7fffffff, 0x00020000);
+    int rec_soff = (t_begin + 3) * W2X_TILE_BYTES;      // (records past a group's last tile exist: the next group's, or the three pad records)
+    // the first K step of the first tile and its descriptor (the two words ride behind the bias in the ring record: an LDS read, not a scalar
+    // load - a scalar load in flight turns every counted LDS wait into a full one); later tiles: fetched in the previous burst's tail
+    Frag16 p0;
+    p0.h = *reinterpret_cast<const f16x8*>(ringl); p0.m = *reinterpret_cast<const f16x8*>(ringl + W2X_LIMB_BYTES); p0.l = *reinterpret_cast<const f16x8*>(ringl + 2 * W2X_LIMB_BYTES);
+    int w0, chan0;
     {
       const int2 dq = *reinterpret_cast<const int2*>(ring + W2X_DESC_OFF);
-      w0n = __builtin_amdgcn_readfirstlane(dq.x); chan0n = __builtin_amdgcn_readfirstlane(dq.y);
+      w0 = __builtin_amdgcn_readfirstlane(dq.x); chan0 = __builtin_amdgcn_readfirstlane(dq.y);
     }
-    for (int t = t_begin; t < t_end; ++t) {
-      const int w0 = w0n, chan0 = chan0n;
-      const int t1 = min(t + 1, t_end - 1);
-      const char* stage = ring + ((t - t_begin) & 3) * W2X_TILE_BYTES;
-      // the bursting wave wins issue arbitration against its SIMD partner's epilogue (round 3's static priority for the later-dispatched half
-      // costs 7 % once the half phases are not separated by a barrier any more; priority during the epilogue instead: +2.5 %)
-      __builtin_amdgcn_s_setprio(1);
-      stamp(0);
-      // ================= burst: 28 MFMAs, everything else of this phase threaded between them =================
-      // Issue order, pinned region by region (one K step each): the first MFMA goes out first (its operands were fetched in the previous
-      // epilogue) and every other instruction of the burst rides in the shadow of an MFMA, one per MFMA: the LDS reads of the fragments two steps
-      // ahead, the epilogue's operands (feature rows, bias), and this thread's two chunks of ring record t+3.
-      const char* rec3 = wrec + (size_t)min(t + 3, t_end - 1) * W2X_TILE_BYTES;
-      const float* Fp = Fr + (w0 >> 16);
-      f32x16 D0, D1, Bs;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { D0[r] = 0.0f; D1[r] = 0.0f; }
-#define X3_PAIR(mask) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(mask, 1, 0); }
-#define X3_BARE { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }
-      __builtin_amdgcn_sched_barrier(0);
-      const Frag16 q2 = lds_frag16(stage, 2, lane);
-      const f32x4 f0 = ldv4(Fp);
-      X3_STEP(MFMA16, p0.h, p0.m, p0.l, H.hi[0], H.mid[0], H.lo[0])
-      X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_BARE X3_BARE
-      __builtin_amdgcn_sched_barrier(0);
-      const Frag16 q3 = lds_frag16(stage, 3, lane);
-      const f16x4 th = *reinterpret_cast<const f16x4*>(stage + 4096 + lane * 8);
-      const f16x4 tm = *reinterpret_cast<const f16x4*>(stage + W2X_LIMB_BYTES + 4096 + lane * 8);
-      const f16x4 tl = *reinterpret_cast<const f16x4*>(stage + 2 * W2X_LIMB_BYTES + 4096 + lane * 8);
-      X3_STEP(MFMA16, p1.h, p1.m, p1.l, H.hi[1], H.mid[1], H.lo[1])
-      X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100)
-      __builtin_amdgcn_sched_barrier(0);
-#ifndef ABL_NO_RING
-      const float4 st0 = *reinterpret_cast<const float4*>(rec3 + fo0);
-      const float4 st1 = *reinterpret_cast<const float4*>(rec3 + fo1);
-#endif
-      X3_STEP(MFMA16, q2.h, q2.m, q2.l, H.hi[2], H.mid[2], H.lo[2])
-#ifndef ABL_NO_RING
-      X3_PAIR(0x020) X3_BARE X3_PAIR(0x020) X3_BARE X3_BARE X3_BARE
-#else
-      X3_BARE X3_BARE X3_BARE X3_BARE X3_BARE X3_BARE
-#endif
-      __builtin_amdgcn_sched_barrier(0);
-      // (this tile's bias: needed at the very start of the epilogue, so its LDS latency runs under the last MFMAs)
-      const float* bp = reinterpret_cast<const float*>(stage + W2X_BIAS_OFF) + hh * 16;
-      const float4 bs0 = ld4(bp), bs1 = ld4(bp + 4), bs2 = ld4(bp + 8), bs3 = ld4(bp + 12);
-      X3_STEP(MFMA16, q3.h, q3.m, q3.l, H.hi[3], H.mid[3], H.lo[3])
-      {     // packed tail: D0 += hi.mid + mid.hi, D1 += lo.hi + hi.lo as one K = 16 MFMA each; mid.mid and hi.hi stay K = 8
-        const f16x8 a_hm = __builtin_shufflevector(th, tm, 0, 1, 2, 3, 4, 5, 6, 7), a_lh = __builtin_shufflevector(tl, th, 0, 1, 2, 3, 4, 5, 6, 7);
-#ifdef ONE_ACC
-        D0 = MFMA16(a_lh, HT.hl, D0);
-        D0 = MFMA8(tm, H.tmid, D0);
-        D0 = MFMA16(a_hm, HT.mh, D0);
-        D0 = MFMA8(th, H.thi, D0);
-#else
-        D1 = MFMA16(a_lh, HT.hl, D1);
-        D0 = MFMA16(a_hm, HT.mh, D0);
-        D1 = MFMA8(tm, H.tmid, D1);
-        D0 = MFMA8(th, H.thi, D0);
-#endif
-      }
-      X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_BARE X3_BARE X3_BARE X3_BARE X3_BARE X3_BARE
-      __builtin_amdgcn_sched_barrier(0);
-#undef X3_PAIR
-#undef X3_BARE
-      __builtin_amdgcn_s_setprio(0);
-      stamp(1);
-#ifndef ABL_NO_BAR
-      if (grp) lds_barrier();          // group B: [epilogue t-1, burst t] | barrier | [epilogue t, burst t+1]
-#endif
-      stamp(2);
-      // ================= epilogue (beside the SIMD partner's burst) =================
-      // requested FIRST: the next tile's descriptor and the first two K steps of the next tile (complete in the ring since the last barrier);
-      // their latency runs under the MFMA drain and the epilogue
-      {
-        Bs[0] = bs0.x; Bs[1] = bs0.y; Bs[2] = bs0.z; Bs[3] = bs0.w; Bs[4] = bs1.x; Bs[5] = bs1.y; Bs[6] = bs1.z; Bs[7] = bs1.w;
-        Bs[8] = bs2.x; Bs[9] = bs2.y; Bs[10] = bs2.z; Bs[11] = bs2.w; Bs[12] = bs3.x; Bs[13] = bs3.y; Bs[14] = bs3.z; Bs[15] = bs3.w;
-      }
-      const char* nxt = ring + ((t1 - t_begin) & 3) * W2X_TILE_BYTES;
-      const int2 dq = *reinterpret_cast<const int2*>(nxt + W2X_DESC_OFF);
-      p0 = lds_frag16(nxt, 0, lane);
-      p1 = lds_frag16(nxt, 1, lane);
-      {     // this thread's chunks of tile t+3 into the stage tile t-1 has left (nobody reads it between barriers t and t+2)
-        char* stg = ring + ((t + 3 - t_begin) & 3) * W2X_TILE_BYTES;
-#ifndef ABL_NO_RING
-        *reinterpret_cast<float4*>(stg + fo0) = st0;
-        *reinterpret_cast<float4*>(stg + fo1) = st1;
-#endif
-      }
-      // the two accumulators and the bias into one
-#ifndef ABL_NO_FOLD      // (ablation builds: timing only, wrong results)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) D0[r] = fmaf(Bs[r], bsc2, D0[r] + D1[r]);
-#else
-      D0[0] = fmaf(Bs[0], bsc2, D0[0] + D1[0]);
-#endif
-      const f32x16& D = D0;
-#ifndef ABL_NO_TP
-      tile_epilogue_s(w0, D, Fp, f0, accA, accV, accX);
-#else
-      accA[0] += D[0] * f0.x;
-#endif
-      if (w0 & 0x80) {   // 6-channel column: accumulator quad 3 holds another a / c row quad for channel pair xp
-        const f32x4 g0 = ldv4(Fr + ((w0 >> 8) & 0x3c));
+    const bool grp_s = __builtin_amdgcn_readfirstlane(grp) != 0;      // provably wave-uniform: the barrier sits behind a scalar branch
+    // the rare part of an epilogue: the packed extra quad of a 6-channel column and the flush of a column the tile closes
+    auto finish_tile = [&](int w0x, int chan0x, const f32x16& D, f32x4 f0x) {
+      if (w0x & 0x80) {   // 6-channel column: accumulator quad 3 holds another a / c row quad for channel pair xp
+        const f32x4 g0 = ldv4(Fr + ((w0x >> 8) & 0x3c));
         const float xv = fmaf(g0.x, D[12], fmaf(g0.y, D[13], fmaf(g0.z, D[14], g0.w * D[15])));
-        const int xp = (w0 >> 8) & 3;
+        const int xp = (w0x >> 8) & 3;
         if (xp == 0) accA[0] += xv; else if (xp == 1) accA[1] += xv; else accA[2] += xv;
       }
-#ifdef ABL_NO_FLUSH
-      const int fl = 0;
-#else
-      const int fl = (w0 >> 2) & 3;
-#endif
+      const int fl = (w0x >> 2) & 3;
       if (fl) {
-        const int nrq = (w0 >> 4) & 7;
+        const int nrq = (w0x >> 4) & 7;
         if (fl == FL_S && nrq == 4) {   // a full scalar column: its four channels in one pass
           float m4[4];
 #pragma unroll
           for (int rq = 0; rq < 4; ++rq) m4[rq] = osc * fmaf(accA[rq], s0, accV[rq][0]);
-          segf_add_n<DET, 4>(node_row + chan0 + hh, 2, m4, seg);
+          segf_add_n<DET, 4>(node_row + chan0x + hh, 2, m4, seg);
         }
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
           if (rq < nrq && !(fl == FL_S && nrq == 4)) {
             if (fl == FL_S) {
               float m1v[1] = {osc * fmaf(accA[rq], s0, accV[rq][0])};
-              segf_add_n<DET, 1>(node_row + chan0 + 2 * rq + hh, 1, m1v, seg);
+              segf_add_n<DET, 1>(node_row + chan0x + 2 * rq + hh, 1, m1v, seg);
             } else {
-              float* d = node_row + chan0 + 3 * (2 * rq + hh);
+              float* d = node_row + chan0x + 3 * (2 * rq + hh);
               // a (x) v  +  s0 * (sum of the "times s0" rows)  +  (sum of the cross rows) x v / sqrt2
               const float sa = accA[rq], wx = vx * inv_s2, wy = vy * inv_s2, wz = vz * inv_s2;
               const float X0 = accX[rq][0], X1 = accX[rq][1], X2 = accX[rq][2];
@@ -697,17 +614,114 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
           }
           accA[rq] = 0.0f; accV[rq][0] = 0.0f; accV[rq][1] = 0.0f; accV[rq][2] = 0.0f; accX[rq][0] = 0.0f; accX[rq][1] = 0.0f; accX[rq][2] = 0.0f;
         }
-        if ((w0 & 3) == T_RTS) {   // rows j = 2,3 of the shared tail open the next (0o) column
+        if ((w0x & 3) == T_RTS) {   // rows j = 2,3 of the shared tail open the next (0o) column
 #pragma unroll
-          for (int rq = 0; rq < 4; ++rq) accV[rq][0] = fmaf(f0.z, D[4 * rq + 2], f0.w * D[4 * rq + 3]);
+          for (int rq = 0; rq < 4; ++rq) accV[rq][0] = fmaf(f0x.z, D[4 * rq + 2], f0x.w * D[4 * rq + 3]);
         }
       }
-      w0n = __builtin_amdgcn_readfirstlane(dq.x); chan0n = __builtin_amdgcn_readfirstlane(dq.y);
-      stamp(3);
-#ifndef ABL_NO_BAR
-      if (!grp) lds_barrier();         // group A: [burst t, epilogue t] | barrier
-#endif
+    };
+    // one tile: burst + epilogue; ST = the tile's ring stage (compile time)
+#define X3_PAIR(mask) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(mask, 1, 0); }
+#define X3_BARE { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }
+#define X3_FRAG(f, off) f.h = *reinterpret_cast<const f16x8*>(ringl + (off)); f.m = *reinterpret_cast<const f16x8*>(ringl + W2X_LIMB_BYTES + (off)); f.l = *reinterpret_cast<const f16x8*>(ringl + 2 * W2X_LIMB_BYTES + (off));
+#define X3_TILE(ST)                                                                                                                          \
+    {                                                                                                                                        \
+      constexpr int SO = (ST) * W2X_TILE_BYTES, SN = (((ST) + 1) & 3) * W2X_TILE_BYTES, SW = (((ST) + 3) & 3) * W2X_TILE_BYTES;              \
+      /* the bursting wave wins issue arbitration against its SIMD partner's epilogue (round 3's static priority for the later-dispatched   \
+         half costs 7 % once the half phases are not separated by a barrier; priority during the epilogue instead: +2.5 %) */                \
+      __builtin_amdgcn_s_setprio(1);                                                                                                         \
+      stamp(0);                                                                                                                              \
+      /* ===== burst: 28 MFMAs; every other instruction rides in an MFMA shadow, pinned region by region (one K step each): the LDS reads    \
+         of the fragments one step ahead, the feature rows, this thread's two chunks of record t+3 and - in the tail - the next tile's       \
+         descriptor and first K step (complete in the ring since the last barrier) ===== */                                                  \
+      const float* Fp = Fr + (w0 >> 16);                                                                                                     \
+      f32x16 D0, D1;                                                                                                                         \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) { D0[r] = 0.0f; D1[r] = 0.0f; }                                                         \
+      __builtin_amdgcn_sched_barrier(0);                                                                                                     \
+      Frag16 p1; X3_FRAG(p1, SO + 1024)                                                                                                      \
+      const f32x4 f0 = ldv4(Fp);                                                                                                             \
+      X3_STEP(MFMA16, p0.h, p0.m, p0.l, H.hi[0], H.mid[0], H.lo[0])                                                                         \
+      X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_BARE X3_BARE                                                            \
+      __builtin_amdgcn_sched_barrier(0);                                                                                                     \
+      Frag16 q2; X3_FRAG(q2, SO + 2048)                                                                                                      \
+      const f16x4 th = *reinterpret_cast<const f16x4*>(ringt + SO + 4096);                                                                   \
+      const f16x4 tm = *reinterpret_cast<const f16x4*>(ringt + SO + W2X_LIMB_BYTES + 4096);                                                  \
+      const f16x4 tl = *reinterpret_cast<const f16x4*>(ringt + SO + 2 * W2X_LIMB_BYTES + 4096);                                              \
+      X3_STEP(MFMA16, p1.h, p1.m, p1.l, H.hi[1], H.mid[1], H.lo[1])                                                                         \
+      X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100)                                              \
+      __builtin_amdgcn_sched_barrier(0);                                                                                                     \
+      const u32x4 st0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)fo0, rec_soff, 0);                                                  \
+      const u32x4 st1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)fo1, rec_soff, 0);                                                  \
+      rec_soff += W2X_TILE_BYTES;                                                                                                            \
+      Frag16 q3; X3_FRAG(q3, SO + 3072)                                                                                                      \
+      X3_STEP(MFMA16, q2.h, q2.m, q2.l, H.hi[2], H.mid[2], H.lo[2])                                                                         \
+      X3_PAIR(0x020) X3_PAIR(0x100) X3_PAIR(0x020) X3_PAIR(0x100) X3_PAIR(0x100) X3_BARE                                                     \
+      __builtin_amdgcn_sched_barrier(0);                                                                                                     \
+      const int2 dq = *reinterpret_cast<const int2*>(ring + SN + W2X_DESC_OFF);                                                              \
+      const f16x8 n0h = *reinterpret_cast<const f16x8*>(ringl + SN), n0m = *reinterpret_cast<const f16x8*>(ringl + SN + W2X_LIMB_BYTES),      \
+                  n0l = *reinterpret_cast<const f16x8*>(ringl + SN + 2 * W2X_LIMB_BYTES);                                                    \
+      X3_STEP(MFMA16, q3.h, q3.m, q3.l, H.hi[3], H.mid[3], H.lo[3])                                                                         \
+      {     /* packed tail: D0 += hi.mid + mid.hi, D1 += lo.hi + hi.lo as one K = 16 MFMA each; mid.mid and hi.hi stay K = 8 */              \
+        const f16x8 a_hm = __builtin_shufflevector(th, tm, 0, 1, 2, 3, 4, 5, 6, 7), a_lh = __builtin_shufflevector(tl, th, 0, 1, 2, 3, 4, 5, 6, 7); \
+        D1 = MFMA16(a_lh, HT.hl, D1);                                                                                                        \
+        D0 = MFMA16(a_hm, HT.mh, D0);                                                                                                        \
+        D1 = MFMA8(tm, H.tmid, D1);                                                                                                          \
+        D0 = MFMA8(th, H.thi, D0);                                                                                                           \
+      }                                                                                                                                      \
+      X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_BARE X3_BARE X3_BARE X3_BARE X3_BARE X3_BARE                            \
+      __builtin_amdgcn_sched_barrier(0);                                                                                                     \
+      __builtin_amdgcn_s_setprio(0);                                                                                                         \
+      stamp(1);                                                                                                                              \
+      if (grp_s) lds_barrier();          /* group B: [epilogue t-1, burst t] | barrier | [epilogue t, burst t+1] */                          \
+      stamp(2);                                                                                                                              \
+      /* ===== epilogue (beside the SIMD partner's burst): the tile's bias, then this thread's chunks of tile t+3 into the stage tile t-1     \
+         has left (nobody reads it between barriers t and t+2) ===== */                                                                      \
+      const float4 bs0 = ld4(reinterpret_cast<const float*>(ringb + SO + W2X_BIAS_OFF)), bs1 = ld4(reinterpret_cast<const float*>(ringb + SO + W2X_BIAS_OFF + 16)); \
+      const float4 bs2 = ld4(reinterpret_cast<const float*>(ringb + SO + W2X_BIAS_OFF + 32)), bs3 = ld4(reinterpret_cast<const float*>(ringb + SO + W2X_BIAS_OFF + 48)); \
+      *reinterpret_cast<u32x4*>(ringw0 + SW) = st0;                                                                                          \
+      *reinterpret_cast<u32x4*>(ringw1 + SW) = st1;                                                                                          \
+      stamp_epi(4);                                                                                                                          \
+      /* the two accumulators and the bias into one */                                                                                       \
+      D0[0] = fmaf(bs0.x, bsc2, D0[0] + D1[0]); D0[1] = fmaf(bs0.y, bsc2, D0[1] + D1[1]); D0[2] = fmaf(bs0.z, bsc2, D0[2] + D1[2]); D0[3] = fmaf(bs0.w, bsc2, D0[3] + D1[3]); \
+      D0[4] = fmaf(bs1.x, bsc2, D0[4] + D1[4]); D0[5] = fmaf(bs1.y, bsc2, D0[5] + D1[5]); D0[6] = fmaf(bs1.z, bsc2, D0[6] + D1[6]); D0[7] = fmaf(bs1.w, bsc2, D0[7] + D1[7]); \
+      D0[8] = fmaf(bs2.x, bsc2, D0[8] + D1[8]); D0[9] = fmaf(bs2.y, bsc2, D0[9] + D1[9]); D0[10] = fmaf(bs2.z, bsc2, D0[10] + D1[10]); D0[11] = fmaf(bs2.w, bsc2, D0[11] + D1[11]); \
+      D0[12] = fmaf(bs3.x, bsc2, D0[12] + D1[12]); D0[13] = fmaf(bs3.y, bsc2, D0[13] + D1[13]); D0[14] = fmaf(bs3.z, bsc2, D0[14] + D1[14]); D0[15] = fmaf(bs3.w, bsc2, D0[15] + D1[15]); \
+      stamp_epi(5);                                                                                                                          \
+      if ((w0 & 0x8e) == 0) {        /* the common tile: scalar rows (T_RA / T_RT), no packed quad, no flush */                              \
+        if (w0 & 1) {                                                                                                                        \
+          _Pragma("unroll") for (int rq = 0; rq < 4; ++rq)                                                                                   \
+            accV[rq][0] = fmaf(f0.x, D0[4 * rq], fmaf(f0.y, D0[4 * rq + 1], fmaf(f0.z, D0[4 * rq + 2], fmaf(f0.w, D0[4 * rq + 3], accV[rq][0])))); \
+        } else {                                                                                                                             \
+          _Pragma("unroll") for (int rq = 0; rq < 4; ++rq)                                                                                   \
+            accA[rq] = fmaf(f0.x, D0[4 * rq], fmaf(f0.y, D0[4 * rq + 1], fmaf(f0.z, D0[4 * rq + 2], fmaf(f0.w, D0[4 * rq + 3], accA[rq])))); \
+        }                                                                                                                                    \
+        stamp_epi(6);                                                                                                                        \
+      } else {                                                                                                                               \
+        tile_epilogue_s(w0, D0, Fp, f0, accA, accV, accX);                                                                                   \
+        stamp_epi(6);                                                                                                                        \
+        finish_tile(w0, chan0, D0, f0);                                                                                                      \
+      }                                                                                                                                      \
+      p0.h = n0h; p0.m = n0m; p0.l = n0l;                                                                                                    \
+      w0 = __builtin_amdgcn_readfirstlane(dq.x); chan0 = __builtin_amdgcn_readfirstlane(dq.y);                                               \
+      stamp_epi(7);                                                                                                                          \
+      stamp(3);                                                                                                                              \
+      first_tile = false;                                                                                                                    \
+      if (!grp_s) lds_barrier();         /* group A: [burst t, epilogue t] | barrier */                                                      \
     }
+    for (int t = t_begin;;) {       // unrolled over the ring's four stages: tile t_begin + i sits in stage i & 3
+      X3_TILE(0)
+      if (++t >= t_end) break;
+      X3_TILE(1)
+      if (++t >= t_end) break;
+      X3_TILE(2)
+      if (++t >= t_end) break;
+      X3_TILE(3)
+      if (++t >= t_end) break;
+    }
+#undef X3_PAIR
+#undef X3_BARE
+#undef X3_FRAG
+#undef X3_TILE
     // hand the next unit to the workgroup.  Group A waits here through group B's last epilogue: this barrier also retires the ring
     // (nobody reads it any more) before the next unit's staging writes
     stamp_unit(0, 0);

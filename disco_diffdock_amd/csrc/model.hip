@@ -1095,7 +1095,7 @@ int ddk_profile_read_forwards(ddk_ctx* ctx, double* out, int32_t max_forwards) {
 // s_memtime stamps of its half phases to trace (DEVICE, [8][1024][8] uint32: burst start, burst end, epilogue start, epilogue end, before K steps 0 / 1 / 2 / 3); null: off
 int ddk_debug_conv_trace(ddk_ctx* ctx, int32_t layer, uint32_t* trace) {
   if (!ctx) return DDK_ERR_INVALID;
-  ctx->conv_trace = trace; ctx->conv_trace_layer = layer >= 100 ? layer - 100 : layer; ctx->conv_trace_coarse = layer >= 100;      // 100 + l: one record per unit
+  ctx->conv_trace = trace; ctx->conv_trace_layer = layer % 100; ctx->conv_trace_coarse = layer / 100;      // 100 + l: one record per unit; 200 + l: four more stamps inside every epilogue
   return DDK_OK;
 }
 

@@ -12,6 +12,7 @@ from disco_diffdock_amd.runtime import Context, Complex
 ap = argparse.ArgumentParser()
 ap.add_argument('--layer', type=int, default=3)
 ap.add_argument('--t', type=float, default=0.6)
+ap.add_argument('--epi', action='store_true', help='four more stamps inside every epilogue: LDS requests + ring stores | fold | tensor product | packed quad, flush, descriptor')
 ap.add_argument('--coarse', action='store_true', help='one record per unit (no stamps inside the tile loop): undisturbed cycles per tile')
 a = ap.parse_args()
 dev = torch.device('cuda:0')
@@ -25,7 +26,7 @@ pos = torch.from_numpy(np.stack([c['lig_pos'] + rng.normal(0, 3.0, size=(1, 3)) 
 for _ in range(3):
     cx.score_forward(pos, a.t, a.t, a.t)
 trace = torch.zeros((8, 1024, 8), dtype=torch.int32, device=dev)
-ctx._check(ctx.L.ddk_debug_conv_trace(ctx.h, a.layer + (100 if a.coarse else 0), C.c_void_p(trace.data_ptr())), 'trace')
+ctx._check(ctx.L.ddk_debug_conv_trace(ctx.h, a.layer + (100 if a.coarse else 200 if a.epi else 0), C.c_void_p(trace.data_ptr())), 'trace')
 cx.score_forward(pos, a.t, a.t, a.t)
 ctx._check(ctx.L.ddk_debug_conv_trace(ctx.h, -1, None), 'trace off')
 torch.cuda.synchronize()
@@ -42,6 +43,23 @@ if a.coarse:
               f'hand-over {d(2, 0)[full].mean():5.0f}  unit {d(2, 4)[full].mean():8.0f}  | column-split units: {int((~full).sum())}, per tile {(d(0, 7)[~full] / np.maximum(tiles[~full], 1)).mean() if (~full).any() else 0:6.0f}')
     sys.exit(0)
 n = int((tr[0, :, 3] != 0).sum())
+if a.epi:
+    print(f'layer {a.layer}: epilogue sub-phases (ticks incl. ~100 per stamp), tiles that are not the first of a unit; by tile class')
+    for w in (0, 4):
+        x = tr[w, :n]
+        ok = x[:, 4] != 0
+        ok[np.nonzero(x[:, 4] != 0)[0]] = True
+        # a unit's first tile carries the prologue stamps in slots 4-7: recognise it by slot 7 < slot 0 (prologue precedes the burst)
+        notfirst = (x[:, 4] > x[:, 2]) & (x[:, 7] > x[:, 4])
+        if not notfirst.any():
+            print('no sub-stamps found; first records:'); print(x[:6])
+        y = x[notfirst]
+        ep = y[:, 3] - y[:, 2]
+        parts = np.stack([y[:, 4] - y[:, 2], y[:, 5] - y[:, 4], y[:, 6] - y[:, 5], y[:, 7] - y[:, 6], y[:, 3] - y[:, 7]], 1)
+        for name, m in (('ordinary (epilogue < 1400)', ep < 1400), ('long (>= 1400: flush / vector tiles)', ep >= 1400)):
+            if m.any():
+                print(f'wave {w} {name}: {int(m.sum())} tiles, epilogue {ep[m].mean():.0f} = requests+stores {parts[m, 0].mean():.0f} | fold {parts[m, 1].mean():.0f} | tensor product {parts[m, 2].mean():.0f} | quad+flush+descriptor {parts[m, 3].mean():.0f} | close {parts[m, 4].mean():.0f};  burst {(y[m, 1] - y[m, 0]).mean():.0f}')
+    sys.exit(0)
 print(f'layer {a.layer}: {n} tiles recorded by workgroup 0 (ticks = shader cycles)')
 for w in range(8):
     x = tr[w, :n]

@@ -173,6 +173,7 @@ __device__ __forceinline__ void segf_add_n(float* dst, int stride, float (&xv)[N
 
 // scalar-accumulator tensor-product epilogue of one W2 tile (wave-uniform branch on the tile kind; the f16 pipe does not compete with the VALU
 // for issue: fewer registers beat fewer instructions here).  T_RTS: only rows j = 0,1 belong to the column that is about to be flushed.
+constexpr int TVQ = 3;      // a vector column has nv = 6 channels = three accumulator quads (quad 3: nothing, or the packed extra unit)
 __device__ __forceinline__ void tile_epilogue_s(int w0, const f32x16& D, const float* Fp, f32x4 f0, float (&accA)[4], float (&accV)[4][3],
                                                 float (&accX)[4][3]) {
   const int kind = w0 & 3;
@@ -182,7 +183,7 @@ __device__ __forceinline__ void tile_epilogue_s(int w0, const f32x16& D, const f
     const f32x4 f1 = ldv4(Fp + 4), f2 = ldv4(Fp + 8);      // y / z components of the 4 feature rows
     if (w0 & 0x4000) {
 #pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
+      for (int rq = 0; rq < TVQ; ++rq) {
         const float d0 = D[4 * rq], d1 = D[4 * rq + 1];
         accX[rq][0] = fmaf(f0.x, d0, fmaf(f0.y, d1, accX[rq][0]));
         accX[rq][1] = fmaf(f1.x, d0, fmaf(f1.y, d1, accX[rq][1]));
@@ -190,7 +191,7 @@ __device__ __forceinline__ void tile_epilogue_s(int w0, const f32x16& D, const f
       }
     } else {
 #pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
+      for (int rq = 0; rq < TVQ; ++rq) {
         const float d0 = D[4 * rq], d1 = D[4 * rq + 1];
         accV[rq][0] = fmaf(f0.x, d0, fmaf(f0.y, d1, accV[rq][0]));
         accV[rq][1] = fmaf(f1.x, d0, fmaf(f1.y, d1, accV[rq][1]));
@@ -199,7 +200,7 @@ __device__ __forceinline__ void tile_epilogue_s(int w0, const f32x16& D, const f
     }
     if (w0 & 0x8000) {
 #pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
+      for (int rq = 0; rq < TVQ; ++rq) {
         const float d2 = D[4 * rq + 2], d3 = D[4 * rq + 3];
         accX[rq][0] = fmaf(f0.z, d2, fmaf(f0.w, d3, accX[rq][0]));
         accX[rq][1] = fmaf(f1.z, d2, fmaf(f1.w, d3, accX[rq][1]));
@@ -207,7 +208,7 @@ __device__ __forceinline__ void tile_epilogue_s(int w0, const f32x16& D, const f
       }
     } else {
 #pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
+      for (int rq = 0; rq < TVQ; ++rq) {
         const float d2 = D[4 * rq + 2], d3 = D[4 * rq + 3];
         accV[rq][0] = fmaf(f0.z, d2, fmaf(f0.w, d3, accV[rq][0]));
         accV[rq][1] = fmaf(f1.z, d2, fmaf(f1.w, d3, accV[rq][1]));

@@ -126,10 +126,16 @@ def pmc_traffic():
         return None, f'profiles/{name}: {e}'
 
 
-def start_poses(c, rng, samples, ctx, dev, tr_sigma_max=19.0):
+def start_poses(c, rng, samples, ctx=None, dev=None, tr_sigma_max=19.0):
     """randomize_position (reference utils/sampling.py:12-34) on the device (ddk_randomize_position): uniform(-pi, pi) torsion angles on every
-    rotatable bond (:16-22), a random rotation about the centroid and a N(0, tr_sigma_max) translation (:24-34) per sample."""
+    rotatable bond (:16-22), a random rotation about the centroid and a N(0, tr_sigma_max) translation (:24-34) per sample.
+    ctx = None (the CPU-oracle sample, development tools): host arithmetic, rigid part only."""
     from scipy.spatial.transform import Rotation
+    if ctx is None:
+        lp = c['lig_pos'].astype(np.float64)
+        ctr = lp.mean(0, keepdims=True)
+        return np.stack([(lp - ctr) @ Rotation.random(random_state=rng).as_matrix().T + rng.normal(0, tr_sigma_max, size=(1, 3))
+                         for _ in range(samples)]).astype(np.float32)
     from disco_diffdock_amd.runtime import Complex
     cx = Complex(ctx, {k: v for k, v in c.items() if not k.startswith('atom_')}, samples)
     rot = np.stack([Rotation.random(random_state=rng).as_matrix() for _ in range(samples)]).astype(np.float32)

@@ -174,6 +174,22 @@ __device__ __forceinline__ void segf_add_n(float* dst, int stride, float (&xv)[N
 // scalar-accumulator tensor-product epilogue of one W2 tile (wave-uniform branch on the tile kind; the f16 pipe does not compete with the VALU
 // for issue: fewer registers beat fewer instructions here).  T_RTS: only rows j = 0,1 belong to the column that is about to be flushed.
 constexpr int TVQ = 3;      // a vector column has nv = 6 channels = three accumulator quads (quad 3: nothing, or the packed extra unit)
+// the tensor product of a vector tile: rows 0,1 / rows 2,3 into the "times s0" set accV or the "cross v" set accX (X01 / X23)
+template <bool X01, bool X23>
+__device__ __forceinline__ void tv_rows(const f32x16& D, f32x4 f0, f32x4 f1, f32x4 f2, float (&accV)[4][3], float (&accX)[4][3]) {
+#pragma unroll
+  for (int rq = 0; rq < TVQ; ++rq) {
+    const float d0 = D[4 * rq], d1 = D[4 * rq + 1], d2 = D[4 * rq + 2], d3 = D[4 * rq + 3];
+    float (&a01)[3] = X01 ? accX[rq] : accV[rq];
+    a01[0] = fmaf(f0.x, d0, fmaf(f0.y, d1, a01[0]));
+    a01[1] = fmaf(f1.x, d0, fmaf(f1.y, d1, a01[1]));
+    a01[2] = fmaf(f2.x, d0, fmaf(f2.y, d1, a01[2]));
+    float (&a23)[3] = X23 ? accX[rq] : accV[rq];
+    a23[0] = fmaf(f0.z, d2, fmaf(f0.w, d3, a23[0]));
+    a23[1] = fmaf(f1.z, d2, fmaf(f1.w, d3, a23[1]));
+    a23[2] = fmaf(f2.z, d2, fmaf(f2.w, d3, a23[2]));
+  }
+}
 __device__ __forceinline__ void tile_epilogue_s(int w0, const f32x16& D, const float* Fp, f32x4 f0, float (&accA)[4], float (&accV)[4][3],
                                                 float (&accX)[4][3]) {
   const int kind = w0 & 3;
@@ -181,39 +197,13 @@ __device__ __forceinline__ void tile_epilogue_s(int w0, const f32x16& D, const f
     // raw p / q rows: rows whose product is "times s0" accumulate into accV, rows that are crossed with v into accX (bits 14 / 15 of the tile
     // word: rows j = 0,1 / j = 2,3 are cross rows); both factors are applied when the column is flushed
     const f32x4 f1 = ldv4(Fp + 4), f2 = ldv4(Fp + 8);      // y / z components of the 4 feature rows
-    if (w0 & 0x4000) {
-#pragma unroll
-      for (int rq = 0; rq < TVQ; ++rq) {
-        const float d0 = D[4 * rq], d1 = D[4 * rq + 1];
-        accX[rq][0] = fmaf(f0.x, d0, fmaf(f0.y, d1, accX[rq][0]));
-        accX[rq][1] = fmaf(f1.x, d0, fmaf(f1.y, d1, accX[rq][1]));
-        accX[rq][2] = fmaf(f2.x, d0, fmaf(f2.y, d1, accX[rq][2]));
-      }
-    } else {
-#pragma unroll
-      for (int rq = 0; rq < TVQ; ++rq) {
-        const float d0 = D[4 * rq], d1 = D[4 * rq + 1];
-        accV[rq][0] = fmaf(f0.x, d0, fmaf(f0.y, d1, accV[rq][0]));
-        accV[rq][1] = fmaf(f1.x, d0, fmaf(f1.y, d1, accV[rq][1]));
-        accV[rq][2] = fmaf(f2.x, d0, fmaf(f2.y, d1, accV[rq][2]));
-      }
-    }
-    if (w0 & 0x8000) {
-#pragma unroll
-      for (int rq = 0; rq < TVQ; ++rq) {
-        const float d2 = D[4 * rq + 2], d3 = D[4 * rq + 3];
-        accX[rq][0] = fmaf(f0.z, d2, fmaf(f0.w, d3, accX[rq][0]));
-        accX[rq][1] = fmaf(f1.z, d2, fmaf(f1.w, d3, accX[rq][1]));
-        accX[rq][2] = fmaf(f2.z, d2, fmaf(f2.w, d3, accX[rq][2]));
-      }
-    } else {
-#pragma unroll
-      for (int rq = 0; rq < TVQ; ++rq) {
-        const float d2 = D[4 * rq + 2], d3 = D[4 * rq + 3];
-        accV[rq][0] = fmaf(f0.z, d2, fmaf(f0.w, d3, accV[rq][0]));
-        accV[rq][1] = fmaf(f1.z, d2, fmaf(f1.w, d3, accV[rq][1]));
-        accV[rq][2] = fmaf(f2.z, d2, fmaf(f2.w, d3, accV[rq][2]));
-      }
+    // one specialised body per (rows 0,1 cross?, rows 2,3 cross?) combination: with a run-time choice of the accumulator set inside ONE body the
+    // compiler computes into temporaries and picks the set with 48 v_cndmask per tile
+    switch ((w0 >> 14) & 3) {
+      case 0: tv_rows<false, false>(D, f0, f1, f2, accV, accX); break;
+      case 1: tv_rows<true, false>(D, f0, f1, f2, accV, accX); break;
+      case 2: tv_rows<false, true>(D, f0, f1, f2, accV, accX); break;
+      default: tv_rows<true, true>(D, f0, f1, f2, accV, accX); break;
     }
   } else if (kind == T_RA) {
 #pragma unroll
@@ -641,8 +631,12 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
       __builtin_amdgcn_sched_barrier(0);                                                                                                     \
       Frag16 p1; X3_FRAG(p1, SO + 1024)                                                                                                      \
       const f32x4 f0 = ldv4(Fp);                                                                                                             \
+      /* this thread's two chunks of record t+3, requested first: ~900 cycles until the epilogue stores them */                              \
+      const u32x4 st0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)fo0, rec_soff, 0);                                                  \
+      const u32x4 st1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)fo1, rec_soff, 0);                                                  \
+      rec_soff += W2X_TILE_BYTES;                                                                                                            \
       X3_STEP(MFMA16, p0.h, p0.m, p0.l, H.hi[0], H.mid[0], H.lo[0])                                                                         \
-      X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_BARE X3_BARE                                                            \
+      X3_PAIR(0x100) X3_PAIR(0x020) X3_PAIR(0x100) X3_PAIR(0x020) X3_PAIR(0x100) X3_PAIR(0x100)                                              \
       __builtin_amdgcn_sched_barrier(0);                                                                                                     \
       Frag16 q2; X3_FRAG(q2, SO + 2048)                                                                                                      \
       const f16x4 th = *reinterpret_cast<const f16x4*>(ringt + SO + 4096);                                                                   \
@@ -651,17 +645,16 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
       X3_STEP(MFMA16, p1.h, p1.m, p1.l, H.hi[1], H.mid[1], H.lo[1])                                                                         \
       X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100)                                              \
       __builtin_amdgcn_sched_barrier(0);                                                                                                     \
-      const u32x4 st0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)fo0, rec_soff, 0);                                                  \
-      const u32x4 st1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)fo1, rec_soff, 0);                                                  \
-      rec_soff += W2X_TILE_BYTES;                                                                                                            \
       Frag16 q3; X3_FRAG(q3, SO + 3072)                                                                                                      \
       X3_STEP(MFMA16, q2.h, q2.m, q2.l, H.hi[2], H.mid[2], H.lo[2])                                                                         \
-      X3_PAIR(0x020) X3_PAIR(0x100) X3_PAIR(0x020) X3_PAIR(0x100) X3_PAIR(0x100) X3_BARE                                                     \
+      X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_BARE X3_BARE X3_BARE                                                                   \
       __builtin_amdgcn_sched_barrier(0);                                                                                                     \
       const int2 dq = *reinterpret_cast<const int2*>(ring + SN + W2X_DESC_OFF);                                                              \
       const f16x8 n0h = *reinterpret_cast<const f16x8*>(ringl + SN), n0m = *reinterpret_cast<const f16x8*>(ringl + SN + W2X_LIMB_BYTES),      \
                   n0l = *reinterpret_cast<const f16x8*>(ringl + SN + 2 * W2X_LIMB_BYTES);                                                    \
       X3_STEP(MFMA16, q3.h, q3.m, q3.l, H.hi[3], H.mid[3], H.lo[3])                                                                         \
+      X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_BARE X3_BARE                                                            \
+      __builtin_amdgcn_sched_barrier(0);                                                                         \
       {     /* packed tail: D0 += hi.mid + mid.hi, D1 += lo.hi + hi.lo as one K = 16 MFMA each; mid.mid and hi.hi stay K = 8 */              \
         const f16x8 a_hm = __builtin_shufflevector(th, tm, 0, 1, 2, 3, 4, 5, 6, 7), a_lh = __builtin_shufflevector(tl, th, 0, 1, 2, 3, 4, 5, 6, 7); \
         D1 = MFMA16(a_lh, HT.hl, D1);                                                                                                        \
@@ -669,7 +662,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
         D1 = MFMA8(tm, H.tmid, D1);                                                                                                          \
         D0 = MFMA8(th, H.thi, D0);                                                                                                           \
       }                                                                                                                                      \
-      X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_BARE X3_BARE X3_BARE X3_BARE X3_BARE X3_BARE                            \
+      X3_BARE X3_BARE X3_BARE X3_BARE                                                                                                        \
       __builtin_amdgcn_sched_barrier(0);                                                                                                     \
       __builtin_amdgcn_s_setprio(0);                                                                                                         \
       stamp(1);                                                                                                                              \

@@ -650,8 +650,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
       X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_BARE X3_BARE X3_BARE                                                                   \
       __builtin_amdgcn_sched_barrier(0);                                                                                                     \
       const int2 dq = *reinterpret_cast<const int2*>(ring + SN + W2X_DESC_OFF);                                                              \
-      const f16x8 n0h = *reinterpret_cast<const f16x8*>(ringl + SN), n0m = *reinterpret_cast<const f16x8*>(ringl + SN + W2X_LIMB_BYTES),      \
-                  n0l = *reinterpret_cast<const f16x8*>(ringl + SN + 2 * W2X_LIMB_BYTES);                                                    \
+      X3_FRAG(p0, SN)       /* (p0's last use was K step 0 of this burst: the next tile's first K step goes straight into its registers) */    \
       X3_STEP(MFMA16, q3.h, q3.m, q3.l, H.hi[3], H.mid[3], H.lo[3])                                                                         \
       X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_BARE X3_BARE                                                            \
       __builtin_amdgcn_sched_barrier(0);                                                                         \
@@ -695,7 +694,6 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
         stamp_epi(6);                                                                                                                        \
         finish_tile(w0, chan0, D0, f0);                                                                                                      \
       }                                                                                                                                      \
-      p0.h = n0h; p0.m = n0m; p0.l = n0l;                                                                                                    \
       w0 = __builtin_amdgcn_readfirstlane(dq.x); chan0 = __builtin_amdgcn_readfirstlane(dq.y);                                               \
       stamp_epi(7);                                                                                                                          \
       stamp(3);                                                                                                                              \

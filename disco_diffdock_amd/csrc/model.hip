@@ -1100,6 +1100,12 @@ int ddk_debug_conv_trace(ddk_ctx* ctx, int32_t layer, uint32_t* trace) {
 }
 
 // Test hook: layer-0 de-duplication of the rec-rec messages on / off (on by default; off = every sample evaluates all its rec-rec messages)
+int ddk_debug_set_conv_workgroups(ddk_ctx* ctx, int32_t n) {
+  if (!ctx || n < 1 || n > 1024) return DDK_ERR_INVALID;
+  ctx->n_cu = n;      // persistent workgroups of a conv launch (default: one per CU); two contexts with half the CUs each can run side by side
+  return DDK_OK;
+}
+
 int ddk_debug_pool_stats(ddk_ctx* ctx, int64_t* out) {
   if (!ctx || !out) return DDK_ERR_INVALID;
   out[0] = ctx->pool_mallocs; out[1] = ctx->pool_reuses; out[2] = ctx->pool_frees; out[3] = (int64_t)ctx->chunk_pool_bytes;

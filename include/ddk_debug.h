@@ -37,6 +37,9 @@ int ddk_debug_set_layer0_dedup(ddk_ctx* ctx, int32_t on);
  * otherwise hipMalloc): out[8] = hipMalloc calls, reuses, hipFree calls, bytes parked in the pool, chunks parked, bytes owned by live
  * complexes, the peak of that, 0. */
 int ddk_debug_pool_stats(ddk_ctx* ctx, int64_t* out);
+
+/* Persistent workgroups of this context's conv launches (default: one per CU).  Experiments with two contexts / streams side by side. */
+int ddk_debug_set_conv_workgroups(ddk_ctx* ctx, int32_t n);
 /* The patch group of the last forward of a latent-conditioned model: counts[B + 1] = exclusive prefix of the patch edges per sample
  * (counts[B] = total), mask[B * n_rec] = 1 for receivers whose rec-rec sum comes from the patch group.  HOST pointers; synchronises. */
 int ddk_debug_read_patch(ddk_ctx* ctx, ddk_complex* cx, int32_t B, int32_t* counts, uint8_t* mask);

@@ -526,6 +526,49 @@ static int build_conv_layer(ddk_ctx* ctx, int mode, int l, ConvLayerDev& L) {
     L.h_b2p[g].assign(b2all.begin() + g * b2sz, b2all.begin() + (g + 1) * b2sz);
   }
   if (mode == 0 && c.conv_kernel == 0 && (rc = pack_x3(ctx, L, NG, w1all, w2all, b2all))) return rc;
+  if (mode == 1 && c.conv_kernel == 0) {
+    // The three-limb kernel keeps the raw p / q rows once ([p0..p5 | q0..q5], quads of four): the l = 2 group of the q rows (T2E), whose two
+    // tiles are [q0 q1 q2 q3], [q4 q5 . .] in the table, reads raw quads 1 and 2 = [. . q0 q1], [q2 q3 q4 q5]: move its weight rows accordingly
+    // (accumulator quads 0..2 only: quad 3 of a 6-channel column is empty or carries a packed extra unit).  x_tile_word() gives the tiles their offsets.
+    std::vector<int> rmx = rowmap;
+    std::vector<float> rsx = rowscale;
+    for (int t = 0; t + 1 < L.n_tiles; ++t) {
+      if ((tiles[t].w0 & 3) != T_TV || (tiles[t].w0 >> 16) != F_T2E) continue;
+      if ((tiles[t + 1].w0 & 3) != T_TV || (tiles[t + 1].w0 >> 16) != F_T2E + 12) return fail(ctx, DDK_ERR_INVALID, "internal: the two tiles of a T2E row group are not adjacent");
+      for (int rq = 0; rq < 3; ++rq)
+        for (int hh = 0; hh < 2; ++hh) {
+          const size_t a = (size_t)t * 32 + 8 * rq + 4 * hh, b = (size_t)(t + 1) * 32 + 8 * rq + 4 * hh;
+          if (rowmap[b + 2] >= 0 || rowmap[b + 3] >= 0) return fail(ctx, DDK_ERR_INVALID, "internal: a T2E row group holds more than six rows");
+          for (int j = 0; j < 2; ++j) {
+            rmx[a + j] = -1; rsx[a + j] = 0.f;
+            rmx[a + 2 + j] = rowmap[a + j]; rsx[a + 2 + j] = rowscale[a + j];
+            rmx[b + j] = rowmap[a + 2 + j]; rsx[b + j] = rowscale[a + 2 + j];
+            rmx[b + 2 + j] = rowmap[b + j]; rsx[b + 2 + j] = rowscale[b + j];
+          }
+        }
+    }
+    std::vector<float> w2x_all(NG * w2sz, 0.f), b2x_all(NG * b2sz, 0.f);
+    for (int g = 0; g < NG; ++g) {
+      const HostTensor* W2 = find_w(ctx, fc_name(g) + lin2 + ".weight", {L.W, ne});
+      const HostTensor* B2 = find_w(ctx, fc_name(g) + lin2 + ".bias", {L.W});
+      if (!W2 || !B2) return DDK_ERR_INVALID;
+      float* w2 = w2x_all.data() + g * w2sz;
+      float* b2 = b2x_all.data() + g * b2sz;
+      for (int t = 0; t < L.n_tiles; ++t) {
+        for (int s_ = 0; s_ < 36; ++s_)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int row = rmx[(size_t)t * 32 + (lane & 31)], hh = lane >> 5;
+            w2[(((size_t)t * 9 + s_ / 4) * 64 + lane) * 4 + (s_ & 3)] = row >= 0 ? W2->data[(size_t)row * ne + hid_of(s_, hh)] * rsx[(size_t)t * 32 + (lane & 31)] : 0.f;
+          }
+        for (int hh = 0; hh < 2; ++hh)
+          for (int r = 0; r < 16; ++r) {
+            const int row = rmx[(size_t)t * 32 + d_row(r, hh)];
+            b2[((size_t)t * 2 + hh) * 16 + r] = row >= 0 ? B2->data[row] * rsx[(size_t)t * 32 + d_row(r, hh)] : 0.f;
+          }
+      }
+    }
+    if ((rc = pack_x3(ctx, L, NG, w1all, w2x_all, b2x_all))) return rc;
+  }
   if (!ctx->host_only) {
     std::vector<float> w2rec((size_t)NG * L.n_tiles * W2_TILE_FLOATS);
     for (int g = 0; g < NG; ++g)

@@ -102,12 +102,22 @@ static inline TileDesc make_tile(int kind, int f_off, int flush, int nrq, int ch
 
 // Descriptor word of a tile for the three-limb kernel: the tile table is written for the F row of k_conv.hip; this moves the feature offset to
 // the kernel's own row (FX_*) and tells a vector tile which of its rows are "times s0" rows and which are crossed with v (bit 14: rows j = 0,1
-// are cross rows, bit 15: rows j = 2,3; T1O = [p s0 (nv) ; q x v (nv)], T1E = [p x v (nv) ; q s0 (nv)]).  -1: not representable.
+// are cross rows, bit 15: rows j = 2,3; T1O = [p s0 (nv) ; q x v (nv)], T1E = [p x v (nv) ; q s0 (nv)]).  The confidence model's l = 2 row groups
+// (T2O: six p rows, T2E: six q rows, contracted with v^ v^T - |v^|^2 I/3) read the same raw rows and accumulate into a third set (bit 24): T2O quad q
+// = raw quad q (rows 2,3 of its second quad are q0, q1: zero weights), T2E's two tiles = raw quads 1 and 2, i.e. [. . q0 q1] and [q2 q3 q4 q5] -
+// pack_x3 moves the weight rows accordingly.  -1: not representable.
+constexpr int32_t X_TILE_L2 = 1 << 24;
 static inline int32_t x_tile_word(int32_t w0) {
   const int kind = w0 & 3, f_off = w0 >> 16;
   int nf = f_off;
   if (kind == T_RT || kind == T_RTS) nf = FX_PQ + (f_off - F_PQ);
-  else if (kind == T_TV) {
+  else if (kind == T_TV && f_off >= F_T2O) {
+    const bool odd = f_off < F_T2E;
+    const int rel = f_off - (odd ? F_T2O : F_T2E), q = rel / 12;
+    if (f_off >= F_STRIDE2 || rel % 12 || q > 1 || (w0 & 0xc000)) return -1;
+    nf = FX_R + 12 * (odd ? q : q + 1);
+    return (w0 & 0xffff) | (nf << 16) | X_TILE_L2;
+  } else if (kind == T_TV) {
     const bool odd = f_off < F_T1E;
     const int rel = f_off - (odd ? F_T1O : F_T1E), q = rel / 12;
     if (f_off < F_T1O || f_off >= F_PQ || rel % 12 || (w0 & 0xc000)) return -1;
@@ -130,7 +140,7 @@ struct ConvLayerDev {          // device copies for one TensorProductConvLayer w
   float* w2r[4] = {};          // [n_tiles][W2_TILE_FLOATS]: per tile the fragments [9][64][4], the bias [2][16], the TileDesc words
   uint8_t* w1x = nullptr;      // three-limb f16 kernel: [groups][3][W1X_TILE_BYTES]
   uint8_t* w2x = nullptr;      // three-limb f16 kernel: [groups][n_tiles][W2X_TILE_BYTES]
-  float w1s[4] = {1, 1, 1, 1}, w2s[4] = {1, 1, 1, 1};   // three-limb f16 kernel: power-of-two range scale of the packed W1 / (W2, b2) of each group
+  float w1s[CONV_MAX_GROUPS] = {1, 1, 1, 1, 1, 1, 1, 1, 1}, w2s[CONV_MAX_GROUPS] = {1, 1, 1, 1, 1, 1, 1, 1, 1};   // three-limb f16 kernel: power-of-two range scale of the packed W1 / W2 of each weight set
   int n_cols = 0;              // flush columns (8 output channels each); col_start[c] = first tile of column c, col_start[n_cols] = n_tiles
   int col_start[17] = {};
   // GEMM1 split: W1 [edge_emb | x_src[:ns] | x_dst[:ns]] = W1a edge_emb + (W1b x[src][:ns] + b1) + W1c x[dst][:ns]; the

@@ -666,7 +666,9 @@ void conv_det_fix(const ConvKArgs& k, const ConvLaunch& a, int dout, hipStream_t
 }
 
 hipError_t launch_conv_fused(const ConvLayerDev& L, const ConvLaunch& a, int n_cu, hipStream_t s) {
-  if (L.w2x != nullptr && a.mode == 0) return launch_conv_fused_x(L, a, n_cu, s);   // the default: exact three-limb product on the f16 matrix pipe
+  // the default: exact three-limb product on the f16 matrix pipe (the confidence model's layers: the gather path of its forward; ddk_conv_forward's
+  // explicit-boundary entry stays on the fp32 kernel for them)
+  if (L.w2x != nullptr && (a.mode == 0 || (a.mode == 1 && a.pre == nullptr))) return launch_conv_fused_x(L, a, n_cu, s);
   ConvKArgs k;
   k.w1x = nullptr; k.w2x = nullptr;
   for (int g = 0; g < 4; ++g) { k.w1s[g] = 1.0f; k.w1u[g] = 1.0f; k.w2s[g] = 1.0f; k.w2u[g] = 1.0f; }

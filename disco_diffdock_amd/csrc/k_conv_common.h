@@ -20,7 +20,7 @@ struct ConvKArgs {
   const float* w2r;   // [4][n_tiles][W2_TILE_FLOATS]
   const uint8_t* w1x;    // three-limb f16 kernel: [groups][3][W1X_TILE_BYTES] GEMM1 fragments
   const uint8_t* w2x;    // three-limb f16 kernel: [groups][n_tiles][W2X_TILE_BYTES] tile records
-  float w1s[4], w1u[4], w2s[4], w2u[4];   // three-limb f16 kernel: weight range scales of GEMM1 / GEMM2 and their inverses
+  float w1s[CONV_MAX_GROUPS], w1u[CONV_MAX_GROUPS], w2s[CONV_MAX_GROUPS], w2u[CONV_MAX_GROUPS];   // three-limb f16 kernel: weight range scales of GEMM1 / GEMM2 per weight set and their inverses
   int n_tiles;
   int n_cols;         // flush columns; col_start[c] .. col_start[c+1] = tiles of column c
   int col_start[17];

@@ -190,10 +190,24 @@ __device__ __forceinline__ void tv_rows(const f32x16& D, f32x4 f0, f32x4 f1, f32
     a23[2] = fmaf(f2.z, d2, fmaf(f2.w, d3, a23[2]));
   }
 }
+// ... all four rows into the l = 2 set accY (confidence model: the six p or six q rows contracted with v^ v^T - |v^|^2 I/3 when the column is flushed)
+__device__ __forceinline__ void tv_rows_l2(const f32x16& D, f32x4 f0, f32x4 f1, f32x4 f2, float (&accY)[3][3]) {
+#pragma unroll
+  for (int rq = 0; rq < TVQ; ++rq) {
+    const float d0 = D[4 * rq], d1 = D[4 * rq + 1], d2 = D[4 * rq + 2], d3 = D[4 * rq + 3];
+    accY[rq][0] = fmaf(f0.x, d0, fmaf(f0.y, d1, fmaf(f0.z, d2, fmaf(f0.w, d3, accY[rq][0]))));
+    accY[rq][1] = fmaf(f1.x, d0, fmaf(f1.y, d1, fmaf(f1.z, d2, fmaf(f1.w, d3, accY[rq][1]))));
+    accY[rq][2] = fmaf(f2.x, d0, fmaf(f2.y, d1, fmaf(f2.z, d2, fmaf(f2.w, d3, accY[rq][2]))));
+  }
+}
+template <int MODE>
 __device__ __forceinline__ void tile_epilogue_s(int w0, const f32x16& D, const float* Fp, f32x4 f0, float (&accA)[4], float (&accV)[4][3],
-                                                float (&accX)[4][3]) {
+                                                float (&accX)[4][3], float (&accY)[3][3]) {
   const int kind = w0 & 3;
-  if (kind == T_TV) {
+  if (MODE == 1 && kind == T_TV && (w0 & X_TILE_L2)) {
+    const f32x4 f1 = ldv4(Fp + 4), f2 = ldv4(Fp + 8);
+    tv_rows_l2(D, f0, f1, f2, accY);
+  } else if (kind == T_TV) {
     // raw p / q rows: rows whose product is "times s0" accumulate into accV, rows that are crossed with v into accX (bits 14 / 15 of the tile
     // word: rows j = 0,1 / j = 2,3 are cross rows); both factors are applied when the column is flushed
     const f32x4 f1 = ldv4(Fp + 4), f2 = ldv4(Fp + 8);      // y / z components of the 4 feature rows
@@ -222,9 +236,11 @@ __device__ __forceinline__ void tile_epilogue_s(int w0, const f32x16& D, const f
 // TRACE: workgroup 0 stamps s_memtime at the four edges of every tile's two half phases (slots 0-3) and, in the first tile's record of a unit, at
 // four points of the unit's prologue (slots 4-7: unit start, indices + ring staging done, GEMM1 done, limbs + F rows done); ddk_debug_conv_trace,
 // tools/conv_trace.py.  Every stamp costs the wave ~100 cycles (s_memtime round trip): read the spans as upper bounds.
-template <bool GATHER, bool SPLIT, bool DET, bool TRACE = false>
+// MODE 1: the confidence model's l <= 2 tensor product (a third accumulator set for the 1o(x)2e / 1e(x)2e row groups, nine edge groups, three accumulator slots)
+template <bool GATHER, bool SPLIT, bool DET, bool TRACE = false, int MODE = 0>
 __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) {
   static_assert(!SPLIT || GATHER, "the GEMM1 split exists for the gather path");
+  static_assert(MODE == 0 || (!SPLIT && !DET && !TRACE), "the confidence model runs the plain paths");
   int trace_n = 0;
   auto stamp = [&](int phase) {
     if constexpr (TRACE) {
@@ -545,9 +561,11 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
       }
     }
     float accA[4], accV[4][3], accX[4][3];      // accX: sums over the rows that are crossed with v (vector columns)
+    float accY[3][3];                           // MODE 1: sums over the rows of the l = 2 groups
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) {
       accA[rq] = 0.0f; accV[rq][0] = 0.0f; accV[rq][1] = 0.0f; accV[rq][2] = 0.0f; accX[rq][0] = 0.0f; accX[rq][1] = 0.0f; accX[rq][2] = 0.0f;
+      if (rq < 3) { accY[rq][0] = 0.0f; accY[rq][1] = 0.0f; accY[rq][2] = 0.0f; }
     }
     // ---- per-lane ring addresses: with the tile loop unrolled over the four ring stages every ring access is ONE base register + an immediate
     // (the ring spans 4 x 13,968 B < 2^16: the 16-bit ds offset reaches all of it), and the records of tile t+3 come through a buffer
@@ -600,10 +618,17 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
               float m3[3] = {osc * fmaf(X1, wz, fmaf(-X2, wy, fmaf(sa, vx, s0 * accV[rq][0]))),
                              osc * fmaf(X2, wx, fmaf(-X0, wz, fmaf(sa, vy, s0 * accV[rq][1]))),
                              osc * fmaf(X0, wy, fmaf(-X1, wx, fmaf(sa, vz, s0 * accV[rq][2])))};
+              if constexpr (MODE == 1) {
+                // + (v^ v^T - |v^|^2 I/3) y with v = sqrt3 v^: (y.v / 3) v - (|v|^2 / 9) y  (|v^| is 1, or 0 for a zero-length edge); constants folded into the weights
+                const float Y0 = accY[rq < 3 ? rq : 0][0], Y1 = accY[rq < 3 ? rq : 0][1], Y2 = accY[rq < 3 ? rq : 0][2];
+                const float dv = (Y0 * vx + Y1 * vy + Y2 * vz) * (1.0f / 3.0f), n3 = (vx * vx + vy * vy + vz * vz) * (1.0f / 9.0f);
+                m3[0] += osc * (dv * vx - Y0 * n3); m3[1] += osc * (dv * vy - Y1 * n3); m3[2] += osc * (dv * vz - Y2 * n3);
+              }
               segf_add_n<DET, 3>(d, 1, m3, seg);
             }
           }
           accA[rq] = 0.0f; accV[rq][0] = 0.0f; accV[rq][1] = 0.0f; accV[rq][2] = 0.0f; accX[rq][0] = 0.0f; accX[rq][1] = 0.0f; accX[rq][2] = 0.0f;
+          if (MODE == 1 && rq < 3) { accY[rq][0] = 0.0f; accY[rq][1] = 0.0f; accY[rq][2] = 0.0f; }
         }
         if ((w0x & 3) == T_RTS) {   // rows j = 2,3 of the shared tail open the next (0o) column
 #pragma unroll
@@ -625,7 +650,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
       /* ===== burst: 28 MFMAs; every other instruction rides in an MFMA shadow, pinned region by region (one K step each): the LDS reads    \
          of the fragments one step ahead, the feature rows, this thread's two chunks of record t+3 and - in the tail - the next tile's       \
          descriptor and first K step (complete in the ring since the last barrier) ===== */                                                  \
-      const float* Fp = Fr + (w0 >> 16);                                                                                                     \
+      const float* Fp = Fr + ((w0 >> 16) & 0xff);                                                                                            \
       f32x16 D0, D1;                                                                                                                         \
       _Pragma("unroll") for (int r = 0; r < 16; ++r) { D0[r] = 0.0f; D1[r] = 0.0f; }                                                         \
       __builtin_amdgcn_sched_barrier(0);                                                                                                     \
@@ -690,7 +715,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
         }                                                                                                                                    \
         stamp_epi(6);                                                                                                                        \
       } else {                                                                                                                               \
-        tile_epilogue_s(w0, D0, Fp, f0, accA, accV, accX);                                                                                   \
+        tile_epilogue_s<MODE>(w0, D0, Fp, f0, accA, accV, accX, accY);                                                                       \
         stamp_epi(6);                                                                                                                        \
         finish_tile(w0, chan0, D0, f0);                                                                                                      \
       }                                                                                                                                      \
@@ -766,19 +791,25 @@ hipError_t conv_prepare_device_x() {
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<true, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)CONV_X_LDS_BYTES);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<true, false, false, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)CONV_X_LDS_BYTES);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<false, false, false, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)CONV_X_LDS_BYTES);
   return e;
 }
 
 void conv_det_fix(const ConvKArgs& k, const ConvLaunch& a, int dout, hipStream_t s);   // k_conv.hip
 
 hipError_t launch_conv_fused_x(const ConvLayerDev& L, const ConvLaunch& a, int n_cu, hipStream_t s) {
-  if (a.mode != 0) return hipErrorInvalidValue;
+  if (a.mode != 0 && a.mode != 1) return hipErrorInvalidValue;
   ConvXArgs X;
   ConvKArgs& k = X.k;
   k.x = a.x; k.src = a.src; k.dst = a.dst; k.edge_attr = a.edge_attr; k.sh = a.sh; k.sum = a.sum;
   k.counter = a.counter;
   k.w1p = nullptr; k.b1p = L.b1p[0]; k.w2r = nullptr; k.w1x = L.w1x; k.w2x = L.w2x; k.n_tiles = L.n_tiles;
-  for (int g = 0; g < 4; ++g) { k.w1s[g] = L.w1s[g]; k.w1u[g] = 1.0f / L.w1s[g]; k.w2s[g] = L.w2s[g]; k.w2u[g] = 1.0f / L.w2s[g]; }
+  for (int g = 0; g < CONV_MAX_GROUPS; ++g) { k.w1s[g] = L.w1s[g]; k.w1u[g] = 1.0f / L.w1s[g]; k.w2s[g] = L.w2s[g]; k.w2u[g] = 1.0f / L.w2s[g]; }
   k.n_cols = L.n_cols;
   for (int c = 0; c <= L.n_cols; ++c) k.col_start[c] = L.col_start[c];
   k.sum_g2 = a.sum_g2; k.g2_node_off = a.g2_node_off;
@@ -787,6 +818,12 @@ hipError_t launch_conv_fused_x(const ConvLayerDev& L, const ConvLaunch& a, int n
   else { k.gbeg = a.tile_info + 5; k.gend = a.tile_info + 6; }   // 4 contiguous groups go[g] .. go[g+1] (explicit-boundary entry point)
   k.pre = a.pre; k.part = a.part;
   X.trace = nullptr; X.trace_coarse = a.trace_coarse;
+  if (a.mode == 1) {      // the confidence model: plain gather path (no node-term split, atomics)
+    if (a.pre != nullptr || a.part != nullptr || a.trace != nullptr) return hipErrorInvalidValue;
+    if (a.gather) hipLaunchKernelGGL((conv_x3_kernel<true, false, false, false, 1>), dim3(n_cu), dim3(64 * CONV_WAVES), CONV_X_LDS_BYTES, s, X);
+    else hipLaunchKernelGGL((conv_x3_kernel<false, false, false, false, 1>), dim3(n_cu), dim3(64 * CONV_WAVES), CONV_X_LDS_BYTES, s, X);
+    return hipGetLastError();
+  }
   if (a.part != nullptr) {       // deterministic scatter
     hipError_t e = (a.gather && a.pre != nullptr) ? launch_x_t<true, true, true>(X, n_cu, s)
                                                   : (!a.gather ? launch_x_t<false, false, true>(X, n_cu, s) : hipErrorInvalidValue);

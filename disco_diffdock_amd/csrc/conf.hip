@@ -16,8 +16,10 @@
 //                                 [ll | lr | la | aa | al | ar | rr | rl | ra]  =  conv_layers.{9l + 0..8}
 //                             with three accumulator slots per node (one per conv feeding that node type), conf_finalize
 //                             (mean, BatchNorm of each conv, sum, residual) and the pooled head.
-// Node numbering: [ligand b*n_lig+i | atom Bm*n_lig + b*n_atom + a | residue Bm*(n_lig+n_atom) + b*n_rec + r] with
-// Bm = max_batch, so the replicated static edge sets are valid for every B <= Bm.
+// Node numbering: [ligand b*n_lig+i | atom Bm*n_lig + b*n_atom + a | residue Bm*n_lig + (Bm+1)*n_atom + b*n_rec + r] with
+// Bm = max_batch, so the replicated static edge sets are valid for every B <= Bm.  Atom / residue sample b = Bm is the VIRTUAL
+// ligand-free sample: the pose-independent work of the first two layers is evaluated on it once per forward and shared by every
+// real sample (layer 0: all static groups; layer 1: the receivers none of whose messages changed; see ddk_confidence_forward).
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -58,20 +60,25 @@ struct ConfComplex {
   int n_atom = 0, E_aa = 0;
   float* atom_pos = nullptr;
   float *lig_x0 = nullptr, *atom_x0 = nullptr, *rec_x0 = nullptr;   // [n, NS]
-  int64_t cap4 = 0, cap_la = 0, cap_total = 0, off_la = 0, off_al = 0, off_aa = 0, off_ar = 0, off_ra = 0;
+  int64_t cap4 = 0, cap_la = 0, cap_total = 0, off_la = 0, off_al = 0, off_aa = 0, off_ar = 0, off_ra = 0, off_vrr = 0;
   int32_t *e_src = nullptr, *e_dst = nullptr, *e_aux = nullptr;
   float *e_emb = nullptr, *e_sh = nullptr;
   int32_t *st_a = nullptr, *st_b = nullptr;      // one copy of the static sets: aa (atom, atom) then ar (atom, residue) local endpoints
   float *st_emb = nullptr, *st_sh = nullptr;
-  int32_t* gtab = nullptr;     // [0..8] gbeg, [9..17] gend, [18] la counter, [19] overflow flag, [32..49] layer-0 table, [64..81] level-A table, [82..85] cursors
+  int32_t* gtab = nullptr;     // [0..8] gbeg, [9..17] gend, [18] la counter, [19] overflow flag, [32..49] layer-0 table, [64..81] level-A table, [82..85] cursors,
+                               // [96..113] level-B table, [114..117] its cursors, [128..145] layer-1 table, [146..149] its cursors
   // backward receptive field of the pooled ligand rows: the second-to-last layer evaluates the static groups (aa, ar, rr, ra) only into the
   // atoms / residues that SEND to a ligand atom in the last layer (level A); their edge records are compacted into a scratch region per forward
   int64_t off_scr = 0, cap_scr = 0;
   uint8_t *flag_a = nullptr, *flag_r = nullptr;      // [2][Bm * n_atom], [2][Bm * n_rec]: level A, level B (= A + the senders of the edges into A)
+  // layer-1 sharing: need[y][node of sample b] = 1 when the receiver's messages of static group y (aa, ar | rr, ra) differ from the ligand-free
+  // receptor's in sample b (the receiver or one of its senders received a ligand message in layer 0)
+  uint8_t* need[4] = {nullptr, nullptr, nullptr, nullptr};      // [Bm * n_atom] x 2, [Bm * n_rec] x 2
+  int32_t* deg_static = nullptr;                     // [(n_atom + n_rec)][3]: in-degrees of the static groups (slot 1, the ligand's, is 0)
   int32_t* deg_scratch = nullptr;
   float *xa = nullptr, *xb = nullptr, *sum3 = nullptr;
   int32_t* deg3 = nullptr;
-  int64_t n_nodes = 0;         // Bm * (n_lig + n_atom + n_rec)
+  int64_t n_nodes = 0;         // Bm * n_lig + (Bm + 1) * (n_atom + n_rec)
 };
 
 static const HostTensor* getw(ddk_ctx* ctx, const std::string& name, std::initializer_list<int64_t> shape) {
@@ -262,67 +269,93 @@ struct LaArgs {
   float *e_emb, *e_sh;
 };
 
+constexpr int LA_LIST = 256;      // per-wave list of the receptor atoms found around one ligand atom (flushed when fewer than 64 slots are left)
+
 // ligand-atom edges: radius(atom.pos, lig.pos, lig_max_radius) (all_atom_score_model.py:413-420) -> group la (src ligand atom,
 // dst receptor atom) and its flip al (src receptor atom, dst ligand atom) with the SAME edge embedding and spherical harmonics
-// (vector atom - ligand for both, :232-238); one wave per ligand atom, the wave reserves a contiguous range of the group.
+// (vector atom - ligand for both, :232-238).  One wave per ligand atom, two phases: the wave first collects the atoms in range into an
+// LDS list (64 distance tests per trip), then evaluates the edge MLP with one edge per lane - all lanes busy - and appends ONE
+// contiguous run per ligand atom to the group (round 3 ran the 1.5 k-FMA MLP inside the search loop with the two or three lanes of
+// a 64-atom chunk that were in range: 276 us for 37 k edges).
 __global__ __launch_bounds__(256) void conf_la_kernel(LaArgs A) {
+  __shared__ int list[4][LA_LIST];
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // grid (B, LA_SLICES): the ligand atoms of a sample are dealt out over LA_SLICES workgroups (edge order inside the group is free:
-  // every wave appends one contiguous run per ligand atom)
+  int* mine = list[wave];
+  // grid (B, LA_SLICES): the ligand atoms of a sample are dealt out over LA_SLICES workgroups (edge order inside the group is free)
   for (int i = wave + 4 * blockIdx.y; i < A.n_lig; i += 4 * gridDim.y) {
     const float* lp = A.lig_pos + ((size_t)b * A.n_lig + i) * 3;
     const float lx = lp[0], ly = lp[1], lz = lp[2];
+    const int ln = b * A.n_lig + i;
+    int n_list = 0;
     for (int j0 = 0; j0 < A.n_atom; j0 += 64) {
-      const int j = j0 + lane;
-      float vx = 0.f, vy = 0.f, vz = 0.f;
-      bool in = false;
-      if (j < A.n_atom) {
-        vx = A.atom_pos[3 * j] - lx; vy = A.atom_pos[3 * j + 1] - ly; vz = A.atom_pos[3 * j + 2] - lz;
-        in = vx * vx + vy * vy + vz * vz < A.r2;
+      {
+        const int j = j0 + lane;
+        bool in = false;
+        if (j < A.n_atom) {
+          const float vx = A.atom_pos[3 * j] - lx, vy = A.atom_pos[3 * j + 1] - ly, vz = A.atom_pos[3 * j + 2] - lz;
+          in = vx * vx + vy * vy + vz * vz < A.r2;
+        }
+        const unsigned long long mask = __ballot(in);
+        if (in) mine[n_list + __popcll(mask & ((1ull << lane) - 1ull))] = j;
+        n_list += __popcll(mask);
       }
-      const unsigned long long mask = __ballot(in);
-      if (mask == 0ull) continue;
+      const bool last = j0 + 64 >= A.n_atom;
+      if (n_list == 0 || (!last && n_list <= LA_LIST - 64)) continue;      // (wave-uniform)
+      // ---- flush: one edge per lane ----
       int base = 0;
-      if (lane == 0) base = atomicAdd(A.gtab + 18, __popcll(mask));
+      if (lane == 0) base = atomicAdd(A.gtab + 18, n_list);
       base = __shfl(base, 0, 64);
-      if (!in) continue;
-      const int64_t p = base + __popcll(mask & ((1ull << lane) - 1ull));
-      if (p >= A.cap) { A.gtab[19] = 1; continue; }
-      const float d = sqrtf(vx * vx + vy * vy + vz * vz);
-      const float inv = 1.7320508075688772f / fmaxf(d, 1e-12f);
-      const float4 shv = make_float4(1.0f, vx * inv, vy * inv, vz * inv);
-      float gs[DE], h[NS];
+      for (int q0 = 0; q0 < n_list; q0 += 64) {
+        const int q = q0 + lane;
+        if (q >= n_list) continue;
+        const int64_t p = (int64_t)base + q;
+        if (p >= A.cap) { A.gtab[19] = 1; continue; }
+        const int j = mine[q];
+        const float vx = A.atom_pos[3 * j] - lx, vy = A.atom_pos[3 * j + 1] - ly, vz = A.atom_pos[3 * j + 2] - lz;
+        const float d = sqrtf(vx * vx + vy * vy + vz * vz);
+        const float inv = 1.7320508075688772f / fmaxf(d, 1e-12f);
+        const float4 shv = make_float4(1.0f, vx * inv, vy * inv, vz * inv);
+        float gs[DE], h[NS];
 #pragma unroll
-      for (int k = 0; k < DE; ++k) { const float t = d - A.mlp.offset[k]; gs[k] = expf(A.mlp.coeff * (t * t)); }
-#pragma unroll 1
-      for (int o = 0; o < NS; ++o) {
-        float a = A.sigb[o];
+        for (int k = 0; k < DE; ++k) { const float t = d - A.mlp.offset[k]; gs[k] = expf(A.mlp.coeff * (t * t)); }
 #pragma unroll
-        for (int k = 0; k < DE; ++k) a += A.mlp.w1d[o * DE + k] * gs[k];
-        h[o] = fmaxf(a, 0.0f);
+        for (int o = 0; o < NS; ++o) {
+          float a = A.sigb[o];
+#pragma unroll
+          for (int k = 0; k < DE; ++k) a += A.mlp.w1d[o * DE + k] * gs[k];
+          h[o] = fmaxf(a, 0.0f);
+        }
+        const int an = A.atom_node_base + b * A.n_atom + j;
+        const int64_t e1 = A.off_la + p, e2 = A.off_al + p;
+        A.e_src[e1] = ln; A.e_dst[e1] = an;
+        A.e_src[e2] = an; A.e_dst[e2] = ln;
+        *reinterpret_cast<float4*>(A.e_sh + 4 * e1) = shv;
+        *reinterpret_cast<float4*>(A.e_sh + 4 * e2) = shv;
+#pragma unroll
+        for (int o4 = 0; o4 < NS / 4; ++o4) {
+          float r[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int o = 4 * o4 + c;
+            float a = A.mlp.b2[o];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) a += A.mlp.w2[o * NS + k] * h[k];
+            r[c] = a;
+          }
+          const float4 rv = make_float4(r[0], r[1], r[2], r[3]);
+          *reinterpret_cast<float4*>(A.e_emb + e1 * NS + 4 * o4) = rv;
+          *reinterpret_cast<float4*>(A.e_emb + e2 * NS + 4 * o4) = rv;
+        }
       }
-      const int ln = b * A.n_lig + i, an = A.atom_node_base + b * A.n_atom + j;
-      const int64_t e1 = A.off_la + p, e2 = A.off_al + p;
-      A.e_src[e1] = ln; A.e_dst[e1] = an;
-      A.e_src[e2] = an; A.e_dst[e2] = ln;
-      *reinterpret_cast<float4*>(A.e_sh + 4 * e1) = shv;
-      *reinterpret_cast<float4*>(A.e_sh + 4 * e2) = shv;
-#pragma unroll 1
-      for (int o = 0; o < NS; ++o) {
-        float a = A.mlp.b2[o];
-#pragma unroll
-        for (int k = 0; k < NS; ++k) a += A.mlp.w2[o * NS + k] * h[k];
-        A.e_emb[e1 * NS + o] = a;
-        A.e_emb[e2 * NS + o] = a;
-      }
+      n_list = 0;
     }
   }
 }
 
 // group table of one forward: [0..8] gbeg, [9..17] gend for [ll lr la aa al ar rr rl ra] from the shared graph kernel's info
 // table (go[0..4] of its [ll | lr | rr | rl] list), the la counter and the static set sizes
-__global__ void conf_gtab_kernel(int32_t* gtab, const int32_t* info, int B, int E_aa, int n_atom, int off_la, int off_al, int off_aa,
-                                 int off_ar, int off_ra, int cap_la) {
+__global__ void conf_gtab_kernel(int32_t* gtab, const int32_t* info, int B, int Bm, int E_aa, int E_rr, int n_atom, int off_la, int off_al, int off_aa,
+                                 int off_ar, int off_ra, int off_vrr, int cap_la) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const int go0 = info[I_GO], go1 = info[I_GO + 1], go2 = info[I_GO + 2], go3 = info[I_GO + 3], go4 = info[I_GO + 4];
   const int n_la = min(gtab[18], cap_la);
@@ -330,11 +363,26 @@ __global__ void conf_gtab_kernel(int32_t* gtab, const int32_t* info, int B, int 
   const int end[9] = {go1, go2, off_la + n_la, off_aa + B * E_aa, off_al + n_la, off_ar + B * n_atom, go3, go4, off_ra + B * n_atom};
   for (int g = 0; g < 9; ++g) { gtab[g] = beg[g]; gtab[9 + g] = end[g]; }
   // layer 0: before the first conv the atom and residue rows (and the static edge sets' features) are the same in every sample, so the
-  // pose-independent groups aa, ar, rr, ra are evaluated for sample 0 only (their edges are stored sample-major) and conf_finalize_kernel
-  // reads sample 0's accumulators for the other samples
+  // pose-independent groups aa, ar, rr, ra are evaluated ONCE, on the virtual ligand-free sample Bm (their edges are stored sample-major;
+  // its rec-rec records are conf_vrr_kernel's copy of sample 0's), and conf_finalize_kernel reads its accumulators for every sample
   int32_t* t0 = gtab + 32;
   for (int g = 0; g < 9; ++g) { t0[g] = beg[g]; t0[9 + g] = end[g]; }
-  t0[9 + 3] = off_aa + E_aa; t0[9 + 5] = off_ar + n_atom; t0[9 + 6] = go2 + (go3 - go2) / B; t0[9 + 8] = off_ra + n_atom;
+  t0[3] = off_aa + Bm * E_aa; t0[9 + 3] = t0[3] + E_aa;
+  t0[5] = off_ar + Bm * n_atom; t0[9 + 5] = t0[5] + n_atom;
+  t0[6] = off_vrr; t0[9 + 6] = off_vrr + E_rr;
+  t0[8] = off_ra + Bm * n_atom; t0[9 + 8] = t0[8] + n_atom;
+}
+
+// rec-rec records of the virtual sample: sample 0's (the first E_rr of the group: the graph kernel stores them sample-major, and their features do
+// not depend on the sample) with the node ids moved to sample Bm
+__global__ void conf_vrr_kernel(const int32_t* gtab, int E_rr, int id_shift, int64_t off_vrr, int32_t* e_src, int32_t* e_dst, float* e_emb, float* e_sh) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = i / 8, q = i % 8;        // 8 threads per edge: six embedding quads, the SH quad, the ids
+  if (k >= E_rr) return;
+  const int64_t e = (int64_t)gtab[6] + k, p = off_vrr + k;
+  if (q < 6) reinterpret_cast<float4*>(e_emb + (size_t)p * NS)[q] = reinterpret_cast<const float4*>(e_emb + (size_t)e * NS)[q];
+  else if (q == 6) *reinterpret_cast<float4*>(e_sh + (size_t)p * 4) = *reinterpret_cast<const float4*>(e_sh + (size_t)e * 4);
+  else { e_src[p] = e_src[e] + id_shift; e_dst[p] = e_dst[e] + id_shift; }
 }
 
 // ---- level A of the backward receptive field (second-to-last layer) ---------------------------------------------------------
@@ -345,9 +393,11 @@ struct ConfLevelArgs {
   const int32_t* gtab;
   int32_t *e_src, *e_dst;
   float *e_emb, *e_sh;
-  uint8_t *flag_a, *flag_r;
+  uint8_t *flag_a, *flag_r;      // level-A flags (conf_level_flags_kernel)
+  const uint8_t* fl[4];          // compaction: the receiver flags of the four static groups aa, ar | rr, ra
+  int with_virtual;              // compaction: sample index B = the virtual sample Bm, every edge kept (layer-1 table)
   int B, n_atom, n_rec, E_aa, E_rr;
-  int64_t atom_base, rec_base, off_aa, off_ar, off_ra, off_scr, Bm;
+  int64_t atom_base, rec_base, off_aa, off_ar, off_ra, off_vrr, off_scr, Bm;
   int32_t* cursors;      // [4] (zeroed by the caller)
   int32_t* tabA;         // [18]
 };
@@ -384,43 +434,91 @@ __global__ void conf_level_b_flags_kernel(ConfLevelBArgs A, int64_t cap_scr) {
   }
 }
 
-// grid (B, 4, slices): sample b, static group y in {aa, ar, rr, ra}: stable compaction of the edges whose receiver is flagged into the scratch region
+// Layer-1 sharing.  After layer 0 the row of an atom / residue differs from the ligand-free receptor's (the virtual sample's) only if it received
+// a ligand message: the receivers of the al / rl edges = the level-A flags.  A receiver's layer-1 messages of static group y are the virtual
+// sample's unless the receiver or one of its senders in y is such a node: need[y][receiver] = flagA[receiver] (the caller copies) | OR over its
+// edges of flagA[sender].  One thread per static edge of the real samples.
+struct ConfNeedArgs {
+  const int32_t* gtab;
+  const int32_t *e_src, *e_dst;
+  const uint8_t *flag_a, *flag_r;
+  uint8_t* need[4];
+  int B, n_atom, n_rec, E_aa, E_rr;
+  int64_t atom_base, rec_base, off_aa, off_ar, off_ra;
+};
+__global__ void conf_need_flags_kernel(ConfNeedArgs A) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n_aa = (int64_t)A.B * A.E_aa, n_at = (int64_t)A.B * A.n_atom, n_rr = (int64_t)A.B * A.E_rr;
+  int y;
+  int64_t e;
+  if (i < n_aa) { y = 0; e = A.off_aa + i; }
+  else if (i < n_aa + n_at) { y = 1; e = A.off_ar + (i - n_aa); }
+  else if (i < n_aa + n_at + n_rr) { y = 2; e = (int64_t)A.gtab[6] + (i - n_aa - n_at); }
+  else if (i < n_aa + 2 * n_at + n_rr) { y = 3; e = A.off_ra + (i - n_aa - n_at - n_rr); }
+  else return;
+  const int sn = A.e_src[e], dn = A.e_dst[e];
+  const bool sender_atom = y == 0 || y == 3;       // aa, ra: the sender (edge_dst) is an atom
+  const bool hit = sender_atom ? A.flag_a[dn - A.atom_base] != 0 : A.flag_r[dn - A.rec_base] != 0;
+  if (hit) A.need[y][sn - (y < 2 ? A.atom_base : A.rec_base)] = 1;
+}
+
+// grid (samples, 4, slices): sample b, static group y in {aa, ar, rr, ra}: stable compaction of the edges whose receiver is flagged into the
+// scratch region (a slice claims one contiguous output range: receivers stay grouped inside a slice).  Two coalesced passes over the slice:
+// count, then per 256-edge chunk a ballot scan for the positions and a cooperative copy of the kept records (seven 16-B words per edge).
 __global__ __launch_bounds__(256) void conf_level_compact_kernel(ConfLevelArgs A) {
-  __shared__ int part[256];
+  __shared__ int wsum[4];
   __shared__ int base_s;
-  const int b = blockIdx.x, y = blockIdx.y, tid = threadIdx.x;
+  __shared__ int keep_e[256], keep_p[256];
+  const int b = blockIdx.x, y = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool virt = A.with_virtual && b == A.B;
+  const int64_t bs = virt ? A.Bm : b;              // segment index of the static sets
   const int n = y == 0 ? A.E_aa : (y == 2 ? A.E_rr : A.n_atom);
-  const int64_t first = y == 0 ? A.off_aa + (int64_t)b * A.E_aa : (y == 1 ? A.off_ar + (int64_t)b * A.n_atom
-                      : (y == 2 ? (int64_t)A.gtab[6] + (int64_t)b * A.E_rr : A.off_ra + (int64_t)b * A.n_atom));
-  const uint8_t* fl = y < 2 ? A.flag_a : A.flag_r;
+  const int64_t first = y == 0 ? A.off_aa + bs * A.E_aa : (y == 1 ? A.off_ar + bs * A.n_atom
+                      : (y == 2 ? (virt ? A.off_vrr : (int64_t)A.gtab[6] + (int64_t)b * A.E_rr) : A.off_ra + bs * A.n_atom));
+  const uint8_t* fl = A.fl[y];
   const int64_t nb = y < 2 ? A.atom_base : A.rec_base;
-  // blockIdx.z: one of gridDim.z contiguous slices of the set (each claims its own output range: receivers stay grouped inside a slice)
   const int n_sl = (n + gridDim.z - 1) / gridDim.z, s0 = min((int)blockIdx.z * n_sl, n), s1 = min(s0 + n_sl, n);
-  const int per = (s1 - s0 + 255) / 256, k0 = min(s0 + tid * per, s1), k1 = min(k0 + per, s1);
+  if (s0 >= s1) return;
   int cnt = 0;
-  for (int k = k0; k < k1; ++k) cnt += fl[A.e_src[first + k] - nb] ? 1 : 0;
-  part[tid] = cnt;
+  if (virt) cnt = (s1 - s0 + 255 - tid) / 256;
+  else for (int k = s0 + tid; k < s1; k += 256) cnt += fl[A.e_src[first + k] - nb] ? 1 : 0;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+  if (lane == 0) wsum[wave] = cnt;
   __syncthreads();
   if (tid == 0) {
-    int run = 0;
-    for (int t = 0; t < 256; ++t) { const int c = part[t]; part[t] = run; run += c; }
-    const int64_t region = A.off_scr + (y == 0 ? 0 : (y == 1 ? A.Bm * A.E_aa : (y == 2 ? A.Bm * ((int64_t)A.E_aa + A.n_atom)
-                                                                                          : A.Bm * ((int64_t)A.E_aa + A.n_atom + A.E_rr))));
-    base_s = (int)region + atomicAdd(A.cursors + y, run);
+    const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    const int64_t region = A.off_scr + (y == 0 ? 0 : (y == 1 ? (A.Bm + 1) * A.E_aa : (y == 2 ? (A.Bm + 1) * ((int64_t)A.E_aa + A.n_atom)
+                                                                                              : (A.Bm + 1) * ((int64_t)A.E_aa + A.n_atom) + (A.Bm + 1) * (int64_t)A.E_rr)));
+    base_s = (int)region + atomicAdd(A.cursors + y, total);
   }
   __syncthreads();
-  int64_t pos = (int64_t)base_s + part[tid];
-  for (int k = k0; k < k1; ++k) {
-    const int64_t e = first + k;
-    const int sn = A.e_src[e];
-    if (!fl[sn - nb]) continue;
-    A.e_src[pos] = sn; A.e_dst[pos] = A.e_dst[e];
-    const float4* es = reinterpret_cast<const float4*>(A.e_emb + (size_t)e * NS);
-    float4* ed = reinterpret_cast<float4*>(A.e_emb + (size_t)pos * NS);
-#pragma unroll
-    for (int q = 0; q < NS / 4; ++q) ed[q] = es[q];
-    *reinterpret_cast<float4*>(A.e_sh + (size_t)pos * 4) = *reinterpret_cast<const float4*>(A.e_sh + (size_t)e * 4);
-    ++pos;
+  int run = base_s;
+  for (int c0 = s0; c0 < s1; c0 += 256) {
+    const int k = c0 + tid;
+    int sn = 0;
+    bool keep = false;
+    if (k < s1) { sn = A.e_src[first + k]; keep = virt || fl[sn - nb] != 0; }
+    const unsigned long long mask = __ballot(keep);
+    __syncthreads();                       // the previous chunk's lists have been consumed
+    if (lane == 0) wsum[wave] = __popcll(mask);
+    __syncthreads();
+    int pre = __popcll(mask & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) pre += wsum[w];
+    const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (keep) {
+      const int pos = run + pre;
+      A.e_src[pos] = sn; A.e_dst[pos] = A.e_dst[first + k];
+      keep_e[pre] = k; keep_p[pre] = pos;
+    }
+    __syncthreads();
+    for (int it = tid; it < tot * 7; it += 256) {
+      const int m = it / 7, q = it - 7 * m;
+      const int64_t e = first + keep_e[m], pos = keep_p[m];
+      if (q < 6) reinterpret_cast<float4*>(A.e_emb + (size_t)pos * NS)[q] = reinterpret_cast<const float4*>(A.e_emb + (size_t)e * NS)[q];
+      else *reinterpret_cast<float4*>(A.e_sh + (size_t)pos * 4) = *reinterpret_cast<const float4*>(A.e_sh + (size_t)e * 4);
+    }
+    run += tot;
   }
 }
 
@@ -428,31 +526,43 @@ __global__ __launch_bounds__(256) void conf_level_compact_kernel(ConfLevelArgs A
 __global__ void conf_level_table_kernel(ConfLevelArgs A) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   for (int g = 0; g < 18; ++g) A.tabA[g] = A.gtab[g];
-  const int64_t r[4] = {A.off_scr, A.off_scr + A.Bm * A.E_aa, A.off_scr + A.Bm * ((int64_t)A.E_aa + A.n_atom),
-                        A.off_scr + A.Bm * ((int64_t)A.E_aa + A.n_atom + A.E_rr)};
+  const int64_t r[4] = {A.off_scr, A.off_scr + (A.Bm + 1) * A.E_aa, A.off_scr + (A.Bm + 1) * ((int64_t)A.E_aa + A.n_atom),
+                        A.off_scr + (A.Bm + 1) * ((int64_t)A.E_aa + A.n_atom) + (A.Bm + 1) * (int64_t)A.E_rr};
   const int gid[4] = {3, 5, 6, 8};
   for (int y = 0; y < 4; ++y) { A.tabA[gid[y]] = (int)r[y]; A.tabA[9 + gid[y]] = (int)r[y] + A.cursors[y]; }
 }
 
-// in-degree of every (node, slot): slot = group % 3
-__global__ void conf_deg_kernel(const int32_t* gtab, const int32_t* e_src, int32_t* deg3, int64_t cap_total) {
+// in-degree of every (node, slot), slot = group % 3: the static groups' (aa, ar | rr, ra) are constants of the complex (deg_static: the same in
+// every sample, the virtual one included), the ligand-dependent groups ll, lr, la, al, rl are counted per forward
+__global__ void conf_deg_init_kernel(const int32_t* deg_static, int64_t atom0, int64_t rec0, int64_t n_nodes, int n_atom, int n_rec, int32_t* deg3) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes * 3) return;
+  const int64_t node = i / 3;
+  const int s = (int)(i - 3 * node);
+  int v = 0;
+  if (node >= rec0) v = deg_static[((int64_t)n_atom + (node - rec0) % n_rec) * 3 + s];
+  else if (node >= atom0) v = deg_static[((node - atom0) % n_atom) * 3 + s];
+  deg3[i] = v;
+}
+__global__ void conf_deg_kernel(const int32_t* gtab, const int32_t* e_src, int32_t* deg3, int64_t n_dyn) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= cap_total) return;
-  for (int g = 0; g < 9; ++g)
+  if (e >= n_dyn) return;
+  const int gid[5] = {0, 1, 2, 4, 7};
+  for (int q = 0; q < 5; ++q) {
+    const int g = gid[q];
     if (e >= gtab[g] && e < gtab[9 + g]) { atomicAdd(deg3 + (size_t)e_src[e] * 3 + (g % 3), 1); return; }
+  }
 }
 
-// initial node features: static embedding broadcast over the samples, zero padded to XW
-__global__ void conf_node_init_kernel(const float* lig_x0, const float* atom_x0, const float* rec_x0, int B, int Bm, int n_lig, int n_atom,
+// initial node features: static embedding broadcast over the samples (Bm ligand samples, Bm + 1 atom / residue samples), zero padded to XW
+__global__ void conf_node_init_kernel(const float* lig_x0, const float* atom_x0, const float* rec_x0, int64_t a0, int64_t r0, int64_t n, int n_lig, int n_atom,
                                       int n_rec, float* x) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t n = (int64_t)Bm * (n_lig + n_atom + n_rec);
   if (i >= n * XW) return;
   const int64_t node = i / XW;
   const int c = (int)(i % XW);
   float v = 0.0f;
   if (c < NS) {
-    const int64_t a0 = (int64_t)Bm * n_lig, r0 = a0 + (int64_t)Bm * n_atom;
     if (node < a0) v = lig_x0[(node % n_lig) * NS + c];
     else if (node < r0) v = atom_x0[((node - a0) % n_atom) * NS + c];
     else v = rec_x0[((node - r0) % n_rec) * NS + c];
@@ -461,31 +571,42 @@ __global__ void conf_node_init_kernel(const float* lig_x0, const float* atom_x0,
 }
 
 // x_out = pad(x_in) + sum over the 3 convs feeding the node type of BN_conv(sum / max(deg,1))   (all_atom_score_model.py:37-50,272-279)
-// share0 (layer 0): slots 0 and 2 of the atom / residue rows (groups aa, ar / rr, ra) were accumulated for sample 0 only: every sample
-// reads sample 0's row (n_atom, n_rec = nodes per sample)
-__global__ void conf_finalize_kernel(const float* sum3, const int32_t* deg3, const float* x_in, const float* bn_mean, const float* bn_scale,
-                                     const float* bn_bias, int64_t n_nodes, int64_t n_update, int64_t atom0, int64_t rec0, int dout, float* x_out,
-                                     int share0, int n_atom, int n_rec) {
+// share 1 (layer 0): slots 0 and 2 of the atom / residue rows (groups aa, ar / rr, ra) were accumulated for the virtual sample only: every
+// sample reads the virtual sample's row; share 2 (layer 1): ... unless need[y] marks the (receiver, group) as evaluated in its own sample.
+// vatom0 / vrec0 = first atom / residue row of the virtual sample; n_atom, n_rec = nodes per sample
+struct ConfFinalizeArgs {
+  const float* sum3; const int32_t* deg3; const float* x_in; const float *bn_mean, *bn_scale, *bn_bias;
+  int64_t n_nodes, n_update, atom0, rec0, vatom0, vrec0;
+  int dout, share, n_atom, n_rec;
+  const uint8_t* need[4];
+  float* x_out;
+};
+__global__ void conf_finalize_kernel(ConfFinalizeArgs A) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_nodes * XW) return;
+  if (i >= A.n_nodes * XW) return;
   const int64_t node = i / XW;
   const int c = (int)(i % XW);
-  float v = x_in[i];
-  if (node < n_update && c < dout) {
-    const int type = node < atom0 ? 0 : (node < rec0 ? 1 : 2);
-    int64_t node_sh = node;        // sample 0's copy of this atom / residue
-    if (share0 && type == 1) node_sh = atom0 + (node - atom0) % n_atom;
-    if (share0 && type == 2) node_sh = rec0 + (node - rec0) % n_rec;
+  float v = A.x_in[i];
+  if (node < A.n_update && c < A.dout) {
+    const int type = node < A.atom0 ? 0 : (node < A.rec0 ? 1 : 2);
+    int64_t node_sh = node;        // the virtual sample's copy of this atom / residue
+    if (A.share && type == 1) node_sh = A.vatom0 + (node - A.atom0) % A.n_atom;
+    if (A.share && type == 2) node_sh = A.vrec0 + (node - A.rec0) % A.n_rec;
+    const bool real = node_sh != node;
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
       const int g = 3 * type + s;
-      const int d = deg3[node * 3 + s];
-      const int64_t nd = (s != 1) ? node_sh : node;
-      const float m = sum3[(nd * 3 + s) * XW + c] / (float)(d > 1 ? d : 1);
-      v += (m - bn_mean[g * XW + c]) * bn_scale[g * XW + c] + bn_bias[g * XW + c];
+      const int d = A.deg3[node * 3 + s];
+      int64_t nd = (s != 1) ? node_sh : node;
+      if (A.share == 2 && s != 1 && real) {
+        const uint8_t* nf = A.need[(type == 1 ? 0 : 2) + (s == 2 ? 1 : 0)];
+        if (nf[node - (type == 1 ? A.atom0 : A.rec0)]) nd = node;
+      }
+      const float m = A.sum3[(nd * 3 + s) * XW + c] / (float)(d > 1 ? d : 1);
+      v += (m - A.bn_mean[g * XW + c]) * A.bn_scale[g * XW + c] + A.bn_bias[g * XW + c];
     }
   }
-  x_out[i] = v;
+  A.x_out[i] = v;
 }
 
 struct HeadCArgs {
@@ -595,11 +716,11 @@ int ddk_complex_set_atoms(ddk_ctx* ctx, ddk_complex* cx, const ddk_atoms_desc* d
   ConfComplex* K = new ConfComplex();
   cx->conf = K;
   K->n_atom = n_atom; K->E_aa = E_aa;
-  const int64_t Bm = cx->max_batch;
+  const int64_t Bm = cx->max_batch, Bv = Bm + 1;
   {   // staged, asynchronous upload of everything below (model.h: cx_put / cx_stage_flush)
     const size_t n_st = (size_t)E_aa + (size_t)n_atom;
     int rc0 = cx_stage_begin(ctx, cx, (size_t)(n_lig + n_atom + n_rec) * NS * 4 + (size_t)n_atom * 12 + (size_t)cx->E_rr * NS * 4 +
-                                          n_st * (8 + NS * 4 + 16) + 16 * 256);
+                                          n_st * (8 + NS * 4 + 16) + (size_t)(n_atom + n_rec) * 12 + 16 * 256);
     if (rc0) return rc0;
   }
   // ---- node embeddings (OldAtomEncoder at t = 0) --------------------------------------------------
@@ -676,15 +797,18 @@ int ddk_complex_set_atoms(ddk_ctx* ctx, ddk_complex* cx, const ddk_atoms_desc* d
     K->cap4 = cx->edge_cap;
     K->cap_la = Bm * (int64_t)n_lig * 96 + 64;       // <= 96 receptor atoms within 5 A of a ligand atom (1.2 A spacing bound ~ 300)
     K->off_la = K->cap4; K->off_al = K->off_la + K->cap_la; K->off_aa = K->off_al + K->cap_la;
-    K->off_ar = K->off_aa + Bm * E_aa; K->off_ra = K->off_ar + Bm * n_atom; K->cap_total = K->off_ra + Bm * n_atom;
-    K->off_scr = K->cap_total; K->cap_scr = Bm * ((int64_t)E_aa + 2 * (int64_t)n_atom + cx->E_rr);     // level-A copies of aa | ar | rr | ra (worst case: all)
-    const int64_t e_all = K->cap_total + 2 * K->cap_scr;       // (a second region for level B, the third-to-last layer)
+    // (Bv = Bm + 1 segments of every static set: the last one belongs to the virtual ligand-free sample; vrr = its rec-rec records)
+    K->off_ar = K->off_aa + Bv * E_aa; K->off_ra = K->off_ar + Bv * n_atom; K->off_vrr = K->off_ra + Bv * n_atom; K->cap_total = K->off_vrr + cx->E_rr;
+    K->off_scr = K->cap_total; K->cap_scr = Bv * ((int64_t)E_aa + 2 * (int64_t)n_atom + cx->E_rr);     // compacted copies of aa | ar | rr | ra (worst case: all)
+    const int64_t e_all = K->cap_total + 3 * K->cap_scr;       // (level A, level B = the third-to-last layer, and layer 1's table)
     if (e_all >= ((int64_t)1 << 31)) return fail(ctx, DDK_ERR_INVALID, "edge capacity exceeds int32 (reduce max_batch)");
     K->e_src = cxu<int32_t>(cx, nullptr, e_all); K->e_dst = cxu<int32_t>(cx, nullptr, e_all);
     K->e_aux = cxu<int32_t>(cx, nullptr, K->cap4);
     K->e_emb = cxu<float>(cx, nullptr, e_all * NS); K->e_sh = cxu<float>(cx, nullptr, e_all * 4);
     K->flag_a = cxu<uint8_t>(cx, nullptr, 2 * Bm * n_atom); K->flag_r = cxu<uint8_t>(cx, nullptr, 2 * Bm * n_rec);
-    if (!K->flag_a || !K->flag_r) return fail(ctx, DDK_ERR_NOMEM, "device allocation failed (confidence level flags)");
+    K->need[0] = cxu<uint8_t>(cx, nullptr, 2 * Bm * n_atom); K->need[2] = cxu<uint8_t>(cx, nullptr, 2 * Bm * n_rec);
+    if (!K->flag_a || !K->flag_r || !K->need[0] || !K->need[2]) return fail(ctx, DDK_ERR_NOMEM, "device allocation failed (confidence level flags)");
+    K->need[1] = K->need[0] + Bm * n_atom; K->need[3] = K->need[2] + Bm * n_rec;
     if (!K->e_src || !K->e_dst || !K->e_aux || !K->e_emb || !K->e_sh) return fail(ctx, DDK_ERR_NOMEM, "device allocation failed (confidence edge arrays)");
     // static sets (atom-atom; atom->residue and its flip)
     // ONE copy of the static sets goes up (E_aa + n_atom edges: local endpoints, embedding, SH); a kernel writes the Bm per-sample
@@ -720,9 +844,16 @@ int ddk_complex_set_atoms(ddk_ctx* ctx, ddk_complex* cx, const ddk_atoms_desc* d
     float* d_sh1 = cxu(cx, sh1.data(), sh1.size());
     if (!d_a1 || !d_b1 || !d_emb1 || !d_sh1) return fail(ctx, DDK_ERR_NOMEM, "device allocation failed (confidence static sets)");
     K->st_a = d_a1; K->st_b = d_b1; K->st_emb = d_emb1; K->st_sh = d_sh1;
+    // in-degrees of the static groups (messages are received at edge_src): atoms [aa, 0, ar = 1], residues [rr, 0, ra = its atoms]
+    std::vector<int32_t> dst((size_t)(n_atom + n_rec) * 3, 0);
+    for (int k = 0; k < E_aa; ++k) dst[(size_t)a1[k] * 3]++;
+    for (int i = 0; i < n_atom; ++i) { dst[(size_t)i * 3 + 2] = 1; dst[(size_t)(n_atom + b1[E_aa + i]) * 3 + 2]++; }
+    for (int k = 0; k < cx->E_rr; ++k) dst[(size_t)(n_atom + ei[k]) * 3]++;
+    K->deg_static = cxu(cx, dst.data(), dst.size());
+    if (!K->deg_static) return fail(ctx, DDK_ERR_NOMEM, "device allocation failed (confidence static degrees)");
   }
-  K->n_nodes = Bm * ((int64_t)n_lig + n_atom + n_rec);
-  K->gtab = cxu<int32_t>(cx, nullptr, 128);       // see ConfComplex::gtab ([96..113] level-B table, [114..117] its cursors)
+  K->n_nodes = Bm * (int64_t)n_lig + Bv * ((int64_t)n_atom + n_rec);
+  K->gtab = cxu<int32_t>(cx, nullptr, 160);       // see ConfComplex::gtab
   K->deg_scratch = cxu<int32_t>(cx, nullptr, K->n_nodes);
   K->xa = cxu<float>(cx, nullptr, K->n_nodes * XW); K->xb = cxu<float>(cx, nullptr, K->n_nodes * XW);
   K->sum3 = cxu<float>(cx, nullptr, K->n_nodes * 3 * XW);
@@ -731,11 +862,11 @@ int ddk_complex_set_atoms(ddk_ctx* ctx, ddk_complex* cx, const ddk_atoms_desc* d
     return fail(ctx, DDK_ERR_NOMEM, "device allocation failed in ddk_complex_set_atoms");
   int rcf = cx_stage_flush(ctx, cx);
   if (rcf) return rcf;
-  {   // replicate the static sets for the Bm samples on the device, behind the upload on the upload stream
-    const int64_t atom_base = Bm * n_lig, rec_base = Bm * ((int64_t)n_lig + n_atom);
-    const int64_t tot = Bm * ((int64_t)E_aa + n_atom);
+  {   // replicate the static sets for the Bm + 1 samples on the device, behind the upload on the upload stream
+    const int64_t atom_base = Bm * n_lig, rec_base = atom_base + Bv * n_atom;
+    const int64_t tot = Bv * ((int64_t)E_aa + n_atom);
     hipLaunchKernelGGL(conf_static_replicate_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->up_stream, K->st_a, K->st_b, K->st_emb,
-                       K->st_sh, E_aa, n_atom, n_rec, (int)Bm, atom_base, rec_base, K->off_aa, K->off_ar, K->off_ra, K->e_src, K->e_dst, K->e_emb, K->e_sh);
+                       K->st_sh, E_aa, n_atom, n_rec, (int)Bv, atom_base, rec_base, K->off_aa, K->off_ar, K->off_ra, K->e_src, K->e_dst, K->e_emb, K->e_sh);
     if (hipGetLastError() != hipSuccess) return fail(ctx, DDK_ERR_HIP, "static set replication launch failed");
     hipError_t e = hipEventRecord(cx->ready, ctx->up_stream);
     if (e != hipSuccess) return hip_fail(ctx, e, "event record");
@@ -756,7 +887,7 @@ int ddk_confidence_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float
   { hipError_t we = cx_wait_ready(cx, s); if (we != hipSuccess) return hip_fail(ctx, we, "wait for the complex upload"); }
   const int n_lig = cx->n_lig, n_rec = cx->n_rec, n_atom = K->n_atom;
   const int64_t Bm = cx->max_batch;
-  const int64_t atom_base = Bm * n_lig, rec_base = Bm * ((int64_t)n_lig + n_atom);
+  const int64_t atom_base = Bm * n_lig, rec_base = atom_base + (Bm + 1) * (int64_t)n_atom;      // (+ 1: the virtual ligand-free sample)
   hipError_t e;
 #define CK(x, what) do { e = (x); if (e != hipSuccess) return hip_fail(ctx, e, what); } while (0)
   // ---- dynamic graphs ------------------------------------------------------------------------------
@@ -783,19 +914,32 @@ int ddk_confidence_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float
   LA.e_src = K->e_src; LA.e_dst = K->e_dst; LA.e_emb = K->e_emb; LA.e_sh = K->e_sh;
   hipLaunchKernelGGL(conf_la_kernel, dim3(B, 8), dim3(256), 0, s, LA);
   CK(hipGetLastError(), "la graph");
-  hipLaunchKernelGGL(conf_gtab_kernel, dim3(1), dim3(64), 0, s, K->gtab, cx->info, B, K->E_aa, n_atom, (int)K->off_la, (int)K->off_al,
-                     (int)K->off_aa, (int)K->off_ar, (int)K->off_ra, (int)K->cap_la);
+  hipLaunchKernelGGL(conf_gtab_kernel, dim3(1), dim3(64), 0, s, K->gtab, cx->info, B, (int)Bm, K->E_aa, cx->E_rr, n_atom, (int)K->off_la, (int)K->off_al,
+                     (int)K->off_aa, (int)K->off_ar, (int)K->off_ra, (int)K->off_vrr, (int)K->cap_la);
   CK(hipGetLastError(), "group table");
-  CK(hipMemsetAsync(K->deg3, 0, (size_t)K->n_nodes * 3 * sizeof(int32_t), s), "deg3");
-  hipLaunchKernelGGL(conf_deg_kernel, dim3((unsigned)((K->cap_total + 255) / 256)), dim3(256), 0, s, K->gtab, K->e_src, K->deg3, K->cap_total);
+  // degrees: the static groups' constants, then the ligand-dependent groups (all of them live in front of the static sets)
+  hipLaunchKernelGGL(conf_deg_init_kernel, dim3((unsigned)((K->n_nodes * 3 + 255) / 256)), dim3(256), 0, s, K->deg_static, atom_base, rec_base, K->n_nodes, n_atom,
+                     n_rec, K->deg3);
+  hipLaunchKernelGGL(conf_deg_kernel, dim3((unsigned)((K->off_aa + 255) / 256)), dim3(256), 0, s, K->gtab, K->e_src, K->deg3, K->off_aa);
   CK(hipGetLastError(), "degrees");
+  // the virtual ligand-free sample (atom / residue sample Bm) carries the pose-independent work of the first layers
+  const bool share0 = B > 1 && c.num_conv_layers >= 2 && ctx->layer0_dedup;
+  if (share0 && cx->E_rr > 0) {
+    hipLaunchKernelGGL(conf_vrr_kernel, dim3((unsigned)((cx->E_rr * 8 + 255) / 256)), dim3(256), 0, s, K->gtab, cx->E_rr, (int)(Bm * n_rec), K->off_vrr, K->e_src,
+                       K->e_dst, K->e_emb, K->e_sh);
+    CK(hipGetLastError(), "virtual rec-rec records");
+  }
   // level-A pruning of the second-to-last layer (ddk_set_receptive_field_pruning; needs a layer between the shared layer 0 and the last one)
   const bool pruneA = ctx->prune && c.num_conv_layers >= 3 && cx->E_rr > 0;
+  // layer 1 evaluates a static group only into the receivers whose messages differ from the virtual sample's (needs layer 1 to be a full layer:
+  // not the last one and not one of the two level layers)
+  const bool share1 = share0 && pruneA && c.num_conv_layers >= 5;
   if (pruneA) {
     ConfLevelArgs LV;
     LV.gtab = K->gtab; LV.e_src = K->e_src; LV.e_dst = K->e_dst; LV.e_emb = K->e_emb; LV.e_sh = K->e_sh; LV.flag_a = K->flag_a; LV.flag_r = K->flag_r;
+    LV.fl[0] = K->flag_a; LV.fl[1] = K->flag_a; LV.fl[2] = K->flag_r; LV.fl[3] = K->flag_r; LV.with_virtual = 0;
     LV.B = B; LV.n_atom = n_atom; LV.n_rec = n_rec; LV.E_aa = K->E_aa; LV.E_rr = cx->E_rr; LV.atom_base = atom_base; LV.rec_base = rec_base;
-    LV.off_aa = K->off_aa; LV.off_ar = K->off_ar; LV.off_ra = K->off_ra; LV.off_scr = K->off_scr; LV.Bm = Bm;
+    LV.off_aa = K->off_aa; LV.off_ar = K->off_ar; LV.off_ra = K->off_ra; LV.off_vrr = K->off_vrr; LV.off_scr = K->off_scr; LV.Bm = Bm;
     LV.cursors = K->gtab + 82; LV.tabA = K->gtab + 64;
     CK(hipMemsetAsync(K->flag_a, 0, (size_t)Bm * n_atom, s), "level flags");
     CK(hipMemsetAsync(K->flag_r, 0, (size_t)Bm * n_rec, s), "level flags");
@@ -815,16 +959,37 @@ int ddk_confidence_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float
       LB.tabA = K->gtab + 64; LB.e_dst = K->e_dst; LB.flag_a = fb_a; LB.flag_r = fb_r; LB.atom_base = atom_base; LB.rec_base = rec_base;
       hipLaunchKernelGGL(conf_level_b_flags_kernel, dim3((unsigned)((K->cap_scr + 255) / 256)), dim3(256), 0, s, LB, K->cap_scr);
       ConfLevelArgs L2 = LV;
-      L2.flag_a = fb_a; L2.flag_r = fb_r; L2.off_scr = K->off_scr + K->cap_scr; L2.cursors = K->gtab + 114; L2.tabA = K->gtab + 96;
+      L2.flag_a = fb_a; L2.flag_r = fb_r; L2.fl[0] = fb_a; L2.fl[1] = fb_a; L2.fl[2] = fb_r; L2.fl[3] = fb_r;
+      L2.off_scr = K->off_scr + K->cap_scr; L2.cursors = K->gtab + 114; L2.tabA = K->gtab + 96;
       hipLaunchKernelGGL(conf_level_compact_kernel, dim3(B, 4, 8), dim3(256), 0, s, L2);
       hipLaunchKernelGGL(conf_level_table_kernel, dim3(1), dim3(64), 0, s, L2);
       CK(hipGetLastError(), "level-B compaction");
+    }
+    if (share1) {      // layer 1: need flags from the level-A flags (= the nodes that received a ligand message in layer 0), third scratch region
+      CK(hipMemcpyAsync(K->need[0], K->flag_a, (size_t)Bm * n_atom, hipMemcpyDeviceToDevice, s), "need flags");
+      CK(hipMemcpyAsync(K->need[1], K->flag_a, (size_t)Bm * n_atom, hipMemcpyDeviceToDevice, s), "need flags");
+      CK(hipMemcpyAsync(K->need[2], K->flag_r, (size_t)Bm * n_rec, hipMemcpyDeviceToDevice, s), "need flags");
+      CK(hipMemcpyAsync(K->need[3], K->flag_r, (size_t)Bm * n_rec, hipMemcpyDeviceToDevice, s), "need flags");
+      CK(hipMemsetAsync(K->gtab + 146, 0, 4 * sizeof(int32_t), s), "layer-1 cursors");
+      ConfNeedArgs NA;
+      NA.gtab = K->gtab; NA.e_src = K->e_src; NA.e_dst = K->e_dst; NA.flag_a = K->flag_a; NA.flag_r = K->flag_r;
+      for (int y = 0; y < 4; ++y) NA.need[y] = K->need[y];
+      NA.B = B; NA.n_atom = n_atom; NA.n_rec = n_rec; NA.E_aa = K->E_aa; NA.E_rr = cx->E_rr; NA.atom_base = atom_base; NA.rec_base = rec_base;
+      NA.off_aa = K->off_aa; NA.off_ar = K->off_ar; NA.off_ra = K->off_ra;
+      const int64_t n_st = (int64_t)B * ((int64_t)K->E_aa + 2 * (int64_t)n_atom + cx->E_rr);
+      hipLaunchKernelGGL(conf_need_flags_kernel, dim3((unsigned)((n_st + 255) / 256)), dim3(256), 0, s, NA);
+      ConfLevelArgs L1 = LV;
+      for (int y = 0; y < 4; ++y) L1.fl[y] = K->need[y];
+      L1.with_virtual = 1; L1.off_scr = K->off_scr + 2 * K->cap_scr; L1.cursors = K->gtab + 146; L1.tabA = K->gtab + 128;
+      hipLaunchKernelGGL(conf_level_compact_kernel, dim3(B + 1, 4, 8), dim3(256), 0, s, L1);
+      hipLaunchKernelGGL(conf_level_table_kernel, dim3(1), dim3(64), 0, s, L1);
+      CK(hipGetLastError(), "layer-1 compaction");
     }
   }
   // ---- node features and the conv stack ----------------------------------------------------------
   float *xin = K->xa, *xout = K->xb;
   const int64_t tot = K->n_nodes * XW;
-  hipLaunchKernelGGL(conf_node_init_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, K->lig_x0, K->atom_x0, K->rec_x0, B, (int)Bm,
+  hipLaunchKernelGGL(conf_node_init_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, K->lig_x0, K->atom_x0, K->rec_x0, atom_base, rec_base, K->n_nodes,
                      n_lig, n_atom, n_rec, xin);
   CK(hipGetLastError(), "node init");
   for (int l = 0; l < c.num_conv_layers; ++l) {
@@ -838,13 +1003,19 @@ int ddk_confidence_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float
     a.mode = 1; a.n_groups = 9; a.n_active = last ? 3 : 9; a.n_slots = 3;
     a.slots = 0;
     for (int g = 0; g < 9; ++g) a.slots |= (uint32_t)(g % 3) << (2 * g);
-    const bool share0 = l == 0 && B > 1 && !last && ctx->layer0_dedup;      // pose-independent groups once per batch (conf_gtab_kernel)
-    const bool levelA = pruneA && l == c.num_conv_layers - 2 && !share0;     // only level-A receivers of the static groups
-    const bool levelB = pruneA && c.num_conv_layers >= 4 && l == c.num_conv_layers - 3 && !share0;
-    a.gbeg = K->gtab + (share0 ? 32 : (levelA ? 64 : (levelB ? 96 : 0))); a.gend = a.gbeg + 9;
+    const bool sh0 = share0 && l == 0 && !last;                               // pose-independent groups once per batch, on the virtual sample (conf_gtab_kernel)
+    const bool sh1 = share1 && l == 1;                                        // ... and in layer 1 for the receivers that see no change
+    const bool levelA = pruneA && l == c.num_conv_layers - 2 && !sh0 && !sh1;     // only level-A receivers of the static groups
+    const bool levelB = pruneA && c.num_conv_layers >= 4 && l == c.num_conv_layers - 3 && !sh0 && !sh1;
+    a.gbeg = K->gtab + (sh0 ? 32 : (sh1 ? 128 : (levelA ? 64 : (levelB ? 96 : 0)))); a.gend = a.gbeg + 9;
     CK(launch_conv_fused(L, a, ctx->n_cu, s), "conv_fused (confidence)");
-    hipLaunchKernelGGL(conf_finalize_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, K->sum3, K->deg3, xin, L.bn_mean, L.bn_scale,
-                       L.bn_bias, K->n_nodes, last ? atom_base : K->n_nodes, atom_base, rec_base, L.dout, xout, share0 ? 1 : 0, n_atom, n_rec);
+    ConfFinalizeArgs FA;
+    FA.sum3 = K->sum3; FA.deg3 = K->deg3; FA.x_in = xin; FA.bn_mean = L.bn_mean; FA.bn_scale = L.bn_scale; FA.bn_bias = L.bn_bias;
+    FA.n_nodes = K->n_nodes; FA.n_update = last ? atom_base : K->n_nodes; FA.atom0 = atom_base; FA.rec0 = rec_base;
+    FA.vatom0 = atom_base + Bm * n_atom; FA.vrec0 = rec_base + Bm * n_rec;
+    FA.dout = L.dout; FA.share = sh0 ? 1 : (sh1 ? 2 : 0); FA.n_atom = n_atom; FA.n_rec = n_rec; FA.x_out = xout;
+    for (int y = 0; y < 4; ++y) FA.need[y] = K->need[y];
+    hipLaunchKernelGGL(conf_finalize_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, FA);
     CK(hipGetLastError(), "conf finalize");
     float* t = xin; xin = xout; xout = t;
   }
@@ -874,6 +1045,15 @@ int ddk_debug_conf_counts(ddk_ctx* ctx, ddk_complex* cx, int32_t* out10) {
     return fail(ctx, DDK_ERR_HIP, "gtab read-back failed");
   for (int k = 0; k < 9; ++k) out10[k] = g[9 + k] - g[k];
   out10[9] = g[19];
+  return DDK_OK;
+}
+
+int ddk_debug_conf_table(ddk_ctx* ctx, ddk_complex* cx, int32_t which, int32_t* out9) {
+  if (!ctx || !cx || !cx->conf || !out9 || which < 0 || which > 4) return DDK_ERR_INVALID;
+  int32_t g[18];
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(g, cx->conf->gtab + 32 * which, sizeof(g), hipMemcpyDeviceToHost) != hipSuccess)
+    return fail(ctx, DDK_ERR_HIP, "gtab read-back failed");
+  for (int k = 0; k < 9; ++k) out9[k] = g[9 + k] - g[k];
   return DDK_OK;
 }
 

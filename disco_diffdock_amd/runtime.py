@@ -349,8 +349,14 @@ class Complex:
             raise RuntimeError('ddk: ligand-atom edge capacity overflow')
         return dict(zip(('ll', 'lr', 'la', 'aa', 'al', 'ar', 'rr', 'rl', 'ra'), v[:9]))
 
+    def confidence_table(self, which):
+        """test hook: edges per group of the table layer `which` ran on (0 full, 1 layer 0, 2 level A, 3 level B, 4 layer 1; include/ddk_debug.h)."""
+        out = (C.c_int32 * 9)()
+        self.ctx._check(self.ctx.L.ddk_debug_conf_table(self.ctx.h, self.h, which, out), 'ddk_debug_conf_table')
+        return dict(zip(('ll', 'lr', 'la', 'aa', 'al', 'ar', 'rr', 'rl', 'ra'), list(out)))
+
     def confidence_nodes(self):
-        n = self.max_batch * (self.n_lig + self.n_atom + self.n_rec)
+        n = self.max_batch * self.n_lig + (self.max_batch + 1) * (self.n_atom + self.n_rec)      # (+ the virtual ligand-free sample)
         x, deg = np.zeros((n, 84), np.float32), np.zeros((n, 3), np.int32)
         self.ctx._check(self.ctx.L.ddk_debug_conf_nodes(self.ctx.h, self.h, x.ctypes.data_as(C.c_void_p), deg.ctypes.data_as(C.c_void_p), n), 'ddk_debug_conf_nodes')
         return x, deg

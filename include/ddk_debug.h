@@ -21,9 +21,13 @@ int ddk_debug_read_edges(ddk_ctx* ctx, ddk_complex* cx, int64_t n, int32_t* src,
 
 /* Confidence model (conf.hip), last ddk_confidence_forward of `cx`:
  *   counts: out[0..8] = edges of the nine groups [ll lr la aa al ar rr rl ra], out[9] = ligand-atom edge capacity overflow flag;
- *   nodes:  x [n, 84] features after the conv stack and deg [n, 3] per-slot in-degrees, n = max_batch * (n_lig + n_atom + n_rec);
+ *   nodes:  x [n, 84] features after the conv stack and deg [n, 3] per-slot in-degrees, n = max_batch * n_lig + (max_batch + 1) * (n_atom + n_rec) (atom / residue sample max_batch = the virtual ligand-free sample of conf.hip);
  *   edges:  group table gt[18] (begin[9], end[9]) when gt != NULL, else n edges from `first`: src, dst, emb [n,24], sh [n,4]. */
 int ddk_debug_conf_counts(ddk_ctx* ctx, ddk_complex* cx, int32_t* out);
+/* ... and the group table one of its layers ran on: which = 0 the full table, 1 layer 0 (static groups on the virtual sample), 2 / 3 the level-A / level-B
+ * tables of the second- / third-to-last layer, 4 layer 1 (static groups: the receivers whose messages differ from the virtual sample's + the virtual sample);
+ * out[0..8] = edges per group.  Tables the last forward did not build hold stale or zero counts. */
+int ddk_debug_conf_table(ddk_ctx* ctx, ddk_complex* cx, int32_t which, int32_t* out);
 int ddk_debug_conf_nodes(ddk_ctx* ctx, ddk_complex* cx, float* x, int32_t* deg, int64_t n);
 int ddk_debug_conf_edges(ddk_ctx* ctx, ddk_complex* cx, int64_t first, int64_t n, int32_t* src, int32_t* dst, float* emb, float* sh,
                          int32_t* gt);

@@ -558,14 +558,16 @@ def test_randomize_position_device_wrapper(dev, golden):
         randomize_position_device(gl, False, False, 19.0, torch.device('cpu'))
 
 
-def test_confidence_model_golden(dev, golden):
+@pytest.mark.parametrize('kernel', [0, 1])
+def test_confidence_model_golden(dev, golden, kernel):
     """ddk_confidence_forward == the reference's all-atom confidence model (golden produced by
-    models/all_atom_score_model.py through get_model on the stand-ins) on the same poses; ligand features after the conv stack too."""
+    models/all_atom_score_model.py through get_model on the stand-ins) on the same poses; ligand features after the conv stack too.
+    kernel 0: the default exact three-limb f16 product (k_conv_x.hip, l = 2 row groups included), 1: the fp32-MFMA fallback."""
     from oracle import confidence_ref as cr
     from disco_diffdock_amd.runtime import Context, Complex
     z, c = golden('confidence_paper_model'), complex_from_npz(golden('complex_confidence'))
     cfg = cr.ConfidenceModelConfig()
-    ctx = Context(device=0, all_atoms=1, embedding_scale=10000.0, num_confidence_outputs=2)
+    ctx = Context(device=0, all_atoms=1, embedding_scale=10000.0, num_confidence_outputs=2, conv_kernel=kernel)
     ctx.load_state_dict(cr.random_state_dict(cfg, seed=int(z['seed'])))
     B = int(z['B'])
     cx = Complex(ctx, c, max_batch=B)

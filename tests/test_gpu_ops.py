@@ -113,15 +113,16 @@ def test_fused_conv_equals_unfused_boundary(dev):
     assert rel_err(fused.cpu(), ref) < 2e-5
 
 
+@pytest.mark.parametrize('kernel', [0, 1])
 @pytest.mark.parametrize('l', range(5))
-def test_confidence_conv_layer_vs_oracle(dev, l):
+def test_confidence_conv_layer_vs_oracle(dev, l, kernel):
     """One conv of the all-atom confidence model (e3nn FCTP with sh 0e+1o+2e, BatchNorm, no residual)
-    through ddk_conv_forward in an all-atom context == the oracle's conv layer."""
+    through ddk_conv_forward in an all-atom context == the oracle's conv layer; both conv kernels (0: three-limb f16, 1: fp32 MFMA)."""
     from oracle import confidence_ref as cr, e3nn_lite as o3
     from disco_diffdock_amd.runtime import Context
     cfg = cr.ConfidenceModelConfig()
     P = {k: v for k, v in cr.random_state_dict(cfg, seed=60 + l).items() if k.startswith('conv_layers.')}
-    ctx = Context(device=0, all_atoms=1, embedding_scale=10000.0, num_confidence_outputs=2)
+    ctx = Context(device=0, all_atoms=1, embedding_scale=10000.0, num_confidence_outputs=2, conv_kernel=kernel)
     ctx.load_state_dict(P)
     i_irr, o_irr = cfg.conv_irreps(l)
     din, dout = smr.irreps_dim(i_irr), smr.irreps_dim(o_irr)

@@ -141,3 +141,42 @@ def test_bench_force_dist_runs_the_multi_rank_path_on_rccl(dev):
     assert d['n_gpus'] == 1 and d['value'] > 0
     with open(os.path.join(ROOT, 'gpurun_out', 'bench_force_dist_nccl.json'), 'w') as f:
         json.dump(d, f)
+
+
+def test_confidence_layer1_sharing_equal_full_and_engaged(dev):
+    """Confidence model, layer 1 (conf.hip): the static groups (atom-atom, atom<-residue, residue-residue, residue<-atom) are evaluated only into
+    the receivers whose messages differ from the virtual ligand-free sample's - the receiver or one of its senders received a ligand message in
+    layer 0 - and every other (receiver, group) reads the virtual sample's sum.  Must equal the evaluation in every sample
+    (ddk_debug_set_layer0_dedup(0)) to the atomic-add order noise, and must actually drop work: a pose far from the receptor contributes no static
+    edge at all, poses in the pocket fewer atom-atom edges than the full group."""
+    from oracle import confidence_ref as cr
+    from disco_diffdock_amd import synthetic
+    from disco_diffdock_amd.runtime import Context, Complex
+    c = synthetic.make_complex(41, n_res=120, n_lig=18)
+    synthetic.add_receptor_atoms(c, np.random.default_rng(41))
+    ctx = Context(device=0, all_atoms=1, embedding_scale=10000.0, num_confidence_outputs=2)
+    ctx.load_state_dict(cr.random_state_dict(cr.ConfidenceModelConfig(), seed=9))
+    B, Bm = 5, 7
+    pos = _poses(c, B, np.random.default_rng(12), spread=3.0)
+    pos[2] += 300.0           # one pose far away: none of its atoms / residues receives a ligand message
+    pos = torch.as_tensor(pos).to(dev)
+    cx = Complex(ctx, c, max_batch=Bm)
+    cx.set_atoms(c['atom_x'], c['atom_pos'], c['atom_edge_index'], c['atom_rec_index'])
+    n_atom, E_aa, E_rr = len(c['atom_x']), c['atom_edge_index'].shape[1], c['rec_edge_index'].shape[1]
+    res = {}
+    for on in (True, False):
+        ctx.debug_set_layer0_dedup(on)
+        conf = cx.confidence_forward(pos)
+        res[on] = (conf.cpu(), cx.lig_node_features(B, dev).cpu())
+        if on:
+            full, t0, t1 = cx.confidence_table(0), cx.confidence_table(1), cx.confidence_table(4)
+    ctx.debug_set_layer0_dedup(True)
+    assert rel_err(res[True][0], res[False][0]) < 1e-5 and rel_err(res[True][1], res[False][1]) < 1e-5      # (atomic-add order noise ~1e-6)
+    assert (full['aa'], full['ar'], full['rr'], full['ra']) == (B * E_aa, B * n_atom, B * E_rr, B * n_atom)
+    assert (t0['aa'], t0['ar'], t0['rr'], t0['ra']) == (E_aa, n_atom, E_rr, n_atom)                       # layer 0: the virtual sample only
+    for g in ('ll', 'lr', 'la', 'al', 'rl'):
+        assert t0[g] == full[g] and t1[g] == full[g]                                                     # ligand-dependent groups: untouched
+    # layer 1: the virtual sample + at most the four poses near the receptor; the atom-atom group (5 A neighbourhoods) drops most of its edges
+    assert E_aa < t1['aa'] < E_aa + (B - 1) * E_aa * 0.9, (t1, E_aa)
+    for g, n1 in (('ar', n_atom), ('rr', E_rr), ('ra', n_atom)):
+        assert n1 <= t1[g] <= n1 + (B - 1) * n1, (g, t1)

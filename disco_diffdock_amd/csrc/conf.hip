@@ -269,6 +269,7 @@ struct LaArgs {
   float *e_emb, *e_sh;
 };
 
+constexpr int COMPACT_SLICES = 32;      // z blocks of conf_level_compact_kernel
 constexpr int LA_LIST = 256;      // per-wave list of the receptor atoms found around one ligand atom (flushed when fewer than 64 slots are left)
 
 // ligand-atom edges: radius(atom.pos, lig.pos, lig_max_radius) (all_atom_score_model.py:413-420) -> group la (src ligand atom,
@@ -477,7 +478,9 @@ __global__ __launch_bounds__(256) void conf_level_compact_kernel(ConfLevelArgs A
                       : (y == 2 ? (virt ? A.off_vrr : (int64_t)A.gtab[6] + (int64_t)b * A.E_rr) : A.off_ra + bs * A.n_atom));
   const uint8_t* fl = A.fl[y];
   const int64_t nb = y < 2 ? A.atom_base : A.rec_base;
-  const int n_sl = (n + gridDim.z - 1) / gridDim.z, s0 = min((int)blockIdx.z * n_sl, n), s1 = min(s0 + n_sl, n);
+  // slices of at least one 256-edge chunk (the kernel is latency bound - a chunk is four dependent memory round trips -, so the large atom-atom set
+  // is cut into many short slices; the small sets leave most of their z blocks idle)
+  const int n_sl = max((n + (int)gridDim.z - 1) / (int)gridDim.z, 256), s0 = min((int)blockIdx.z * n_sl, n), s1 = min(s0 + n_sl, n);
   if (s0 >= s1) return;
   int cnt = 0;
   if (virt) cnt = (s1 - s0 + 255 - tid) / 256;
@@ -546,11 +549,22 @@ __global__ void conf_deg_init_kernel(const int32_t* deg_static, int64_t atom0, i
 }
 __global__ void conf_deg_kernel(const int32_t* gtab, const int32_t* e_src, int32_t* deg3, int64_t n_dyn) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n_dyn) return;
+  const int lane = threadIdx.x & 63;
   const int gid[5] = {0, 1, 2, 4, 7};
-  for (int q = 0; q < 5; ++q) {
-    const int g = gid[q];
-    if (e >= gtab[g] && e < gtab[9 + g]) { atomicAdd(deg3 + (size_t)e_src[e] * 3 + (g % 3), 1); return; }
+  int key = -1 - lane;                     // (distinct negative keys: lanes outside every group never join a run)
+  if (e < n_dyn)
+    for (int q = 0; q < 5; ++q) {
+      const int g = gid[q];
+      if (e >= gtab[g] && e < gtab[9 + g]) { key = e_src[e] * 3 + (g % 3); break; }
+    }
+  // the groups are sorted by receiver (or made of runs): one atomic per run of equal (receiver, slot) inside the wave instead of one per edge
+  const int prev = __shfl_up(key, 1, 64);
+  const bool head = lane == 0 || key != prev;
+  const unsigned long long heads = __ballot(head);
+  if (head && key >= 0) {
+    const unsigned long long later = lane == 63 ? 0ull : (heads >> (lane + 1));
+    const int len = later ? __ffsll((long long)later) : 64 - lane;
+    atomicAdd(deg3 + key, len);
   }
 }
 
@@ -946,7 +960,7 @@ int ddk_confidence_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float
     CK(hipMemsetAsync(K->gtab + 82, 0, 4 * sizeof(int32_t), s), "level cursors");
     const int64_t n_mark = K->cap_la + (int64_t)B * n_lig * n_rec;      // upper bounds of the al and rl edge counts
     hipLaunchKernelGGL(conf_level_flags_kernel, dim3((unsigned)((n_mark + 255) / 256)), dim3(256), 0, s, LV);
-    hipLaunchKernelGGL(conf_level_compact_kernel, dim3(B, 4, 8), dim3(256), 0, s, LV);
+    hipLaunchKernelGGL(conf_level_compact_kernel, dim3(B, 4, COMPACT_SLICES), dim3(256), 0, s, LV);
     hipLaunchKernelGGL(conf_level_table_kernel, dim3(1), dim3(64), 0, s, LV);
     CK(hipGetLastError(), "level-A compaction");
     if (c.num_conv_layers >= 4) {      // level B for the third-to-last layer: the same compaction on the wider flag set, second scratch region
@@ -961,7 +975,7 @@ int ddk_confidence_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float
       ConfLevelArgs L2 = LV;
       L2.flag_a = fb_a; L2.flag_r = fb_r; L2.fl[0] = fb_a; L2.fl[1] = fb_a; L2.fl[2] = fb_r; L2.fl[3] = fb_r;
       L2.off_scr = K->off_scr + K->cap_scr; L2.cursors = K->gtab + 114; L2.tabA = K->gtab + 96;
-      hipLaunchKernelGGL(conf_level_compact_kernel, dim3(B, 4, 8), dim3(256), 0, s, L2);
+      hipLaunchKernelGGL(conf_level_compact_kernel, dim3(B, 4, COMPACT_SLICES), dim3(256), 0, s, L2);
       hipLaunchKernelGGL(conf_level_table_kernel, dim3(1), dim3(64), 0, s, L2);
       CK(hipGetLastError(), "level-B compaction");
     }
@@ -981,7 +995,7 @@ int ddk_confidence_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float
       ConfLevelArgs L1 = LV;
       for (int y = 0; y < 4; ++y) L1.fl[y] = K->need[y];
       L1.with_virtual = 1; L1.off_scr = K->off_scr + 2 * K->cap_scr; L1.cursors = K->gtab + 146; L1.tabA = K->gtab + 128;
-      hipLaunchKernelGGL(conf_level_compact_kernel, dim3(B + 1, 4, 8), dim3(256), 0, s, L1);
+      hipLaunchKernelGGL(conf_level_compact_kernel, dim3(B + 1, 4, COMPACT_SLICES), dim3(256), 0, s, L1);
       hipLaunchKernelGGL(conf_level_table_kernel, dim3(1), dim3(64), 0, s, L1);
       CK(hipGetLastError(), "layer-1 compaction");
     }

@@ -18,7 +18,7 @@ class ddk_config(C.Structure):
                 ('tr_sigma_min', C.c_float), ('tr_sigma_max', C.c_float), ('rot_sigma_min', C.c_float),
                 ('rot_sigma_max', C.c_float), ('tor_sigma_min', C.c_float), ('tor_sigma_max', C.c_float),
                 ('device', C.c_int32), ('all_atoms', C.c_int32), ('num_confidence_outputs', C.c_int32),
-                ('confidence_no_batchnorm', C.c_int32), ('conv_kernel', C.c_int32), ('deterministic', C.c_int32)]
+                ('confidence_no_batchnorm', C.c_int32), ('conv_kernel', C.c_int32), ('deterministic', C.c_int32), ('confidence_mode', C.c_int32)]
 
 
 class ddk_complex_desc(C.Structure):
@@ -41,7 +41,7 @@ SYMBOLS = ['ddk_create', 'ddk_destroy', 'ddk_last_error', 'ddk_version', 'ddk_lo
            'ddk_score_forward', 'ddk_se3_update', 'ddk_sample', 'ddk_last_graph_stats', 'ddk_last_node_features',
            'ddk_profile_enable', 'ddk_profile_read', 'ddk_profile_read_forwards', 'ddk_set_latents', 'ddk_set_guidance',
            'ddk_set_keep_receptor_features', 'ddk_randomize_position', 'ddk_complex_set_atoms',
-           'ddk_confidence_forward', 'ddk_pose_metrics', 'ddk_build_graph', 'ddk_set_receptive_field_pruning', 'ddk_ar_logits', 'ddk_ar_decode', 'ddk_confidence_status']
+           'ddk_confidence_forward', 'ddk_score_confidence', 'ddk_pose_metrics', 'ddk_build_graph', 'ddk_set_receptive_field_pruning', 'ddk_ar_logits', 'ddk_ar_decode', 'ddk_confidence_status']
 
 # test hooks (include/ddk_debug.h): not part of the drop-in boundary
 DEBUG_SYMBOLS = ['ddk_debug_export', 'ddk_debug_read_edges', 'ddk_debug_conf_counts', 'ddk_debug_conf_table', 'ddk_debug_conf_nodes', 'ddk_debug_conf_edges', 'ddk_debug_kabsch', 'ddk_debug_axis_angle', 'ddk_debug_set_layer0_dedup', 'ddk_debug_read_patch', 'ddk_debug_split3', 'ddk_debug_conv_trace', 'ddk_debug_pool_stats', 'ddk_debug_set_conv_workgroups']
@@ -77,6 +77,7 @@ def lib():
     L.ddk_randomize_position.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp]
     L.ddk_complex_set_atoms.argtypes = [vp, vp, vp, vp, vp, i32]
     L.ddk_confidence_forward.argtypes = [vp, vp, i32, vp, vp, vp]
+    L.ddk_score_confidence.argtypes = [vp, vp, i32, vp, C.c_float, C.c_float, C.c_float, vp, vp]
     L.ddk_pose_metrics.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp]
     L.ddk_sample.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp]
     L.ddk_last_graph_stats.argtypes = [vp, vp, vp, vp]

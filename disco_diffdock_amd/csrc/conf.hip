@@ -50,9 +50,7 @@ struct ConfModel {
   std::vector<float> rec_lin_w, rec_lin_b;           // linear over ESM[:32]
   std::vector<float> rec_lm_w, rec_lm_b;             // lm_embedding_layer [NS][lm + NS]
   float emb0[SIG];
-  // confidence_predictor (device): W0 [NS][2NS], affine0 [NS] x2, W4 [NS][NS], affine4, W8 [n_out][NS], b8
-  float *w0 = nullptr, *s0 = nullptr, *t0 = nullptr, *w4 = nullptr, *s4 = nullptr, *t4 = nullptr, *w8 = nullptr, *b8 = nullptr;
-  int n_out = 1;
+  ConfPredictorDev pred;      // confidence_predictor (device): W0 [NS][2NS], affine0 [NS] x2, W4 [NS][NS], affine4, W8 [n_out][NS], b8
   bool ready = false;
 };
 
@@ -213,39 +211,46 @@ int conf_model_finalize(ddk_ctx* ctx) {
   if (!load_mlp(ctx, "ar_edge_embedding", 0, "rec", c.rec_max_radius, M->emb0, M->h_ar, nullptr)) return DDK_ERR_INVALID;
   M->sp.tr_sigma = 0.0f; M->sp.rot_sigma = 0.0f; M->sp.tor_sigma = 0.0f;
   M->sp.cross_cutoff = c.dynamic_max_cross ? 20.0f : c.cross_max_distance;       // 3 * complex_t['tr'] + 20 with complex_t = 0
-  // ---- confidence_predictor: Linear, BN1d, ReLU, Dropout, Linear, BN1d, ReLU, Dropout, Linear (:143-153) ----
-  {
-    M->n_out = c.num_confidence_outputs;
-    GET(w0, "confidence_predictor.0.weight", NS, 2 * NS);
-    GET(b0, "confidence_predictor.0.bias", NS);
-    GET(w4, "confidence_predictor.4.weight", NS, NS);
-    GET(b4, "confidence_predictor.4.bias", NS);
-    GET(w8, "confidence_predictor.8.weight", M->n_out, NS);
-    GET(b8, "confidence_predictor.8.bias", M->n_out);
-    auto affine = [&](int idx, const HostTensor* lin_b, std::vector<float>& s, std::vector<float>& t) -> bool {
-      s.assign(NS, 1.f); t = lin_b->data;     // y = s * (W x) + t
-      if (c.confidence_no_batchnorm) return true;
-      const std::string p = "confidence_predictor." + std::to_string(idx);
-      const HostTensor *g = getw(ctx, p + ".weight", {NS}), *be = getw(ctx, p + ".bias", {NS}), *mu = getw(ctx, p + ".running_mean", {NS}),
-                       *var = getw(ctx, p + ".running_var", {NS});
-      if (!g || !be || !mu || !var) return false;
-      for (int o = 0; o < NS; ++o) {
-        s[o] = g->data[o] / sqrtf(var->data[o] + 1e-5f);
-        t[o] = (lin_b->data[o] - mu->data[o]) * s[o] + be->data[o];
-      }
-      return true;
-    };
-    std::vector<float> s0, t0, s4, t4;
-    if (!affine(1, b0, s0, t0) || !affine(5, b4, s4, t4)) return DDK_ERR_INVALID;
-    M->w0 = dev_upload(ctx, w0->data); M->s0 = dev_upload(ctx, s0); M->t0 = dev_upload(ctx, t0);
-    M->w4 = dev_upload(ctx, w4->data); M->s4 = dev_upload(ctx, s4); M->t4 = dev_upload(ctx, t4);
-    M->w8 = dev_upload(ctx, w8->data); M->b8 = dev_upload(ctx, b8->data);
-    if (!M->w0 || !M->s0 || !M->t0 || !M->w4 || !M->s4 || !M->t4 || !M->w8 || !M->b8) return fail(ctx, DDK_ERR_NOMEM, "alloc");
-  }
+  { int rcp = conf_predictor_load(ctx, M->pred); if (rcp) return rcp; }
 #undef GET
   for (int l = 0; l < c.num_conv_layers; ++l)
     if (!ctx->conv[l].has_weights) return fail(ctx, DDK_ERR_INVALID, "confidence checkpoint lacks conv_layers." + std::to_string(9 * l));
   M->ready = true;
+  return DDK_OK;
+}
+
+// ---- confidence_predictor: Linear, BN1d, ReLU, Dropout, Linear, BN1d, ReLU, Dropout, Linear (:143-153; score_model.py:110-121) ----
+int conf_predictor_load(ddk_ctx* ctx, ConfPredictorDev& P) {
+  const ddk_config& c = ctx->cfg;
+  if (c.num_confidence_outputs < 1 || c.num_confidence_outputs > CONF_MAX_OUT) return fail(ctx, DDK_ERR_INVALID, "num_confidence_outputs out of range");
+#define GET(var, name, ...) const HostTensor* var = getw(ctx, name, {__VA_ARGS__}); if (!var) return DDK_ERR_INVALID
+  P.n_out = c.num_confidence_outputs;
+  GET(w0, "confidence_predictor.0.weight", NS, 2 * NS);
+  GET(b0, "confidence_predictor.0.bias", NS);
+  GET(w4, "confidence_predictor.4.weight", NS, NS);
+  GET(b4, "confidence_predictor.4.bias", NS);
+  GET(w8, "confidence_predictor.8.weight", P.n_out, NS);
+  GET(b8, "confidence_predictor.8.bias", P.n_out);
+#undef GET
+  auto affine = [&](int idx, const HostTensor* lin_b, std::vector<float>& s, std::vector<float>& t) -> bool {
+    s.assign(NS, 1.f); t = lin_b->data;     // y = s * (W x) + t
+    if (c.confidence_no_batchnorm) return true;
+    const std::string p = "confidence_predictor." + std::to_string(idx);
+    const HostTensor *g = getw(ctx, p + ".weight", {NS}), *be = getw(ctx, p + ".bias", {NS}), *mu = getw(ctx, p + ".running_mean", {NS}),
+                     *var = getw(ctx, p + ".running_var", {NS});
+    if (!g || !be || !mu || !var) return false;
+    for (int o = 0; o < NS; ++o) {
+      s[o] = g->data[o] / sqrtf(var->data[o] + 1e-5f);
+      t[o] = (lin_b->data[o] - mu->data[o]) * s[o] + be->data[o];
+    }
+    return true;
+  };
+  std::vector<float> s0, t0, s4, t4;
+  if (!affine(1, b0, s0, t0) || !affine(5, b4, s4, t4)) return DDK_ERR_INVALID;
+  P.w0 = dev_upload(ctx, w0->data); P.s0 = dev_upload(ctx, s0); P.t0 = dev_upload(ctx, t0);
+  P.w4 = dev_upload(ctx, w4->data); P.s4 = dev_upload(ctx, s4); P.t4 = dev_upload(ctx, t4);
+  P.w8 = dev_upload(ctx, w8->data); P.b8 = dev_upload(ctx, b8->data);
+  if (!P.w0 || !P.s0 || !P.t0 || !P.w4 || !P.s4 || !P.t4 || !P.w8 || !P.b8) return fail(ctx, DDK_ERR_NOMEM, "alloc");
   return DDK_OK;
 }
 
@@ -657,8 +662,16 @@ __global__ __launch_bounds__(64) void conf_head_kernel(HeadCArgs A) {
     for (int k = 0; k < NS; ++k) a += A.w8[t * NS + k] * h2[k];
     // an overflowed edge list means a truncated graph: the result must not look like a confidence (sampling() maps NaN to -1000 like the
     // reference's nan_to_num, utils/sampling.py:246)
-    A.out[(size_t)b * A.n_out + t] = *A.ovf ? __builtin_nanf("") : a;
+    A.out[(size_t)b * A.n_out + t] = (A.ovf != nullptr && *A.ovf) ? __builtin_nanf("") : a;
   }
+}
+
+hipError_t launch_conf_head(const ConfPredictorDev& P, const float* x, int B, int n_lig, float* out, const int32_t* ovf, hipStream_t s) {
+  HeadCArgs H;
+  H.x = x; H.B = B; H.n_lig = n_lig; H.n_out = P.n_out;
+  H.w0 = P.w0; H.s0 = P.s0; H.t0 = P.t0; H.w4 = P.w4; H.s4 = P.s4; H.t4 = P.t4; H.w8 = P.w8; H.b8 = P.b8; H.out = out; H.ovf = ovf;
+  hipLaunchKernelGGL(conf_head_kernel, dim3(B), dim3(64), 0, s, H);
+  return hipGetLastError();
 }
 
 // per-sample replicas of the static edge sets: aa (src = atom a, dst = atom b), ar (src = atom, dst = its residue) and ra (the flip with
@@ -1035,11 +1048,7 @@ int ddk_confidence_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float
   }
   cx->x_last = xin;
   cx->last_B = B;
-  HeadCArgs H;
-  H.x = xin; H.B = B; H.n_lig = n_lig; H.n_out = M->n_out;
-  H.w0 = M->w0; H.s0 = M->s0; H.t0 = M->t0; H.w4 = M->w4; H.s4 = M->s4; H.t4 = M->t4; H.w8 = M->w8; H.b8 = M->b8; H.out = out; H.ovf = K->gtab + 19;
-  hipLaunchKernelGGL(conf_head_kernel, dim3(B), dim3(64), 0, s, H);
-  CK(hipGetLastError(), "confidence head");
+  CK(launch_conf_head(M->pred, xin, B, n_lig, out, K->gtab + 19, s), "confidence head");
 #undef CK
   return DDK_OK;
 }

@@ -665,7 +665,7 @@ void model_destroy(ddk_ctx* ctx);   // model.hip
 
 extern "C" {
 
-const char* ddk_version(void) { return "ddk 0.4 (gfx950)"; }      // 0.4: three-limb records carry limbs at their own weight + tile descriptors; conv_f16x3 removed (INTEGRATION.md "ABI notes")
+const char* ddk_version(void) { return "ddk 0.5 (gfx950)"; }      // 0.5: ddk_config.confidence_mode + ddk_score_confidence; 0.4: three-limb records carry limbs at their own weight + tile descriptors; conv_f16x3 removed (INTEGRATION.md "ABI notes")
 
 int ddk_create(const ddk_config* cfg, ddk_ctx** out) {
   if (!cfg || !out) return DDK_ERR_INVALID;

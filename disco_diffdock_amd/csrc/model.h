@@ -120,9 +120,21 @@ struct ModelHost {   // host copies needed per forward / per complex
   bool ready = false;
 };
 
+// confidence_predictor of a model in confidence_mode (score_model.py:110-121 / all_atom_score_model.py:143-153):
+// Linear - BatchNorm1d - ReLU - Dropout - Linear - BatchNorm1d - ReLU - Dropout - Linear, the eval-mode BatchNorm folded into y = s (W x) + t
+struct ConfPredictorDev {
+  float *w0 = nullptr, *s0 = nullptr, *t0 = nullptr, *w4 = nullptr, *s4 = nullptr, *t4 = nullptr, *w8 = nullptr, *b8 = nullptr;
+  int n_out = 1;
+};
+int conf_predictor_load(ddk_ctx* ctx, ConfPredictorDev& P);      // conf.hip
+// scatter_mean of [x[:, :ns] | x[:, -ns:]] over every graph's ligand atoms + the predictor; ovf != null: a non-zero word turns the batch into NaN
+hipError_t launch_conf_head(const ConfPredictorDev& P, const float* x, int B, int n_lig, float* out, const int32_t* ovf, hipStream_t s);
+
 struct Model {
   ModelDev dev;
   ModelHost host;
+  bool confidence_mode = false;      // TensorProductScoreModel(confidence_mode=True): no score heads, a confidence_predictor (ddk_score_confidence)
+  ConfPredictorDev pred;
   bool has_ar = false;     // latent_{s,r}_predictor.* tensors were loaded into this context (the AR checkpoint's score-model copy)
   ArMlpDev ar_s, ar_r;
   int ar_ns = 0, ar_H = 0;

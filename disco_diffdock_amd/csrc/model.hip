@@ -128,10 +128,20 @@ int model_finalize(ddk_ctx* ctx) {
   if (!edge_mlp("lig_edge_embedding", 4, true, D.lig_edge, &H.le_w1s, &H.le_b1, nullptr, LE, "lig_edge_unconditional_embedding")) return DDK_ERR_INVALID;
   if (!edge_mlp("rec_edge_embedding", 0, true, D.rec_edge, &H.re_w1s, &H.re_b1, &H.re_w1d, LE, "rec_edge_unconditional_embedding")) return DDK_ERR_INVALID;
   if (!edge_mlp("cross_edge_embedding", 0, true, D.cross_edge, &H.ce_w1s, &H.ce_b1, nullptr, LE, "cross_edge_unconditional_embedding")) return DDK_ERR_INVALID;
-  if (!edge_mlp("center_edge_embedding", 0, false, D.center_edge, &H.cen_w1s, &H.cen_b1, nullptr)) return DDK_ERR_INVALID;
   if (!smearing(ctx, "lig", c.lig_max_radius, D.lig_edge, nullptr, nullptr)) return fail(ctx, DDK_ERR_NOMEM, "alloc");
   if (!smearing(ctx, "rec", c.rec_max_radius, D.rec_edge, &H.rec_offset, &H.rec_coeff)) return fail(ctx, DDK_ERR_NOMEM, "alloc");
   if (!smearing(ctx, "cross", c.cross_max_distance, D.cross_edge, nullptr, nullptr)) return fail(ctx, DDK_ERR_NOMEM, "alloc");
+  M->confidence_mode = c.confidence_mode != 0;
+  if (M->confidence_mode) {
+    // score_model.py:110-121: the confidence_predictor replaces the centre / torsion heads; it reads [x[:, :ns] | x[:, -ns:]] of the ligand rows,
+    // the full-width layout of num_conv_layers >= 3 (:264)
+    if (c.num_conv_layers < 3) return fail(ctx, DDK_ERR_INVALID, "confidence_mode needs num_conv_layers >= 3 (the predictor reads the 0e and 0o scalars)");
+    if (c.latent_dim > 0) return fail(ctx, DDK_ERR_INVALID, "confidence_mode with latent conditioning is not implemented");
+    int rcp = conf_predictor_load(ctx, M->pred);
+    if (rcp) return rcp;
+  }
+  if (!M->confidence_mode) {
+  if (!edge_mlp("center_edge_embedding", 0, false, D.center_edge, &H.cen_w1s, &H.cen_b1, nullptr)) return DDK_ERR_INVALID;
   if (!smearing(ctx, "center", c.center_max_distance, D.center_edge, nullptr, nullptr)) return fail(ctx, DDK_ERR_NOMEM, "alloc");
   // ---- tr / rot head -------------------------------------------------------------------------
   {
@@ -184,6 +194,7 @@ int model_finalize(ddk_ctx* ctx) {
     GET(f3, "tor_final_layer.3.weight", 1, NS);
     D.tf_w0 = dev_upload(ctx, f0->data); D.tf_w3 = dev_upload(ctx, f3->data);
   }
+  }      // (!confidence_mode)
 #undef GET
   for (int l = 0; l < c.num_conv_layers; ++l)
     if (!ctx->conv[l].has_weights) return fail(ctx, DDK_ERR_INVALID, "score model checkpoint lacks conv_layers." + std::to_string(l));
@@ -248,6 +259,7 @@ static void matvec(const std::vector<float>& W, const float* x, int rows, int co
 static int make_step_params(ddk_ctx* ctx, float t_tr, float t_rot, float t_tor, StepParams& sp) {
   const ddk_config& c = ctx->cfg;
   const ModelHost& H = ((Model*)ctx->model)->host;
+  const bool conf_mode = ((Model*)ctx->model)->confidence_mode;
   // sinusoidal_embedding(embedding_scale * t, 32)  (utils/diffusion_utils.py:58-69)
   float emb[SIG];
   const int half = SIG / 2;
@@ -264,6 +276,13 @@ static int make_step_params(ddk_ctx* ctx, float t_tr, float t_rot, float t_tor, 
   matvec(H.le_w1s, emb, NS, SIG, H.le_b1.data(), sp.lig_edge_sigb);
   matvec(H.re_w1s, emb, NS, SIG, H.re_b1.data(), sp.rec_edge_sigb);
   matvec(H.ce_w1s, emb, NS, SIG, H.ce_b1.data(), sp.cross_edge_sigb);
+  if (conf_mode) {
+    // score_model.py:186-189: in confidence_mode complex_t is used as sigma directly (the cross cutoff is 3 t_tr + 20); no heads
+    sp.tr_sigma = t_tr; sp.rot_sigma = t_rot; sp.tor_sigma = t_tor;
+    sp.cross_cutoff = c.dynamic_max_cross ? sp.tr_sigma * 3.0f + 20.0f : c.cross_max_distance;
+    sp.so3_norm = 1.0f; sp.torus_norm_sqrt = 1.0f;
+    return DDK_OK;
+  }
   matvec(H.cen_w1s, emb, NS, SIG, H.cen_b1.data(), sp.center_edge_sigb);
   matvec(H.tr_w0s, emb, NS, SIG, H.tr_b0.data(), sp.tr_sigb);
   matvec(H.rot_w0s, emb, NS, SIG, H.rot_b0.data(), sp.rot_sigb);
@@ -556,6 +575,7 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
   cx->last_B = B;
   cx->last_full = cx->keep_rec;
   cx->sum_clean = !rr0_dirty;       // (a one-layer model leaves the shared rows to the memset of the next forward)
+  if (M->confidence_mode) return DDK_OK;      // no score heads: ddk_score_confidence pools the ligand rows
   // heads: both are tensor-product convolutions -> the fused conv kernel on their own small edge lists (k_heads.hip)
   const bool torsion = !c.no_torsion && tor_out != nullptr && cx->R > 0;
   HeadArgs Hd;
@@ -826,10 +846,26 @@ void ddk_complex_destroy(ddk_ctx* ctx, ddk_complex* cx) {
   delete cx;
 }
 
+int ddk_score_confidence(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* lig_pos, float t_tr, float t_rot, float t_tor, float* out,
+                         void* stream) {
+  int rc = check_model(ctx, cx, B);
+  if (rc) return rc;
+  Model* M = (Model*)ctx->model;
+  if (!M->confidence_mode) return fail(ctx, DDK_ERR_STATE, "ddk_score_confidence needs a context created with confidence_mode = 1");
+  if (!lig_pos || !out) return fail(ctx, DDK_ERR_INVALID, "ddk_score_confidence: null argument");
+  { hipError_t we = cx_wait_ready(cx, (hipStream_t)stream); if (we != hipSuccess) return hip_fail(ctx, we, "wait for the complex upload"); }
+  StepParams sp;
+  if ((rc = make_step_params(ctx, t_tr, t_rot, t_tor, sp))) return rc;
+  if ((rc = score_forward_impl(ctx, cx, B, lig_pos, sp, nullptr, nullptr, nullptr, (hipStream_t)stream))) return rc;
+  hipError_t e = launch_conf_head(M->pred, cx->x_last, B, cx->n_lig, out, nullptr, (hipStream_t)stream);
+  return e == hipSuccess ? DDK_OK : hip_fail(ctx, e, "confidence head");
+}
+
 int ddk_score_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* lig_pos, float t_tr, float t_rot, float t_tor,
                       float* tr_out, float* rot_out, float* tor_out, void* stream) {
   int rc = check_model(ctx, cx, B);
   if (rc) return rc;
+  if (((Model*)ctx->model)->confidence_mode) return fail(ctx, DDK_ERR_STATE, "a confidence_mode context has no score heads (ddk_score_confidence)");
   { hipError_t we = cx_wait_ready(cx, (hipStream_t)stream); if (we != hipSuccess) return hip_fail(ctx, we, "wait for the complex upload"); }
   StepParams sp;
   if ((rc = make_step_params(ctx, t_tr, t_rot, t_tor, sp))) return rc;
@@ -905,6 +941,7 @@ int ddk_sample(ddk_ctx* ctx, ddk_complex* cx, int32_t B, int32_t steps, const fl
                const float* noise_coeff, const float* noise, float* pos, void* stream) {
   int rc = check_model(ctx, cx, B);
   if (rc) return rc;
+  if (((Model*)ctx->model)->confidence_mode) return fail(ctx, DDK_ERR_STATE, "a confidence_mode context has no score heads (ddk_score_confidence)");
   { hipError_t we = cx_wait_ready(cx, (hipStream_t)stream); if (we != hipSuccess) return hip_fail(ctx, we, "wait for the complex upload"); }
   if (steps < 1 || !t || !score_coeff || !noise_coeff || !pos) return fail(ctx, DDK_ERR_INVALID, "ddk_sample: null argument");
   hipStream_t s = (hipStream_t)stream;

@@ -13,8 +13,6 @@ def get_model(args, device, t_to_sigma, no_parallel=False, confidence_mode=False
             raise RuntimeError('ddk: the all-atom model is implemented in confidence_mode only (the all-atom SCORE model is outside the hot path)')
         from .confidence import ConfidenceModel       # utils/model_utils.py:26-27 -> AAScoreModel
         return ConfidenceModel(args, device)
-    if confidence_mode:
-        raise RuntimeError('ddk: confidence_mode is implemented for all-atom checkpoints (all_atoms: true) only')
     g = lambda k, d: getattr(args, k, d)
     if g('latent_dim', 0) > 0 and g('latent_vocab', 0) != 1:
         raise RuntimeError('ddk: latent conditioning is implemented for the equivariant-latent models (latent_vocab == 1) only')
@@ -30,6 +28,8 @@ def get_model(args, device, t_to_sigma, no_parallel=False, confidence_mode=False
         use_old_atom_encoder=g('use_old_atom_encoder', True), latent_dim=g('latent_dim', 0), latent_vocab=g('latent_vocab', 0),
         latent_cross_attention=g('latent_cross_attention', False), latent_droprate=g('latent_droprate', 0),
         embedding_scale=args.embedding_scale,
+        num_confidence_outputs=len(g('rmsd_classification_cutoff', None)) + 1 if isinstance(g('rmsd_classification_cutoff', None), list) else 1,
+        confidence_no_batchnorm=g('confidence_no_batchnorm', False), confidence_dropout=g('confidence_dropout', 0),
         sigma_limits=dict(tr_sigma_min=args.tr_sigma_min, tr_sigma_max=args.tr_sigma_max, rot_sigma_min=args.rot_sigma_min,
                           rot_sigma_max=args.rot_sigma_max, tor_sigma_min=args.tor_sigma_min, tor_sigma_max=args.tor_sigma_max))
     if hasattr(args, 'latent_vocab'):

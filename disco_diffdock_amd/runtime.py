@@ -17,7 +17,7 @@ DEFAULTS = dict(ns=24, nv=6, num_conv_layers=5, sigma_embed_dim=32, distance_emb
                 latent_dim=0, latent_vocab=0, latent_droprate=0.0, lm_embedding_dim=1280,
                 tr_sigma_min=0.1, tr_sigma_max=19.0, rot_sigma_min=0.03, rot_sigma_max=1.55,
                 tor_sigma_min=0.03, tor_sigma_max=3.14, device=0, all_atoms=0, num_confidence_outputs=1, confidence_no_batchnorm=0,
-                conv_kernel=0, deterministic=0)
+                conv_kernel=0, deterministic=0, confidence_mode=0)
 
 
 def config_from_args(args, device=0):
@@ -332,6 +332,16 @@ class Complex:
         self.ctx._check(self.ctx.L.ddk_confidence_forward(self.ctx.h, self.h, B, _ptr(pos), _ptr(out), _stream()), 'ddk_confidence_forward')
         if check:
             self.confidence_counts()      # one host sync per confidence batch: fails loudly if the ligand-atom edge capacity overflowed
+        return out
+
+    def score_confidence(self, pos, t_tr, t_rot, t_tor):
+        """coarse-grained confidence model (ddk_config.confidence_mode) on B poses of this complex at the given complex_t -> [B, num_confidence_outputs]
+        (device); utils/sampling.py:239-240."""
+        pos = pos.contiguous().float().reshape(-1, self.n_lig, 3)
+        B = pos.shape[0]
+        out = torch.empty((B, int(self.ctx.cfg.num_confidence_outputs)), dtype=torch.float32, device=pos.device)
+        self.ctx._check(self.ctx.L.ddk_score_confidence(self.ctx.h, self.h, B, _ptr(pos), float(t_tr), float(t_rot), float(t_tor), _ptr(out), _stream()),
+                        'ddk_score_confidence')
         return out
 
     def confidence_status_async(self):

@@ -263,13 +263,16 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
         raise RuntimeError('ddk: visualisation is outside the accelerated hot path')
     confidence, confidence_loader = None, None
     if confidence_model is not None:      # utils/sampling.py:59-62
+        cg_conf = getattr(confidence_model, 'score_model', confidence_model)
         if confidence_data_list is None:
-            # utils/sampling.py:239-240 evaluates a coarse-grained confidence model (TensorProductScoreModel in confidence_mode, reached by
-            # evaluate.py's use_original_model_cache / transfer_weights flags) on the score batch itself; the device path implements the
-            # all-atom confidence model of the shipped paper_confidence_model only (INTEGRATION.md "Not covered")
-            raise RuntimeError('ddk: the confidence model on the device is the all-atom model and needs confidence_data_list (the score '
-                               'graphs carry no atoms); coarse-grained confidence models (utils/sampling.py:239-240) are not covered')
-        confidence_loader = iter(DataLoader(confidence_data_list, batch_size=batch_size))
+            # utils/sampling.py:239-240: a coarse-grained confidence model (TensorProductScoreModel in confidence_mode, reached by evaluate.py's
+            # use_original_model_cache / transfer_weights flags) evaluated on the score batch itself
+            if not getattr(cg_conf, 'confidence_mode', False):
+                raise RuntimeError('ddk: an all-atom confidence model needs confidence_data_list (the score graphs carry no atoms); only a '
+                                   'coarse-grained confidence model (get_model(args, ..., confidence_mode=True) without all_atoms) runs on the score batch')
+        else:
+            cg_conf = None
+        confidence_loader = iter(DataLoader(confidence_data_list, batch_size=batch_size)) if confidence_data_list is not None else None
         confidence = []
     conf_checks = []
     latent_model = use_latent and getattr(model_args, 'latent_dim', 0) > 0
@@ -321,7 +324,12 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
             else:
                 z = draw_noise(inference_steps, b, cx.R, R, nc, device)
             cx.sample(pos, t_arr, sc, nc, z)
-            if confidence_model is not None:   # utils/sampling.py:230-243: final poses into the all-atom graphs, t = 0
+            if confidence_model is not None and cg_conf is not None:
+                # utils/sampling.py:239-240: the score batch itself at the final poses; its times are the LAST step's (the reference resets them
+                # only in the confidence_data_list branch), which confidence_mode reads as sigmas
+                out = cg_conf.confidence(batch, pos, (float(tr_schedule[-1]), float(rot_schedule[-1]), float(tor_schedule[-1])))
+                confidence.append(out)
+            elif confidence_model is not None:   # utils/sampling.py:230-243: final poses into the all-atom graphs, t = 0
                 cbatch = next(confidence_loader)
                 cbatch['ligand'].pos = pos.reshape(-1, 3)
                 set_time(cbatch, 0, 0, 0, b, confidence_model_args.all_atoms if confidence_model_args is not None else True, device)

@@ -133,15 +133,18 @@ class TensorProductScoreModel(nn.Module):
                  center_max_distance=30, distance_embed_dim=32, cross_distance_embed_dim=32, no_torsion=False,
                  scale_by_sigma=True, use_second_order_repr=False, batch_norm=True, dynamic_max_cross=False, dropout=0.0,
                  lm_embedding_type=None, confidence_mode=False, use_old_atom_encoder=False, latent_dim=0, latent_vocab=32,
-                 latent_cross_attention=False, latent_droprate=0.0, embedding_scale=1000.0, sigma_limits=None, conv_kernel=None, **unused):
+                 latent_cross_attention=False, latent_droprate=0.0, embedding_scale=1000.0, sigma_limits=None, conv_kernel=None,
+                 confidence_dropout=0, confidence_no_batchnorm=False, num_confidence_outputs=1, **unused):
         super().__init__()
         if 'conv_f16x3' in unused or os.environ.get('DDK_CONV_F16X3') is not None:
             # round 2's switch had the opposite sense (1 = the f16 kernel); round 3 replaced it by conv_kernel (0 = exact three-limb f16, the
             # default; 1 = fp32 MFMA).  Swallowing the old spelling would switch kernels silently.
             raise RuntimeError("ddk: the conv_f16x3 option / DDK_CONV_F16X3 variable was replaced by the conv_kernel option "
                                "(0 = exact three-limb f16 product, default; 1 = fp32 MFMA) - see INTEGRATION.md")
-        if sh_lmax != 1 or use_second_order_repr or confidence_mode or use_old_atom_encoder or latent_cross_attention:
+        if sh_lmax != 1 or use_second_order_repr or use_old_atom_encoder or latent_cross_attention:
             raise RuntimeError('ddk implements the sh_lmax=1 first-order score model with the new AtomEncoder only')
+        if confidence_mode and (num_conv_layers < 3 or latent_dim):
+            raise RuntimeError('ddk: confidence_mode of the coarse-grained model needs num_conv_layers >= 3 and no latents')
         if in_lig_edge_features != 4:
             raise RuntimeError('ddk: in_lig_edge_features must be 4')
         lim = sigma_limits or {k: DEFAULTS[k] for k in ('tr_sigma_min', 'tr_sigma_max', 'rot_sigma_min', 'rot_sigma_max',
@@ -156,6 +159,9 @@ class TensorProductScoreModel(nn.Module):
                         scale_by_sigma=int(bool(scale_by_sigma)), no_torsion=int(bool(no_torsion)), batch_norm=int(bool(batch_norm)),
                         latent_dim=int(latent_dim), latent_vocab=int(latent_vocab), latent_droprate=float(latent_droprate),
                         lm_embedding_dim=1280 if lm_embedding_type == 'esm' else 0, **lim)
+        self.confidence_mode = bool(confidence_mode)
+        if confidence_mode:      # models/score_model.py:110-121: no score heads, a confidence_predictor on the pooled ligand scalars (ddk_score_confidence)
+            self.cfg.update(confidence_mode=1, num_confidence_outputs=int(num_confidence_outputs), confidence_no_batchnorm=int(bool(confidence_no_batchnorm)))
         if conv_kernel is not None:      # extra (not in the reference ctor): 1 selects the fp32-MFMA conv kernel (ddk_config.conv_kernel)
             self.cfg['conv_kernel'] = int(conv_kernel)
         self.ctx = Context(device=dev_index, **self.cfg)
@@ -169,10 +175,12 @@ class TensorProductScoreModel(nn.Module):
         c = self.cfg
         ns, sig, dist, lm = c['ns'], c['sigma_embed_dim'], c['distance_embed_dim'], c['lm_embedding_dim']
         spec = dict(score_model_state_dict_spec(ns=ns, nv=c['nv'], num_conv_layers=c['num_conv_layers'], sigma=sig, dist=dist, lm=lm,
-                                                latent_dim=c['latent_dim'], latent_droprate=c['latent_droprate']))
+                                                latent_dim=c['latent_dim'], latent_droprate=c['latent_droprate'],
+                                                confidence_mode=getattr(self, 'confidence_mode', False), num_confidence_outputs=c.get('num_confidence_outputs', 1),
+                                                confidence_no_batchnorm=bool(c.get('confidence_no_batchnorm', 0))))
         if not c['batch_norm']:
             spec = {k: v for k, v in spec.items() if '.batch_norm.' not in k}
-        if c['no_torsion']:
+        if c['no_torsion'] and not getattr(self, 'confidence_mode', False):
             spec = {k: v for k, v in spec.items() if not k.startswith(('final_edge_embedding', 'tor_bond_conv', 'tor_final_layer'))}
         return spec
 
@@ -181,7 +189,9 @@ class TensorProductScoreModel(nn.Module):
         """``nn.Module.load_state_dict`` semantics on the reference key set: with ``strict`` a missing, unexpected or mis-shaped
         key raises; e3nn's internal buffers of real checkpoints (:func:`_is_e3nn_internal`) are ignored.  ``extra``: further tensors
         for the same ddk context (the AR model's predictor weights, already validated by the caller)."""
-        spec = self.expected_state_dict_spec()
+        # (BatchNorm1d's num_batches_tracked counters of the confidence_predictor carry nothing the eval-mode forward reads: optional)
+        spec = {k: v for k, v in self.expected_state_dict_spec().items() if not k.endswith('num_batches_tracked')}
+        state_dict = {k: v for k, v in state_dict.items() if not k.endswith('num_batches_tracked')}
         have, missing, unexpected = check_state_dict(spec, state_dict, strict)
         if extra:
             self.ctx.load_state_dict(extra, finalize=False)
@@ -205,12 +215,25 @@ class TensorProductScoreModel(nn.Module):
         unc = float(lig.unconditional.reshape(-1)[0]) if 'unconditional' in lig else 0.0
         cx.set_latents(lig.latent_h.to(self.device), rec.latent_h.to(self.device), unc)
 
+    def confidence(self, data, pos, t):
+        """confidence_mode: [B] or [B, k] for the poses ``pos`` of the batch's complex at complex_t = ``t`` (three floats, used as sigmas:
+        models/score_model.py:186-189, 263-266).  No host synchronisation (sampling() calls this behind its device loop)."""
+        if not self._loaded:
+            raise RuntimeError('ddk score model: load_state_dict() first')
+        if not pos.is_cuda:
+            raise RuntimeError('ddk score model runs on the GPU only (no CPU fallback)')
+        cx, B = complex_for_batch(data, pos.device, ctx=self.ctx)
+        self.last_complex = cx
+        return cx.score_confidence(pos.reshape(B, -1, 3), *t).squeeze(dim=-1)
+
     def forward(self, data, keep_receptor_features=False):
         if not self._loaded:
             raise RuntimeError('ddk score model: load_state_dict() first')
         pos = data['ligand'].pos
         if not pos.is_cuda:
             raise RuntimeError('ddk score model runs on the GPU only (no CPU fallback)')
+        if self.confidence_mode:
+            return self.confidence(data, pos, [float(data.complex_t[k][0]) for k in ('tr', 'rot', 'tor')])
         cx, B = complex_for_batch(data, pos.device, ctx=self.ctx)
         self._bind_latents(cx, data)
         cx.keep_receptor_features(keep_receptor_features)

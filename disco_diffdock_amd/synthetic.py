@@ -274,7 +274,8 @@ def make_complex(seed, n_res=300, n_lig=None, cutoff=15.0, max_neighbor=24, esm_
     return out
 
 
-def score_model_state_dict_spec(ns=24, nv=6, num_conv_layers=5, sigma=32, dist=32, lm=1280, latent_dim=0, latent_droprate=0.0):
+def score_model_state_dict_spec(ns=24, nv=6, num_conv_layers=5, sigma=32, dist=32, lm=1280, latent_dim=0, latent_droprate=0.0,
+                                confidence_mode=False, num_confidence_outputs=1, confidence_no_batchnorm=False):
     """name -> shape of the DiffDock-S ``score_model.state_dict()`` (171 tensors / 2 107 134 elements); with
     latent_dim = 2, latent_droprate > 0 the DisCo-DiffDock-S layout (176 tensors / 2 107 638 elements: + latent_dim node columns,
     + 2 latent_dim edge columns, five unconditional embeddings; models/score_model.py:46-62)."""
@@ -297,7 +298,7 @@ def score_model_state_dict_spec(ns=24, nv=6, num_conv_layers=5, sigma=32, dist=3
     lin('rec_edge_embedding.3', ns, ns)
     lin('cross_edge_embedding.0', ns, sigma + dist + 2 * ld)
     lin('cross_edge_embedding.3', ns, ns)
-    for k in ('lig', 'rec', 'cross', 'center'):
+    for k in ('lig', 'rec', 'cross') + (() if confidence_mode else ('center',)):
         spec[f'{k}_distance_expansion.offset'] = (dist,)
     seq = [(ns, 0, 0, 0), (ns, nv, 0, 0), (ns, nv, nv, 0), (ns, nv, nv, ns)]
     for l in range(num_conv_layers):
@@ -310,6 +311,16 @@ def score_model_state_dict_spec(ns=24, nv=6, num_conv_layers=5, sigma=32, dist=3
         spec[f'conv_layers.{l}.batch_norm.bias'] = (o[0],)
         spec[f'conv_layers.{l}.batch_norm.running_mean'] = (o[0],)
         spec[f'conv_layers.{l}.batch_norm.running_var'] = (sum(o),)
+    if confidence_mode:      # models/score_model.py:110-121: the confidence_predictor replaces the heads
+        lin('confidence_predictor.0', ns, 2 * ns if num_conv_layers >= 3 else ns)
+        lin('confidence_predictor.4', ns, ns)
+        lin('confidence_predictor.8', num_confidence_outputs, ns)
+        if not confidence_no_batchnorm:
+            for i in (1, 5):
+                spec.update({f'confidence_predictor.{i}.weight': (ns,), f'confidence_predictor.{i}.bias': (ns,),
+                             f'confidence_predictor.{i}.running_mean': (ns,), f'confidence_predictor.{i}.running_var': (ns,),
+                             f'confidence_predictor.{i}.num_batches_tracked': ()})
+        return spec
     lin('center_edge_embedding.0', ns, dist + sigma)
     lin('center_edge_embedding.3', ns, ns)
     lin('final_conv.fc.0', 2 * ns, 2 * ns)
@@ -334,18 +345,22 @@ def score_model_state_dict_spec(ns=24, nv=6, num_conv_layers=5, sigma=32, dist=3
     return spec
 
 
-def random_score_model_state_dict(seed=0, latent_dim=0, latent_droprate=0.0):
+def random_score_model_state_dict(seed=0, latent_dim=0, latent_droprate=0.0, **spec_kw):
     """Random-init DiffDock-S (or, with latent_dim = 2 / latent_droprate = 0.1, DisCo-DiffDock-S) weights (PyTorch-default style,
     randomised BatchNorm statistics) - no checkpoints exist offline."""
     import math
     import torch
     g = torch.Generator().manual_seed(seed)
     stops = {'lig': 5.0, 'rec': 30.0, 'cross': 80.0, 'center': 30.0}
-    spec = score_model_state_dict_spec(latent_dim=latent_dim, latent_droprate=latent_droprate)
+    spec = score_model_state_dict_spec(latent_dim=latent_dim, latent_droprate=latent_droprate, **spec_kw)
     P = {}
     for name, shape in spec.items():
         if name.endswith('distance_expansion.offset'):
             P[name] = torch.linspace(0.0, stops[name.split('_')[0]], shape[0])
+        elif name.endswith('num_batches_tracked'):
+            P[name] = torch.zeros((), dtype=torch.long)
+        elif name.startswith('confidence_predictor') and name.split('.')[1] in ('1', '5'):      # BatchNorm1d with randomised statistics
+            P[name] = torch.randn(shape, generator=g) * 0.1 if name.endswith(('running_mean', 'bias')) else torch.rand(shape, generator=g) + 0.5
         elif name.endswith('unconditional_embedding'):
             P[name] = torch.randn(shape, generator=g) * 0.1
         elif 'atom_embedding_list' in name:

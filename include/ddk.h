@@ -62,6 +62,11 @@ typedef struct ddk_config {
    *    0 (default): wave-level segmented sums + fp32 atomics on the run tails (~1e-7 relative run-to-run noise).  Applies to
    *    ddk_score_forward / ddk_sample; ddk_conv_forward (caller-ordered edges) keeps the atomics; not with all_atoms. */
   int32_t deterministic;
+  /* 1 (with all_atoms = 0): the coarse-grained model in confidence_mode - TensorProductScoreModel(confidence_mode=True) as
+   *    get_model(args, ..., confidence_mode=True) builds it for a checkpoint without all_atoms (models/score_model.py:110-121, 186-189, 263-266):
+   *    the score model's graph, embeddings and conv stack, complex_t used as sigma directly, no centre / torsion heads, a confidence_predictor
+   *    on the pooled ligand scalars.  Evaluated by ddk_score_confidence; ddk_score_forward / ddk_sample refuse such a context. */
+  int32_t confidence_mode;
 } ddk_config;
 
 /* ---- lifetime ---------------------------------------------------------------------------- */
@@ -136,6 +141,14 @@ int ddk_complex_set_atoms(ddk_ctx* ctx, ddk_complex* cx, const ddk_atoms_desc* a
 /* confidence_model(batch) -> [B, num_confidence_outputs]  (utils/sampling.py:230-243 with set_time(..., 0, 0, 0);
  * models/all_atom_score_model.py:203-284): lig_pos [B, n_lig, 3] DEVICE, out [B, num_confidence_outputs] DEVICE. */
 int ddk_confidence_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* lig_pos, float* out, void* stream);
+
+/* confidence_model(complex_graph_batch) of utils/sampling.py:239-240 - the branch WITHOUT confidence_data_list: a coarse-grained confidence
+ * model (ddk_config.confidence_mode) evaluated on the score model's own graphs at the final poses.  The reference does not reset the times in that
+ * branch: (t_tr, t_rot, t_tor) are the LAST step's schedule values, which confidence_mode uses as sigmas (models/score_model.py:186-189).
+ * cx: a complex created in THIS context from the same ddk_complex_desc the score model's was; lig_pos [B, n_lig, 3] DEVICE,
+ * out [B, num_confidence_outputs] DEVICE. */
+int ddk_score_confidence(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* lig_pos, float t_tr, float t_rot, float t_tor, float* out,
+                         void* stream);
 
 /* Status words of the last ddk_confidence_forward of `cx`, copied WITHOUT synchronising: enqueues an asynchronous copy of 20 int32 into
  * host_out (HOST, pinned memory if the copy is to overlap): [0..8] first edge and [9..17] end of the nine edge groups [ll lr la aa al ar

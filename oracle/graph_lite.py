@@ -123,7 +123,9 @@ def collate(data_list):
 class DataLoader:
     def __init__(self, data_list, batch_size=1, shuffle=False, **kw):
         assert not shuffle
-        self.data_list, self.batch_size = list(data_list), batch_size
+        # (a None dataset is legal until the first batch is asked for, as with torch's DataLoader: utils/sampling.py:61 builds
+        # iter(DataLoader(confidence_data_list)) even when confidence_data_list is None)
+        self.data_list, self.batch_size = (list(data_list) if data_list is not None else None), batch_size
 
     def __len__(self):
         return (len(self.data_list) + self.batch_size - 1) // self.batch_size

@@ -54,6 +54,9 @@ class ScoreModelConfig:
     rot_sigma_max: float = 1.55
     tor_sigma_min: float = 0.03
     tor_sigma_max: float = 3.14
+    confidence_mode: bool = False      # score_model.py:110-121, 186-189, 263-266: confidence_predictor instead of the score heads
+    num_confidence_outputs: int = 1
+    confidence_no_batchnorm: bool = False
 
     @staticmethod
     def from_namespace(args):
@@ -331,7 +334,10 @@ def embed(P, cfg, data, dtype=torch.float32, return_graph=False):
         latent_h = (data['ligand'].latent_h.to(dtype), data['receptor'].latent_h.to(dtype))
     else:
         latent_h = None
-    tr_sigma, rot_sigma, tor_sigma = t_to_sigma(*[data.complex_t[k] for k in ('tr', 'rot', 'tor')], cfg)
+    if not cfg.confidence_mode:
+        tr_sigma, rot_sigma, tor_sigma = t_to_sigma(*[data.complex_t[k] for k in ('tr', 'rot', 'tor')], cfg)
+    else:      # score_model.py:186-189: complex_t IS the sigma in confidence_mode
+        tr_sigma, rot_sigma, tor_sigma = [data.complex_t[k] for k in ('tr', 'rot', 'tor')]
 
     lig_node_attr, lig_edge_index, lig_edge_attr, lig_edge_sh, lig_sig = build_lig_conv_graph(data, cfg, latent_h, dtype)
     lig_node_attr = atom_encoder(lig_node_attr, P, 'lig_node_embedding', len(LIG_FEATURE_DIMS))
@@ -466,6 +472,23 @@ def score_model_forward(P, cfg, data, so3_table, torus_table, dtype=torch.float3
 # ---------------------------------------------------------------------------------------------
 # seeded synthetic weights in the reference state_dict layout (SURVEY.md §8b, §8d "Weights")
 # ---------------------------------------------------------------------------------------------
+def confidence_forward(P, cfg, data, dtype=torch.float32):
+    """models/score_model.py:259-266 (TensorProductScoreModel.forward, confidence_mode=True): the pooled ligand scalars through the
+    confidence_predictor (:110-121: Linear, BatchNorm1d, ReLU, Dropout, Linear, BatchNorm1d, ReLU, Dropout, Linear; eval mode)."""
+    assert cfg.confidence_mode
+    ns = cfg.ns
+    lig_node_attr = embed(P, cfg, data, dtype)[0]
+    scalar = torch.cat([lig_node_attr[:, :ns], lig_node_attr[:, -ns:]], dim=1) if cfg.num_conv_layers >= 3 else lig_node_attr[:, :ns]
+    h = scatter(scalar, data['ligand'].batch, dim=0, dim_size=data.num_graphs, reduce='mean')
+    for i_lin, i_bn in ((0, 1), (4, 5)):
+        h = torch.nn.functional.linear(h, P[f'confidence_predictor.{i_lin}.weight'].to(dtype), P[f'confidence_predictor.{i_lin}.bias'].to(dtype))
+        if not cfg.confidence_no_batchnorm:
+            k = f'confidence_predictor.{i_bn}'
+            h = (h - P[f'{k}.running_mean'].to(dtype)) / torch.sqrt(P[f'{k}.running_var'].to(dtype) + 1e-5) * P[f'{k}.weight'].to(dtype) + P[f'{k}.bias'].to(dtype)
+        h = torch.relu(h)
+    return torch.nn.functional.linear(h, P['confidence_predictor.8.weight'].to(dtype), P['confidence_predictor.8.bias'].to(dtype)).squeeze(dim=-1)
+
+
 def state_dict_spec(cfg):
     """name -> shape for ``score_model.state_dict()`` (parameters + BN buffers, no e3nn-internal buffers)."""
     ns, sd, dd, cd = cfg.ns, cfg.sigma_embed_dim, cfg.distance_embed_dim, cfg.cross_distance_embed_dim
@@ -491,7 +514,7 @@ def state_dict_spec(cfg):
     if cfg.latent_droprate > 0:
         for k in ('lig_node', 'rec_node', 'lig_edge', 'rec_edge', 'cross_edge'):
             spec[f'{k}_unconditional_embedding'] = (1, ns)
-    for k, n in (('lig', dd), ('rec', dd), ('cross', cd), ('center', dd)):
+    for k, n in (('lig', dd), ('rec', dd), ('cross', cd)) + (() if cfg.confidence_mode else (('center', dd),)):
         spec[f'{k}_distance_expansion.offset'] = (n,)
     for l in range(cfg.num_conv_layers):
         i_irr, o_irr = cfg.conv_irreps(l)
@@ -500,6 +523,15 @@ def state_dict_spec(cfg):
             lin(f'conv_layers.{l}.fc.{g}.0', 3 * ns, 3 * ns)
             lin(f'conv_layers.{l}.fc.{g}.4', W, 3 * ns)
         _bn_spec(spec, f'conv_layers.{l}.batch_norm', o_irr)
+    if cfg.confidence_mode:      # score_model.py:110-121
+        lin('confidence_predictor.0', ns, 2 * ns if cfg.num_conv_layers >= 3 else ns)
+        lin('confidence_predictor.4', ns, ns)
+        lin('confidence_predictor.8', cfg.num_confidence_outputs, ns)
+        if not cfg.confidence_no_batchnorm:
+            for i in (1, 5):
+                for k in ('weight', 'bias', 'running_mean', 'running_var'):
+                    spec[f'confidence_predictor.{i}.{k}'] = (ns,)
+        return spec
     lin('center_edge_embedding.0', ns, dd + sd)
     lin('center_edge_embedding.3', ns, ns)
     conv_out = cfg.conv_irreps(cfg.num_conv_layers - 1)[1]
@@ -549,7 +581,7 @@ def random_state_dict(cfg, seed=0):
             P[name] = (torch.rand(shape, generator=g) * 2 - 1) * a
         elif name.endswith('unconditional_embedding'):
             P[name] = torch.randn(shape, generator=g) * 0.1
-        elif '.batch_norm.' in name:
+        elif '.batch_norm.' in name or (name.startswith('confidence_predictor') and name.split('.')[1] in ('1', '5')):
             if name.endswith('running_mean'):
                 P[name] = torch.randn(shape, generator=g) * 0.1
             elif name.endswith('running_var') or name.endswith('weight'):

@@ -368,9 +368,73 @@ def confidence_golden():
          seed=77, score_seed=7, conf_seed=31)
 
 
+def cg_confidence_golden():
+    """Tier B: a COARSE-GRAINED confidence model - models/score_model.py in confidence_mode as the reference's get_model(args, ...,
+    confidence_mode=True) builds it from the DiffDock-S yml + rmsd_classification_cutoff (no all_atoms) - evaluated directly and through the
+    reference sampling(confidence_model=..., confidence_data_list=None) (utils/sampling.py:239-240: the score batch itself, times NOT reset)."""
+    np.random.seed(0)
+    torch.manual_seed(0)
+    install_standins()
+    from functools import partial
+    from utils import diffusion_utils, sampling as ref_sampling
+    from utils.model_utils import get_model
+    with open(os.path.join(REF, 'workdir', 'diffdockS_score_model', 'model_parameters.yml')) as f:
+        sargs = Namespace(**yaml.full_load(f))
+    cargs = Namespace(**{**vars(sargs), 'rmsd_classification_cutoff': [2.0, 5.0]})      # three outputs
+    s_t2s = partial(diffusion_utils.t_to_sigma, args=sargs)
+    cmodel = get_model(cargs, torch.device('cpu'), s_t2s, no_parallel=True, confidence_mode=True)
+    csm = cmodel.score_model if hasattr(cmodel, 'score_model') else cmodel
+    ccfg = smr.ScoreModelConfig.from_namespace(cargs)
+    ccfg.confidence_mode, ccfg.num_confidence_outputs = True, 3
+    P = smr.random_state_dict(ccfg, seed=43)
+    sd = csm.state_dict()
+    extra = [k for k in sd if k not in P and not k.endswith('num_batches_tracked') and '.tp.' not in k]
+    assert not extra, extra
+    csm.load_state_dict({**P, **{k: v for k, v in sd.items() if k.endswith('num_batches_tracked')}}, strict=True)      # pins the key layout
+    cmodel.eval()
+    print('CG confidence model state_dict tensors', len(P), 'elements', sum(v.numel() for v in P.values()))
+    c = tiny_complex(17, 40, 12)
+    Bs = 3
+    dl = [to_graph(c) for _ in range(Bs)]
+    rng = np.random.default_rng(5)
+    for d_ in dl:
+        d_['ligand'].pos = d_['ligand'].pos + torch.from_numpy(rng.normal(0, 2.0, size=(1, 3))).float()
+    b = graph_lite.collate(dl)
+    t = (0.3, 0.25, 0.2)
+    diffusion_utils.set_time(b, *t, Bs, False, torch.device('cpu'))
+    with torch.no_grad():
+        conf = csm(b)
+    conf_o = smr.confidence_forward(P, ccfg, b)
+    lig_o = smr.embed(P, ccfg, b)[0]
+    print('reference vs oracle restatement:', float((conf - conf_o).abs().max()))
+    save('cg_confidence_model', pos=b['ligand'].pos, t=np.asarray(t), confidence=conf, lig_node_attr=lig_o, B=Bs, seed=43)
+    save('complex_cg_confidence', **{k: v for k, v in c.items() if k != 'name'})
+    # ---- reference sampling() with the coarse-grained confidence model and confidence_data_list=None
+    smodel = get_model(sargs, torch.device('cpu'), s_t2s, no_parallel=True)
+    sm = smodel.score_model if hasattr(smodel, 'score_model') else smodel
+    sm.load_state_dict(smr.random_state_dict(smr.ScoreModelConfig.from_namespace(sargs), seed=7), strict=True)
+    smodel.eval()
+    steps = 2
+    sched = diffusion_utils.get_t_schedule(steps)
+    dl = [to_graph(c) for _ in range(Bs)]
+    rng = np.random.default_rng(6)
+    for d_ in dl:
+        d_['ligand'].pos = d_['ligand'].pos + torch.from_numpy(rng.normal(0, 1.0, size=(1, 3))).float()
+    pos0 = torch.cat([d_['ligand'].pos for d_ in dl])
+    torch.manual_seed(78)
+    out_list, conf2 = ref_sampling.sampling(dl, smodel, steps, sched, sched, sched, torch.device('cpu'), s_t2s, sargs, batch_size=Bs,
+                                            no_final_step_noise=True, use_latent=False, confidence_model=cmodel, confidence_data_list=None,
+                                            confidence_model_args=cargs, temp_sampling=1.0, temp_psi=0.0, temp_sigma_data=0.5)
+    save('trajectory_cg_confidence', pos0=pos0, pos_out=torch.cat([d_['ligand'].pos for d_ in out_list]), confidence=conf2, steps=steps,
+         seed=78, score_seed=7, conf_seed=43)
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'confidence':
         confidence_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'cg_confidence':
+        cg_confidence_golden()
     else:
         main()
         confidence_golden()
+        cg_confidence_golden()

@@ -180,3 +180,75 @@ def test_confidence_layer1_sharing_equal_full_and_engaged(dev):
     assert E_aa < t1['aa'] < E_aa + (B - 1) * E_aa * 0.9, (t1, E_aa)
     for g, n1 in (('ar', n_atom), ('rr', E_rr), ('ra', n_atom)):
         assert n1 <= t1[g] <= n1 + (B - 1) * n1, (g, t1)
+
+
+def _cg_conf_model(dev, seed):
+    """get_model(args, ..., confidence_mode=True) for a checkpoint WITHOUT all_atoms: the coarse-grained model in confidence_mode
+    (utils/model_utils.py:25-68 -> models/score_model.py:110-121)."""
+    from argparse import Namespace
+    from functools import partial
+    from test_gpu_model import ARGS_S
+    from disco_diffdock_amd.model_utils import get_model
+    from disco_diffdock_amd.diffusion_utils import t_to_sigma
+    cargs = Namespace(**{**vars(ARGS_S), 'rmsd_classification_cutoff': [2.0, 5.0]})
+    cm = get_model(cargs, dev, partial(t_to_sigma, args=ARGS_S), no_parallel=True, confidence_mode=True)
+    cfg = smr.ScoreModelConfig(latent_vocab=64, confidence_mode=True, num_confidence_outputs=3)
+    cm.score_model.load_state_dict(smr.random_state_dict(cfg, seed=seed), strict=True)
+    cm.eval()
+    return cm, cargs
+
+
+def test_cg_confidence_model_golden(dev, golden):
+    """the coarse-grained confidence model on the device (ddk_config.confidence_mode, ddk_score_confidence) == the reference's own
+    models/score_model.py in confidence_mode (golden produced through the reference's get_model on the stand-ins): confidences [B, 3] and the ligand
+    rows after the conv stack, at complex_t = (0.3, 0.25, 0.2) used as sigmas (score_model.py:186-189)."""
+    from helpers import complex_from_npz
+    from disco_diffdock_amd.data import from_arrays, collate
+    from disco_diffdock_amd.diffusion_utils import set_time
+    z, c = golden('cg_confidence_model'), complex_from_npz(golden('complex_cg_confidence'))
+    cm, _ = _cg_conf_model(dev, int(z['seed']))
+    B = int(z['B'])
+    b = collate([from_arrays(c) for _ in range(B)])
+    b['ligand'].pos = torch.as_tensor(z['pos']).float().reshape(-1, 3)
+    b = b.to(dev)
+    set_time(b, *[float(x) for x in z['t']], B, False, dev)
+    conf = cm(b)
+    sm = cm.score_model
+    lig = sm.last_complex.lig_node_features(B, dev)
+    assert rel_err(lig.cpu(), z['lig_node_attr']) < 1e-4
+    assert tuple(conf.shape) == (B, 3) and rel_err(conf.cpu(), z['confidence']) < 1e-4
+    # a confidence_mode context has no score heads: the score entry points refuse it
+    with pytest.raises(RuntimeError, match='confidence_mode'):
+        sm.last_complex.score_forward(b['ligand'].pos.reshape(B, -1, 3), 0.3, 0.3, 0.3)
+    # strict loading: the score model's head keys are unexpected, the predictor's are required
+    bad = smr.random_state_dict(smr.ScoreModelConfig(latent_vocab=64), seed=1)
+    with pytest.raises(RuntimeError):
+        sm.load_state_dict(bad, strict=True)
+
+
+def test_sampling_with_cg_confidence_golden(dev, golden):
+    """utils/sampling.py:239-240: sampling(confidence_model=<coarse-grained model>, confidence_data_list=None) - DiffDock-S reverse diffusion followed
+    by the confidence model on the score batch itself at the last step's times - against the reference's own sampling() output."""
+    from functools import partial
+    from helpers import complex_from_npz
+    from test_gpu_model import ARGS_S, _ref_noise
+    from disco_diffdock_amd.sampling import sampling
+    from disco_diffdock_amd.model_utils import get_model
+    from disco_diffdock_amd.data import from_arrays
+    from disco_diffdock_amd.diffusion_utils import t_to_sigma, get_t_schedule
+    z, c = golden('trajectory_cg_confidence'), complex_from_npz(golden('complex_cg_confidence'))
+    model = get_model(ARGS_S, dev, partial(t_to_sigma, args=ARGS_S), no_parallel=True)
+    model.score_model.load_state_dict(smr.random_state_dict(smr.ScoreModelConfig(latent_vocab=64), seed=int(z['score_seed'])), strict=True)
+    cm, cargs = _cg_conf_model(dev, int(z['conf_seed']))
+    n = len(c['lig_pos'])
+    B, steps = len(z['pos0']) // n, int(z['steps'])
+    dl = [from_arrays(c) for _ in range(B)]
+    for i, d in enumerate(dl):
+        d['ligand'].pos = torch.from_numpy(z['pos0'][i * n:(i + 1) * n])
+    sched = get_t_schedule(steps)
+    noise = [_ref_noise(int(z['seed']), steps, B, int(c['edge_mask'].sum()))]
+    out, conf = sampling(dl, model, steps, sched, sched, sched, dev, partial(t_to_sigma, args=ARGS_S), ARGS_S, batch_size=B,
+                         no_final_step_noise=True, use_latent=False, noise=noise, confidence_model=cm, confidence_data_list=None,
+                         confidence_model_args=cargs, temp_sampling=1.0, temp_psi=0.0, temp_sigma_data=0.5)
+    assert rel_err(torch.cat([d['ligand'].pos for d in out]).cpu(), z['pos_out']) < 1e-4
+    assert tuple(conf.shape) == z['confidence'].shape and rel_err(conf.cpu(), z['confidence']) < 1e-4

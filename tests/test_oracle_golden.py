@@ -322,3 +322,52 @@ def test_sampling_with_confidence_golden(golden, tables):
     b.complex_t = {k: torch.zeros(B) for k in ('tr', 'rot', 'tor')}
     conf = cr.confidence_forward(cr.random_state_dict(ccfg, seed=int(z['conf_seed'])), ccfg, b)
     assert rel_err(conf, z['confidence']) < 1e-4
+
+
+def _cg_conf_cfg():
+    cfg = _cfg_for('diffdockS_score_model')
+    cfg.confidence_mode, cfg.num_confidence_outputs = True, 3
+    return cfg
+
+
+def test_cg_confidence_model_golden(golden):
+    """The oracle's coarse-grained confidence model (score_model_ref.confidence_forward: models/score_model.py in confidence_mode, complex_t used as
+    sigma) reproduces the reference's own model built by get_model(DiffDock-S yml + rmsd_classification_cutoff, confidence_mode=True)."""
+    from oracle import graph_lite
+    z, c = golden('cg_confidence_model'), complex_from_npz(golden('complex_cg_confidence'))
+    cfg = _cg_conf_cfg()
+    P = smr.random_state_dict(cfg, seed=int(z['seed']))
+    assert 'center_edge_embedding.0.weight' not in P and 'final_conv.fc.0.weight' not in P and P['confidence_predictor.8.weight'].shape == (3, 24)
+    B = int(z['B'])
+    b = graph_lite.collate([to_graph(c) for _ in range(B)])
+    b['ligand'].pos = T(z['pos']).float()
+    spr.set_time(b, *[float(x) for x in z['t']], B)
+    assert rel_err(smr.embed(P, cfg, b)[0], z['lig_node_attr']) < 1e-5
+    conf = smr.confidence_forward(P, cfg, b)
+    assert tuple(conf.shape) == (B, 3) and rel_err(conf, z['confidence']) < 1e-5
+
+
+def test_sampling_with_cg_confidence_golden(golden, tables):
+    """Reference sampling(confidence_model=<coarse-grained model>, confidence_data_list=None) (utils/sampling.py:239-240) == the oracle sampler followed
+    by the oracle's confidence model on the score batch at the LAST step's times (the reference does not reset them in this branch)."""
+    from oracle import graph_lite
+    z, c = golden('trajectory_cg_confidence'), complex_from_npz(golden('complex_cg_confidence'))
+    cfg = _cfg_for('diffdockS_score_model')
+    P = smr.random_state_dict(cfg, seed=int(z['score_seed']))
+    n = len(c['lig_pos'])
+    B, steps = len(z['pos0']) // n, int(z['steps'])
+    dl = [to_graph(c) for _ in range(B)]
+    for i, d in enumerate(dl):
+        d['ligand'].pos = T(z['pos0'][i * n:(i + 1) * n])
+    sched = spr.get_t_schedule(steps)
+    torch.manual_seed(int(z['seed']))
+    out, _ = spr.sampling(dl, P, cfg, tables[0], tables[1], steps, sched, sched, sched, batch_size=B, no_final_step_noise=True,
+                          temp_sampling=1.0, temp_psi=0.0, temp_sigma_data=0.5)
+    pos = torch.cat([d['ligand'].pos for d in out])
+    assert rel_err(pos, z['pos_out']) < 1e-4
+    ccfg = _cg_conf_cfg()
+    b = graph_lite.collate([to_graph(c) for _ in range(B)])
+    b['ligand'].pos = pos.float()
+    spr.set_time(b, float(sched[-1]), float(sched[-1]), float(sched[-1]), B)
+    conf = smr.confidence_forward(smr.random_state_dict(ccfg, seed=int(z['conf_seed'])), ccfg, b)
+    assert rel_err(conf, z['confidence']) < 1e-4

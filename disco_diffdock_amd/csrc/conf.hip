@@ -925,8 +925,10 @@ int ddk_confidence_forward(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float
   G.lig_r2 = c.lig_max_radius * c.lig_max_radius; G.cross_cutoff = M->sp.cross_cutoff;
   G.counts = cx->counts; G.offs = cx->offs; G.info = cx->info; G.levels = cx->levels; G.e_src = K->e_src; G.e_dst = K->e_dst; G.e_aux = K->e_aux;
   G.deg = K->deg_scratch; G.rec_node_base = (int)rec_base;
+  G.cross_mirror = graph_cross_mirror_fits(n_lig, n_rec);      // lr / rl: one evaluation of the edge MLP per pair
   CK(launch_graph(G, K->cap4, s), "graph");
   EdgeFeatArgs EF;
+  EF.cross_mirror = G.cross_mirror;
   EF.lig_pos = lig_pos; EF.rec_pos = cx->rec_pos; EF.bond_attr = cx->bond_attr; EF.rr_pre1 = cx->rr_pre1; EF.rr_sh = cx->rr_sh;
   EF.e_src = K->e_src; EF.e_dst = K->e_dst; EF.e_aux = K->e_aux; EF.info = cx->info; EF.e_emb = K->e_emb; EF.e_sh = K->e_sh;
   EF.lig = M->lig_edge; EF.rec = M->rec_edge; EF.cross = M->lr_edge; EF.sp = M->sp;

@@ -285,7 +285,8 @@ struct NodePreArgs {
   const uint8_t* rr0_mask = nullptr;         // [n_rec_total] 1: this residue row takes no shared layer-0 rec-rec row (its messages came per sample)
   const uint8_t* levels; int max_level;      // [B * n_rec] receptive-field level of the residues (k_graph.hip) and the deepest one this layer still needs; null: all
 };
-hipError_t launch_node_finalize_pre(const NodePreArgs& a, bool finalize, hipStream_t s);
+struct NodeEmbedArgs;      // model.h
+hipError_t launch_node_finalize_pre(const NodePreArgs& a, bool finalize, hipStream_t s, const NodeEmbedArgs* embed = nullptr);      // embed != null (finalize false): the node embedding first
 hipError_t launch_node_finalize(float* sum, const int32_t* deg, const float* x_in /*[N,XW] or null*/,
                                 const float* bn_mean, const float* bn_scale, const float* bn_bias, int64_t n, int dout,
                                 int out_stride, float* out, hipStream_t s, const float* sum_rr0 = nullptr,

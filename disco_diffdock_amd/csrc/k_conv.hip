@@ -36,6 +36,7 @@
 #include <stdlib.h>
 
 #include "k_conv_common.h"
+#include "model.h"
 
 namespace ddk {
 
@@ -495,8 +496,11 @@ __global__ void node_finalize_kernel(float* sum, const int32_t* deg, const float
 // of one node type, thread t = (role slot t / 72, hidden position t % 72) with its 24 weights in registers; the node scalars are read
 // from LDS as broadcast 16-B words (one LDS instruction per four FMAs).  Bound by the 1152 B per node it writes.
 constexpr int PRE_TILE = 32;
-template <bool FINALIZE>
-__global__ __launch_bounds__(PRE_W) void node_finalize_pre_kernel(NodePreArgs A) {
+// MODE 0: the node terms of the rows of x_out; 1: node_finalize of a layer first; 2: the node embedding first (node_embed_kernel's arithmetic: layer 0's
+// terms without a launch of their own between the embedding and the first conv)
+template <int MODE>
+__global__ __launch_bounds__(PRE_W) void node_finalize_pre_kernel(NodePreArgs A, NodeEmbedArgs E) {
+  constexpr bool FINALIZE = MODE == 1;
   __shared__ __attribute__((aligned(16))) float xs[PRE_TILE][NS];
   __shared__ unsigned char dead[PRE_TILE];      // residues outside the heads' backward receptive field at this depth: nothing reads their rows
   const int tid = threadIdx.x;
@@ -561,6 +565,33 @@ __global__ __launch_bounds__(PRE_W) void node_finalize_pre_kernel(NodePreArgs A)
       *reinterpret_cast<float4*>(A.x_out + r * XW + c) = o;
       if (c < NS) *reinterpret_cast<float4*>(&xs[n][c]) = o;
     }
+  } else if (MODE == 2) {
+    // AtomEncoder's static part + the per-step sigma part (+ latent columns), zero padded to XW (k_graph.hip: node_embed_kernel)
+    constexpr int XW4 = XW / 4;
+    for (int idx = tid; idx < cnt * XW4; idx += PRE_W) {
+      const int n = idx / XW4, c = 4 * (idx - n * XW4);
+      const int64_t r = node0 + n;
+      float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (c < NS) {
+        const float* st = lig ? E.lig_static + (r % E.n_lig) * NS : E.rec_static + ((r - A.n_lig_total) % E.n_rec) * NS;
+        const float* sg = lig ? E.sp.lig_node_sig : E.sp.rec_node_sig;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = st[c + k] + sg[c + k];
+        if (E.latent_dim > 0) {
+          const float* lat = lig ? E.lig_latent + r * E.latent_dim : E.rec_latent + (r - A.n_lig_total) * E.latent_dim;
+          const float* u = lig ? E.lig_unc : E.rec_unc;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float* w = (lig ? E.lig_w_lat : E.rec_w_lat) + (c + k) * E.latent_dim;
+            for (int j = 0; j < E.latent_dim; ++j) v[k] += w[j] * lat[j];
+            if (u != nullptr) v[k] += E.unconditional * u[c + k];
+          }
+        }
+      }
+      const float4 o = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(A.x_out + r * XW + c) = o;
+      if (c < NS) *reinterpret_cast<float4*>(&xs[n][c]) = o;
+    }
   } else {
     for (int idx = tid; idx < cnt * NS; idx += PRE_W) {
       const int n = idx / NS, c = idx - n * NS;
@@ -585,11 +616,14 @@ __global__ __launch_bounds__(PRE_W) void node_finalize_pre_kernel(NodePreArgs A)
   }
 }
 
-hipError_t launch_node_finalize_pre(const NodePreArgs& a, bool finalize, hipStream_t s) {
+hipError_t launch_node_finalize_pre(const NodePreArgs& a, bool finalize, hipStream_t s, const NodeEmbedArgs* embed) {
   const int tiles = (a.n_lig_total + PRE_TILE - 1) / PRE_TILE + (a.n_rec_total + PRE_TILE - 1) / PRE_TILE;
   if (tiles == 0) return hipSuccess;
-  if (finalize) hipLaunchKernelGGL(node_finalize_pre_kernel<true>, dim3(tiles), dim3(PRE_W), 0, s, a);
-  else hipLaunchKernelGGL(node_finalize_pre_kernel<false>, dim3(tiles), dim3(PRE_W), 0, s, a);
+  NodeEmbedArgs e = {};
+  if (embed) e = *embed;
+  if (finalize) hipLaunchKernelGGL(node_finalize_pre_kernel<1>, dim3(tiles), dim3(PRE_W), 0, s, a, e);
+  else if (embed) hipLaunchKernelGGL(node_finalize_pre_kernel<2>, dim3(tiles), dim3(PRE_W), 0, s, a, e);
+  else hipLaunchKernelGGL(node_finalize_pre_kernel<0>, dim3(tiles), dim3(PRE_W), 0, s, a, e);
   return hipGetLastError();
 }
 

@@ -239,7 +239,7 @@ __device__ void write_group_tables(const GraphArgs& G, const int* tot) {
   int bs = 0;
   G.info[I_FB] = 0;
   for (int g = 0; g < 5; ++g) {
-    bs += ((g < 4 ? go[g + 1] - go[g] : n_shared) + 255) / 256;
+    bs += (g == 3 && G.cross_mirror) ? 0 : ((g < 4 ? go[g + 1] - go[g] : n_shared) + 255) / 256;      // (mirror: the lig->rec blocks write the rec->lig features too)
     G.info[I_FB + 1 + g] = bs;
   }
   for (int g = 0; g < 5; ++g) G.info[I_GO + g] = go[g];
@@ -354,6 +354,9 @@ __global__ __launch_bounds__(GT) void graph_fill_kernel(GraphArgs G) {
   float* rp = lp + MAX_LIG * 3;                       // [n_rec*3]
   int* c_rl = reinterpret_cast<int*>(rp + 3 * G.n_rec);   // [n_rec] -> exclusive prefix; later the per-level prefix of the rec-rec edges
   uint8_t* lvl = reinterpret_cast<uint8_t*>(c_rl + G.n_rec);   // [n_rec] receptive-field level of the residue
+  // cross_mirror: bit i of row j = ligand atom i is within the cross cutoff of residue j (the rank of a pair inside the residue's run of the rec->lig group)
+  unsigned long long* cmask = reinterpret_cast<unsigned long long*>(lvl + ((G.n_rec + 15) & ~15));   // [n_rec][LW]
+  const int LW = (G.n_lig + 63) >> 6;
   __shared__ unsigned adj[MAX_LIG][MAX_LIG / 32];
   __shared__ int bdeg[MAX_LIG], odeg[MAX_LIG], c_lr[MAX_LIG], ll_pre[MAX_LIG], lr_pre[MAX_LIG], scan_tmp[GT / 64], lvl_tmp[GT / 64][4], lvl_tot[4];
   // FILL_SLICES workgroups per sample: each repeats the (cheap) counting / prefix phase and writes one slice of the edge list --
@@ -399,8 +402,18 @@ __global__ __launch_bounds__(GT) void graph_fill_kernel(GraphArgs G) {
   for (int j = tid; j < n_rec; j += GT) {
     const float rx = rp[3 * j], ry = rp[3 * j + 1], rz = rp[3 * j + 2];
     int cnt = 0;
+    if (G.cross_mirror) {
+      for (int w = 0; w < LW; ++w) {
+        unsigned long long word = 0ull;
+        const int i1 = min(n_lig, 64 * (w + 1));
+        for (int i = 64 * w; i < i1; ++i) word |= (unsigned long long)(cross_within4(lps[i], rx, ry, rz) ? 1 : 0) << (i & 63);
+        cmask[(size_t)j * LW + w] = word;
+        cnt += __popcll(word);
+      }
+    } else {
 #pragma unroll 4
-    for (int i = 0; i < n_lig; ++i) cnt += cross_within4(lps[i], rx, ry, rz) ? 1 : 0;
+      for (int i = 0; i < n_lig; ++i) cnt += cross_within4(lps[i], rx, ry, rz) ? 1 : 0;
+    }
     c_rl[j] = cnt;
     lvl[j] = G.levels[(size_t)b * n_rec + j];        // receptive-field level, computed by graph_count_kernel
   }
@@ -476,7 +489,13 @@ __global__ __launch_bounds__(GT) void graph_fill_kernel(GraphArgs G) {
       const unsigned long long mask = __ballot(in);
       if (in) {
         const int p = pos + __popcll(mask & ((1ull << lane) - 1ull));
-        G.e_src[p] = lig0 + i; G.e_dst[p] = rec0 + j; G.e_aux[p] = -1;
+        int aux = -1;
+        if (G.cross_mirror) {      // slot of the flipped copy: start of residue j's run (c_rl: exclusive prefix) + the ligand atoms before i in it
+          int rank = __popcll(cmask[(size_t)j * LW + (i >> 6)] & ((1ull << (i & 63)) - 1ull));
+          for (int w = 0; w < (i >> 6); ++w) rank += __popcll(cmask[(size_t)j * LW + w]);
+          aux = g3 + off1 + c_rl[j] + rank;
+        }
+        G.e_src[p] = lig0 + i; G.e_dst[p] = rec0 + j; G.e_aux[p] = aux;
       }
       pos += __popcll(mask);
     }
@@ -610,6 +629,7 @@ __global__ __launch_bounds__(256) void edge_features_kernel(EdgeFeatArgs A) {
 #pragma unroll
   for (int o = 0; o < NS; ++o) h[o] = fmaxf(h[o], 0.0f);
   float* out = A.e_emb + (size_t)e * NS;
+  float* out2 = (g == 1 && A.cross_mirror) ? A.e_emb + (size_t)aux * NS : nullptr;      // the flipped copy carries the SAME embedding and sh (score_model.py:220-223)
   const float uncw = (A.latent_dim > 0 && M.unc != nullptr) ? A.unconditional : 0.0f;
 #pragma unroll
   for (int o4 = 0; o4 < NS / 4; ++o4) {
@@ -624,8 +644,10 @@ __global__ __launch_bounds__(256) void edge_features_kernel(EdgeFeatArgs A) {
       r[q] = a;
     }
     *reinterpret_cast<float4*>(out + 4 * o4) = make_float4(r[0], r[1], r[2], r[3]);
+    if (out2) *reinterpret_cast<float4*>(out2 + 4 * o4) = make_float4(r[0], r[1], r[2], r[3]);
   }
   *reinterpret_cast<float4*>(A.e_sh + 4 * (size_t)e) = shv;
+  if (out2) *reinterpret_cast<float4*>(A.e_sh + 4 * (size_t)aux) = shv;
 }
 
 // node embeddings: static part (categorical embeddings, ESM projection, bias) + the per-step sigma part
@@ -737,6 +759,14 @@ static inline size_t graph_lds_bytes(int n_rec) {
 // of the 160 KB (the attribute is per device: a process-wide "granted so far" would leave every device but the first without it), and
 // report the largest receptor a complex on this device may have - ddk_complex_create refuses more with a message instead of letting every
 // forward fail with a raw launch error.
+static size_t g_graph_dyn[64] = {};      // dynamic LDS the fill kernel may use, per device (graph_prepare_device)
+static inline size_t graph_lds_bytes_mirror(int n_rec, int n_lig) { return graph_lds_bytes(n_rec) + (size_t)n_rec * ((n_lig + 63) / 64) * 8; }
+int graph_cross_mirror_fits(int n_lig, int n_rec) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  return g_graph_dyn[dev] > 0 && graph_lds_bytes_mirror(n_rec, n_lig) <= g_graph_dyn[dev];
+}
+
 hipError_t graph_prepare_device(int* max_rec) {
   hipFuncAttributes a1, a2;
   hipError_t e = hipFuncGetAttributes(&a1, reinterpret_cast<const void*>(&graph_count_kernel));
@@ -750,6 +780,8 @@ hipError_t graph_prepare_device(int* max_rec) {
   int n = MAX_REC;
   while (n > 1 && graph_lds_bytes(n) > dyn) --n;
   *max_rec = n;
+  int dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) g_graph_dyn[dev] = 160 * 1024 - a2.sharedSizeBytes;
   return hipSuccess;
 }
 
@@ -758,7 +790,7 @@ hipError_t launch_graph(const GraphArgs& G, int64_t edge_cap, hipStream_t s) {
   GraphArgs Gc = G;
   Gc.edge_cap = edge_cap;
   hipLaunchKernelGGL(graph_count_kernel, dim3(G.B), dim3(GT), lds, s, Gc);
-  hipLaunchKernelGGL(graph_fill_kernel, dim3(G.B, FILL_SLICES), dim3(GT), lds, s, Gc);
+  hipLaunchKernelGGL(graph_fill_kernel, dim3(G.B, FILL_SLICES), dim3(GT), G.cross_mirror ? graph_lds_bytes_mirror(G.n_rec, G.n_lig) : lds, s, Gc);
   return hipGetLastError();
 }
 

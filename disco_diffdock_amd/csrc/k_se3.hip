@@ -137,13 +137,71 @@ hipError_t launch_debug_axis_angle(const float* aa, int n, float* R_out, hipStre
   return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void se3_update_kernel(Se3Args A) {
+// POST: the workgroup of sample b first finishes the sample's scores from the heads' accumulators - heads_post_kernel's arithmetic (k_heads.hip:
+// tor_bond_conv's mean / BatchNorm / tor_final_layer, final_conv's mean / BatchNorm and the tr / rot magnitude MLPs; same summation orders) - so that
+// a reverse step needs no launch between the head convolutions and the update (ddk_sample without classifier-free guidance)
+template <bool POST>
+__global__ __launch_bounds__(256) void se3_update_kernel(Se3Args A, HeadArgs H) {
   __shared__ float rig[MAX_LIG * 3], flx_a[MAX_LIG * 3], flx2[MAX_LIG * 3];
   __shared__ float upd[6], ctr[3], Rm[9], cA[3], cB[3], Rk[9], tk[3], rot_th[64];
   __shared__ int2 rot_uv[64];
   __shared__ double S[9];
   float* flx = flx_a;
   const int b = blockIdx.x, tid = threadIdx.x, n = A.n_lig, R = A.R;
+  if constexpr (POST) {
+    __shared__ float v48[64][2 * NS], hid[64][NS], g12[12];
+    if (H.prof_out != nullptr && b == (int)gridDim.x - 1 && tid < PROF_INTS) H.prof_out[tid] = H.exec_info[tid];
+    if (A.tor != nullptr && R > 0) {
+      for (int r0 = 0; r0 < R; r0 += 64) {
+        const int chunk = min(64, R - r0);
+        for (int i = tid; i < chunk * 2 * NS; i += 256) {
+          const int rr = i / (2 * NS), c = i - rr * 2 * NS;
+          const int bond = b * R + r0 + rr;
+          float* row = H.h_sum + (size_t)(H.B + bond) * XW;
+          const int ne = H.h_deg[bond];
+          const float sv = row[c] / (float)(ne > 1 ? ne : 1);
+          row[c] = 0.0f;
+          v48[rr][c] = (sv - H.md.tb_bn_mean[c]) * H.md.tb_bn_scale[c] + H.md.tb_bn_bias[c];
+        }
+        __syncthreads();
+        for (int i = tid; i < chunk * NS; i += 256) {      // tor_final_layer: Linear(48,24,no bias) -> tanh -> Linear(24,1,no bias)
+          const int rr = i / NS, k = i - rr * NS;
+          float a = 0.0f;
+          for (int j = 0; j < 2 * NS; ++j) a += H.md.tf_w0[k * 2 * NS + j] * v48[rr][j];
+          hid[rr][k] = H.md.tf_w3[k] * tanhf(a);
+        }
+        __syncthreads();
+        if (tid < chunk) {
+          float o = 0.0f;
+          for (int j = 0; j < NS; ++j) o += hid[tid][j];
+          if (H.scale_by_sigma) o *= H.sp.torus_norm_sqrt;
+          H.tor_out[(size_t)b * R + r0 + tid] = o;
+        }
+        __syncthreads();
+      }
+    }
+    float* row = H.h_sum + (size_t)b * XW;
+    if (tid < 12) {
+      g12[tid] = (row[tid] / (float)H.n_lig) * H.md.fc_bn_scale[tid / 3];
+      row[tid] = 0.0f;
+    }
+    __syncthreads();
+    if (tid < 2) {   // tid 0: translation, tid 1: rotation  (score_model.py:274-286)
+      const int o = 3 * tid;
+      const float px = g12[o] + g12[6 + o], py = g12[o + 1] + g12[7 + o], pz = g12[o + 2] + g12[8 + o];
+      const float nrm = sqrtf(px * px + py * py + pz * pz);
+      const float* w0n = tid == 0 ? H.md.tr_w0n : H.md.rot_w0n;
+      const float* w3 = tid == 0 ? H.md.tr_w3 : H.md.rot_w3;
+      const float* sb = tid == 0 ? H.sp.tr_sigb : H.sp.rot_sigb;
+      float sv = tid == 0 ? H.md.tr_b3 : H.md.rot_b3;
+      for (int k = 0; k < NS; ++k) sv += w3[k] * fmaxf(w0n[k] * nrm + sb[k], 0.0f);
+      float f = sv / nrm;
+      if (H.scale_by_sigma) f = tid == 0 ? f / H.sp.tr_sigma : f * H.sp.so3_norm;
+      float* out = (tid == 0 ? H.tr_out : H.rot_out) + 3 * (size_t)b;
+      out[0] = px * f; out[1] = py * f; out[2] = pz * f;
+    }
+    __syncthreads();      // the scores written above are read back through A.tr / A.rot / A.tor below (same workgroup)
+  }
   const float* nz = A.noise ? A.noise + (size_t)b * (6 + R) : nullptr;
   for (int i = tid; i < n * 3; i += 256) rig[i] = A.pos[(size_t)b * n * 3 + i];
   if (tid < 6) {
@@ -367,8 +425,9 @@ hipError_t launch_cfg_combine(float* score, const float* uncond, float weight, i
   return hipGetLastError();
 }
 
-hipError_t launch_se3(const Se3Args& A, hipStream_t s) {
-  hipLaunchKernelGGL(se3_update_kernel, dim3(A.B), dim3(256), 0, s, A);
+hipError_t launch_se3(const Se3Args& A, hipStream_t s, const HeadArgs* post) {
+  if (post) hipLaunchKernelGGL(se3_update_kernel<true>, dim3(A.B), dim3(256), 0, s, A, *post);
+  else { HeadArgs H = {}; hipLaunchKernelGGL(se3_update_kernel<false>, dim3(A.B), dim3(256), 0, s, A, H); }
   return hipGetLastError();
 }
 

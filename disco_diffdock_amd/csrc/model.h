@@ -167,6 +167,7 @@ struct GraphArgs {
   int rec_node_base = -1;   // node id of sample 0's first residue (-1: B*n_lig, the score model's [lig | rec] numbering)
   int64_t patch_off = -1;   // >= 0: first edge of the DisCo patch group (I_TABX / I_PATCH / I_FBX are maintained)
   int64_t edge_cap = 0;     // capacity of the edge arrays (set by launch_graph)
+  int cross_mirror = 0;     // 1: e_aux of a lig->rec edge = the slot of its flipped copy in the rec->lig group (edge_features_kernel evaluates the pair once); needs graph_cross_mirror_fits
 };
 
 // DisCo layer-0 patches: receivers whose rec-rec messages differ from the shared (sample-0) evaluation
@@ -202,6 +203,7 @@ struct EdgeFeatArgs {
   int rec_node_base = -1;  // -1: n_lig_total
   int n_rec;
   int n_shared = 0;        // edges of the shared rec-rec copy (E_rr or 0)
+  int cross_mirror = 0;    // 1: the lig->rec edges write their features into the flipped copies too (GraphArgs::cross_mirror); the rec->lig group has no feature blocks
   int g2_live_only = 0;    // 1: only the rec-rec edges of the level segments A, B, C get features (no layer evaluates the rest)
   int64_t patch_off = -1;  // >= 0: the DisCo patch group's edges start here (count in info[I_PATCH], feature blocks behind the shared copy's)
   const float* lig_latent; // [B*n_lig, latent_dim] or null
@@ -268,6 +270,7 @@ void conf_model_destroy(ddk_ctx* ctx);
 struct ConfComplex;
 
 hipError_t launch_graph(const GraphArgs& G, int64_t edge_cap, hipStream_t s);
+int graph_cross_mirror_fits(int n_lig, int n_rec);      // k_graph.hip: does the current device's LDS hold the residue x ligand-atom bit matrix of GraphArgs::cross_mirror?
 hipError_t launch_edge_features(const EdgeFeatArgs& A, int64_t edge_cap, hipStream_t s);
 struct NodeEmbedArgs {
   const float* lig_static; const float* rec_static; StepParams sp; int B, n_lig, n_rec; float* x;
@@ -281,7 +284,7 @@ hipError_t launch_complex_static(const RecStaticArgs& R, const int32_t* rr_src, 
 hipError_t launch_zero_fill(void* p, size_t bytes, hipStream_t s);      // k_graph.hip: 16-B stores (hipMemsetAsync's fill kernel is 50x slower at a few MB)
 hipError_t launch_heads_pre(const HeadArgs& A, bool torsion, hipStream_t s);
 hipError_t launch_heads_post(const HeadArgs& A, bool torsion, hipStream_t s);
-hipError_t launch_se3(const Se3Args& A, hipStream_t s);
+hipError_t launch_se3(const Se3Args& A, hipStream_t s, const HeadArgs* post = nullptr);      // post != null: heads_post_kernel's work first, in the same launch
 hipError_t launch_cfg_combine(float* score, const float* uncond, float weight, int64_t n, hipStream_t s);
 
 }  // namespace ddk

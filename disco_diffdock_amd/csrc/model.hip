@@ -427,9 +427,10 @@ static T* cx_upload(ddk_complex* cx, const T* src, size_t n) {
 
 // a6-a8 + the merge of score_model.py:218-225: counts, offsets and the sorted edge list of B poses into the complex' workspace
 static hipError_t build_graph(ddk_ctx* ctx, ddk_complex* cx, int B, const float* lig_pos, float cross_cutoff, bool prune, bool shared_rr,
-                              hipStream_t s, int64_t patch_off = -1) {
+                              hipStream_t s, int64_t patch_off = -1, int cross_mirror = 0) {
   const ddk_config& c = ctx->cfg;
   GraphArgs G;
+  G.cross_mirror = cross_mirror;
   G.lig_pos = lig_pos; G.rec_pos = cx->rec_pos; G.bond_src = cx->bond_src; G.bond_dst = cx->bond_dst;
   G.rr_src = cx->rr_src; G.rr_dst = cx->rr_dst; G.rr_outdeg = cx->rr_outdeg; G.rr_start = cx->rr_start;
   G.prune = prune ? 1 : 0; G.shared_rr = shared_rr ? 1 : 0; G.patch_off = patch_off;
@@ -440,8 +441,9 @@ static hipError_t build_graph(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
   return launch_graph(G, cx->edge_cap, s);
 }
 
+// defer_post != null: the launch that finishes the scores (heads_post) is left to the caller, who hands *defer_post to the SE(3) update's launch
 static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float* lig_pos, const StepParams& sp,
-                              float* tr_out, float* rot_out, float* tor_out, hipStream_t s) {
+                              float* tr_out, float* rot_out, float* tor_out, hipStream_t s, HeadArgs* defer_post = nullptr) {
   const ddk_config& c = ctx->cfg;
   Model* M = (Model*)ctx->model;
   const int n_lig = cx->n_lig, n_rec = cx->n_rec;
@@ -468,8 +470,11 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
   }
   // backward receptive-field pruning of the rec-rec messages (k_graph.hip): off when the caller wants the receptor rows of the last layer
   const bool prune = ctx->prune && !cx->keep_rec && cx->E_rr > 0;
-  CK(build_graph(ctx, cx, B, lig_pos, sp.cross_cutoff, prune, dedup, s, (dedup && patched) ? cx->patch_off : -1), "graph build");
+  // the flipped cross edges carry the same embedding and sh as the lig->rec edges: evaluated once per pair when the fill kernel's LDS holds the pair matrix
+  const int mirror = graph_cross_mirror_fits(n_lig, n_rec);
+  CK(build_graph(ctx, cx, B, lig_pos, sp.cross_cutoff, prune, dedup, s, (dedup && patched) ? cx->patch_off : -1, mirror), "graph build");
   EdgeFeatArgs F;
+  F.cross_mirror = mirror;
   F.lig_pos = lig_pos; F.rec_pos = cx->rec_pos; F.bond_attr = cx->bond_attr; F.rr_pre1 = cx->rr_pre1; F.rr_sh = cx->rr_sh;
   F.e_src = cx->e_src; F.e_dst = cx->e_dst; F.e_aux = cx->e_aux; F.info = cx->info; F.e_emb = cx->e_emb; F.e_sh = cx->e_sh;
   F.lig = M->dev.lig_edge; F.rec = M->dev.rec_edge; F.cross = M->dev.cross_edge; F.sp = sp;
@@ -488,14 +493,15 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
   NE_.lig_static = cx->lig_node_static; NE_.rec_static = cx->rec_node_static; NE_.sp = sp; NE_.B = B; NE_.n_lig = n_lig; NE_.n_rec = n_rec;
   NE_.x = xin; NE_.lig_latent = cx->lig_latent; NE_.rec_latent = cx->rec_latent; NE_.lig_w_lat = M->dev.lig_w_lat; NE_.rec_w_lat = M->dev.rec_w_lat;
   NE_.lig_unc = M->dev.lig_node_unc; NE_.rec_unc = M->dev.rec_node_unc; NE_.unconditional = cx->unconditional; NE_.latent_dim = c.latent_dim;
-  CK(launch_node_embed(NE_, s), "node embed");
-  // per-node terms of layer 0's GEMM1 (ConvLayerDev::wn)
+  // per-node terms of layer 0's GEMM1 (ConvLayerDev::wn): one launch with the node embedding itself
   const bool split = ctx->conv[0].wn != nullptr && cx->pre != nullptr;
   if (split) {
     NodePreArgs PA = {};
     PA.x_out = xin; PA.n_lig_total = B * n_lig; PA.n_rec_total = B * n_rec; PA.n_rec = n_rec;
     PA.wn = ctx->conv[0].wn; PA.bnp = ctx->conv[0].bnp; PA.pre = cx->pre; PA.n_slots = 1; PA.lig_roles = 15; PA.rec_roles = 15;
-    CK(launch_node_finalize_pre(PA, false, s), "node_pre");
+    CK(launch_node_finalize_pre(PA, false, s, &NE_), "node embed + node_pre");
+  } else {
+    CK(launch_node_embed(NE_, s), "node embed");
   }
   // accumulators: node_finalize zeroes what it reads, so a forward that ran to its end leaves them clean for the next one
   if (!cx->sum_clean) {
@@ -610,7 +616,8 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
     CK(hipEventRecord(ctx->ev_join, ctx->head_stream), "head join");
     CK(hipStreamWaitEvent(s, ctx->ev_join, 0), "head join");
   }
-  CK(launch_heads_post(Hd, torsion, s), "heads_post");
+  if (defer_post) *defer_post = Hd;
+  else CK(launch_heads_post(Hd, torsion, s), "heads_post");
 #undef CK
   return DDK_OK;
 }
@@ -955,8 +962,10 @@ int ddk_sample(ddk_ctx* ctx, ddk_complex* cx, int32_t B, int32_t steps, const fl
     if ((rc = make_step_params(ctx, t[3 * k], t[3 * k + 1], t[3 * k + 2], sps[k]))) return rc;
   const size_t n_sc = (size_t)B * (6 + (torsion ? R : 0));
   for (int k = 0; k < steps; ++k) {
-    if ((rc = score_forward_impl(ctx, cx, B, pos, sps[k], tr, rot, torsion ? tor : nullptr, s))) return rc;
-    if (cx->cfg_weight != 0.0f && ctx->cfg.latent_dim > 0 && t[3 * k] <= cx->cfg_start && t[3 * k] >= cx->cfg_end) {
+    const bool guided = cx->cfg_weight != 0.0f && ctx->cfg.latent_dim > 0 && t[3 * k] <= cx->cfg_start && t[3 * k] >= cx->cfg_end;
+    HeadArgs post;
+    if ((rc = score_forward_impl(ctx, cx, B, pos, sps[k], tr, rot, torsion ? tor : nullptr, s, guided ? nullptr : &post))) return rc;
+    if (guided) {
       // second, unconditional forward: unconditional = 1, latents zeroed (sampling.py:119-129)
       const float* ll = cx->lig_latent; const float* rl = cx->rec_latent; const float un = cx->unconditional;
       cx->lig_latent = cx->zero_lat; cx->rec_latent = cx->zero_lat + (size_t)B * cx->n_lig * ctx->cfg.latent_dim; cx->unconditional = 1.0f;
@@ -975,7 +984,7 @@ int ddk_sample(ddk_ctx* ctx, ddk_complex* cx, int32_t B, int32_t steps, const fl
     for (int j = 0; j < 3; ++j) { A.sc[j] = score_coeff[3 * k + j]; A.nc[j] = noise_coeff[3 * k + j]; }
     A.rot_u = cx->rot_u; A.rot_v = cx->rot_v; A.mask_rotate = cx->mask_rotate; A.B = B; A.n_lig = cx->n_lig; A.R = R;
     A.pos_out = pos;       // in place: the workgroup of sample b stages pos[b] in LDS before it writes pos[b] (k_se3.hip)
-    hipError_t e = launch_se3(A, s);
+    hipError_t e = launch_se3(A, s, guided ? nullptr : &post);
     if (e != hipSuccess) return hip_fail(ctx, e, "se3_update launch");
   }
   return DDK_OK;

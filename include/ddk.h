@@ -49,12 +49,13 @@ typedef struct ddk_config {
   int32_t all_atoms;                   /* 1: AAScoreModel in confidence_mode (sh_lmax=2 FCTP, OldAtomEncoder, 9 convs/layer) */
   int32_t num_confidence_outputs;      /* len(rmsd_classification_cutoff)+1 when it is a list, else 1 */
   int32_t confidence_no_batchnorm;
-  /* which matrix pipe the radial-MLP GEMMs (Linear(72,72) + ReLU + Linear(72,W), tensor_layers.py:140-143) of the score model's fused conv
+  /* which matrix pipe the radial-MLP GEMMs (Linear(72,72) + ReLU + Linear(72,W), tensor_layers.py:140-143) of the fused conv
    * kernel run on.  0 (default): the f16 matrix pipe with EXACT fp32 operands - every fp32 weight / activation is split into three fp16 limbs
    *    x = hi + mid + lo (exact for every value within 2^-15 of its range-scaling group's maximum, off by <= 2^-39 of that maximum below),
    *    six of the nine limb products are kept (the dropped ones are <= 3 * 2^-33 relative, below the rounding of the fp32 accumulation
    *    itself), fp32 accumulators (k_conv_x.hip).
-   * 1: v_mfma_f32_32x32x2_f32, plain fp32 FMA chains (k_conv.hip) - the stated fallback; the all-atom confidence model always uses it. */
+   * 1: v_mfma_f32_32x32x2_f32, plain fp32 FMA chains (k_conv.hip) - the stated fallback.  Both apply to the score model and to the all-atom
+   *    confidence model's conv layers. */
   int32_t conv_kernel;
   /* 1: fixed summation order per node in the score model's conv layers and heads (scatter_mean of tensor_layers.py:159): edges are
    *    sorted by the receiving node, so run tails STORE and the runs that straddle 32-edge tiles are folded in tile order by a second

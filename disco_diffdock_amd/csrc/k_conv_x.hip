@@ -237,6 +237,9 @@ __device__ __forceinline__ void tile_epilogue_s(int w0, const f32x16& D, const f
 // four points of the unit's prologue (slots 4-7: unit start, indices + ring staging done, GEMM1 done, limbs + F rows done); ddk_debug_conv_trace,
 // tools/conv_trace.py.  Every stamp costs the wave ~100 cycles (s_memtime round trip): read the spans as upper bounds.
 // MODE 1: the confidence model's l <= 2 tensor product (a third accumulator set for the 1o(x)2e / 1e(x)2e row groups, nine edge groups, three accumulator slots)
+#ifndef X_PROLOGUE_TILES
+#define X_PROLOGUE_TILES 6.5f
+#endif
 template <bool GATHER, bool SPLIT, bool DET, bool TRACE = false, int MODE = 0>
 __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) {
   static_assert(!SPLIT || GATHER, "the GEMM1 split exists for the gather path");
@@ -309,8 +312,11 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
   int split = 1;
   if (rest > 0) {
     float best = 1e30f;
+    // rounds of the last blocks' chunks x the length of a chunk in tile periods: its share of the tiles + the unit prologue every chunk repeats
+    // (gathers, GEMM1, limbs: ~17 k cycles = X_PROLOGUE_TILES tile periods; round 3's rule charged 5 % of a block per extra chunk - a third of the
+    // real cost at 59 tiles - and cut the small launches of the late reverse steps into too many chunks)
     for (int sp = 1; sp <= A.n_cols; ++sp) {
-      const float cost = (float)((rest * sp + nwg - 1) / nwg) / (float)sp * (1.0f + 0.05f * (float)(sp - 1));
+      const float cost = (float)((rest * sp + nwg - 1) / nwg) * ((float)n_tiles / (float)sp + X_PROLOGUE_TILES);
       if (cost < best - 1e-6f) { best = cost; split = sp; }
     }
   }

@@ -495,7 +495,10 @@ __global__ void node_finalize_kernel(float* sum, const int32_t* deg, const float
 // node_finalize of one layer (FINALIZE) + the per-node terms of the NEXT layer's GEMM1 (ConvLayerDev::wn): one workgroup = PRE_TILE nodes
 // of one node type, thread t = (role slot t / 72, hidden position t % 72) with its 24 weights in registers; the node scalars are read
 // from LDS as broadcast 16-B words (one LDS instruction per four FMAs).  Bound by the 1152 B per node it writes.
-constexpr int PRE_TILE = 32;
+#ifndef PRE_TILE_N
+#define PRE_TILE_N 16      // nodes per workgroup: 16 -> 10.2 us, 32 -> 12.5 us, 64 -> 17.9 us, 8 -> 9.7 us per launch at 13 200 nodes (the phase-2 loop is a serial chain per thread)
+#endif
+constexpr int PRE_TILE = PRE_TILE_N;
 // MODE 0: the node terms of the rows of x_out; 1: node_finalize of a layer first; 2: the node embedding first (node_embed_kernel's arithmetic: layer 0's
 // terms without a launch of their own between the embedding and the first conv)
 template <int MODE>

@@ -119,6 +119,15 @@ static bool load_mlp(ddk_ctx* ctx, const char* name, int n_bond, const char* exp
   h.coeff = (float)(-0.5 / (d * d));
   if (dev) {
     dev->w1d = dev_upload(ctx, h.w1d);
+    {
+      std::vector<float> t1((size_t)NS * DE), t2((size_t)NS * NS);
+      for (int o = 0; o < NS; ++o) {
+        for (int k = 0; k < DE; ++k) t1[(size_t)k * NS + o] = h.w1d[(size_t)o * DE + k];
+        for (int k = 0; k < NS; ++k) t2[(size_t)k * NS + o] = w3->data[(size_t)o * NS + k];
+      }
+      dev->w1d_t = dev_upload(ctx, t1); dev->w2_t = dev_upload(ctx, t2);
+      if (!dev->w1d_t || !dev->w2_t) return false;
+    }
     dev->w1b = n_bond ? dev_upload(ctx, h.w1b) : nullptr;
     dev->w2 = dev_upload(ctx, h.w2);
     dev->b2 = dev_upload(ctx, h.b2);
@@ -324,31 +333,34 @@ __global__ __launch_bounds__(256) void conf_la_kernel(LaArgs A) {
         float gs[DE], h[NS];
 #pragma unroll
         for (int k = 0; k < DE; ++k) { const float t = d - A.mlp.offset[k]; gs[k] = expf(A.mlp.coeff * (t * t)); }
+        // input-major weights (EdgeMlpDev::w1d_t / w2_t): one uniform load of an input's 24 weights feeds 24 independent accumulators; the
+        // summation order per output is the row-major form's
 #pragma unroll
-        for (int o = 0; o < NS; ++o) {
-          float a = A.sigb[o];
+        for (int o = 0; o < NS; ++o) h[o] = A.sigb[o];
 #pragma unroll
-          for (int k = 0; k < DE; ++k) a += A.mlp.w1d[o * DE + k] * gs[k];
-          h[o] = fmaxf(a, 0.0f);
+        for (int k = 0; k < DE; ++k) {
+#pragma unroll
+          for (int o = 0; o < NS; ++o) h[o] = fmaf(A.mlp.w1d_t[k * NS + o], gs[k], h[o]);
         }
+#pragma unroll
+        for (int o = 0; o < NS; ++o) h[o] = fmaxf(h[o], 0.0f);
         const int an = A.atom_node_base + b * A.n_atom + j;
         const int64_t e1 = A.off_la + p, e2 = A.off_al + p;
         A.e_src[e1] = ln; A.e_dst[e1] = an;
         A.e_src[e2] = an; A.e_dst[e2] = ln;
         *reinterpret_cast<float4*>(A.e_sh + 4 * e1) = shv;
         *reinterpret_cast<float4*>(A.e_sh + 4 * e2) = shv;
+        float y[NS];
+#pragma unroll
+        for (int o = 0; o < NS; ++o) y[o] = A.mlp.b2[o];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+#pragma unroll
+          for (int o = 0; o < NS; ++o) y[o] = fmaf(A.mlp.w2_t[k * NS + o], h[k], y[o]);
+        }
 #pragma unroll
         for (int o4 = 0; o4 < NS / 4; ++o4) {
-          float r[4];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const int o = 4 * o4 + c;
-            float a = A.mlp.b2[o];
-#pragma unroll
-            for (int k = 0; k < NS; ++k) a += A.mlp.w2[o * NS + k] * h[k];
-            r[c] = a;
-          }
-          const float4 rv = make_float4(r[0], r[1], r[2], r[3]);
+          const float4 rv = make_float4(y[4 * o4], y[4 * o4 + 1], y[4 * o4 + 2], y[4 * o4 + 3]);
           *reinterpret_cast<float4*>(A.e_emb + e1 * NS + 4 * o4) = rv;
           *reinterpret_cast<float4*>(A.e_emb + e2 * NS + 4 * o4) = rv;
         }

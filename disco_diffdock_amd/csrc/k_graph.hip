@@ -600,12 +600,13 @@ __global__ __launch_bounds__(256) void edge_features_kernel(EdgeFeatArgs A) {
       const float t = d - M.offset[k];
       gs[k] = expf(M.coeff * (t * t));
     }
+    // input-major: h[o] += w1d_t[k][o] * gs[k], k ascending (the same summation order per output as the row-major form, 24 independent chains)
 #pragma unroll
-    for (int o = 0; o < NS; ++o) {
-      float a = sigb[o];
+    for (int o = 0; o < NS; ++o) h[o] = sigb[o];
 #pragma unroll
-      for (int k = 0; k < DE; ++k) a += M.w1d[o * DE + k] * gs[k];
-      h[o] = a;
+    for (int k = 0; k < DE; ++k) {
+#pragma unroll
+      for (int o = 0; o < NS; ++o) h[o] = fmaf(M.w1d_t[k * NS + o], gs[k], h[o]);
     }
     if (g == 0 && aux >= 0) {
       const float4 ba = *reinterpret_cast<const float4*>(A.bond_attr + 4 * (size_t)aux);
@@ -631,20 +632,23 @@ __global__ __launch_bounds__(256) void edge_features_kernel(EdgeFeatArgs A) {
   float* out = A.e_emb + (size_t)e * NS;
   float* out2 = (g == 1 && A.cross_mirror) ? A.e_emb + (size_t)aux * NS : nullptr;      // the flipped copy carries the SAME embedding and sh (score_model.py:220-223)
   const float uncw = (A.latent_dim > 0 && M.unc != nullptr) ? A.unconditional : 0.0f;
+  float y[NS];
+#pragma unroll
+  for (int o = 0; o < NS; ++o) y[o] = M.b2[o];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+#pragma unroll
+    for (int o = 0; o < NS; ++o) y[o] = fmaf(M.w2_t[k * NS + o], h[k], y[o]);
+  }
+  if (uncw != 0.0f) {      // + unconditional[src] * *_edge_unconditional_embedding (score_model.py:213-215)
+#pragma unroll
+    for (int o = 0; o < NS; ++o) y[o] += uncw * M.unc[o];
+  }
 #pragma unroll
   for (int o4 = 0; o4 < NS / 4; ++o4) {
-    float r[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int o = 4 * o4 + q;
-      float a = M.b2[o];
-#pragma unroll
-      for (int k = 0; k < NS; ++k) a += M.w2[o * NS + k] * h[k];
-      if (uncw != 0.0f) a += uncw * M.unc[o];     // + unconditional[src] * *_edge_unconditional_embedding (score_model.py:213-215)
-      r[q] = a;
-    }
-    *reinterpret_cast<float4*>(out + 4 * o4) = make_float4(r[0], r[1], r[2], r[3]);
-    if (out2) *reinterpret_cast<float4*>(out2 + 4 * o4) = make_float4(r[0], r[1], r[2], r[3]);
+    const float4 rv = make_float4(y[4 * o4], y[4 * o4 + 1], y[4 * o4 + 2], y[4 * o4 + 3]);
+    *reinterpret_cast<float4*>(out + 4 * o4) = rv;
+    if (out2) *reinterpret_cast<float4*>(out2 + 4 * o4) = rv;
   }
   *reinterpret_cast<float4*>(A.e_sh + 4 * (size_t)e) = shv;
   if (out2) *reinterpret_cast<float4*>(A.e_sh + 4 * (size_t)aux) = shv;

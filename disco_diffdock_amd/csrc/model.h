@@ -62,6 +62,10 @@ struct EdgeMlpDev {
   float coeff;        // GaussianSmearing coeff
   float step;         // offset spacing (offset_k = k*step)
   const float* offset;  // [DE]
+  // the same two weight matrices input-major ([DE][NS], [NS in][NS out]) for edge_features_kernel: a uniform (scalar) load of one input's 24 weights feeds 24
+  // INDEPENDENT accumulators, and consecutive inputs are contiguous (k_graph.hip)
+  const float* w1d_t = nullptr;
+  const float* w2_t = nullptr;
 };
 
 struct ModelDev {

@@ -44,6 +44,13 @@ static bool smearing(ddk_ctx* ctx, const char* name, float stop, EdgeMlpDev& m, 
   return m.offset != nullptr;
 }
 
+static std::vector<float> transpose_rm(const std::vector<float>& w, int rows, int cols_) {      // [rows][cols] -> [cols][rows]
+  std::vector<float> t((size_t)rows * cols_);
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < cols_; ++c) t[(size_t)c * rows + r] = w[(size_t)r * cols_ + c];
+  return t;
+}
+
 int model_finalize(ddk_ctx* ctx) {
   if (ctx->model) { delete (Model*)ctx->model; ctx->model = nullptr; }
   if (ctx->host_only || ctx->weights.find("lig_node_embedding.additional_features_embedder.weight") == ctx->weights.end())
@@ -110,6 +117,8 @@ int model_finalize(ddk_ctx* ctx) {
     std::vector<float> w1d = cols(w0, c_d, c_d + DE);
     if (w1d_host) *w1d_host = w1d;
     m.w1d = dev_upload(ctx, w1d);
+    m.w1d_t = dev_upload(ctx, transpose_rm(w1d, NS, DE));
+    m.w2_t = dev_upload(ctx, transpose_rm(w3->data, NS, NS));
     m.w1b = n_bond ? dev_upload(ctx, cols(w0, 0, n_bond)) : nullptr;
     m.w2 = dev_upload(ctx, w3->data);
     m.b2 = dev_upload(ctx, b3->data);
@@ -122,7 +131,7 @@ int model_finalize(ddk_ctx* ctx) {
     }
     if (w1s) *w1s = cols(w0, c_sig, c_sig + SIG);
     *b1 = b0->data;
-    return m.w1d && m.w2 && m.b2;
+    return m.w1d && m.w2 && m.b2 && m.w1d_t && m.w2_t;
   };
   std::vector<float> fe_b1;
   if (!edge_mlp("lig_edge_embedding", 4, true, D.lig_edge, &H.le_w1s, &H.le_b1, nullptr, LE, "lig_edge_unconditional_embedding")) return DDK_ERR_INVALID;

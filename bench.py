@@ -396,6 +396,11 @@ def main():
             if (k - warmup) % len(mine) == 0 and k > warmup:
                 sm_mod._complex_cache.clear()    # K > #complexes: the second pass over the shard must not hit the cache either
             out, conf = one_call(k)
+            if os.environ.get('DDK_BENCH_TRACE'):
+                print(f'[bench] call {k - warmup} complex {order[k]} n_lig {complexes[order[k]]["lig_pos"].shape[0]} queued', file=sys.stderr, flush=True)
+            if os.environ.get('DDK_BENCH_SYNC'):      # debugging aid: a GPU fault then names the call it belongs to (the timing is meaningless)
+                torch.cuda.synchronize()
+                print(f'[bench] call {k - warmup} complex {order[k]} n_lig {complexes[order[k]]["lig_pos"].shape[0]} ok', file=sys.stderr, flush=True)
             call_ev[k - warmup + 1].record()
             if (k - warmup) % 8 == 0:                # device memory in use (driver query, no synchronisation), sampled every 8th call
                 fr, tot_mem = torch.cuda.mem_get_info(dev)
@@ -422,6 +427,11 @@ def main():
         for p in final.values():
             assert bool(torch.isfinite(p).all()), 'non-finite pose'
         pool1 = ctx.pool_stats()
+        if os.environ.get('DDK_BENCH_TRACE'):
+            fr, tot_mem = torch.cuda.mem_get_info(dev)
+            print('[bench] bracket done: score pool', pool1, 'conf pool', extra['confidence_model'].ctx.pool_stats() if with_conf else None,
+                  'ar pool', extra['ar_model'].score_model.ctx.pool_stats() if disco and hasattr(extra['ar_model'], 'score_model') else None,
+                  'device memory in use GB', round((tot_mem - fr) / 2**30, 1), file=sys.stderr, flush=True)
         stream = {'complexes_created': a.steps, 'distinct_complexes': len(mine),
                   'ligand_atoms_min_max': [int(min(complexes[i]['lig_pos'].shape[0] for i in mine)), int(max(complexes[i]['lig_pos'].shape[0] for i in mine))],
                   'chunk_pool_hipMalloc_in_timed_region': pool1['hipMalloc_calls'] - pool0['hipMalloc_calls'],
@@ -445,7 +455,13 @@ def main():
                 'conv_share_of_wall': conv_ms * 1e-3 / r['elapsed'],
                 'min_cross_edges_per_sample_over_steps': None if cross is None else float(cross.min())}
 
-    head = bracket(poses_all, a.warmup)
+    for _rep in range(int(os.environ.get('DDK_BENCH_REPEAT', '1')) - 1):      # debugging aid: the pocket-bound bracket several times in one process
+        print(f'[bench] repeat {_rep}', file=sys.stderr, flush=True)
+        bracket({i: pocket_poses(complexes[i], np.random.default_rng(1000 + i), SAMPLES) for i in mine}, a.warmup, noise_scale=0.2)
+    if os.environ.get('DDK_BENCH_HEADLINE_POCKET'):      # debugging aid: the pocket-bound workload in the headline's place (with --no-extras: that bracket alone)
+        head = bracket({i: pocket_poses(complexes[i], np.random.default_rng(1000 + i), SAMPLES) for i in mine}, a.warmup, noise_scale=0.2)
+    else:
+        head = bracket(poses_all, a.warmup)
     elapsed, prof, final, confs = head['elapsed'], head['prof'], head['final'], head['confs']
 
     # ---- the one exchange of the path: final poses (and confidences) of every complex to every rank (RCCL over xGMI) ----------
@@ -471,11 +487,14 @@ def main():
     pruning_off = pocket_bound = None
     if not a.no_extras:
         w2 = min(a.warmup, 2)
+        print('[bench] extras: pruning_off bracket', file=sys.stderr, flush=True)
         pruning_off = summary(bracket(poses_all, w2, prune=False), n_done)
         pruning_off['note'] = ('the same sampling() bracket, workload and noise with ddk_set_receptive_field_pruning(ctx, 0): every layer evaluates all '
                                'rec-rec messages (layer-0 de-duplication and the last layer\'s ligand-only evaluation stay) - the guaranteed floor of value')
         pk_poses = {i: pocket_poses(complexes[i], np.random.default_rng(1000 + i), SAMPLES) for i in mine}
+        print('[bench] extras: pocket_bound bracket', file=sys.stderr, flush=True)
         pocket_bound = summary(bracket(pk_poses, w2, noise_scale=0.2), n_done)
+        print('[bench] extras done', file=sys.stderr, flush=True)
         pocket_bound['note'] = ('the same bracket with the pruning ON, start poses inside the pocket (rotation about the centroid + N(0, 1 A)) and the N(0,1) '
                                 'draws scaled by 0.2 (pre-drawn per call): every sample keeps cross edges for all 20 steps, as the trajectories of a '
                                 'trained model do; the default workload starts from randomize_position (N(0, 19 A)) and random-init weights let the '

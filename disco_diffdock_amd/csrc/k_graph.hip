@@ -5,13 +5,21 @@
 // with every group sorted by edge_src so that the fused conv kernel's segmented reduction sees long runs.
 // One workgroup per sample; ligand and receptor coordinates live in LDS (n_rec*12 B: 3.6 KB for 300 residues,
 // 24 KB for 2000), neighbour tests are brute force over the sample (30 x 300 .. 30 x 2000 pairs).
+#include <stdlib.h>
 #include "model.h"
 
 namespace ddk {
 
 
+// The neighbour tests below are evaluated at SEVERAL places for the same pair - the counting kernel, the fill kernel's own counts, its write loops,
+// the pair matrix of cross_mirror - and the edge lists are only consistent if every place gets the same answer for a pair that sits on the cutoff.
+// With floating-point contraction on, the compiler is free to fuse the sum of squares differently at every inlined copy (fma chains vs mul + add):
+// a pair within an ulp of the cutoff was then counted by one kernel and not written by the other, which left ONE slot of a cross-edge group with
+// whatever the reused device chunk held - a garbage node index, and a GPU memory fault once in a few hundred complexes (round 4, the 363-complex
+// stream; chunks fresh from hipMalloc are zero, which hid it).  Hence: no contraction in these three functions - plain IEEE mul / add in source order.
 // torch_cluster.radius on coordinates rescaled by the per-graph cutoff (score_model.py:379-381): |x/c - y/c|^2 < 1
 __device__ __forceinline__ bool cross_within(const float* lp, const float* rp, float c) {
+#pragma clang fp contract(off)
   const float dx = rp[0] / c - lp[0] / c, dy = rp[1] / c - lp[1] / c, dz = rp[2] / c - lp[2] / c;
   return dx * dx + dy * dy + dz * dz < 1.0f;
 }
@@ -20,11 +28,13 @@ __device__ __forceinline__ bool cross_within(const float* lp, const float* rp, f
 // divisions per pair were ~90 % of the instructions of the counting / fill loops): the ligand atom as one 16-B LDS word
 // (x, y, z, -), the residue in registers
 __device__ __forceinline__ bool cross_within4(const float4 a, float rx, float ry, float rz) {
+#pragma clang fp contract(off)
   const float dx = rx - a.x, dy = ry - a.y, dz = rz - a.z;
   return dx * dx + dy * dy + dz * dz < 1.0f;
 }
 
 __device__ __forceinline__ float dist2(const float* a, const float* b) {
+#pragma clang fp contract(off)
   const float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
   return dx * dx + dy * dy + dz * dz;
 }
@@ -766,6 +776,8 @@ static inline size_t graph_lds_bytes(int n_rec) {
 static size_t g_graph_dyn[64] = {};      // dynamic LDS the fill kernel may use, per device (graph_prepare_device)
 static inline size_t graph_lds_bytes_mirror(int n_rec, int n_lig) { return graph_lds_bytes(n_rec) + (size_t)n_rec * ((n_lig + 63) / 64) * 8; }
 int graph_cross_mirror_fits(int n_lig, int n_rec) {
+  static const bool off = getenv("DDK_NO_CROSS_MIRROR") != nullptr;      // debugging aid: both directions evaluate their own features
+  if (off) return 0;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
   return g_graph_dyn[dev] > 0 && graph_lds_bytes_mirror(n_rec, n_lig) <= g_graph_dyn[dev];

@@ -1,5 +1,7 @@
 // Score-model level device structures (internal; see include/ddk.h for the ABI).
 #pragma once
+#include <stdio.h>
+#include <stdlib.h>
 #include <thread>
 
 #include "ddk_internal.h"
@@ -344,6 +346,8 @@ struct ddk_complex {
   hipStream_t last_stream = nullptr;  // stream of the last launch that used this complex (ordering of the chunks' reuse)
   std::vector<hipStream_t> streams;   // every stream an entry point was given for this complex (ddk_complex_destroy joins them)
   bool used = false;
+  struct Canary { char* tail; size_t bytes; };
+  std::vector<Canary> canaries;       // DDK_CANARY debugging aid
   std::vector<int32_t> h_rr;          // host copies the confidence level needs again (ddk_complex_set_atoms)
   std::vector<float> h_rec_pos;
 };
@@ -378,8 +382,9 @@ bool cx_put(ddk_complex* cx, void* dst, const void* src, size_t bytes); // host 
 int cx_stage_flush(ddk_ctx* ctx, ddk_complex* cx);                      // enqueue the staged copies, record cx->ready
 hipError_t cx_wait_ready(ddk_complex* cx, hipStream_t s);               // first thing every launch entry point does with a complex
 inline void cx_reserve(ddk_complex* cx, size_t bytes) { cx->reserve_hint = bytes; }
+inline bool cx_canary_on() { static const bool on = getenv("DDK_CANARY") != nullptr; return on; }      // debugging aid: 4 KB of 0xA5 behind every array, checked at destroy
 inline void* cx_alloc(ddk_complex* cx, size_t bytes) {
-  const size_t need = ((bytes ? bytes : 4) + 255) & ~(size_t)255;
+  const size_t need = (((bytes ? bytes : 4) + 255) & ~(size_t)255) + (cx_canary_on() ? 4096 : 0);
   if (!cx->chunk || cx->chunk_off + need > cx->chunk_cap) {
     size_t cap = need > cx->reserve_hint ? need : cx->reserve_hint;
     if (cap < ((size_t)1 << 20)) cap = (size_t)1 << 20;
@@ -389,6 +394,16 @@ inline void* cx_alloc(ddk_complex* cx, size_t bytes) {
   }
   void* r = cx->chunk + cx->chunk_off;
   cx->chunk_off += need;
+  if (cx_canary_on()) {
+    char* tail = (char*)r + (need - 4096);
+    hipMemset(tail, 0xA5, 4096);
+    cx->canaries.push_back({tail, bytes});
+  }
+  {      // debugging aid (DDK_TRACE_ALLOC): every array of a complex with its address range, to match a GPU fault address against
+    static const bool trace = getenv("DDK_TRACE_ALLOC") != nullptr;
+    if (trace && bytes >= 4096) fprintf(stderr, "[ddk alloc] cx %p ctx %p  %p .. %p  (%zu B, chunk %p + %zu of %zu)\n", (void*)cx, (void*)cx->owner, r, (void*)((char*)r + bytes), bytes,
+                                        (void*)cx->chunk, cx->chunk_off - need, cx->chunk_cap);
+  }
   return r;
 }
 }  // namespace ddk

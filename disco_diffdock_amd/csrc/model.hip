@@ -822,6 +822,17 @@ void ddk_complex_destroy(ddk_ctx* ctx, ddk_complex* cx) {
   if (!cx) return;
   if (!ctx) ctx = cx->owner;
   hipSetDevice(ctx->cfg.device);
+  if (!cx->canaries.empty()) {      // DDK_CANARY: who wrote behind its array?
+    hipDeviceSynchronize();
+    std::vector<unsigned char> h(4096);
+    for (size_t i = 0; i < cx->canaries.size(); ++i) {
+      if (hipMemcpy(h.data(), cx->canaries[i].tail, 4096, hipMemcpyDeviceToHost) != hipSuccess) continue;
+      size_t bad = 0, first = 4096;
+      for (size_t k = 0; k < 4096; ++k) if (h[k] != 0xA5) { ++bad; if (first == 4096) first = k; }
+      if (bad) fprintf(stderr, "[ddk canary] cx %p (n_lig %d n_rec %d all_atoms %d): allocation #%zu of %zu B overrun: %zu bytes changed, first at +%zu\n", (void*)cx, cx->n_lig, cx->n_rec,
+                       ctx->cfg.all_atoms, i, cx->canaries[i].bytes, bad, first);
+    }
+  }
   if (cx->stage_idx >= 0) { ctx->stage_pool[cx->stage_idx].in_flight = false; cx->stage_idx = -1; }   // a create that failed half way
   // the chunks go back to the context's pool (hipFree would synchronise the device); whoever takes one waits for this complex' last launch.
   // A complex that was driven from several streams (the API takes a stream per call): the last one first waits for the work still in

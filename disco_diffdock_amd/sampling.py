@@ -4,6 +4,8 @@ SDE perturbation, SE(3)/torsion update, Kabsch re-alignment - runs inside libddk
 host synchronisation; this file only prepares the per-step host scalars exactly as the reference computes them.
 Options outside the accelerated path (visualisation, the oracle latent encoder)
 raise instead of silently doing something else."""
+import collections
+
 import numpy as np
 import torch
 

@@ -252,3 +252,42 @@ def test_sampling_with_cg_confidence_golden(dev, golden):
                          confidence_model_args=cargs, temp_sampling=1.0, temp_psi=0.0, temp_sigma_data=0.5)
     assert rel_err(torch.cat([d['ligand'].pos for d in out]).cpu(), z['pos_out']) < 1e-4
     assert tuple(conf.shape) == z['confidence'].shape and rel_err(conf.cpu(), z['confidence']) < 1e-4
+
+
+def test_cutoff_boundary_pairs_give_consistent_cross_edge_groups(dev):
+    """Pairs that sit within a few ulp of the cross cutoff: the counting kernel, the fill kernel's counts, its two write loops and the pair matrix of the
+    mirrored features all test the same pair, and must agree - round 4 found them compiled with different fused-multiply-add contractions, so that a
+    boundary pair was counted but not written and ONE slot of a cross-edge group kept stale device memory (a garbage node index; a GPU memory fault
+    once in a few hundred complexes).  Geometry: all ligand atoms of a sample in one point, the residues on a sphere of radius cutoff * (1 +- k ulp)."""
+    from disco_diffdock_amd import synthetic
+    from disco_diffdock_amd.runtime import Context, Complex
+    ctx = Context(device=0)
+    ctx.load_state_dict(synthetic.random_score_model_state_dict(seed=0))
+    t = 0.37
+    sigma = np.float32(0.1) ** np.float32(1.0 - t) * np.float32(19.0) ** np.float32(t)
+    cut = np.float32(3.0) * np.float32(sigma) + np.float32(20.0)
+    rng = np.random.default_rng(5)
+    c = synthetic.make_complex(3, n_res=300, n_lig=24)
+    u = rng.normal(size=(300, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    k = rng.integers(-6, 7, size=300)
+    c['rec_pos'] = (u * (np.float64(cut) * (1.0 + k * 2.0 ** -24))[:, None]).astype(np.float32)
+    B = 16
+    cx = Complex(ctx, c, B)
+    n_lig, n_bad, n_pairs = 24, 0, 0
+    for trial in range(6):
+        centre = rng.normal(0, 3e-6, size=(B, 1, 3))
+        pos = torch.as_tensor(np.broadcast_to(centre, (B, n_lig, 3)).astype(np.float32).copy()).to(dev)
+        ei, off = cx.build_graph(pos, t)
+        ei, off = ei.cpu().numpy(), [int(v) for v in off]
+        lr, rl = ei[:, off[1]:off[2]], ei[:, off[3]:off[4]]
+        assert lr.shape[1] == rl.shape[1]
+        N = B * (n_lig + 300)
+        assert lr.min() >= 0 and lr.max() < N and rl.min() >= 0 and rl.max() < N          # every slot was written with a node of this batch
+        a = set(map(tuple, lr.T.tolist()))
+        b_ = set((d, s) for s, d in rl.T.tolist())
+        n_bad += len(a ^ b_)
+        n_pairs += lr.shape[1]
+        assert len(a) == lr.shape[1] and len(b_) == rl.shape[1]                               # no slot written twice / left over
+    assert 0 < n_pairs < 6 * B * n_lig * 300          # the sphere really straddles the cutoff
+    assert n_bad == 0, f'{n_bad} cross edges without their flipped copy'

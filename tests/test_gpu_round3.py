@@ -74,7 +74,9 @@ def test_bench_line_reports_executed_work_and_both_floors(dev):
     pocket-bound workload are in the line, and the per-step executed-edge fractions cover the 20 steps."""
     out = _bench('--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-alt', '--no-device-loop')
     rf = out['roofline']
-    assert 0.0 < rf['frac'] <= 1.0 and rf['peak'] == 2500.0 and rf['fp32_equivalent_TFLOPs'] > 0
+    # (a suite run with DDK_CONV_KERNEL=1 puts the fp32-MFMA kernel under the bench too: its roofline is priced against the fp32 matrix peak)
+    peak = 157.3 if os.environ.get('DDK_CONV_KERNEL') == '1' else 2500.0
+    assert 0.0 < rf['frac'] <= 1.0 and rf['peak'] == peak and rf['fp32_equivalent_TFLOPs'] > 0
     assert abs(rf['frac'] - rf['flop_per_launch'] / (rf['avg_launch_ms'] * 1e-3) / 1e12 / rf['peak']) < 1e-6 * rf['frac'] + 1e-9
     assert abs(rf['achieved'] - rf['frac'] * rf['peak']) < 1e-6 * rf['achieved']
     ex = out['extra']

@@ -6,10 +6,17 @@
 #include <string.h>
 
 #include "ddk_internal.h"
+#include "k_conv_common.h"
 
 using namespace ddk;
 
 namespace ddk {
+
+// DDK_CONV_Y=0: every three-limb launch runs round 4's alternating kernel (k_conv_x.hip); default: the software-pipelined k_conv_y.hip where it applies
+bool conv_y_enabled() {
+  static const int v = [] { const char* e = getenv("DDK_CONV_Y"); return e == nullptr ? 1 : atoi(e); }();
+  return v != 0;
+}
 
 int fail(ddk_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->err = msg;
@@ -387,7 +394,7 @@ static int pack_x3(ddk_ctx* ctx, ConvLayerDev& L, int NG, const std::vector<floa
     return std::ldexp(1.0f, 15 - e);
   };
   // (+ three zero records behind the last group: the kernel requests record t+3 without clamping at a group's last tile)
-  std::vector<uint8_t> w2x((size_t)(NG * L.n_tiles + 3) * W2X_TILE_BYTES, 0), w1x((size_t)NG * 3 * W1X_TILE_BYTES, 0);
+  std::vector<uint8_t> w2x((size_t)(NG * L.n_tiles + 4) * W2X_TILE_BYTES, 0), w1x((size_t)NG * 3 * W1X_TILE_BYTES, 0);
   // one tile of fp32 fragments [9][64][4] -> three limbs x [4 x [64][8] | [64][4]]
   auto frags = [&](const float* src, float sc, uint8_t* dst) {
     for (int r = 0; r < 36; ++r)
@@ -418,6 +425,7 @@ static int pack_x3(ddk_ctx* ctx, ConvLayerDev& L, int NG, const std::vector<floa
   }
   if (!exact) return fail(ctx, DDK_ERR_INVALID, "internal: the three-limb fp16 split of a conv weight is not exact");
   L.h_w2x = w2x; L.h_w1x = w1x;
+  L.y_ok = conv_y_layer_ok(L.h_tiles);      // k_conv_y.hip serves the layer's gather launches (score-model conv layers)
   if (ctx->host_only) return DDK_OK;
   L.w2x = (uint8_t*)dev_alloc(ctx, w2x.size());
   L.w1x = (uint8_t*)dev_alloc(ctx, w1x.size());

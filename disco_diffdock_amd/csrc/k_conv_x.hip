@@ -46,12 +46,6 @@ typedef unsigned int u32x4 __attribute__((vector_size(16)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 #define MFMA8(a, b, c) __builtin_amdgcn_mfma_f32_32x32x8f16((a), (b), (c), 0, 0, 0)
 
-struct ConvXArgs {
-  ConvKArgs k;
-  uint32_t* trace;                  // TRACE instantiation: [8 waves][CONV_TRACE_TILES][8] s_memtime stamps of workgroup 0
-  int trace_coarse;                 // 1: one record per UNIT (slots 4-7 prologue, 0 = tile loop done, 1 = tiles, 2 = unit handed over): no stamp inside the tile loop
-};
-
 // Exact power-of-two range scale: 2^(14 - floor(log2 max(m, 2^-40))) and its inverse (max|x| lands in [2^14, 2^15))
 __device__ __forceinline__ float range_scale(float m, float& inv) {
   const uint32_t eb = max((__float_as_uint(m) >> 23) & 0xffu, 87u);   // biased exponent; 0 and subnormals map to the 2^-40 floor
@@ -803,6 +797,7 @@ hipError_t conv_prepare_device_x() {
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<false, false, false, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)CONV_X_LDS_BYTES);
+  if (e == hipSuccess) e = conv_prepare_device_y();
   return e;
 }
 
@@ -836,6 +831,10 @@ hipError_t launch_conv_fused_x(const ConvLayerDev& L, const ConvLaunch& a, int n
     if (e != hipSuccess) return e;
     conv_det_fix(k, a, L.dout, s);
     return hipGetLastError();
+  }
+  if (a.gather && a.pre != nullptr && (a.trace == nullptr || a.trace_coarse == 1) && L.y_ok && conv_y_enabled()) {   // round 5: the software-pipelined form (k_conv_y.hip)
+    X.trace = a.trace;      // (its TRACE instantiation writes the per-unit records only)
+    return launch_conv_y(X, n_cu, s);
   }
   X.trace = a.trace;
   if (a.trace != nullptr) {

@@ -327,9 +327,12 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
                 z = draw_noise(inference_steps, b, cx.R, R, nc, device)
             cx.sample(pos, t_arr, sc, nc, z)
             if confidence_model is not None and cg_conf is not None:
-                # utils/sampling.py:239-240: the score batch itself at the final poses; its times are the LAST step's (the reference resets them
-                # only in the confidence_data_list branch), which confidence_mode reads as sigmas
-                out = cg_conf.confidence(batch, pos, (float(tr_schedule[-1]), float(rot_schedule[-1]), float(tor_schedule[-1])))
+                # utils/sampling.py:239-240: the score batch itself at the final poses; its times are those of the LAST EXECUTED step
+                # (t_idx = inference_steps - 1, utils/sampling.py:105-111: the reference resets them only in the confidence_data_list branch),
+                # which confidence_mode reads as sigmas.  evaluate.py:269 passes the full schedule with inference_steps = actual_steps, so this
+                # is schedule[inference_steps - 1], not schedule[-1]
+                last = inference_steps - 1
+                out = cg_conf.confidence(batch, pos, (float(tr_schedule[last]), float(rot_schedule[last]), float(tor_schedule[last])))
                 confidence.append(out)
             elif confidence_model is not None:   # utils/sampling.py:230-243: final poses into the all-atom graphs, t = 0
                 cbatch = next(confidence_loader)

@@ -40,7 +40,8 @@ if a.coarse:
         tiles = x[:, 1]
         full = tiles == np.max(tiles)
         print(f'wave {w}: units {n} ({int(full.sum())} with all {int(np.max(tiles))} tiles)  prologue {d(7, 4)[full].mean():7.0f}  tile loop {d(0, 7)[full].mean():8.0f} = {(d(0, 7)[full] / tiles[full]).mean():6.0f} per tile  '
-              f'hand-over {d(2, 0)[full].mean():5.0f}  unit {d(2, 4)[full].mean():8.0f}  | column-split units: {int((~full).sum())}, per tile {(d(0, 7)[~full] / np.maximum(tiles[~full], 1)).mean() if (~full).any() else 0:6.0f}')
+              f'hand-over {d(2, 0)[full].mean():5.0f}  unit {d(2, 4)[full].mean():8.0f}  | column-split units: {int((~full).sum())}, per tile {(d(0, 7)[~full] / np.maximum(tiles[~full], 1)).mean() if (~full).any() else 0:6.0f}'
+              + (f'  | k_conv_y: block a prologue {d(5, 4)[full].mean():6.0f}, block b {d(6, 5)[full].mean():6.0f}, rest {d(7, 6)[full].mean():5.0f}, drain {d(3, 0)[full].mean():5.0f}' if x[0, 3] != 0 else ''))
     sys.exit(0)
 n = int((tr[0, :, 3] != 0).sum())
 if a.epi:

@@ -147,16 +147,17 @@ def start_poses(c, rng, samples, ctx=None, dev=None, tr_sigma_max=19.0):
     return out.astype(np.float32)
 
 
-def cpu_baseline(c, P, coeffs, gpu_scores, n_res, seconds_budget=40.0):
-    """The CPU oracle on a bounded sample: b samples x 1 reverse step of one complex at t in {1.0, 0.5, 0.05} (the cross graph shrinks
-    with t), >= 3 warm runs each; the mean of the per-t medians is extrapolated to 20 steps x 40 samples.  The oracle's scores are
-    compared with the GPU's on the same inputs (the oracle is the checker here, never the path)."""
+def cpu_baseline(c, P, coeffs, gpu_scores, n_res, poses, seconds_budget=150.0, chunk=8):
+    """The CPU oracle on a bounded sample of the SAME workload: the full batch (40 samples, the bench's own start poses of this complex: randomize_position
+    with tr_sigma_max = 19) x ONE reverse step (score model forward + modify_conformer_batch) at t in {1.0, 0.5, 0.05} (the cross graph shrinks with t), evaluated in
+    chunks of `chunk` samples (the samples of a batch are independent; the reference's own fallback halves the batch the same way, evaluate.py:397-398)
+    because the materialised [E, W] weights of 40 samples do not fit comfortably.  No extrapolation over the batch; x 20 steps over the trajectory.  The oracle's
+    scores are compared with the GPU's on the same inputs (the oracle is the checker here, never the path)."""
     from oracle import score_model_ref as smr, sampler_ref as spr, graph_lite
     cfg = smr.ScoreModelConfig(latent_vocab=64)
     d = os.path.join(ROOT, 'disco_diffdock_amd', 'data')
     tables = (np.load(os.path.join(d, 'so3_exp_score_norms.npy')), np.load(os.path.join(d, 'torus_score_norm_seed0.npy')))
-    b = 2
-    pos = start_poses(c, np.random.default_rng(0), b, tr_sigma_max=6.0)
+    b = len(poses)
 
     def graph():
         g = graph_lite.make_complex(c['lig_x'], c['lig_pos'], c['bond_index'], c['bond_attr'], c['edge_mask'], c['mask_rotate'],
@@ -164,37 +165,42 @@ def cpu_baseline(c, P, coeffs, gpu_scores, n_res, seconds_budget=40.0):
         g['ligand'].mask_rotate = [g['ligand'].mask_rotate]
         return g
     t_arr, sc, nc = coeffs
-    per_t, worst, t_used, t_start = {}, 0.0, [], time.perf_counter()
+
+    def step(pos, t):
+        dl = [graph() for _ in range(len(pos))]
+        for g, p in zip(dl, pos):
+            g['ligand'].pos = torch.from_numpy(p)
+        batch = graph_lite.collate(dl)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            spr.set_time(batch, t, t, t, len(pos))
+            tr, rot, tor = smr.score_model_forward(P, cfg, batch, tables[0], tables[1])
+            spr.modify_conformer_batch(batch['ligand'].pos, batch, sc[0, 0] * tr, sc[0, 1] * rot, sc[0, 2] * tor, torch.from_numpy(np.asarray(c['mask_rotate'])))
+        return time.perf_counter() - t0, tr, rot, tor
+    step(poses[:2], 0.5)                 # warm-up (thread pool, lazy initialisation)
+    per_t, worst, t_start = {}, 0.0, time.perf_counter()
     for t in (1.0, 0.5, 0.05):
-        times = []
-        for rep in range(4):           # 1 cold + 3 warm
-            dl = [graph() for _ in range(b)]
-            for g, p in zip(dl, pos):
-                g['ligand'].pos = torch.from_numpy(p)
-            batch = graph_lite.collate(dl)
-            t0 = time.perf_counter()
-            with torch.no_grad():
-                spr.set_time(batch, t, t, t, b)
-                tr, rot, tor = smr.score_model_forward(P, cfg, batch, tables[0], tables[1])
-                spr.modify_conformer_batch(batch['ligand'].pos, batch, sc[0, 0] * tr, sc[0, 1] * rot, sc[0, 2] * tor,
-                                           torch.from_numpy(np.asarray(c['mask_rotate'])))
-            times.append(time.perf_counter() - t0)
-            if rep >= 1 and time.perf_counter() - t_start > seconds_budget and len(times) >= 2:
-                break
-        per_t[t] = float(np.median(times[1:]))
-        t_used.append(len(times) - 1)
-        g_tr, g_rot, g_tor = gpu_scores(pos, t)
-        for a, r in ((g_tr, tr), (g_rot, rot), (g_tor, tor)):
+        if per_t and time.perf_counter() - t_start > seconds_budget * len(per_t) / 3.0 + seconds_budget / 3.0:
+            break                        # (a slow host: fewer diffusion times, said in `sample`)
+        tot, outs = 0.0, []
+        for a0 in range(0, b, chunk):
+            dt, tr, rot, tor = step(poses[a0:a0 + chunk], t)
+            tot += dt
+            outs.append((tr, rot, tor))
+        per_t[t] = tot
+        tr, rot, tor = (torch.cat([o[k] for o in outs]) for k in range(3))
+        g_tr, g_rot, g_tor = gpu_scores(poses, t)
+        for a_, r in ((g_tr, tr), (g_rot, rot), (g_tor, tor)):
             if r.numel():
-                worst = max(worst, float((a.cpu() - r).abs().max() / r.abs().max()))
+                worst = max(worst, float((a_.cpu() - r).abs().max() / r.abs().max()))
     assert worst < 1e-4, f'GPU scores differ from the CPU oracle on the cpu_baseline sample: {worst:.2e}'
     t_step = float(np.mean(list(per_t.values())))
-    per_complex = t_step * STEPS * (SAMPLES / b)
+    per_complex = t_step * STEPS
     return dict(value=1.0 / per_complex, unit='complexes/s', cores=torch.get_num_threads(), kind='port',
                 gpu_vs_oracle_rel_err=worst,
-                sample=f'oracle (PyTorch-CPU restatement, materialised [E,W] weights): {b} samples x 1 reverse step of one {n_res}-residue complex at '
-                       f't = 1.0 / 0.5 / 0.05, median of {min(t_used)} warm runs each = ' + ' / '.join(f'{per_t[t]:.2f}' for t in per_t) +
-                       f' s, mean {t_step:.2f} s extrapolated x{STEPS} steps x{SAMPLES // b} (batch {SAMPLES}); oracle scores == GPU scores to {worst:.1e}')
+                sample=f'oracle (PyTorch-CPU restatement, materialised [E,W] weights): {b} samples (the full batch, the bench\'s own start poses, in chunks of {chunk}) x 1 '
+                       f'reverse step of one {n_res}-residue complex at t = ' + ' / '.join(f'{t:g}' for t in per_t) + ': ' + ' / '.join(f'{per_t[t]:.1f}' for t in per_t) +
+                       f' s, mean {t_step:.1f} s per step x{STEPS} steps (no extrapolation over the batch); oracle scores == GPU scores to {worst:.1e}')
 
 
 def pocket_poses(c, rng, samples, sigma=1.0):
@@ -205,6 +211,39 @@ def pocket_poses(c, rng, samples, sigma=1.0):
     ctr = lp.mean(0, keepdims=True)
     return np.stack([(lp - ctr) @ Rotation.random(random_state=rng).as_matrix().T + ctr + rng.normal(0, sigma, size=(1, 3))
                      for _ in range(samples)]).astype(np.float32)
+
+
+def _make_complex(job):
+    """one synthetic complex of the workload (top level: the large sets are generated by a process pool)"""
+    from disco_diffdock_amd import synthetic
+    seed, n_res, spread_ligands, with_conf = job
+    c = synthetic.make_complex(seed, n_res=n_res, n_lig=int(np.random.default_rng(7000 + seed).integers(10, 81)) if spread_ligands else None)
+    if with_conf:
+        synthetic.add_receptor_atoms(c, np.random.default_rng(seed))
+    return c
+
+
+def timesplit_stream():
+    """north_star's own workload inside the driver's line: BASELINE config 4 (DisCo-DiffDock-S + AR latent model + all-atom confidence model)
+    over 363 DISTINCT synthetic complexes with a 10-80-atom ligand spread (a timesplit_test-sized set, reference README.md:20, evaluate.py:221-293), every
+    complex streamed ONCE through sampling() - as its own process behind this one's measurements (the GPU is idle by then), the three brackets of the headline."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--config', '4', '--complexes', '363', '--steps', '363', '--warmup', '2', '--no-cpu-baseline', '--no-alt',
+           '--no-device-loop', '--no-timesplit']
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+        if r.returncode != 0 or not line:
+            return {'error': f'rc {r.returncode}: ' + (r.stderr or '')[-400:]}
+        o = json.loads(line[-1])
+    except Exception as e:      # noqa: BLE001  (the headline must not die with its extra)
+        return {'error': repr(e)}
+    return {'command': ' '.join(cmd[1:]), 'workload': o['config']['workload'], 'value': o['value'], 'value_pruning_off': o.get('value_pruning_off'),
+            'value_pocket_bound': o.get('value_pocket_bound'), 'unit': 'complexes/s', 'complexes': 363, 'ms_per_complex': o['ms_per_step'],
+            'roofline_frac': o['roofline']['frac'], 'avg_conv_launch_ms': o['roofline']['avg_launch_ms'], 'conv_share_of_wall': o['roofline']['conv_share_of_wall'],
+            'min_cross_edges_per_sample_pocket_bound': (o['extra'].get('pocket_bound') or {}).get('min_cross_edges_per_sample_over_steps'),
+            'stream': o['extra']['stream'], 'wall_s_of_the_subprocess': round(time.perf_counter() - t0, 1)}
 
 
 def self_launch(a):
@@ -235,6 +274,7 @@ def main():
     ap.add_argument('--no-alt', action='store_true', help='skip the measurement of the fallback fp32-MFMA kernel')
     ap.add_argument('--no-device-loop', action='store_true', help='skip the resident-loop comparison figure')
     ap.add_argument('--no-extras', action='store_true', help='skip the pruning-off and pocket-bound brackets')
+    ap.add_argument('--no-timesplit', action='store_true', help='skip extra.timesplit_stream (config 4 over 363 distinct complexes, its own process)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl == RCCL; gloo for smoke tests)')
     ap.add_argument('--single-device', action='store_true', help='smoke test of the N > 1 path on a one-GPU box: every rank uses cuda:0')
     ap.add_argument('--complexes', type=int, default=0, help='distinct synthetic complexes per rank (default 8 of ~30 ligand atoms; N > 8: ligand sizes '
@@ -302,13 +342,13 @@ def main():
         mine = [rank * n_cx + i for i in range(n_cx)]
         lo, hi = 0, SAMPLES
     b_local = hi - lo
-    made = []
-    for i in mine:
-        seed = a.complex_offset + i % n_cx
-        c = synthetic.make_complex(seed, n_res=n_res, n_lig=int(np.random.default_rng(7000 + seed).integers(10, 81)) if spread_ligands else None)
-        if with_conf:
-            synthetic.add_receptor_atoms(c, np.random.default_rng(a.complex_offset + i % n_cx))
-        made.append(c)
+    jobs = [(a.complex_offset + i % n_cx, n_res, spread_ligands, with_conf) for i in mine]
+    if len(jobs) > 32:       # a timesplit-sized set: the synthetic generator (rejection sampling, ~0.25 s per complex) on the host's cores, not in a loop
+        import multiprocessing as mp
+        with mp.get_context('spawn').Pool(min(32, os.cpu_count() or 1)) as pool:
+            made = pool.map(_make_complex, jobs, chunksize=4)
+    else:
+        made = [_make_complex(j) for j in jobs]
     cache_path = os.path.join(tempfile.gettempdir(), f'ddk_bench_cfg{cfg_id}_rank{rank}.ddkg')
     graph_cache.save_complexes(cache_path, made)
     complexes = dict(zip(mine, graph_cache.load_complexes(cache_path)))
@@ -560,6 +600,9 @@ def main():
         out = {
             'metric': 'complexes/sec, 20-step 40-sample inference',
             'value': n_done / elapsed, 'unit': 'complexes/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            # the three figures belong together: value rests on where random-init weights push the ligand; value_pocket_bound is what a trained
+            # checkpoint's trajectories look like (every sample keeps >= 2 500 cross edges for all 20 steps), value_pruning_off the guaranteed floor of value
+            'value_pocket_bound': pocket_bound['value'] if pocket_bound else None, 'value_pruning_off': pruning_off['value'] if pruning_off else None,
             'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True, 'scaling': 'strong' if big else 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'dtype_note': 'every operand and accumulator of the path is fp32; the radial-MLP GEMMs multiply the fp32 operands exactly as three f16 limbs each on the f16 '
@@ -603,6 +646,9 @@ def main():
                       'headline': {k: v for k, v in summary(head, n_done).items() if k != 'value'},
                       'device_loop': device_loop, 'per_call_ms': head['per_call_ms'] if a.steps <= 64 else head['per_call_ms'][:64] + ['...'], 'stream': head['stream']},
         }
+        if int(getattr(ctx.cfg, 'conv_kernel', 0)) == 2:
+            out['roofline']['kernel'] = ('ddk::conv_y_kernel<false> (k_conv_y.hip: the same six limb products per K step on one accumulator chain, software-pipelined: one '
+                                         'wave per SIMD, two 32-edge blocks per wave; ddk_config.conv_kernel = 2)')
         if int(getattr(ctx.cfg, 'conv_kernel', 0)) == 1:
             # the whole run was switched to the fallback kernel (DDK_CONV_KERNEL=1): its work is fp32 MFMA chains, priced against the fp32 MFMA peak
             r_ = out['roofline']
@@ -621,11 +667,11 @@ def main():
             out['dtype_note'] = 'every operand and accumulator of the path is fp32 (fallback kernel: fp32 MFMA chains)'
         if world == 1 and not a.no_cpu_baseline and not disco:
             c0 = complexes[mine[0]]
-            cx0 = Complex(ctx, c0, 2)
+            cx0 = Complex(ctx, c0, SAMPLES)
 
             def gpu_scores(pos, t):
                 return cx0.score_forward(torch.from_numpy(pos).to(dev), t, t, t)
-            out['cpu_baseline'] = cpu_baseline(c0, P, coeffs, gpu_scores, n_res)
+            out['cpu_baseline'] = cpu_baseline(c0, P, coeffs, gpu_scores, n_res, poses_all[mine[0]], chunk=8 if n_res <= 300 else 2)
         else:
             out['cpu_baseline'] = None
         if world == 1 and cfg_id == 2 and not a.no_alt:
@@ -648,6 +694,8 @@ def main():
             out['fallback_fp32_kernel'] = {'mode': 'ddk_config.conv_kernel = 1: v_mfma_f32_32x32x2_f32 chains (k_conv.hip), resident-loop bracket (compare with '
                                                    'extra.device_loop)',
                                            'value': a.steps / e2, 'unit': 'complexes/s', 'ms_per_step': 1e3 * e2 / a.steps}
+        if world == 1 and cfg_id == 2 and not a.no_extras and not a.no_timesplit and a.complexes == 0:
+            out['extra']['timesplit_stream'] = timesplit_stream()
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

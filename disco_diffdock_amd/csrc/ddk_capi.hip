@@ -12,9 +12,9 @@ using namespace ddk;
 
 namespace ddk {
 
-// DDK_CONV_Y=0: every three-limb launch runs round 4's alternating kernel (k_conv_x.hip); default: the software-pipelined k_conv_y.hip where it applies
+// DDK_CONV_Y=1 (development aid for same-box A/Bs): the score model's conv layers run k_conv_y.hip as with ddk_config.conv_kernel = 2
 bool conv_y_enabled() {
-  static const int v = [] { const char* e = getenv("DDK_CONV_Y"); return e == nullptr ? 1 : atoi(e); }();
+  static const int v = [] { const char* e = getenv("DDK_CONV_Y"); return e == nullptr ? 0 : atoi(e); }();
   return v != 0;
 }
 
@@ -533,8 +533,8 @@ static int build_conv_layer(ddk_ctx* ctx, int mode, int l, ConvLayerDev& L) {
     L.h_w2p[g].assign(w2all.begin() + g * w2sz, w2all.begin() + (g + 1) * w2sz);
     L.h_b2p[g].assign(b2all.begin() + g * b2sz, b2all.begin() + (g + 1) * b2sz);
   }
-  if (mode == 0 && c.conv_kernel == 0 && (rc = pack_x3(ctx, L, NG, w1all, w2all, b2all))) return rc;
-  if (mode == 1 && c.conv_kernel == 0) {
+  if (mode == 0 && c.conv_kernel != 1 && (rc = pack_x3(ctx, L, NG, w1all, w2all, b2all))) return rc;
+  if (mode == 1 && c.conv_kernel != 1) {
     // The three-limb kernel keeps the raw p / q rows once ([p0..p5 | q0..q5], quads of four): the l = 2 group of the q rows (T2E), whose two
     // tiles are [q0 q1 q2 q3], [q4 q5 . .] in the table, reads raw quads 1 and 2 = [. . q0 q1], [q2 q3 q4 q5]: move its weight rows accordingly
     // (accumulator quads 0..2 only: quad 3 of a 6-channel column is empty or carries a packed extra unit).  x_tile_word() gives the tiles their offsets.
@@ -650,7 +650,7 @@ int build_head_layer(ddk_ctx* ctx, int mode, ConvLayerDev& L) {
   }
   L.h_w1p.assign(1, w1); L.h_b1p.assign(1, b1); L.h_w2p.assign(1, w2); L.h_b2p.assign(1, b2);
   L.h_bn_mean.assign(XW, 0.f); L.h_bn_scale.assign(XW, 1.f); L.h_bn_bias.assign(XW, 0.f);
-  if (ctx->cfg.conv_kernel == 0 && (rc = pack_x3(ctx, L, 1, w1, w2, b2))) return rc;
+  if (ctx->cfg.conv_kernel != 1 && (rc = pack_x3(ctx, L, 1, w1, w2, b2))) return rc;
   if (ctx->host_only) return DDK_OK;
   std::vector<float> w2rec((size_t)L.n_tiles * W2_TILE_FLOATS);
   for (int t = 0; t < L.n_tiles; ++t) {
@@ -688,7 +688,8 @@ int ddk_create(const ddk_config* cfg, ddk_ctx** out) {
     return fail(ctx, DDK_ERR_INVALID, "only 32-wide sigma / distance embeddings are compiled in");
   if (cfg->deterministic && cfg->all_atoms)
     return fail(ctx, DDK_ERR_INVALID, "deterministic scatter is implemented for the score model (not with all_atoms)");
-  if (cfg->conv_kernel != 0 && cfg->conv_kernel != 1) return fail(ctx, DDK_ERR_INVALID, "conv_kernel must be 0 (three-limb f16) or 1 (fp32 MFMA)");
+  if (cfg->conv_kernel < 0 || cfg->conv_kernel > 2)
+    return fail(ctx, DDK_ERR_INVALID, "conv_kernel must be 0 (three-limb f16), 1 (fp32 MFMA) or 2 (three-limb f16, software-pipelined conv layers)");
   if (cfg->device < 0) {
     ctx->host_only = true;   // packing-only context (CPU tests); every launch entry point refuses to run
     return DDK_OK;

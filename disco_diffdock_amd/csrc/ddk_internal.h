@@ -265,6 +265,7 @@ struct ConvLaunch {
   const int32_t* gend = nullptr;
   uint32_t* trace = nullptr;   // != null (three-limb kernel, split gather path): workgroup 0 records its half-phase time stamps here
   int trace_coarse = 0;        // one record per unit instead of per tile (no stamps inside the tile loop)
+  bool use_y = false;          // ddk_config.conv_kernel = 2: k_conv_y.hip where the layer's tile table allows it (gather path with node terms, atomics)
 };
 hipError_t launch_conv_fused(const ConvLayerDev& L, const ConvLaunch& a, int n_cu, hipStream_t s);
 hipError_t launch_conv_fused_x(const ConvLayerDev& L, const ConvLaunch& a, int n_cu, hipStream_t s);   // k_conv_x.hip (exact three-limb f16)

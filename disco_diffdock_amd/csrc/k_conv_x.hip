@@ -832,7 +832,7 @@ hipError_t launch_conv_fused_x(const ConvLayerDev& L, const ConvLaunch& a, int n
     conv_det_fix(k, a, L.dout, s);
     return hipGetLastError();
   }
-  if (a.gather && a.pre != nullptr && (a.trace == nullptr || a.trace_coarse == 1) && L.y_ok && conv_y_enabled()) {   // round 5: the software-pipelined form (k_conv_y.hip)
+  if (a.gather && a.pre != nullptr && (a.trace == nullptr || a.trace_coarse == 1) && L.y_ok && (a.use_y || conv_y_enabled())) {   // ddk_config.conv_kernel = 2: the software-pipelined form (k_conv_y.hip)
     X.trace = a.trace;      // (its TRACE instantiation writes the per-unit records only)
     return launch_conv_y(X, n_cu, s);
   }

@@ -315,7 +315,7 @@ __global__ __launch_bounds__(64 * Y_WAVES) __attribute__((amdgpu_waves_per_eu(1,
       rsrc[3] = 0x00020000;
     }
     // ---- stage records 0 and 1 of this unit, request record 2 (the ring is idle: the previous unit ended with a barrier) ----
-    i32x4 c00, c10, c20, c30, c01, c11, c21, c31;      // ring chunks in flight: two register sets (AGPRs), the set of a tile's parity holds record i+2 during tile i
+    i32x4 c00, c10, c20, c30;      // ring chunks in flight (AGPRs): record i+2 during tile i
     {
       const char* wr0 = wrec + (size_t)t_begin * TB;
       const char* wr1 = wrec + (size_t)min(t_begin + 1, t_end - 1) * TB;
@@ -370,14 +370,12 @@ __global__ __launch_bounds__(64 * Y_WAVES) __attribute__((amdgpu_waves_per_eu(1,
 #pragma unroll
       for (int c = 0; c < 3; ++c) { accVa[rq][c] = 0.0f; accXa[rq][c] = 0.0f; accVb[rq][c] = 0.0f; accXb[rq][c] = 0.0f; }
     }
-    // records 2 and 3 of the unit (stored during tiles 0 and 1); everything the prologue requested has landed behind the wait below, so the loop's vmcnt
-    // counts are its own.  Requests past the unit's last tile re-read it (soffmax)
+    // record 2 of the unit (stored during tile 0); everything the prologue requested has landed behind the wait below, so the loop's vmcnt counts are
+    // its own.  Requests past the unit's last tile re-read it (soffmax)
     const int soffmax = (t_end - 1) * TB;
     int soff = min((t_begin + 2) * TB, soffmax);
     BUFLDA(c00, ck0, rsrc, soff); BUFLDA(c10, ck1, rsrc, soff); BUFLDA(c20, ck2, rsrc, soff); BUFLDA(c30, ck3, rsrc, soff);
-    soff = min((t_begin + 3) * TB, soffmax);
-    BUFLDA(c01, ck0, rsrc, soff); BUFLDA(c11, ck1, rsrc, soff); BUFLDA(c21, ck2, rsrc, soff); BUFLDA(c31, ck3, rsrc, soff);
-    soff = (t_begin + 4) * TB;
+    soff = (t_begin + 3) * TB;
     stamp(7, 0);
     y_lds_barrier();      // ring stages 0 / 1 and the F rows are visible
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -405,7 +403,7 @@ __global__ __launch_bounds__(64 * Y_WAVES) __attribute__((amdgpu_waves_per_eu(1,
     const int ring0d = (int)(ring0 + W2X_DESC_OFF);
     int t0_, t1_, t2_, t3_, sel2_, pk0_, pk1_, pk2_;
     // half-burst a: the MFMAs of block a, tile i; epilogue slot of block b, tile i-1 (descriptor wP).  half-burst b: block b, tile i; epilogue slot of
-    // block a, tile i (descriptor wC); it ends the tile: next descriptor, barrier.  Unrolled over the two chunk register sets.
+    // block a, tile i (descriptor wC); it ends the tile: next descriptor, barrier.
 #ifdef Y_EXP_NO_FLUSH         // timing experiment (wrong results): no column is ever flushed inside the tile loop
 #define Y_SEL1_A (i == 0 ? 3 : 0)
 #define Y_SEL1_B 0
@@ -421,10 +419,6 @@ __global__ __launch_bounds__(64 * Y_WAVES) __attribute__((amdgpu_waves_per_eu(1,
     for (int i = 0;;) {
       { const int sel1_ = Y_SEL1_A; Y_HB_a0(); }
       { const int sel1_ = Y_SEL1_B; Y_HB_b0(); }
-      Y_EXP_SOFF
-      if (++i >= n_t) break;
-      { const int sel1_ = Y_SEL1_A; Y_HB_a1(); }
-      { const int sel1_ = Y_SEL1_B; Y_HB_b1(); }
       Y_EXP_SOFF
       if (++i >= n_t) break;
     }

@@ -558,6 +558,7 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
       pr.layer = l; pr.slot = ctx->prof_slots; pr.tab = tab; pr.lig_only = lig_only; pr.r01_skipped = shared0 ? (patched ? -1 : (int64_t)(B - 1) * cx->E_rr) : 0;      // (-1: E - executed edges, the patch count lives on the device)
       CK(hipEventRecord(pr.a, s), "event record");
     }
+    a.use_y = ctx->cfg.conv_kernel == 2;
     if (ctx->conv_trace != nullptr && ctx->conv_trace_layer == l) { a.trace = ctx->conv_trace; a.trace_coarse = ctx->conv_trace_coarse; }
     CK(launch_conv_fused(L, a, ctx->n_cu, s), "conv_fused");
     if (prof_slot) {

@@ -72,7 +72,7 @@ def test_bench_gpus2_launches_two_ranks_by_itself(dev):
 def test_bench_line_reports_executed_work_and_both_floors(dev):
     """roofline.frac is the EXECUTED fraction (<= 1, = flop_per_launch / avg_launch_ms / peak), the pruning-off floor and the
     pocket-bound workload are in the line, and the per-step executed-edge fractions cover the 20 steps."""
-    out = _bench('--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-alt', '--no-device-loop')
+    out = _bench('--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-alt', '--no-device-loop', '--no-timesplit')
     rf = out['roofline']
     # (a suite run with DDK_CONV_KERNEL=1 puts the fp32-MFMA kernel under the bench too: its roofline is priced against the fp32 matrix peak)
     peak = 157.3 if os.environ.get('DDK_CONV_KERNEL') == '1' else 2500.0
@@ -82,6 +82,7 @@ def test_bench_line_reports_executed_work_and_both_floors(dev):
     ex = out['extra']
     assert ex['pruning_off']['edges_executed_over_unpruned'] == pytest.approx(1.0)
     assert ex['pruning_off']['value'] > 0 and ex['pocket_bound']['value'] > 0
+    assert out['value_pocket_bound'] == ex['pocket_bound']['value'] and out['value_pruning_off'] == ex['pruning_off']['value']      # (round 5: beside `value`)
     assert ex['pocket_bound']['min_cross_edges_per_sample_over_steps'] > 0          # the pocket-bound samples never lose contact
     assert ex['pocket_bound']['edges_executed_over_unpruned'] >= rf['edges_executed_over_unpruned'] - 1e-9
     assert len(ex['per_step']) == 20 and all(0 < s['edges_executed_over_unpruned'] <= 1 for s in ex['per_step'])
@@ -162,7 +163,7 @@ def test_three_limb_product_at_least_as_accurate_as_fp32_chain(dev):
 # ------------------------------------------------------------------------------------------------------------------------------------------
 # the core parity tests once more under every (conv kernel, scatter) mode, inside the driver's single `pytest -m gpu` (VERDICT r02 #5d)
 # ------------------------------------------------------------------------------------------------------------------------------------------
-@pytest.fixture(params=[(0, 0), (0, 1), (1, 0), (1, 1)], ids=['x3-atomics', 'x3-deterministic', 'fp32-atomics', 'fp32-deterministic'])
+@pytest.fixture(params=[(0, 0), (0, 1), (1, 0), (1, 1), (2, 0)], ids=['x3-atomics', 'x3-deterministic', 'fp32-atomics', 'fp32-deterministic', 'x3-pipelined-atomics'])
 def mode(request, monkeypatch):
     """every ddk context created inside the test runs the given conv kernel / scatter mode (runtime.Context reads the switches)"""
     kernel, det = request.param

@@ -355,11 +355,11 @@ def gen_s1(X, Y, pend, hb):
         1: [('lds', 'a1m', dsr128('%[a1m]', fa, LIMB + 1024)), ('lds', 'b1', dsr128(tup(B[4:8]), '%[vea]', BIAS_OFF + 16))],
         2: [('lds', 'a1l', dsr128('%[a1l]', fa, 2 * LIMB + 1024)), ('lds', 'b2', dsr128(tup(B[8:12]), '%[vea]', BIAS_OFF + 32))],
         3: [('lds', 'b3', dsr128(tup(B[12:16]), '%[vea]', BIAS_OFF + 48))],
-        # the ring: this thread's two chunks of record i+2 (requested TWO tiles ago into the AGPR set of this tile's parity: one tile of distance left the
-        # L2 misses - 16 % of the requests, four groups' records do not fit an XCD's L2 - exposed, ~200 cycles per tile) into the stage tile i-2 has left;
-        # the request for record i+4 follows in S2.  vmcnt(6): everything but the requests of the last three half-bursts has landed (ops retire in order;
-        # a flush's atomics in between only make the wait stricter)
-        4: ['s_waitcnt vmcnt(6)', ('lds', 'w0', f'ds_write_b128 {VWA0}, %[c0]')],
+        # the ring: this thread's two chunks of record i+2 (requested one tile ago, into AGPRs) into the stage tile i-2 has left; the request for record
+        # i+3 follows in S2.  vmcnt(2): everything but the two requests of the previous half-burst has landed (ops retire in order; a flush's atomics sit
+        # BEFORE its half-burst's requests).  Measured: the wait itself costs nothing (vmcnt(63): same time); ISSUING the four 1-KB requests per wave and
+        # tile costs ~170 cycles per tile (no requests: 2283 -> 2115) - a lone wave has nothing behind the one MFMA in flight to cover a VMEM issue
+        4: ['s_waitcnt vmcnt(2)', ('lds', 'w0', f'ds_write_b128 {VWA0}, %[c0]')],
         5: [('lds', 'w1', f'ds_write_b128 {VWA1}, %[c1]')],
         6: [('lds', 'a0h', dsr128('%[a0h]', fa, 2048))],
         7: [('lds', 'a0m', dsr128('%[a0m]', fa, LIMB + 2048))],
@@ -533,7 +533,7 @@ def frag_ops():
 def main():
     out = ['// GENERATED by tools/gen_conv_y.py - do not edit; the schedule (what rides in which MFMA shadow) lives in the generator.\n']
     for hb, (X, Y) in enumerate((('a', 'b'), ('b', 'a'))):
-      for par in (0, 1):
+      for par in (0,):      # (two chunk register sets with requests two tiles ahead were measured: 2308 -> 2283 cycles per tile, not worth twice the code)
             c0, c1 = (f'c0{par}', f'c1{par}') if hb == 0 else (f'c2{par}', f'c3{par}')
             k0, k1 = ('ck0', 'ck1') if hb == 0 else ('ck2', 'ck3')
             r0, r1 = ('ringw0', 'ringw1') if hb == 0 else ('ringw2', 'ringw3')

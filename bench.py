@@ -274,6 +274,9 @@ def main():
     ap.add_argument('--no-alt', action='store_true', help='skip the measurement of the fallback fp32-MFMA kernel')
     ap.add_argument('--no-device-loop', action='store_true', help='skip the resident-loop comparison figure')
     ap.add_argument('--no-extras', action='store_true', help='skip the pruning-off and pocket-bound brackets')
+    ap.add_argument('--shard-set', action='store_true', help='configs 2-4: the --complexes complexes are ONE set, partitioned over the ranks with distributed.shard_indices (LPT by '
+                    'n_rec * n_lig) and streamed once; RNG seeded per complex, so that the gathered poses do not depend on the number of ranks (extra.pose_digest)')
+    ap.add_argument('--dump-poses', default=None, help='rank 0 writes the gathered final poses (npz, one array per complex) here: the N = 1 / N = 8 comparisons of tools/ranks8_check.sh')
     ap.add_argument('--no-timesplit', action='store_true', help='skip extra.timesplit_stream (config 4 over 363 distinct complexes, its own process)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend for N > 1 (nccl == RCCL; gloo for smoke tests)')
     ap.add_argument('--single-device', action='store_true', help='smoke test of the N > 1 path on a one-GPU box: every rank uses cuda:0')
@@ -316,7 +319,7 @@ def main():
     from disco_diffdock_amd.model_utils import get_model, get_ar_model
     from disco_diffdock_amd.sampling import sampling, step_coefficients, draw_noise
     from disco_diffdock_amd.diffusion_utils import t_to_sigma, get_t_schedule
-    from disco_diffdock_amd.distributed import shard_samples, gather_poses, gather_samples, gather_confidences
+    from disco_diffdock_amd.distributed import shard_samples, shard_indices, gather_poses, gather_samples, gather_confidences
     if rank == 0:
         build.build(verbose=False)       # no-op when the shipped libddk.so is current; never build concurrently
     if use_dist:
@@ -332,9 +335,15 @@ def main():
     #      PDBBind graphs in, disco_diffdock_amd/graph_cache.py) ---------------------------------------------------------------
     n_cx = a.complexes if a.complexes > 0 else (4 if big else N_COMPLEXES)
     spread_ligands = a.complexes > N_COMPLEXES
+    shard_set = a.shard_set and not big
     if big:                                  # samples sharded: every rank works on the same complexes
         mine = list(range(n_cx))
         lo, hi = shard_samples(SAMPLES, rank, world)
+    elif shard_set:                          # ONE set of n_cx complexes, partitioned by cost (the layout a real dataset gets)
+        n_total = n_cx
+        n_lig_of = [int(np.random.default_rng(7000 + a.complex_offset + i).integers(10, 81)) if spread_ligands else 30 for i in range(n_cx)]
+        mine = shard_indices([n_res * max(v, 16) for v in n_lig_of], rank, world)
+        lo, hi = 0, SAMPLES
     else:
         n_total = n_cx * world
         # weak scaling with the per-GPU work held EXACTLY fixed: every rank holds the same n_cx receptor / ligand pairs (content seed = id mod n_cx)
@@ -342,6 +351,8 @@ def main():
         mine = [rank * n_cx + i for i in range(n_cx)]
         lo, hi = 0, SAMPLES
     b_local = hi - lo
+    if shard_set:       # this rank's timed sampling() calls: its share of the set, every complex once
+        a.steps, a.warmup = len(mine), (min(a.warmup, len(mine)))
     jobs = [(a.complex_offset + i % n_cx, n_res, spread_ligands, with_conf) for i in mine]
     if len(jobs) > 32:       # a timesplit-sized set: the synthetic generator (rejection sampling, ~0.25 s per complex) on the host's cores, not in a loop
         import multiprocessing as mp
@@ -376,7 +387,9 @@ def main():
     coeffs = step_coefficients(STEPS, sched, sched, sched, tsig, margs, False, False, True, temps['temp_sampling'], temps['temp_psi'],
                                temps['temp_sigma_data'])
     t_arr, sc, nc = coeffs
-    order = [mine[k % len(mine)] for k in range(a.warmup + a.steps)]
+    order = (mine[:a.warmup] + mine) if shard_set else [mine[k % len(mine)] for k in range(a.warmup + a.steps)]
+    # rank r computes on cuda:LOCAL_RANK - the r-th device AFTER any HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES remapping - and its ddk_ctx lives there
+    assert int(score_model.ctx.device) == local and torch.cuda.current_device() == local
     ctx = score_model.ctx
 
     # host data_lists of every call, prepared BEFORE the clock starts like evaluate.py:232-233 (deepcopy + randomize_position)
@@ -404,9 +417,14 @@ def main():
         calls = [data_lists(i, poses) for i in order[:warmup + a.steps]]
         torch.cuda.manual_seed(977 + rank)
         noises = None
+        Rs = {i: int(np.asarray(complexes[i]['mask_rotate']).shape[0]) for i in mine}
         if noise_scale is not None:
-            Rs = {i: int(np.asarray(complexes[i]['mask_rotate']).shape[0]) for i in mine}
             noises = [[noise_scale * draw_noise(STEPS, b_local, Rs[i], Rs[i], nc, dev)] for i in order[:warmup + a.steps]]
+        elif big and a.dump_poses:      # (comparison runs) the N(0,1) draws of ALL samples of a complex from a per-complex seed; this rank takes its samples' slice
+            noises = []
+            for i in order[:warmup + a.steps]:
+                torch.cuda.manual_seed(5000 + i)
+                noises.append([draw_noise(STEPS, SAMPLES, Rs[i], Rs[i], nc, dev)[:, lo:hi].contiguous()])
         ctx.set_pruning(prune)
 
         def one_call(k):
@@ -435,6 +453,8 @@ def main():
         for k in range(warmup, warmup + a.steps):
             if (k - warmup) % len(mine) == 0 and k > warmup:
                 sm_mod._complex_cache.clear()    # K > #complexes: the second pass over the shard must not hit the cache either
+            if shard_set:
+                torch.cuda.manual_seed(5000 + order[k])      # noise and AR picks of a complex do not depend on which rank runs it, or after what
             out, conf = one_call(k)
             if os.environ.get('DDK_BENCH_TRACE'):
                 print(f'[bench] call {k - warmup} complex {order[k]} n_lig {complexes[order[k]]["lig_pos"].shape[0]} queued', file=sys.stderr, flush=True)
@@ -516,12 +536,28 @@ def main():
             nl[i] = complexes[i]['lig_pos'].shape[0]
         if use_dist:
             dist.all_reduce(nl)
+        pose_digest = None
         if len(final) == len(mine):
             gathered = gather_poses(final, [int(v) for v in nl.tolist()], SAMPLES, dev)
             assert len(gathered) == n_total
+            gconf = None
             if with_conf:
-                assert len(gather_confidences(confs, n_total, dev)) == n_total
-        n_done = world * a.steps
+                gconf = gather_confidences(confs, n_total, dev)
+                assert len(gconf) == n_total
+            if shard_set and rank == 0:
+                import hashlib
+                h = hashlib.sha256()
+                for i in sorted(gathered):
+                    h.update(gathered[i].cpu().numpy().tobytes())
+                pose_digest = {'sha256_of_the_gathered_poses': h.hexdigest(), 'complexes': n_total,
+                               'pose_checksum': float(sum(float(gathered[i].double().sum()) for i in gathered)),
+                               'confidence_checksum': None if gconf is None else float(sum(float(gconf[i].double().sum()) for i in gconf)),
+                               'complexes_per_rank': [len(shard_indices([n_res * max(v, 16) for v in n_lig_of], r, world)) for r in range(world)],
+                               'note': 'DDK_DETERMINISTIC=1: bit-identical for every number of ranks (the confidence model keeps its atomics: its checksum agrees to ~1e-6)'}
+        n_done = n_total if shard_set else world * a.steps
+
+    if a.dump_poses and rank == 0:
+        np.savez(a.dump_poses, **{f'c{i}': gathered[i].cpu().numpy() for i in sorted(gathered)})
 
     # ---- what the headline rests on: the same bracket without the receptive-field pruning (the floor) and on a pocket-bound workload ----
     pruning_off = pocket_bound = None
@@ -603,7 +639,7 @@ def main():
             # the three figures belong together: value rests on where random-init weights push the ligand; value_pocket_bound is what a trained
             # checkpoint's trajectories look like (every sample keeps >= 2 500 cross edges for all 20 steps), value_pruning_off the guaranteed floor of value
             'value_pocket_bound': pocket_bound['value'] if pocket_bound else None, 'value_pruning_off': pruning_off['value'] if pruning_off else None,
-            'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True, 'scaling': 'strong' if big else 'weak', 'vs_baseline': None,
+            'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True, 'scaling': 'strong' if (big or shard_set) else 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'dtype_note': 'every operand and accumulator of the path is fp32; the radial-MLP GEMMs multiply the fp32 operands exactly as three f16 limbs each on the f16 '
                           'matrix pipe (six of nine limb products, dropped terms <= 3 * 2^-33 relative) with fp32 accumulation (DESIGN.md 3.3)',
@@ -641,7 +677,7 @@ def main():
                                         'fp32_equivalent_TFLOPs': p['edges'] * layer_flop[l] / max(p['ms'], 1e-9) / 1e9,
                                         'edges_executed_frac': p['edges'] / max(p['edges_unpruned'], 1)}
                                        for l, p in enumerate(prof)]},
-            'extra': {'pruning_off': pruning_off, 'pocket_bound': pocket_bound, 'per_step': per_step, 'create_ms': create_ms,
+            'extra': {'pruning_off': pruning_off, 'pocket_bound': pocket_bound, 'per_step': per_step, 'create_ms': create_ms, 'pose_digest': None if big else pose_digest,
                       'per_call_spread_same_complex': per_call_spread,
                       'headline': {k: v for k, v in summary(head, n_done).items() if k != 'value'},
                       'device_loop': device_loop, 'per_call_ms': head['per_call_ms'] if a.steps <= 64 else head['per_call_ms'][:64] + ['...'], 'stream': head['stream']},

@@ -119,3 +119,69 @@ def test_create_on_a_missing_device_fails_cleanly(dev):
     assert 'device' in str(ei.value).lower() or 'hip' in str(ei.value).lower(), str(ei.value)
     ctx = Context(device=0)          # ... and the process is still usable
     assert ctx.h is not None
+
+
+def test_pocket_bound_trajectory_vs_oracle(dev, tables):
+    """the pocket-bound bracket of bench.py (`value_pocket_bound`: start poses inside the pocket = rotation about the centroid + N(0, 1 A), the
+    N(0,1) draws scaled by 0.2, README low-temperature coefficients) as a 20-step trajectory of the WHOLE 40-sample batch on the device - stepped one reverse
+    step per call so that every step's scores and cross-edge count can be read - against oracle.sampler_ref on four of the samples (the samples of a batch are
+    independent; same noise).  Every step keeps >= 2 500 cross edges per sample (what a trained checkpoint's trajectories look like; every other 20-step oracle
+    test uses wandering ligands).  Bars: final poses 1e-3 of the receptor scale, per-step scores 1e-4 (relative to each score vector's largest element)."""
+    from functools import partial
+    from argparse import Namespace
+    from scipy.spatial.transform import Rotation
+    from disco_diffdock_amd import synthetic
+    from disco_diffdock_amd.runtime import Context, Complex
+    from disco_diffdock_amd.sampling import step_coefficients
+    from disco_diffdock_amd.diffusion_utils import t_to_sigma, get_t_schedule
+    from helpers import to_graph
+    from test_gpu_model import README_S
+    from test_gpu_round3 import _record_drift
+    args = Namespace(tr_sigma_min=0.1, tr_sigma_max=19.0, rot_sigma_min=0.03, rot_sigma_max=1.55, tor_sigma_min=0.03, tor_sigma_max=3.14, no_torsion=False)
+    c = synthetic.make_complex(0, n_res=300)          # (the bench's first complex)
+    P = smr.random_state_dict(CFG, seed=21)
+    ctx = Context(device=0)
+    ctx.load_state_dict(P)
+    B, steps = 40, 20
+    cx = Complex(ctx, c, B)
+    sched = get_t_schedule(steps)
+    t_arr, sc, nc = step_coefficients(steps, sched, sched, sched, partial(t_to_sigma, args=args), args, False, False, True, README_S['temp_sampling'],
+                                      README_S['temp_psi'], README_S['temp_sigma_data'])
+    rng = np.random.default_rng(1000)
+    lp = c['lig_pos'].astype(np.float64)
+    ctr = lp.mean(0, keepdims=True)
+    pos0 = np.stack([(lp - ctr) @ Rotation.random(random_state=rng).as_matrix().T + ctr + rng.normal(0, 1.0, size=(1, 3)) for _ in range(B)]).astype(np.float32)
+    z = 0.2 * torch.randn(steps, B, 6 + cx.R, generator=torch.Generator().manual_seed(19))
+    sub = [0, 13, 26, 39]
+    pos = T(pos0.copy()).to(dev)
+    dev_scores, cross = [], []
+    for s in range(steps):
+        t = float(sched[s])
+        tr, rot, tor = cx.score_forward(pos, t, t, t)
+        cross.append(cx.graph_stats()['E_lr'] / B)
+        dev_scores.append((tr.cpu()[sub], rot.cpu()[sub], tor.cpu().reshape(B, -1)[sub].reshape(-1)))
+        cx.sample(pos, t_arr[s:s + 1], sc[s:s + 1], nc[s:s + 1], z[s:s + 1].to(dev))
+    assert min(cross) >= 2500, cross
+    dl = []
+    for i in sub:
+        g = to_graph(c)
+        g['ligand'].pos = T(pos0[i])
+        dl.append(g)
+    zs = z[:, sub]
+    nf = lambda b, t, name, shape: {'tr': zs[t, :, 0:3], 'rot': zs[t, :, 3:6], 'tor': zs[t, :, 6:].reshape(-1)}[name]
+    trace = []
+    ref, _ = spr.sampling(dl, P, CFG, tables[0], tables[1], steps, sched, sched, sched, noise_fn=nf, batch_size=len(dl), no_final_step_noise=True, trace=trace, **README_S)
+    r = torch.cat([g['ligand'].pos for g in ref])
+    err_pos = rel_err(pos.cpu()[sub].reshape(-1, 3), r)
+    per_step = []
+    for s in range(steps):
+        e = 0.0
+        for a, b in zip(dev_scores[s], (trace[s]['tr_score'], trace[s]['rot_score'], trace[s]['tor_score'])):
+            if b.numel():
+                e = max(e, rel_err(a, b))
+        per_step.append(e)
+    print(f'pocket-bound 20-step trajectory, B = 40 (oracle on samples {sub}): poses {err_pos:.2e}, per-step scores max {max(per_step):.2e} '
+          f'(first {per_step[0]:.1e}, last {per_step[-1]:.1e}); cross edges per sample {min(cross):.0f} .. {max(cross):.0f}')
+    _record_drift('pocket_bound_trajectory_20_steps_300_residues_B40_poses_vs_oracle', err_pos, bar=1e-3, min_cross_edges_per_sample=float(min(cross)))
+    _record_drift('pocket_bound_trajectory_20_steps_300_residues_B40_per_step_scores_vs_oracle', max(per_step), bar=1e-4, per_step=[float(v) for v in per_step])
+    assert err_pos < 1e-3 and max(per_step) < 1e-4

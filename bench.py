@@ -530,7 +530,7 @@ def main():
         assert all(g.shape[0] == SAMPLES for g in gathered.values())
         n_done = a.steps                                    # the ranks worked on the SAME K complexes
     else:
-        n_total = n_cx * world
+        n_total = n_cx if shard_set else n_cx * world
         nl = torch.zeros(n_total, dtype=torch.int64, device=dev)
         for i in mine:
             nl[i] = complexes[i]['lig_pos'].shape[0]

@@ -284,6 +284,45 @@ struct LaArgs {
 };
 
 constexpr int COMPACT_SLICES = 32;      // z blocks of conf_level_compact_kernel
+// max over the points a of the number of points within `r` of a (a itself included): uniform cell grid of edge r, 27 cells per point
+static int max_neighbours_within(const float* pos, int n, float r) {
+  if (n <= 0) return 0;
+  float lo[3] = {pos[0], pos[1], pos[2]}, hi[3] = {pos[0], pos[1], pos[2]};
+  for (int i = 1; i < n; ++i)
+    for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], pos[3 * i + k]); hi[k] = std::max(hi[k], pos[3 * i + k]); }
+  int dim[3];
+  for (int k = 0; k < 3; ++k) dim[k] = std::min(256, (int)((hi[k] - lo[k]) / r) + 1);
+  auto cell_of = [&](int i, int k) { return std::min(dim[k] - 1, (int)((pos[3 * i + k] - lo[k]) / r)); };      // (clamped grids only merge cells: still a superset search)
+  std::vector<int> start((size_t)dim[0] * dim[1] * dim[2] + 1, 0), item(n);
+  auto cid = [&](int cx, int cy, int cz) { return ((size_t)cx * dim[1] + cy) * dim[2] + cz; };
+  for (int i = 0; i < n; ++i) ++start[cid(cell_of(i, 0), cell_of(i, 1), cell_of(i, 2)) + 1];
+  for (size_t q = 1; q < start.size(); ++q) start[q] += start[q - 1];
+  std::vector<int> fill(start.begin(), start.end() - 1);
+  for (int i = 0; i < n; ++i) item[fill[cid(cell_of(i, 0), cell_of(i, 1), cell_of(i, 2))]++] = i;
+  const float r2 = r * r;
+  // a clamped axis (more than 256 cells of edge r) has cells wider than r only if the extent exceeds 256 r: search the neighbouring cells by coordinate range instead
+  int best = 0;
+  for (int i = 0; i < n; ++i) {
+    int cnt = 0;
+    int c0[3], c1[3];
+    for (int k = 0; k < 3; ++k) {
+      c0[k] = std::max(0, std::min(dim[k] - 1, (int)((pos[3 * i + k] - r - lo[k]) / r)));
+      c1[k] = std::max(0, std::min(dim[k] - 1, (int)((pos[3 * i + k] + r - lo[k]) / r)));
+      if (pos[3 * i + k] - r < lo[k]) c0[k] = 0;
+    }
+    for (int cx = c0[0]; cx <= c1[0]; ++cx)
+      for (int cy = c0[1]; cy <= c1[1]; ++cy)
+        for (int cz = c0[2]; cz <= c1[2]; ++cz)
+          for (int q = start[cid(cx, cy, cz)]; q < start[cid(cx, cy, cz) + 1]; ++q) {
+            const int j = item[q];
+            const float dx = pos[3 * j] - pos[3 * i], dy = pos[3 * j + 1] - pos[3 * i + 1], dz = pos[3 * j + 2] - pos[3 * i + 2];
+            cnt += dx * dx + dy * dy + dz * dz < r2;
+          }
+    best = std::max(best, cnt);
+  }
+  return best;
+}
+
 constexpr int LA_LIST = 256;      // per-wave list of the receptor atoms found around one ligand atom (flushed when fewer than 64 slots are left)
 
 // ligand-atom edges: radius(atom.pos, lig.pos, lig_max_radius) (all_atom_score_model.py:413-420) -> group la (src ligand atom,
@@ -834,7 +873,12 @@ int ddk_complex_set_atoms(ddk_ctx* ctx, ddk_complex* cx, const ddk_atoms_desc* d
     // static sets need rec_pos on the host below
     // ---- edge arrays: [4-group region of the shared graph kernel | la | al | aa | ar | ra] -------------
     K->cap4 = cx->edge_cap;
-    K->cap_la = Bm * (int64_t)n_lig * 96 + 64;       // <= 96 receptor atoms within 5 A of a ligand atom (1.2 A spacing bound ~ 300)
+    // ligand-atom edges (radius(atom.pos, ligand.pos, lig_max_radius, max_num_neighbors = 10000), all_atom_score_model.py:409-410): a capacity that CANNOT
+    // overflow, from the receptor's own geometry.  If any atom a lies within r of a point x, every atom within r of x lies within 2r of a: no ligand atom,
+    // wherever a pose puts it, collects more than max_a |{b : |b - a| < 2r}| neighbours (round 4 assumed 96 per ligand atom on average and turned the whole
+    // batch into NaN / -1000 when a dense pocket exceeded it).  ~250 for protein heavy atoms at r = 5 A; a cell grid makes the count O(n_atom)
+    const int la_bound = std::min(n_atom, max_neighbours_within(d->atom_pos, n_atom, 2.0f * c.lig_max_radius));
+    K->cap_la = Bm * (int64_t)n_lig * std::max(la_bound, 1) + 64;
     K->off_la = K->cap4; K->off_al = K->off_la + K->cap_la; K->off_aa = K->off_al + K->cap_la;
     // (Bv = Bm + 1 segments of every static set: the last one belongs to the virtual ligand-free sample; vrr = its rec-rec records)
     K->off_ar = K->off_aa + Bv * E_aa; K->off_ra = K->off_ar + Bv * n_atom; K->off_vrr = K->off_ra + Bv * n_atom; K->cap_total = K->off_vrr + cx->E_rr;

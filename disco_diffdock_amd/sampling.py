@@ -91,8 +91,9 @@ class _Bookkeeping:
     complex while the GPU works.  ``resolve()`` (first access of ``d.latent_str`` / ``d.latent_pos`` on this module's graph
     container, the next sampling() call once the copies have landed, or immediately for foreign containers) fills every graph of the
     batch that is still alive (the graphs are held weakly: a batch nobody kept costs nothing).
-    A confidence batch whose ligand-atom edge list overflowed needs no host action to be SEEN: the device writes NaN into its
-    confidences (conf_head_kernel), which sampling() returns as -1000 like the reference's nan_to_num; the flag only adds a warning."""
+    The capacity flag cannot be raised by the ligand-atom edge list any more (round 5: ddk_complex_set_atoms sizes it from the receptor's geometry, a bound no pose
+    can exceed); it stays as a guard of the other edge groups' worst-case capacities: a batch that raised it would carry NaN confidences (conf_head_kernel),
+    returned as -1000 like the reference's nan_to_num, and the warning below."""
 
     def __init__(self, graphs, choices, flat, len_lig, latent_dim, conf_cx):
         import weakref

@@ -185,3 +185,47 @@ def test_pocket_bound_trajectory_vs_oracle(dev, tables):
     _record_drift('pocket_bound_trajectory_20_steps_300_residues_B40_poses_vs_oracle', err_pos, bar=1e-3, min_cross_edges_per_sample=float(min(cross)))
     _record_drift('pocket_bound_trajectory_20_steps_300_residues_B40_per_step_scores_vs_oracle', max(per_step), bar=1e-4, per_step=[float(v) for v in per_step])
     assert err_pos < 1e-3 and max(per_step) < 1e-4
+
+
+def test_confidence_ligand_atom_capacity_cannot_overflow(dev):
+    """the ligand-atom edge list of the all-atom confidence model (radius(atom.pos, ligand.pos, 5 A, max_num_neighbors = 10000),
+    all_atom_score_model.py:409-410; the reference has no capacity) is sized from the receptor's own geometry (no ligand atom, wherever a pose puts it, has more
+    atoms within r than the densest atom has within 2r).  A receptor whose atoms are packed 2.2 x closer than a protein's, with compressed ligands dropped on its
+    densest spot: round 4's capacity (96 per ligand atom on average) overflowed here and returned -1000 for the whole batch; now the edge count matches the
+    oracle's, the status flag stays clear and the confidences agree."""
+    from oracle import confidence_ref as cr, graph_lite
+    from disco_diffdock_amd import synthetic
+    from disco_diffdock_amd.runtime import Context, Complex
+    from helpers import to_graph
+    c = synthetic.make_complex(43, n_res=120, n_lig=30)
+    synthetic.add_receptor_atoms(c, np.random.default_rng(43))
+    c['atom_pos'] = (0.45 * np.asarray(c['atom_pos'], np.float64)).astype(np.float32)          # ~11 x the heavy-atom density of a protein
+    ap = c['atom_pos'].astype(np.float64)
+    d2 = ((ap[:, None] - ap[None]) ** 2).sum(-1)
+    dense = int((d2 < 25.0).sum(1).argmax())
+    assert int((d2[dense] < 25.0).sum()) > 150                                                   # far beyond 96 atoms within 5 A
+    cfg = cr.ConfidenceModelConfig()
+    P = cr.random_state_dict(cfg, seed=7)
+    B = 3
+    base = c['lig_pos'].astype(np.float64)
+    rng = np.random.default_rng(2)
+    pos = np.stack([ap[dense] + 0.3 * (base - base.mean(0)) + rng.normal(0, 0.3, size=(1, 3)) for _ in range(B)]).astype(np.float32)
+    b = graph_lite.collate([graph_lite.add_atoms(to_graph(c), c['atom_x'], c['atom_pos'], c['atom_edge_index'], c['atom_rec_index']) for _ in range(B)])
+    b['ligand'].pos = T(pos.reshape(-1, 3))
+    for nt in ('ligand', 'receptor', 'atom'):
+        b[nt].node_t = {k: torch.zeros(b[nt].num_nodes) for k in ('tr', 'rot', 'tor')}
+    b.complex_t = {k: torch.zeros(B) for k in ('tr', 'rot', 'tor')}
+    want, inter = cr.confidence_forward(P, cfg, b, return_intermediates=True)
+    n_lig = base.shape[0]
+    assert inter['counts']['la'] > 96 * n_lig * B                                                # round 4's capacity
+    ctx = Context(device=0, all_atoms=1, embedding_scale=10000.0, num_confidence_outputs=2)
+    ctx.load_state_dict(P)
+    cx = Complex(ctx, c, max_batch=B)
+    cx.set_atoms(c['atom_x'], c['atom_pos'], c['atom_edge_index'], c['atom_rec_index'])
+    got = cx.confidence_forward(T(pos).to(dev))
+    cnt = cx.confidence_counts()
+    assert cnt['la'] == inter['counts']['la']
+    st = cx.confidence_status_async()
+    torch.cuda.synchronize()
+    assert int(st[19]) == 0
+    assert bool(torch.isfinite(got).all()) and rel_err(got.cpu(), want.reshape(B, -1)) < 1e-4

@@ -673,7 +673,7 @@ void model_destroy(ddk_ctx* ctx);   // model.hip
 
 extern "C" {
 
-const char* ddk_version(void) { return "ddk 0.5 (gfx950)"; }      // 0.5: ddk_config.confidence_mode + ddk_score_confidence; 0.4: three-limb records carry limbs at their own weight + tile descriptors; conv_f16x3 removed (INTEGRATION.md "ABI notes")
+const char* ddk_version(void) { return "ddk 0.6 (gfx950)"; }      // 0.6: conv_kernel = 2 (k_conv_y.hip), streaming ddk_tp_forward, confidence edge capacity from geometry; 0.5: ddk_config.confidence_mode + ddk_score_confidence; 0.4: three-limb records carry limbs at their own weight + tile descriptors; conv_f16x3 removed (INTEGRATION.md "ABI notes")
 
 int ddk_create(const ddk_config* cfg, ddk_ctx** out) {
   if (!cfg || !out) return DDK_ERR_INVALID;
@@ -683,7 +683,9 @@ int ddk_create(const ddk_config* cfg, ddk_ctx** out) {
   if (cfg->ns != NS || cfg->nv != NV)
     return fail(ctx, DDK_ERR_INVALID, "only ns=24, nv=6 (DiffDock-S / DisCo-DiffDock-S) is compiled in");
   if (cfg->num_conv_layers < 4 || cfg->num_conv_layers > 16)
-    return fail(ctx, DDK_ERR_INVALID, "num_conv_layers must be in [4,16] (heads assume the full 0e+1o+1e+0o irreps)");
+    return fail(ctx, DDK_ERR_INVALID, "num_conv_layers must be in [4,16] (the heads and the confidence predictor assume the full 0e+1o+1e+0o irreps)");
+  if (cfg->confidence_mode && cfg->all_atoms)
+    return fail(ctx, DDK_ERR_INVALID, "confidence_mode selects the COARSE-GRAINED score model's confidence head; the all-atom confidence model is all_atoms = 1 alone (include/ddk.h)");
   if (cfg->sigma_embed_dim != 32 || cfg->distance_embed_dim != 32 || cfg->cross_distance_embed_dim != 32)
     return fail(ctx, DDK_ERR_INVALID, "only 32-wide sigma / distance embeddings are compiled in");
   if (cfg->deterministic && cfg->all_atoms)

@@ -703,12 +703,12 @@ void conv_det_fix(const ConvKArgs& k, const ConvLaunch& a, int dout, hipStream_t
 }
 
 hipError_t launch_conv_fused(const ConvLayerDev& L, const ConvLaunch& a, int n_cu, hipStream_t s) {
-  // the default: exact three-limb product on the f16 matrix pipe (the confidence model's layers: the gather path of its forward; ddk_conv_forward's
-  // explicit-boundary entry stays on the fp32 kernel for them)
+  // the default: exact three-limb product on the f16 matrix pipe - the score model's launches and, for the confidence model's layers (mode 1, no node
+  // terms), both the gather path of its forward and ddk_conv_forward's explicit-boundary entry (test_confidence_conv_layer_vs_oracle[kernel 0])
   if (L.w2x != nullptr && (a.mode == 0 || (a.mode == 1 && a.pre == nullptr))) return launch_conv_fused_x(L, a, n_cu, s);
   ConvKArgs k;
   k.w1x = nullptr; k.w2x = nullptr;
-  for (int g = 0; g < 4; ++g) { k.w1s[g] = 1.0f; k.w1u[g] = 1.0f; k.w2s[g] = 1.0f; k.w2u[g] = 1.0f; }
+  for (int g = 0; g < CONV_MAX_GROUPS; ++g) { k.w1s[g] = 1.0f; k.w1u[g] = 1.0f; k.w2s[g] = 1.0f; k.w2u[g] = 1.0f; }
   k.x = a.x; k.src = a.src; k.dst = a.dst; k.edge_attr = a.edge_attr; k.sh = a.sh; k.sum = a.sum;
   k.counter = a.counter;
   k.w1p = L.w1p[0]; k.b1p = L.b1p[0]; k.w2r = L.w2r[0]; k.n_tiles = L.n_tiles;

@@ -143,8 +143,8 @@ class TensorProductScoreModel(nn.Module):
                                "(0 = exact three-limb f16 product, default; 1 = fp32 MFMA) - see INTEGRATION.md")
         if sh_lmax != 1 or use_second_order_repr or use_old_atom_encoder or latent_cross_attention:
             raise RuntimeError('ddk implements the sh_lmax=1 first-order score model with the new AtomEncoder only')
-        if confidence_mode and (num_conv_layers < 3 or latent_dim):
-            raise RuntimeError('ddk: confidence_mode of the coarse-grained model needs num_conv_layers >= 3 and no latents')
+        if confidence_mode and (num_conv_layers < 4 or latent_dim):      # (ddk_create: num_conv_layers in [4, 16]; the predictor reads the full 0e+1o+1e+0o rows)
+            raise RuntimeError('ddk: confidence_mode of the coarse-grained model needs num_conv_layers >= 4 and no latents')
         if in_lig_edge_features != 4:
             raise RuntimeError('ddk: in_lig_edge_features must be 4')
         lim = sigma_limits or {k: DEFAULTS[k] for k in ('tr_sigma_min', 'tr_sigma_max', 'rot_sigma_min', 'rot_sigma_max',

@@ -229,3 +229,36 @@ def test_confidence_ligand_atom_capacity_cannot_overflow(dev):
     torch.cuda.synchronize()
     assert int(st[19]) == 0
     assert bool(torch.isfinite(got).all()) and rel_err(got.cpu(), want.reshape(B, -1)) < 1e-4
+
+
+def test_cg_confidence_reads_the_last_executed_steps_time(dev, golden):
+    """evaluate.py:269 passes the FULL schedule with inference_steps = actual_steps; the reference leaves complex_t at the last EXECUTED step
+    (utils/sampling.py:105-111), which a coarse-grained confidence model (confidence_data_list = None, :239-240) reads as its sigmas.  A 25-entry schedule
+    run for 20 steps: the confidences are those of t = schedule[19], not schedule[24]."""
+    from functools import partial
+    from helpers import complex_from_npz
+    from test_gpu_model import ARGS_S, _ref_noise
+    from test_gpu_round4 import _cg_conf_model
+    from disco_diffdock_amd.sampling import sampling
+    from disco_diffdock_amd.model_utils import get_model
+    from disco_diffdock_amd.data import from_arrays, DataLoader
+    from disco_diffdock_amd.diffusion_utils import t_to_sigma, get_t_schedule
+    z, c = golden('trajectory_cg_confidence'), complex_from_npz(golden('complex_cg_confidence'))
+    model = get_model(ARGS_S, dev, partial(t_to_sigma, args=ARGS_S), no_parallel=True)
+    model.score_model.load_state_dict(smr.random_state_dict(smr.ScoreModelConfig(latent_vocab=64), seed=int(z['score_seed'])), strict=True)
+    cm, cargs = _cg_conf_model(dev, int(z['conf_seed']))
+    n = len(c['lig_pos'])
+    B, steps = len(z['pos0']) // n, 20
+    dl = [from_arrays(c) for _ in range(B)]
+    for i, d in enumerate(dl):
+        d['ligand'].pos = torch.from_numpy(z['pos0'][i * n:(i + 1) * n])
+    sched = get_t_schedule(25)
+    noise = [_ref_noise(int(z['seed']), steps, B, int(c['edge_mask'].sum()))]
+    out, conf = sampling(dl, model, steps, sched, sched, sched, dev, partial(t_to_sigma, args=ARGS_S), ARGS_S, batch_size=B, no_final_step_noise=True, use_latent=False,
+                         noise=noise, confidence_model=cm, confidence_data_list=None, confidence_model_args=cargs, temp_sampling=1.0, temp_psi=0.0, temp_sigma_data=0.5)
+    pos = torch.stack([d['ligand'].pos for d in out]).to(dev)
+    cg = getattr(cm, 'score_model', cm)
+    batch = next(iter(DataLoader([from_arrays(c) for _ in range(B)], batch_size=B)))
+    at = lambda k: cg.confidence(batch, pos.clone(), (float(sched[k]),) * 3).cpu()
+    assert rel_err(conf.cpu(), at(steps - 1)) < 1e-6
+    assert rel_err(conf.cpu(), at(24)) > 1e-4          # (the two times give different confidences: the test can see the difference)

@@ -37,6 +37,7 @@
 #include <stdlib.h>
 
 #include "k_conv_common.h"
+#include "k_conv_x_epi_gen.inc"      // the tile epilogue as one asm statement per ring stage (tools/gen_conv_x_epi.py; round 5)
 
 namespace ddk {
 
@@ -297,6 +298,14 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
   // every thread moves two 16-B chunks of a tile record: chunk tid and chunk tid + 512 (threads past the record's end move its last chunk
   // again: same bytes to the same place, no branch in the burst)
   const uint32_t fo0 = 16u * tid, fo1 = 16u * min(tid + 64 * WAVES, REC16 - 1);
+  // the hot instantiation (score-model conv layers: gather + node terms, atomics) runs its tile epilogue as ONE asm statement (k_conv_x_epi_gen.inc): the
+  // accumulators are in/out operands of every tile kind's code alike, so the compiler has nothing to copy or select at a merge (VERDICT r04 #1a)
+  constexpr bool ASM_EPI = GATHER && SPLIT && !DET && !TRACE && MODE == 0;
+  const unsigned ring0_u = (unsigned)(WAVES * 32 * FS * 4), ringb_u = ring0_u + 64u * hh, ringw0_u = ring0_u + fo0, ringw1_u = ring0_u + fo1;
+  const unsigned fra_u = (unsigned)((wave * 32 + el) * FS * 4), hh4_u = 4u * hh, hh12_u = 12u * hh;
+  int t0_, t1_, t2_, sel_, pk0_, pk1_, pk2_;
+  unsigned long long sv_;
+  (void)ringb_u; (void)ringw0_u; (void)ringw1_u; (void)fra_u; (void)hh4_u; (void)hh12_u;
 
   // work units: whole blocks, except that the last (bs4 mod #workgroups) blocks are split into column chunks so that the final round of the
   // persistent workgroups is a fraction of a block long (same rule as k_conv.hip)
@@ -560,6 +569,14 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
         else if (sn == snl && last_cont) node_row = prow + XW;
       }
     }
+    // (asm epilogue) the node row as a 32-bit byte offset from the accumulator array, run tails as an exec mask, lanes past the group's end scaled to zero
+    const bool shared2_ = g2_shared && g == 2;
+    const float* sumbase = shared2_ ? A.sum_g2 : A.sum;
+    const unsigned vrow = shared2_ ? (unsigned)(sn - A.g2_node_off) * (unsigned)(XW * 4)
+                                   : ((unsigned)sn * (unsigned)A.n_slots + ((A.slots >> (2 * g)) & 3u)) * (unsigned)(XW * 4);
+    const unsigned long long tail_mask = __ballot(seg.tail);
+    const float oscv = seg.valid ? osc : 0.0f;
+    (void)sumbase; (void)vrow; (void)tail_mask; (void)oscv;
     float accA[4], accV[4][3], accX[4][3];      // accX: sums over the rows that are crossed with v (vector columns)
     float accY[3][3];                           // MODE 1: sums over the rows of the l = 2 groups
 #pragma unroll
@@ -694,6 +711,11 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
       stamp(2);                                                                                                                              \
       /* ===== epilogue (beside the SIMD partner's burst): the tile's bias, then this thread's chunks of tile t+3 into the stage tile t-1     \
          has left (nobody reads it between barriers t and t+2) ===== */                                                                      \
+      if constexpr (ASM_EPI) {                                                                                                               \
+        const unsigned fpa_u = fra_u + 4u * (unsigned)((w0 >> 16) & 0xff);                                                                   \
+        const int chan4_ = chan0 * 4;                                                                                                        \
+        X3_EPI_##ST();                                                                                                                       \
+      } else {                                                                                                                               \
       const float4 bs0 = ld4(reinterpret_cast<const float*>(ringb + SO + W2X_BIAS_OFF)), bs1 = ld4(reinterpret_cast<const float*>(ringb + SO + W2X_BIAS_OFF + 16)); \
       const float4 bs2 = ld4(reinterpret_cast<const float*>(ringb + SO + W2X_BIAS_OFF + 32)), bs3 = ld4(reinterpret_cast<const float*>(ringb + SO + W2X_BIAS_OFF + 48)); \
       *reinterpret_cast<u32x4*>(ringw0 + SW) = st0;                                                                                          \
@@ -718,6 +740,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
         tile_epilogue_s<MODE>(w0, D0, Fp, f0, accA, accV, accX, accY);                                                                       \
         stamp_epi(6);                                                                                                                        \
         finish_tile(w0, chan0, D0, f0);                                                                                                      \
+      }                                                                                                                                      \
       }                                                                                                                                      \
       w0 = __builtin_amdgcn_readfirstlane(dq.x); chan0 = __builtin_amdgcn_readfirstlane(dq.y);                                               \
       stamp_epi(7);                                                                                                                          \

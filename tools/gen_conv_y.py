@@ -139,7 +139,7 @@ def packed_stream():
     return out
 
 
-def main_stream(kind):
+def main_stream(kind, packed=True):
     out = [('need', 'f0')]
     f = [F[0:4], F[4:8], F[8:12]]
     if kind in ('RA', 'RT'):
@@ -147,7 +147,8 @@ def main_stream(kind):
         for j in (3, 2, 1, 0):          # fmaf(f.x, D0, fmaf(f.y, D1, fmaf(f.z, D2, fmaf(f.w, D3, acc))))
             for rq in range(4):
                 out.append(f'v_fmac_f32 {acc(rq)}, {f[0][j]}, {dy(4 * rq + j)}')
-        out += packed_stream()
+        if packed:
+            out += packed_stream()
     elif kind.startswith('TV'):
         x = int(kind[2])
         x01, x23 = bool(x & 1), bool(x & 2)
@@ -159,7 +160,7 @@ def main_stream(kind):
                 for rq in range(3):
                     tgt = aX(rq, c) if cross else aV(rq, c)
                     out.append(f'v_fmac_f32 {tgt}, {f[c][j]}, {dy(4 * rq + j)}')
-            if c == 0:
+            if c == 0 and packed:
                 out += packed_stream()
     elif kind == 'RTS':
         for j in (1, 0):
@@ -169,7 +170,8 @@ def main_stream(kind):
             out.append(f'v_mul_f32 %[R{rq}], {f[0][3]}, {dy(4 * rq + 3)}')
         for rq in range(4):
             out.append(f'v_fmac_f32 %[R{rq}], {f[0][2]}, {dy(4 * rq + 2)}')
-        out += packed_stream()
+        if packed:
+            out += packed_stream()
     return out
 
 

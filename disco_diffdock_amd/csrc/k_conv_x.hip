@@ -73,12 +73,15 @@ struct Limbs {
 };
 // The K = 8 tail step costs the matrix pipe as much as a K = 16 step, and four of its six limb products come in pairs on the same accumulator:
 // hi.mid + mid.hi and hi.lo + lo.hi each fit ONE 32x32x16 MFMA on concatenated operands ({W_hi, W_mid} x {h_mid, h_hi}, {W_lo, W_hi} x {h_hi, h_lo}),
-// so the tail is 4 MFMAs instead of 6 (28 per tile).  B-side operands of those two, built once per unit:
-struct TailB { f16x8 mh, hl; };      // {h_mid, h_hi}, {h_hi, h_lo} of the 4-value tail
+// so do hi.hi + mid.mid once mid.mid (relative order 2^-22, the one small term of the tail that then rounds with D0's sum instead of among the small
+// terms: the MFMA adds the products of its K range exactly and rounds once, so nothing is rounded that was not before) joins D0:
+// {W_hi, W_mid} x {h_hi, h_mid}.  The tail is 3 MFMAs instead of 6 (27 per tile; round 4: 28).  B-side operands, built once per unit:
+struct TailB { f16x8 mh, hl, hm; };      // {h_mid, h_hi}, {h_hi, h_lo}, {h_hi, h_mid} of the 4-value tail
 __device__ __forceinline__ TailB make_tailb(const Limbs& L) {
   TailB t;
   t.mh = __builtin_shufflevector(L.tmid, L.thi, 0, 1, 2, 3, 4, 5, 6, 7);
   t.hl = __builtin_shufflevector(L.thi, L.tlo, 0, 1, 2, 3, 4, 5, 6, 7);
+  t.hm = __builtin_shufflevector(L.thi, L.tmid, 0, 1, 2, 3, 4, 5, 6, 7);
   return t;
 }
 
@@ -149,6 +152,7 @@ __device__ __forceinline__ void segf_add_n(float* dst, int stride, float (&xv)[N
 
 // six-term product of one K step into the two accumulators, alternating (D0: hi.hi and the 2^-11 terms, D1: the 2^-22 terms)
 #ifdef ONE_ACC
+#define X3_TAIL3(a_lh, a_hm) D0 = MFMA16(a_lh, HT.hl, D0); D0 = MFMA16(a_hm, HT.mh, D0); D0 = MFMA16(a_hm, HT.hm, D0);
 #define X3_STEP(MF, ah, am, al, bh, bm, bl)   \
   D0 = MF(ah, bl, D0);                        \
   D0 = MF(al, bh, D0);                        \
@@ -157,6 +161,7 @@ __device__ __forceinline__ void segf_add_n(float* dst, int stride, float (&xv)[N
   D0 = MF(am, bh, D0);                        \
   D0 = MF(ah, bh, D0);
 #else
+#define X3_TAIL3(a_lh, a_hm) D0 = MFMA16(a_hm, HT.mh, D0); D1 = MFMA16(a_lh, HT.hl, D1); D0 = MFMA16(a_hm, HT.hm, D0);
 #define X3_STEP(MF, ah, am, al, bh, bm, bl)   \
   D1 = MF(ah, bl, D1);                        \
   D0 = MF(ah, bm, D0);                        \
@@ -300,7 +305,11 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
   const uint32_t fo0 = 16u * tid, fo1 = 16u * min(tid + 64 * WAVES, REC16 - 1);
   // the hot instantiation (score-model conv layers: gather + node terms, atomics) runs its tile epilogue as ONE asm statement (k_conv_x_epi_gen.inc): the
   // accumulators are in/out operands of every tile kind's code alike, so the compiler has nothing to copy or select at a merge (VERDICT r04 #1a)
-  constexpr bool ASM_EPI = GATHER && SPLIT && !DET && !TRACE && MODE == 0;
+#ifdef X3_CXX_EPI          // (A/B switch: the compiler-scheduled epilogue everywhere)
+  constexpr bool ASM_EPI = false;
+#else
+  constexpr bool ASM_EPI = GATHER && SPLIT && !DET && MODE == 0;     // (the trace build too: its stamps 4-6 inside the epilogue exist only under X3_CXX_EPI)
+#endif
   const unsigned ring0_u = (unsigned)(WAVES * 32 * FS * 4), ringb_u = ring0_u + 64u * hh, ringw0_u = ring0_u + fo0, ringw1_u = ring0_u + fo1;
   const unsigned fra_u = (unsigned)((wave * 32 + el) * FS * 4), hh4_u = 4u * hh, hh12_u = 12u * hh;
   int t0_, t1_, t2_, sel_, pk0_, pk1_, pk2_;
@@ -696,14 +705,11 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
       X3_STEP(MFMA16, q3.h, q3.m, q3.l, H.hi[3], H.mid[3], H.lo[3])                                                                         \
       X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_BARE X3_BARE                                                            \
       __builtin_amdgcn_sched_barrier(0);                                                                         \
-      {     /* packed tail: D0 += hi.mid + mid.hi, D1 += lo.hi + hi.lo as one K = 16 MFMA each; mid.mid and hi.hi stay K = 8 */              \
+      {     /* packed tail: D0 += hi.mid + mid.hi, D1 += lo.hi + hi.lo, D0 += hi.hi + mid.mid as one K = 16 MFMA each */                     \
         const f16x8 a_hm = __builtin_shufflevector(th, tm, 0, 1, 2, 3, 4, 5, 6, 7), a_lh = __builtin_shufflevector(tl, th, 0, 1, 2, 3, 4, 5, 6, 7); \
-        D1 = MFMA16(a_lh, HT.hl, D1);                                                                                                        \
-        D0 = MFMA16(a_hm, HT.mh, D0);                                                                                                        \
-        D1 = MFMA8(tm, H.tmid, D1);                                                                                                          \
-        D0 = MFMA8(th, H.thi, D0);                                                                                                           \
+        X3_TAIL3(a_lh, a_hm)                                                                                                                 \
       }                                                                                                                                      \
-      X3_BARE X3_BARE X3_BARE X3_BARE                                                                                                        \
+      X3_BARE X3_BARE X3_BARE                                                                                                                \
       __builtin_amdgcn_sched_barrier(0);                                                                                                     \
       __builtin_amdgcn_s_setprio(0);                                                                                                         \
       stamp(1);                                                                                                                              \

@@ -76,19 +76,25 @@ def kind_body(kind):
 def epilogue(ST):
     SO, SW = ST * TB, ((ST + 3) & 3) * TB
     L = []
-    for j in range(4):
-        L.append(f'ds_read_b128 v[{4 * j}:{4 * j + 3}], %[ringb] offset:{SO + BIAS_OFF + 16 * j}')
+    ABL = os.environ.get('GEN_ABL', '')          # timing-only ablations (results invalid): nobias, noring, nofold, nofma
+    if 'nobias' not in ABL:
+        for j in range(4):
+            L.append(f'ds_read_b128 v[{4 * j}:{4 * j + 3}], %[ringb] offset:{SO + BIAS_OFF + 16 * j}')
     # this thread's two chunks of record t+3 (requested at the start of the burst) into the stage tile t-1 has left
-    L += ['s_waitcnt vmcnt(1)', f'ds_write_b128 %[rw0], %[st0] offset:{SW}', 's_waitcnt vmcnt(0)', f'ds_write_b128 %[rw1], %[st1] offset:{SW}']
-    for r in range(16):
-        L.append(f'v_add_f32 v{16 + r}, v{16 + r}, v{32 + r}')
-    L.append('s_waitcnt lgkmcnt(2)')
-    for r in range(16):
-        L.append(f'v_fmac_f32 v{16 + r}, v{r}, %[bsc2]')
+    if 'noring' not in ABL:
+        L += ['s_waitcnt vmcnt(1)', f'ds_write_b128 %[rw0], %[st0] offset:{SW}', 's_waitcnt vmcnt(0)', f'ds_write_b128 %[rw1], %[st1] offset:{SW}']
+    if not os.environ.get('GEN_ONE_ACC') and 'nofold' not in ABL:      # (experiment: one accumulator chain, nothing to fold)
+        for r in range(16):
+            L.append(f'v_add_f32 v{16 + r}, v{16 + r}, v{32 + r}')
+    if 'nobias' not in ABL:
+        L.append('s_waitcnt lgkmcnt(2)' if 'noring' not in ABL else 's_waitcnt lgkmcnt(0)')
+        for r in range(16):
+            L.append(f'v_fmac_f32 v{16 + r}, v{r}, %[bsc2]')
     # tile kind -> selector (1 RA, 2 RT, 3 + cross bits TV, 7 RTS)
     L += ['s_and_b32 %[t0], %[w0], 3', 's_bfe_u32 %[t1], %[w0], 0x2000e', 's_add_i32 %[t1], %[t1], 3', 's_add_i32 %[t2], %[t0], 1',
           's_cmp_eq_u32 %[t0], 2', 's_cselect_b32 %[t2], %[t1], %[t2]', 's_cmp_eq_u32 %[t0], 3', 's_cselect_b32 %[sel], 7, %[t2]']
-    variants = [(1, kind_body('RA')), (2, kind_body('RT'))] + [(3 + x, kind_body(f'TV{x}')) for x in range(4)] + [(7, kind_body('RTS'))]
+    one = (lambda b: b[:1]) if 'nofma' in ABL else (lambda b: b)
+    variants = [(1, one(kind_body('RA'))), (2, one(kind_body('RT')))] + [(3 + x, kind_body(f'TV{x}')) for x in range(4)] + [(7, kind_body('RTS'))]
     inl, ool_k = G.dispatch_split(variants, 'sel', 'k')
     L += inl
     # packed quad (6-channel columns: accumulator quad 3 carries another a / c row quad for channel pair xp)

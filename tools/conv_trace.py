@@ -13,13 +13,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--layer', type=int, default=3)
 ap.add_argument('--t', type=float, default=0.6)
 ap.add_argument('--epi', action='store_true', help='four more stamps inside every epilogue: LDS requests + ring stores | fold | tensor product | packed quad, flush, descriptor')
+ap.add_argument('--samples', type=int, default=40, help='poses in the batch (5: every node row fits every L2)')
 ap.add_argument('--coarse', action='store_true', help='one record per unit (no stamps inside the tile loop): undisturbed cycles per tile')
 a = ap.parse_args()
 dev = torch.device('cuda:0')
 ctx = Context(device=0)
 ctx.load_state_dict(synthetic.random_score_model_state_dict(seed=0))
 c = synthetic.make_complex(0, n_res=300)
-B = 40
+B = a.samples
 cx = Complex(ctx, c, B)
 rng = np.random.default_rng(0)
 pos = torch.from_numpy(np.stack([c['lig_pos'] + rng.normal(0, 3.0, size=(1, 3)) for _ in range(B)]).astype(np.float32)).to(dev)

@@ -94,7 +94,7 @@ CONFIG_TEXT = {
 }
 
 
-CONV_KERNEL_SOURCES = ('k_conv_x.hip', 'k_conv_common.h', 'ddk_internal.h')      # what the dominant kernel is compiled from
+CONV_KERNEL_SOURCES = ('k_conv_x.hip', 'k_conv_x_epi_gen.inc', 'k_conv_common.h', 'ddk_internal.h')      # what the dominant kernel is compiled from
 
 
 def conv_kernel_source_sha():

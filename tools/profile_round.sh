@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof
 rm -rf "$OUT"; mkdir -p "$OUT"
-CMD="python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-alt --no-device-loop --no-extras"   # the driver's timed region (20 steps, 5 warm-up) without the CPU leg, the fallback leg and the extra brackets
+CMD="python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-alt --no-device-loop --no-extras --no-timesplit"   # the driver's timed region (20 steps, 5 warm-up) without the CPU leg, the fallback leg and the extra brackets
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- $CMD > "$OUT/trace.log" 2>&1
 i=0

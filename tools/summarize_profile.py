@@ -26,7 +26,7 @@ for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
     lines.append(f'| {k[:92]} | {len(v)} | {sum(v) / 1e3:.2f} | {sum(v) / len(v):.1f} | {min(v):.1f} | {max(v):.1f} | {100 * sum(v) / tot:.1f} |')
 conv = [v for k, v in agg.items() if KERNEL in k]
 conv = conv[0] if conv else []
-head = (f'# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-alt --no-device-loop --no-extras (MI355X)\n\n'
+head = (f'# rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-alt --no-device-loop --no-extras --no-timesplit (MI355X)\n\n'
         f'{len(conv)} fused TP-conv launches, average {sum(conv) / max(len(conv), 1):.1f} us.\n\n')
 open(os.path.join(out, 'kernel_stats.md'), 'w').write(head + '\n'.join(lines) + '\n')
 
@@ -34,9 +34,9 @@ open(os.path.join(out, 'kernel_stats.md'), 'w').write(head + '\n'.join(lines) + 
 import hashlib
 _root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
 _h = hashlib.sha256()
-for _n in ('k_conv_x.hip', 'k_conv_common.h', 'ddk_internal.h'):          # == bench.py CONV_KERNEL_SOURCES: bench.py quotes this profile only for these sources
+for _n in ('k_conv_x.hip', 'k_conv_x_epi_gen.inc', 'k_conv_common.h', 'ddk_internal.h'):          # == bench.py CONV_KERNEL_SOURCES: bench.py quotes this profile only for these sources
     _h.update(open(os.path.join(_root, 'disco_diffdock_amd', 'csrc', _n), 'rb').read())
-res = {'kernel_source_sha256': _h.hexdigest(), 'command': 'rocprofv3 --kernel-trace --pmc <group> (one group per pass) -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-alt --no-device-loop --no-extras',
+res = {'kernel_source_sha256': _h.hexdigest(), 'command': 'rocprofv3 --kernel-trace --pmc <group> (one group per pass) -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-alt --no-device-loop --no-extras --no-timesplit',
        'kernel': 'ddk::' + KERNEL + ', false>', 'avg_launch_us_kernel_trace': sum(conv) / max(len(conv), 1)}
 for d in sorted(glob.glob(os.path.join(src, 'pmc*'))):
     if not os.path.isdir(d):

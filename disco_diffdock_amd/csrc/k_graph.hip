@@ -456,6 +456,9 @@ __global__ __launch_bounds__(GT) void graph_fill_kernel(GraphArgs G) {
       if (i < n_lig) { ll_pre[i] = a + xa - va; lr_pre[i] = c + xc - vc; }
       a += __shfl(xa, 63, 64); c += __shfl(xc, 63, 64);
     }
+    // guard: the group offsets come from graph_count_kernel's counts, the slots are written from THIS kernel's recount - the two must agree
+    // (the neighbour predicates compile without fp contraction for that reason); a disagreement would leave a slot of a reused chunk unwritten
+    if (lane == 0 && slice == 0 && (a != G.counts[CNT_STRIDE * b] + G.M || c != G.counts[CNT_STRIDE * b + 1])) atomicOr(&G.info[I_MISMATCH], 1);
   }
   block_exclusive_scan(c_rl, n_rec, scan_tmp);   // exclusive prefix of the per-residue rec->lig counts (in place; ends with a barrier)
   // ---- group 0: lig-lig, sorted by src: bonds of the atom (bond order) then radius edges (ascending dst); one wave per atom, ballot compaction

@@ -24,6 +24,8 @@ enum InfoSlot : int {
   I_FB = 18,      // [18..23] edge-feature block prefix over 5 feature groups (the 4 groups + the shared rec-rec copy), 256 edges per block
   I_E = 24,       // total edges of the reference graph (go[4])
   I_OVF = 25,     // capacity overflow flag
+  I_MISMATCH = 31,   // sticky: graph_fill_kernel's recount of a sample's lig-lig / cross edges disagreed with graph_count_kernel's (the offsets come from one, the
+                     // writes from the other: a slot would keep what the reused chunk held - ADVICE r04); reported by ddk_last_graph_stats out[11]
   I_SEG = 27,     // [27..30] first edge of the four level segments [A | B | C | rest] of group 2
   I_SHARED = 26,  // first edge of the shared rec-rec copy (= go[4]; E_rr edges in sample-0 numbering, layer-0 de-duplication) or -1
   I_TAB = 32,     // group tables: [32 + 8k + g] = gbeg, [36 + 8k + g] = gend of table k (N_TAB tables)

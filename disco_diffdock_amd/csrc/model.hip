@@ -1024,7 +1024,7 @@ int ddk_last_graph_stats(ddk_ctx* ctx, ddk_complex* cx, int64_t* out, void* stre
   out[7] = cx->edge_cap;
   // rec-rec edges inside the backward receptive field of the heads: levels A, A+B, A+B+C (k_graph.hip); = E_rr * B when pruning is off
   out[8] = info[I_SEG + 1] - info[I_SEG]; out[9] = info[I_SEG + 2] - info[I_SEG]; out[10] = info[I_SEG + 3] - info[I_SEG];
-  out[11] = 0;
+  out[11] = info[I_MISMATCH];      // != 0: count / fill kernels disagreed about a sample's edges in some forward since the complex was created
   return DDK_OK;
 }
 

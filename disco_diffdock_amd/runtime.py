@@ -459,6 +459,8 @@ class Complex:
         v = list(out)
         if v[6]:
             raise RuntimeError('ddk: edge capacity overflow')
+        if v[11]:
+            raise RuntimeError('ddk: the graph count and fill kernels disagreed about an edge count (internal consistency guard)')
         return dict(E_ll=v[0], E_lr=v[1], E_rr=v[2], E_rl=v[3], E_shared=v[4], E=v[5], cap=v[7], E_rr_live=(v[8], v[9], v[10]))
 
     def keep_receptor_features(self, on=True):

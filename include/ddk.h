@@ -270,7 +270,8 @@ int ddk_build_graph(ddk_ctx* ctx, ddk_complex* cx, int32_t B, const float* lig_p
 /* Copies the last forward's edge counts into out[12] (HOST, synchronises the stream): [0..3] = E_ll, E_lr, E_rr, E_rl of the reference
  * graph, [4] = edges of the shared receptor-receptor copy (layer-0 de-duplication), [5] = E, [6] = capacity overflow flag,
  * [7] = edge capacity, [8..10] = receptor-receptor edges inside the heads' backward receptive field one / two / three layers below
- * the last conv layer (= E_rr when the pruning is off), [11] = 0. */
+ * the last conv layer (= E_rr when the pruning is off), [11] != 0: the graph's count and fill kernels disagreed about a sample's edge count in some
+ * forward since the complex was created (an internal consistency guard: the edge list of that forward is not to be trusted). */
 int ddk_last_graph_stats(ddk_ctx* ctx, ddk_complex* cx, int64_t* out, void* stream);
 /* Node features after the conv stack of the last forward: lig [B*n_lig, 84], rec [B*n_rec, 84] (device ptrs, may be NULL).
  * rec_out != NULL requires ddk_set_keep_receptor_features(on) before that forward (DDK_ERR_STATE otherwise). */

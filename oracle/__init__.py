@@ -27,4 +27,14 @@ Pinning status
   on top of these stand-ins.  They are cross-checked by equivariance and self-consistency
   tests (e.g. FasterTensorProduct == FCTP with re-laid-out weights) but no reference-owned
   test vector pins them.
+  Round 5 narrowed what "unpinned" covers (tests/test_tier_b.py, CPU, no e3nn wheel needed):
+  closed forms w3j(1,1,0) = delta / sqrt3, w3j(1,1,1) = eps / sqrt6 (signs anchored to the
+  reference's own dot / cross products through FasterTP == FCTP), w3j(1,1,2) and w3j(1,2,1) =
+  the symmetric-traceless embedding of the l = 2 basis the harmonics define (harmonics and
+  symbols are mutually consistent), component normalisation and parity of the harmonics, and
+  rotation AND inversion equivariance of EVERY FullyConnectedTensorProduct / FullTensorProduct
+  instance the score and confidence models build (D-matrices of l <= 2 derived from the
+  harmonics, l = 3 through w3j(1,2,3)).  What remains unpinned is convention, not arithmetic:
+  the overall sign of w3j(1,2,1) (a global sign of the torsion head's 1o x 2e path), e3nn's
+  path normalisation, and torch_cluster's tie-break under the neighbour cap.
 """

@@ -82,6 +82,8 @@ def test_pipelined_conv_kernel_engaged_and_equal(dev):
     that kernel writes) and give the scores / node rows of kernel 0 up to the association of the accumulation (one MFMA chain per tile instead of two)."""
     from disco_diffdock_amd import synthetic
     from disco_diffdock_amd.runtime import Context, Complex
+    if os.environ.get('DDK_DETERMINISTIC'):
+        pytest.skip('the deterministic scatter exists in k_conv_x.hip only: conv_kernel = 2 falls back to it (k_conv_x.hip: launch_conv_x3)')
     c = synthetic.make_complex(3, n_res=300)
     P = smr.random_state_dict(CFG, seed=9)
     B = 40

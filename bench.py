@@ -621,6 +621,9 @@ def main():
         launches = sum(p['launches'] for p in prof)
         tf = lambda f: f / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         traffic, traffic_file = pmc_traffic()
+        if not (a.config == 2 and a.steps == 20 and a.warmup == 5 and not a.complexes and world == 1):
+            # the PMC passes are taken over the driver's command: their per-launch mean is that workload's, not another config's
+            traffic, traffic_file = None, 'the PMC profile is of the driver command (config 2, --steps 20 --warmup 5): not quoted for another workload'
         fw = head['fw']
         per_step = None
         if len(fw) == a.steps * STEPS:

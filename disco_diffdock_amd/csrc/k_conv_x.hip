@@ -430,6 +430,8 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
         for (int i = 0; i < 8; ++i) { const Limb3 q = split3(bin[i] * s1); b0h[i] = q.h; b0m[i] = q.m; b0l[i] = q.l; }
 #pragma unroll
         for (int i = 0; i < 4; ++i) { const Limb3 q = split3(bin[8 + i] * s1); b1h[i] = q.h; b1m[i] = q.m; b1l[i] = q.l; }
+        const f16x8 b1_mh = __builtin_shufflevector(b1m, b1h, 0, 1, 2, 3, 4, 5, 6, 7), b1_hl = __builtin_shufflevector(b1h, b1l, 0, 1, 2, 3, 4, 5, 6, 7),
+                    b1_hm = __builtin_shufflevector(b1h, b1m, 0, 1, 2, 3, 4, 5, 6, 7);
         const float bsc = s1 * A.w1s[gw], usc = inv1 * A.w1u[gw];
 #pragma unroll
         for (int T = 0; T < 3; ++T) {
@@ -456,7 +458,11 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
             const f16x4 ah = *reinterpret_cast<const f16x4*>(wt + 1024 + lane * 16);
             const f16x4 am = *reinterpret_cast<const f16x4*>(wt + W2X_LIMB_BYTES + 1024 + lane * 16);
             const f16x4 al = *reinterpret_cast<const f16x4*>(wt + 2 * W2X_LIMB_BYTES + 1024 + lane * 16);
-            X3_STEP(MFMA8, ah, am, al, b1h, b1m, b1l)
+            // (the K = 8 half step packed like the tile tail: hi.mid + mid.hi, lo.hi + hi.lo, hi.hi + mid.mid as one K = 16 MFMA each: 9 instead of 12 per row tile)
+            const f16x8 a_hm = __builtin_shufflevector(ah, am, 0, 1, 2, 3, 4, 5, 6, 7), a_lh = __builtin_shufflevector(al, ah, 0, 1, 2, 3, 4, 5, 6, 7);
+            D0 = MFMA16(a_hm, b1_mh, D0);
+            D1 = MFMA16(a_lh, b1_hl, D1);
+            D0 = MFMA16(a_hm, b1_hm, D0);
           }
           const int nr = T < 2 ? 16 : 4;
 #pragma unroll

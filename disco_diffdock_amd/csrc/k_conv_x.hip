@@ -96,6 +96,18 @@ __device__ __forceinline__ void make_limbs(Limbs& L, const float (&v)[36], float
 
 // workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also drains vmcnt, i.e. the global atomics of a flush and
 // the tile record requests that are meant to stay in flight across the barrier
+#if defined(X3_ABL_NOBARRIER)      // (timing-only ablation: no barrier inside the tile loop - ring races, results invalid)
+#define X3_LOOP_BARRIER(ST) ((void)0)
+#elif defined(X3_ABL_BAR2)         // (timing-only: a barrier every second tile)
+#define X3_LOOP_BARRIER(ST) do { if (((ST) & 1) == 0) lds_barrier(); } while (0)
+#else
+#define X3_LOOP_BARRIER(ST) lds_barrier()
+#endif
+#ifdef X3_ABL_PRIO_B2              // (timing-only: the later-dispatched half bursts at priority 2 - the arbiter prefers the older wave at equal priority)
+#define X3_BURST_PRIO() do { if (grp_s) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); } while (0)
+#else
+#define X3_BURST_PRIO() __builtin_amdgcn_s_setprio(1)
+#endif
 __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");      // s_waitcnt lgkmcnt(0)
   __builtin_amdgcn_s_barrier();
@@ -677,7 +689,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
       constexpr int SO = (ST) * W2X_TILE_BYTES, SN = (((ST) + 1) & 3) * W2X_TILE_BYTES, SW = (((ST) + 3) & 3) * W2X_TILE_BYTES;              \
       /* the bursting wave wins issue arbitration against its SIMD partner's epilogue (round 3's static priority for the later-dispatched   \
          half costs 7 % once the half phases are not separated by a barrier; priority during the epilogue instead: +2.5 %) */                \
-      __builtin_amdgcn_s_setprio(1);                                                                                                         \
+      X3_BURST_PRIO();                                                                                                                       \
       stamp(0);                                                                                                                              \
       /* ===== burst: 28 MFMAs; every other instruction rides in an MFMA shadow, pinned region by region (one K step each): the LDS reads    \
          of the fragments one step ahead, the feature rows, this thread's two chunks of record t+3 and - in the tail - the next tile's       \
@@ -719,7 +731,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
       __builtin_amdgcn_sched_barrier(0);                                                                                                     \
       __builtin_amdgcn_s_setprio(0);                                                                                                         \
       stamp(1);                                                                                                                              \
-      if (grp_s) lds_barrier();          /* group B: [epilogue t-1, burst t] | barrier | [epilogue t, burst t+1] */                          \
+      if (grp_s) X3_LOOP_BARRIER(ST);          /* group B: [epilogue t-1, burst t] | barrier | [epilogue t, burst t+1] */                          \
       stamp(2);                                                                                                                              \
       /* ===== epilogue (beside the SIMD partner's burst): the tile's bias, then this thread's chunks of tile t+3 into the stage tile t-1     \
          has left (nobody reads it between barriers t and t+2) ===== */                                                                      \
@@ -758,7 +770,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
       stamp_epi(7);                                                                                                                          \
       stamp(3);                                                                                                                              \
       first_tile = false;                                                                                                                    \
-      if (!grp_s) lds_barrier();         /* group A: [burst t, epilogue t] | barrier */                                                      \
+      if (!grp_s) X3_LOOP_BARRIER(ST);         /* group A: [burst t, epilogue t] | barrier */                                                      \
     }
     for (int t = t_begin;;) {       // unrolled over the ring's four stages: tile t_begin + i sits in stage i & 3
       X3_TILE(0)

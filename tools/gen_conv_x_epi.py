@@ -81,15 +81,19 @@ def epilogue(ST):
         for j in range(4):
             L.append(f'ds_read_b128 v[{4 * j}:{4 * j + 3}], %[ringb] offset:{SO + BIAS_OFF + 16 * j}')
     # this thread's two chunks of record t+3 (requested at the start of the burst) into the stage tile t-1 has left
-    if 'noring' not in ABL:
-        L += ['s_waitcnt vmcnt(1)', f'ds_write_b128 %[rw0], %[st0] offset:{SW}', 's_waitcnt vmcnt(0)', f'ds_write_b128 %[rw1], %[st1] offset:{SW}']
+    RING = os.environ.get('GEN_RING', 'first')       # where the ring stores sit: first (default) | mid (behind the fold) | late (behind the tile kind's FMAs)
+    ring = ['s_waitcnt vmcnt(1)', f'ds_write_b128 %[rw0], %[st0] offset:{SW}', 's_waitcnt vmcnt(0)', f'ds_write_b128 %[rw1], %[st1] offset:{SW}'] if 'noring' not in ABL else []
+    if RING == 'first':
+        L += ring
     if not os.environ.get('GEN_ONE_ACC') and 'nofold' not in ABL:      # (experiment: one accumulator chain, nothing to fold)
         for r in range(16):
             L.append(f'v_add_f32 v{16 + r}, v{16 + r}, v{32 + r}')
     if 'nobias' not in ABL:
-        L.append('s_waitcnt lgkmcnt(2)' if 'noring' not in ABL else 's_waitcnt lgkmcnt(0)')
+        L.append('s_waitcnt lgkmcnt(2)' if ('noring' not in ABL and RING == 'first') else 's_waitcnt lgkmcnt(0)')
         for r in range(16):
             L.append(f'v_fmac_f32 v{16 + r}, v{r}, %[bsc2]')
+    if RING == 'mid':
+        L += ring
     # tile kind -> selector (1 RA, 2 RT, 3 + cross bits TV, 7 RTS)
     L += ['s_and_b32 %[t0], %[w0], 3', 's_bfe_u32 %[t1], %[w0], 0x2000e', 's_add_i32 %[t1], %[t1], 3', 's_add_i32 %[t2], %[t0], 1',
           's_cmp_eq_u32 %[t0], 2', 's_cselect_b32 %[t2], %[t1], %[t2]', 's_cmp_eq_u32 %[t0], 3', 's_cselect_b32 %[sel], 7, %[t2]']
@@ -97,6 +101,8 @@ def epilogue(ST):
     variants = [(1, one(kind_body('RA'))), (2, one(kind_body('RT')))] + [(3 + x, kind_body(f'TV{x}')) for x in range(4)] + [(7, kind_body('RTS'))]
     inl, ool_k = G.dispatch_split(variants, 'sel', 'k')
     L += inl
+    if RING == 'late':
+        L += ring
     # packed quad (6-channel columns: accumulator quad 3 carries another a / c row quad for channel pair xp)
     L += ['s_bitcmp0_b32 %[w0], 7', 's_cbranch_scc1 .Lnp_%=',
           's_lshr_b32 %[t0], %[w0], 6', 's_and_b32 %[t0], %[t0], 0xf0', 'v_add_u32 v52, %[t0], %[fra]', 'ds_read_b128 v[8:11], v52',

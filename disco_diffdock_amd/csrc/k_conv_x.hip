@@ -461,15 +461,25 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
           for (int r = 0; r < 16; ++r) D1[r] = 0.0f;
           const char* wt = w1 + (size_t)T * W1X_TILE_BYTES;
           {
+#ifdef X3_ABL_NOW1      // (timing-only ablation: no W1 fragment loads)
+            f16x8 ah, am, al;
+            for (int i = 0; i < 8; ++i) { ah[i] = (_Float16)(float)(lane + T); am[i] = (_Float16)(float)(lane + 2 * T); al[i] = (_Float16)(float)(lane + 3 * T); }
+#else
             const f16x8 ah = *reinterpret_cast<const f16x8*>(wt + lane * 16);
             const f16x8 am = *reinterpret_cast<const f16x8*>(wt + W2X_LIMB_BYTES + lane * 16);
             const f16x8 al = *reinterpret_cast<const f16x8*>(wt + 2 * W2X_LIMB_BYTES + lane * 16);
+#endif
             X3_STEP(MFMA16, ah, am, al, b0h, b0m, b0l)
           }
           {     // registers 8..11: the first half of step 1's fragment
+#ifdef X3_ABL_NOW1
+            f16x4 ah, am, al;
+            for (int i = 0; i < 4; ++i) { ah[i] = (_Float16)(float)(lane + T + 1); am[i] = (_Float16)(float)(lane + 2 * T + 1); al[i] = (_Float16)(float)(lane + 3 * T + 1); }
+#else
             const f16x4 ah = *reinterpret_cast<const f16x4*>(wt + 1024 + lane * 16);
             const f16x4 am = *reinterpret_cast<const f16x4*>(wt + W2X_LIMB_BYTES + 1024 + lane * 16);
             const f16x4 al = *reinterpret_cast<const f16x4*>(wt + 2 * W2X_LIMB_BYTES + 1024 + lane * 16);
+#endif
             // (the K = 8 half step packed like the tile tail: hi.mid + mid.hi, lo.hi + hi.lo, hi.hi + mid.mid as one K = 16 MFMA each: 9 instead of 12 per row tile)
             const f16x8 a_hm = __builtin_shufflevector(ah, am, 0, 1, 2, 3, 4, 5, 6, 7), a_lh = __builtin_shufflevector(al, ah, 0, 1, 2, 3, 4, 5, 6, 7);
             D0 = MFMA16(a_hm, b1_mh, D0);

@@ -635,6 +635,10 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
     // load - a scalar load in flight turns every counted LDS wait into a full one); later tiles: fetched in the previous burst's tail
     Frag16 p0;
     p0.h = *reinterpret_cast<const f16x8*>(ringl); p0.m = *reinterpret_cast<const f16x8*>(ringl + W2X_LIMB_BYTES); p0.l = *reinterpret_cast<const f16x8*>(ringl + 2 * W2X_LIMB_BYTES);
+#ifdef X3_PF2          // (experiment: fragments requested TWO K steps ahead: p0 / p1 of a tile in the previous burst's last two steps, +12 VGPRs across the epilogue)
+    Frag16 p1;
+    p1.h = *reinterpret_cast<const f16x8*>(ringl + 1024); p1.m = *reinterpret_cast<const f16x8*>(ringl + W2X_LIMB_BYTES + 1024); p1.l = *reinterpret_cast<const f16x8*>(ringl + 2 * W2X_LIMB_BYTES + 1024);
+#endif
     int w0, chan0;
     {
       const int2 dq = *reinterpret_cast<const int2*>(ring + W2X_DESC_OFF);
@@ -694,20 +698,34 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
 #define X3_PAIR(mask) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(mask, 1, 0); }
 #define X3_BARE { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }
 #define X3_FRAG(f, off) f.h = *reinterpret_cast<const f16x8*>(ringl + (off)); f.m = *reinterpret_cast<const f16x8*>(ringl + W2X_LIMB_BYTES + (off)); f.l = *reinterpret_cast<const f16x8*>(ringl + 2 * W2X_LIMB_BYTES + (off));
-#define X3_TILE(ST)                                                                                                                          \
-    {                                                                                                                                        \
-      constexpr int SO = (ST) * W2X_TILE_BYTES, SN = (((ST) + 1) & 3) * W2X_TILE_BYTES, SW = (((ST) + 3) & 3) * W2X_TILE_BYTES;              \
-      /* the bursting wave wins issue arbitration against its SIMD partner's epilogue (round 3's static priority for the later-dispatched   \
-         half costs 7 % once the half phases are not separated by a barrier; priority during the epilogue instead: +2.5 %) */                \
-      X3_BURST_PRIO();                                                                                                                       \
-      stamp(0);                                                                                                                              \
-      /* ===== burst: 28 MFMAs; every other instruction rides in an MFMA shadow, pinned region by region (one K step each): the LDS reads    \
-         of the fragments one step ahead, the feature rows, this thread's two chunks of record t+3 and - in the tail - the next tile's       \
-         descriptor and first K step (complete in the ring since the last barrier) ===== */                                                  \
-      const float* Fp = Fr + ((w0 >> 16) & 0xff);                                                                                            \
-      f32x16 D0, D1;                                                                                                                         \
-      _Pragma("unroll") for (int r = 0; r < 16; ++r) { D0[r] = 0.0f; D1[r] = 0.0f; }                                                         \
+#ifdef X3_PF2
+#define X3_BURST_BODY(ST)                                                                                                                    \
+      Frag16 q2; X3_FRAG(q2, SO + 2048)                                                                                                      \
+      const f32x4 f0 = ldv4(Fp);                                                                                                             \
+      const u32x4 st0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)fo0, rec_soff, 0);                                                  \
+      const u32x4 st1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)fo1, rec_soff, 0);                                                  \
+      rec_soff += W2X_TILE_BYTES;                                                                                                            \
+      X3_STEP(MFMA16, p0.h, p0.m, p0.l, H.hi[0], H.mid[0], H.lo[0])                                                                         \
+      X3_PAIR(0x100) X3_PAIR(0x020) X3_PAIR(0x100) X3_PAIR(0x020) X3_PAIR(0x100) X3_PAIR(0x100)                                              \
       __builtin_amdgcn_sched_barrier(0);                                                                                                     \
+      Frag16 q3; X3_FRAG(q3, SO + 3072)                                                                                                      \
+      const f16x4 th = *reinterpret_cast<const f16x4*>(ringt + SO + 4096);                                                                   \
+      const f16x4 tm = *reinterpret_cast<const f16x4*>(ringt + SO + W2X_LIMB_BYTES + 4096);                                                  \
+      const f16x4 tl = *reinterpret_cast<const f16x4*>(ringt + SO + 2 * W2X_LIMB_BYTES + 4096);                                              \
+      X3_STEP(MFMA16, p1.h, p1.m, p1.l, H.hi[1], H.mid[1], H.lo[1])                                                                         \
+      X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100)                                              \
+      __builtin_amdgcn_sched_barrier(0);                                                                                                     \
+      const int2 dq = *reinterpret_cast<const int2*>(ring + SN + W2X_DESC_OFF);                                                              \
+      X3_FRAG(p0, SN)                                                                                                                        \
+      X3_STEP(MFMA16, q2.h, q2.m, q2.l, H.hi[2], H.mid[2], H.lo[2])                                                                         \
+      X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_BARE X3_BARE                                                            \
+      __builtin_amdgcn_sched_barrier(0);                                                                                                     \
+      X3_FRAG(p1, SN + 1024)                                                                                                                 \
+      X3_STEP(MFMA16, q3.h, q3.m, q3.l, H.hi[3], H.mid[3], H.lo[3])                                                                         \
+      X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_BARE X3_BARE X3_BARE                                                                   \
+      __builtin_amdgcn_sched_barrier(0);
+#else
+#define X3_BURST_BODY(ST)                                                                                                                    \
       Frag16 p1; X3_FRAG(p1, SO + 1024)                                                                                                      \
       const f32x4 f0 = ldv4(Fp);                                                                                                             \
       /* this thread's two chunks of record t+3, requested first: ~900 cycles until the epilogue stores them */                              \
@@ -732,7 +750,23 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
       X3_FRAG(p0, SN)       /* (p0's last use was K step 0 of this burst: the next tile's first K step goes straight into its registers) */    \
       X3_STEP(MFMA16, q3.h, q3.m, q3.l, H.hi[3], H.mid[3], H.lo[3])                                                                         \
       X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_BARE X3_BARE                                                            \
-      __builtin_amdgcn_sched_barrier(0);                                                                         \
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+#define X3_TILE(ST)                                                                                                                          \
+    {                                                                                                                                        \
+      constexpr int SO = (ST) * W2X_TILE_BYTES, SN = (((ST) + 1) & 3) * W2X_TILE_BYTES, SW = (((ST) + 3) & 3) * W2X_TILE_BYTES;              \
+      /* the bursting wave wins issue arbitration against its SIMD partner's epilogue (round 3's static priority for the later-dispatched   \
+         half costs 7 % once the half phases are not separated by a barrier; priority during the epilogue instead: +2.5 %) */                \
+      X3_BURST_PRIO();                                                                                                                       \
+      stamp(0);                                                                                                                              \
+      /* ===== burst: 28 MFMAs; every other instruction rides in an MFMA shadow, pinned region by region (one K step each): the LDS reads    \
+         of the fragments one step ahead, the feature rows, this thread's two chunks of record t+3 and - in the tail - the next tile's       \
+         descriptor and first K step (complete in the ring since the last barrier) ===== */                                                  \
+      const float* Fp = Fr + ((w0 >> 16) & 0xff);                                                                                            \
+      f32x16 D0, D1;                                                                                                                         \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) { D0[r] = 0.0f; D1[r] = 0.0f; }                                                         \
+      __builtin_amdgcn_sched_barrier(0);                                                                                                     \
+      X3_BURST_BODY(ST)                                                                                                                      \
       {     /* packed tail: D0 += hi.mid + mid.hi, D1 += lo.hi + hi.lo, D0 += hi.hi + mid.mid as one K = 16 MFMA each */                     \
         const f16x8 a_hm = __builtin_shufflevector(th, tm, 0, 1, 2, 3, 4, 5, 6, 7), a_lh = __builtin_shufflevector(tl, th, 0, 1, 2, 3, 4, 5, 6, 7); \
         X3_TAIL3(a_lh, a_hm)                                                                                                                 \
@@ -796,6 +830,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
 #undef X3_BARE
 #undef X3_FRAG
 #undef X3_TILE
+#undef X3_BURST_BODY
     // hand the next unit to the workgroup.  Group A waits here through group B's last epilogue: this barrier also retires the ring
     // (nobody reads it any more) before the next unit's staging writes
     stamp_unit(0, 0);

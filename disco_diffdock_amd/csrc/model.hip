@@ -1107,7 +1107,7 @@ int ddk_profile_enable(ddk_ctx* ctx, int32_t on) {
   ctx->prof_recs.clear();
   ctx->prof_slots = 0;
   if (on && !ctx->prof_edges) {
-    ctx->prof_cap = 4096;      // forwards
+    ctx->prof_cap = 32768;     // forwards (a 363-complex stream of config 4 is ~8 700; round 4's 4096 silently stopped recording after 205 complexes)
     if (hipHostMalloc((void**)&ctx->prof_edges, (size_t)ctx->prof_cap * PROF_INTS * sizeof(int32_t)) != hipSuccess)
       return fail(ctx, DDK_ERR_NOMEM, "hipHostMalloc failed");
   }

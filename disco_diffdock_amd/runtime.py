@@ -163,13 +163,15 @@ class Context:
         a = np.array(list(buf)).reshape(-1, 5)
         return [dict(ms=float(r[0]), launches=int(r[1]), edges=int(r[2]), edges_unpruned=int(r[3]), edges_reference=int(r[4])) for r in a]
 
-    def profile_read_forwards(self, max_forwards=4096):
+    def profile_read_forwards(self, max_forwards=32768):
         """per forward since profile_enable(True), in launch order: array [n, 4] = conv kernel ms, edges evaluated, edges without the
         receptive-field pruning, cross edges of the forward's graph"""
         buf = (C.c_double * (4 * max_forwards))()
         n = self.L.ddk_profile_read_forwards(self.h, buf, max_forwards)
         if n < 0:
             raise RuntimeError(f'ddk_profile_read_forwards: {self.L.ddk_last_error(self.h).decode()}')
+        if n >= max_forwards:
+            raise RuntimeError(f'ddk_profile_read_forwards: {n} forwards recorded, the profile buffer holds {max_forwards}: later launches were not timed')
         return np.array(buf[:4 * min(n, max_forwards)]).reshape(-1, 4)
 
     def set_pruning(self, on=True):

@@ -89,3 +89,6 @@ if os.environ.get('CONV_TRACE_PER_TILE'):
         print('   ' + ' '.join('%4d' % v for v in ep))
         print('   burst by tile position:')
         print('   ' + ' '.join('%4d' % v for v in bu))
+        pe = np.stack([(x[s + 1:s + T, 0] - x[s:s + T - 1, 0]) for s in full]).mean(0)
+        print('   period (burst start to next burst start) by tile position; sum over the unit %d, %d tiles x the median period = %d:' % (pe.sum(), T - 1, (T - 1) * np.median(pe)))
+        print('   ' + ' '.join('%4d' % v for v in pe))

@@ -645,6 +645,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
       w0 = __builtin_amdgcn_readfirstlane(dq.x); chan0 = __builtin_amdgcn_readfirstlane(dq.y);
     }
     const bool grp_s = __builtin_amdgcn_readfirstlane(grp) != 0;      // provably wave-uniform: the barrier sits behind a scalar branch
+    const int grp_i = __builtin_amdgcn_readfirstlane(grp); (void)grp_i;
     // the rare part of an epilogue: the packed extra quad of a 6-channel column and the flush of a column the tile closes
     auto finish_tile = [&](int w0x, int chan0x, const f32x16& D, f32x4 f0x) {
       if (w0x & 0x80) {   // 6-channel column: accumulator quad 3 holds another a / c row quad for channel pair xp

@@ -112,6 +112,8 @@ def epilogue(ST):
     L += fix([it for it in G.packed_stream() if not isinstance(it, tuple)])
     L.append('.Lnp_%=:')
     # flush of the column this tile closes
+    if 'noflushA' in ABL:      # (timing only: group A never flushes - what would aligning A's flush with B's be worth?)
+        L += ['s_cmp_eq_u32 %[grp], 0', 's_cbranch_scc1 .Lnf_%=']
     L += ['s_bfe_u32 %[t0], %[w0], 0x20002', 's_cmp_eq_u32 %[t0], 0', 's_cbranch_scc1 .Lnf_%=', 's_cmp_eq_u32 %[t0], 2', 's_cbranch_scc1 .Lfv_%=',
           's_cmp_eq_u32 %[sel], 7', 's_cbranch_scc1 .Lfr_%=']
     L += flush('S', False) + ['s_branch .Lnf_%=', '.Lfr_%=:'] + flush('S', True) + ['s_branch .Lnf_%=', '.Lfv_%=:'] + flush('V', False)
@@ -127,7 +129,7 @@ def main():
            ('rw1', 'v', 'ringw1_u'), ('fpa', 'v', 'fpa_u'), ('fra', 'v', 'fra_u'), ('bsc2', 'v', 'bsc2'), ('oscv', 'v', 'oscv'), ('s0', 'v', 's0'), ('vx', 'v', 'vx'),
            ('vy', 'v', 'vy'), ('vz', 'v', 'vz'), ('sm1', 'v', 'seg.m1'), ('sm2', 'v', 'seg.m2'), ('sm4', 'v', 'seg.m4'), ('sm8', 'v', 'seg.m8'), ('sm16', 'v', 'seg.m16'),
            ('vrow', 'v', 'vrow'), ('hh4', 'v', 'hh4_u'), ('hh12', 'v', 'hh12_u'), ('w0', 's', 'w0'), ('chan4', 's', 'chan4_'), ('tail', 's', 'tail_mask'),
-           ('sumbase', 's', 'sumbase')]
+           ('sumbase', 's', 'sumbase')] + ([('grp', 's', 'grp_i')] if 'noflushA' in os.environ.get('GEN_ABL', '') else [])
     for ST in range(4):
         lines = epilogue(ST)
         txt = G.asm_stmt(f'X3_EPI_{ST}', lines, outs, ins, CLOBBER + ['memory', 'scc'])

@@ -24,7 +24,7 @@
 // products, when D0 + D1 is formed); the tile descriptors ride in the kernel arguments (scalar loads).
 // The fragments are streamed from the ring INSIDE the burst (no register double buffer: h's three limbs need the registers).
 //
-// Two waves share a SIMD and with it ONE matrix pipe; a wave's tile is a burst of 28 MFMAs (896 pipe cycles; the K=8 tail packs two products per
+// Two waves share a SIMD and with it ONE matrix pipe; a wave's tile is a burst of 27 MFMAs (864 pipe cycles; the K=8 tail packs two products per
 // 32x32x16) followed by a VALU / LDS epilogue.  The workgroup runs as two half-groups in ALTERNATION with ONE barrier per tile: between two
 // barriers waves 0-3 (group A, one per SIMD) run [burst t, epilogue t] and waves 4-7 (group B, their SIMD partners) [epilogue t-1, burst t], so
 // that a burst always sits beside the partner's epilogue and the pipe sees one burst after the other; where an epilogue is shorter than the
@@ -646,6 +646,11 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
     }
     const bool grp_s = __builtin_amdgcn_readfirstlane(grp) != 0;      // provably wave-uniform: the barrier sits behind a scalar branch
     const int grp_i = __builtin_amdgcn_readfirstlane(grp); (void)grp_i;
+    // (asm epilogue generated with GEN_DEFER=1 - an experiment, default off) group A's flush runs one tile late, in the interval in which group B flushes the same
+    // column: the column's values, its kind (0 none / 1 scalar / 2 vector) and its channel offset wait here
+    float P_[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int pend_ = 0, pchan_ = 0;
+    (void)P_; (void)pend_; (void)pchan_;
     // the rare part of an epilogue: the packed extra quad of a 6-channel column and the flush of a column the tile closes
     auto finish_tile = [&](int w0x, int chan0x, const f32x16& D, f32x4 f0x) {
       if (w0x & 0x80) {   // 6-channel column: accumulator quad 3 holds another a / c row quad for channel pair xp
@@ -760,7 +765,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
          half costs 7 % once the half phases are not separated by a barrier; priority during the epilogue instead: +2.5 %) */                \
       X3_BURST_PRIO();                                                                                                                       \
       stamp(0);                                                                                                                              \
-      /* ===== burst: 28 MFMAs; every other instruction rides in an MFMA shadow, pinned region by region (one K step each): the LDS reads    \
+      /* ===== burst: 27 MFMAs; every other instruction rides in an MFMA shadow, pinned region by region (one K step each): the LDS reads    \
          of the fragments one step ahead, the feature rows, this thread's two chunks of record t+3 and - in the tail - the next tile's       \
          descriptor and first K step (complete in the ring since the last barrier) ===== */                                                  \
       const float* Fp = Fr + ((w0 >> 16) & 0xff);                                                                                            \
@@ -827,6 +832,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
       X3_TILE(3)
       if (++t >= t_end) break;
     }
+    if constexpr (ASM_EPI) { X3_EPI_DRAIN(); }      // group A's last column (group B is still in its last epilogue: nobody waits for this)
 #undef X3_PAIR
 #undef X3_BARE
 #undef X3_FRAG

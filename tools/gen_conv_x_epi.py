@@ -11,6 +11,7 @@ import os
 import gen_conv_y as G
 
 TB, LIMB = 13968, 4608
+DEFER = os.environ.get('GEN_DEFER', '0') != '0'      # 1: group A's flush one tile late (built and measured: no gain, profiles/r05_conv_kernel_experiments.md); default: both half-groups flush in the closing tile's epilogue
 BIAS_OFF = 3 * LIMB
 # registers: D0 = v[16:31] (in/out: folded in place), D1 = v[32:47], f0 = v[48:51]; scratch v0..v15 (bias; then f1 v0-3, f2 v4-7, g0 v8-11, R v12-15; flush values v0-8,
 # w = v / sqrt2 in v9-11), v52 packed-quad sum / g0 address, v53 flush address
@@ -53,6 +54,27 @@ def flush(mode, rts):
         return res
     pre = ['v_mul_f32 v9, 0x3f3504f3, %[vx]', 'v_mul_f32 v10, 0x3f3504f3, %[vy]', 'v_mul_f32 v11, 0x3f3504f3, %[vz]']
     return pre + [ln.replace('%[wx]', 'v9').replace('%[wy]', 'v10').replace('%[wz]', 'v11') for ln in lines]
+
+
+PEND = [f'%[P{i}]' for i in range(9)]
+
+
+def flush_split(mode, rts):
+    """(phase 1, phase 2) of a flush whose values live in the pending registers P0..P8: phase 1 = the column's values and the accumulator resets, phase 2 = address,
+    segmented scan, atomics (on the column offset kept in pchan)"""
+    keep = list(G.FQ)
+    G.FQ[:] = PEND
+    lines = flush(mode, rts)
+    G.FQ[:] = keep
+    k = [i for i, ln in enumerate(lines) if ln.startswith('v_add3_u32')][0]
+    return lines[:k], [ln.replace('%[chan4]', '%[pchan]') for ln in lines[k:]]
+
+
+def phase2_block(tag):
+    """the pending flush, by kind (pend = 1: scalar column, 2: vector column)"""
+    _, s2 = flush_split('S', False)
+    _, v2 = flush_split('V', False)
+    return (['s_cmp_eq_u32 %[pend], 2', f's_cbranch_scc1 .L{tag}v_%='] + s2 + [f's_branch .L{tag}d_%=', f'.L{tag}v_%=:'] + v2 + [f'.L{tag}d_%=:', 's_mov_b32 %[pend], 0'])
 
 
 def kind_body(kind):
@@ -114,9 +136,21 @@ def epilogue(ST):
     # flush of the column this tile closes
     if 'noflushA' in ABL:      # (timing only: group A never flushes - what would aligning A's flush with B's be worth?)
         L += ['s_cmp_eq_u32 %[grp], 0', 's_cbranch_scc1 .Lnf_%=']
-    L += ['s_bfe_u32 %[t0], %[w0], 0x20002', 's_cmp_eq_u32 %[t0], 0', 's_cbranch_scc1 .Lnf_%=', 's_cmp_eq_u32 %[t0], 2', 's_cbranch_scc1 .Lfv_%=',
-          's_cmp_eq_u32 %[sel], 7', 's_cbranch_scc1 .Lfr_%=']
-    L += flush('S', False) + ['s_branch .Lnf_%=', '.Lfr_%=:'] + flush('S', True) + ['s_branch .Lnf_%=', '.Lfv_%=:'] + flush('V', False)
+    if DEFER:
+        # The two half-groups of a workgroup run the same tile one interval apart (k_conv_x.hip), so a flush tile's long epilogue lengthens TWO consecutive intervals:
+        # group A's in the tile's own interval, group B's in the next one (profiles/r05_conv_kernel_experiments.md: 4 % of the tile loop, half of it the double counting).
+        # Group A therefore keeps the column's values in P0..P8 and runs scan + atomics in its NEXT epilogue - the interval in which group B flushes the same column.
+        L += ['s_cmp_eq_u32 %[pend], 0', 's_cbranch_scc1 .Lown_%=', 's_mov_b32 %[t2], 0', '.Lp2_%=:'] + phase2_block('q')
+        L += ['s_cmp_eq_u32 %[t2], 1', 's_cbranch_scc1 .Lnf_%=', '.Lown_%=:']
+        L += ['s_bfe_u32 %[t0], %[w0], 0x20002', 's_cmp_eq_u32 %[t0], 0', 's_cbranch_scc1 .Lnf_%=', 's_cmp_eq_u32 %[t0], 2', 's_cbranch_scc1 .Lfv_%=',
+              's_cmp_eq_u32 %[sel], 7', 's_cbranch_scc1 .Lfr_%=']
+        s1, r1, v1 = flush_split('S', False)[0], flush_split('S', True)[0], flush_split('V', False)[0]
+        L += s1 + ['s_mov_b32 %[pend], 1', 's_branch .Lset_%=', '.Lfr_%=:'] + r1 + ['s_mov_b32 %[pend], 1', 's_branch .Lset_%=', '.Lfv_%=:'] + v1 + ['s_mov_b32 %[pend], 2']
+        L += ['.Lset_%=:', 's_mov_b32 %[pchan], %[chan4]', 's_cmp_eq_u32 %[grp], 0', 's_cbranch_scc1 .Lnf_%=', 's_mov_b32 %[t2], 1', 's_branch .Lp2_%=']
+    else:
+        L += ['s_bfe_u32 %[t0], %[w0], 0x20002', 's_cmp_eq_u32 %[t0], 0', 's_cbranch_scc1 .Lnf_%=', 's_cmp_eq_u32 %[t0], 2', 's_cbranch_scc1 .Lfv_%=',
+              's_cmp_eq_u32 %[sel], 7', 's_cbranch_scc1 .Lfr_%=']
+        L += flush('S', False) + ['s_branch .Lnf_%=', '.Lfr_%=:'] + flush('S', True) + ['s_branch .Lnf_%=', '.Lfv_%=:'] + flush('V', False)
     L += ['.Lnf_%=:', 's_waitcnt lgkmcnt(0)', 's_branch .Lexit_%='] + ool_k + ['.Lexit_%=:']
     return L
 
@@ -129,11 +163,23 @@ def main():
            ('rw1', 'v', 'ringw1_u'), ('fpa', 'v', 'fpa_u'), ('fra', 'v', 'fra_u'), ('bsc2', 'v', 'bsc2'), ('oscv', 'v', 'oscv'), ('s0', 'v', 's0'), ('vx', 'v', 'vx'),
            ('vy', 'v', 'vy'), ('vz', 'v', 'vz'), ('sm1', 'v', 'seg.m1'), ('sm2', 'v', 'seg.m2'), ('sm4', 'v', 'seg.m4'), ('sm8', 'v', 'seg.m8'), ('sm16', 'v', 'seg.m16'),
            ('vrow', 'v', 'vrow'), ('hh4', 'v', 'hh4_u'), ('hh12', 'v', 'hh12_u'), ('w0', 's', 'w0'), ('chan4', 's', 'chan4_'), ('tail', 's', 'tail_mask'),
-           ('sumbase', 's', 'sumbase')] + ([('grp', 's', 'grp_i')] if 'noflushA' in os.environ.get('GEN_ABL', '') else [])
+           ('sumbase', 's', 'sumbase')] + ([('grp', 's', 'grp_i')] if ('noflushA' in os.environ.get('GEN_ABL', '') and not DEFER) else [])
+    if DEFER:
+        pend_ops = [(f'P{i}', '+v', f'P_[{i}]') for i in range(9)] + [('pend', '+s', 'pend_'), ('pchan', '+s', 'pchan_')]
+        outs = outs[:1] + accs + pend_ops + outs[1 + len(accs):]
+        ins = ins + [('grp', 's', 'grp_i')]
     for ST in range(4):
         lines = epilogue(ST)
         txt = G.asm_stmt(f'X3_EPI_{ST}', lines, outs, ins, CLOBBER + ['memory', 'scc'])
         out.append(txt)
+    if DEFER:      # behind a unit's last tile: group A's pending flush (group B has none)
+        d_outs = [(f'P{i}', '+v', f'P_[{i}]') for i in range(9)] + [('pend', '+s', 'pend_'), ('sv', '=&s', 'sv_')]
+        d_ins = [(n, 'v', e) for n, e in (('sm1', 'seg.m1'), ('sm2', 'seg.m2'), ('sm4', 'seg.m4'), ('sm8', 'seg.m8'), ('sm16', 'seg.m16'), ('vrow', 'vrow'), ('hh4', 'hh4_u'), ('hh12', 'hh12_u'))]
+        d_ins += [('pchan', 's', 'pchan_'), ('tail', 's', 'tail_mask'), ('sumbase', 's', 'sumbase')]
+        lines = ['s_cmp_eq_u32 %[pend], 0', 's_cbranch_scc1 .Ldr_%='] + phase2_block('r') + ['.Ldr_%=:']
+        out.append(G.asm_stmt('X3_EPI_DRAIN', lines, d_outs, d_ins, ['v53', 'memory', 'scc']))
+    else:
+        out.append('#define X3_EPI_DRAIN() ((void)0)\n')
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'disco_diffdock_amd', 'csrc', 'k_conv_x_epi_gen.inc')
     with open(path, 'w') as f:
         f.write('\n'.join(out))

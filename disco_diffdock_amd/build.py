@@ -47,7 +47,7 @@ def _stamp_ok(path, digest):
 def build(force=False, verbose=True):
     """Incremental and CONTENT based (a stamp with the hash of the source, every header and the flags sits next to each object):
     file times do not survive the copy to the GPU box, and a rebuild there must only happen when something really changed."""
-    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')) + [os.path.join(HERE, '..', 'include', 'ddk.h'), os.path.join(HERE, '..', 'include', 'ddk_debug.h')]
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h') or f.endswith('.inc'))      # (.inc: the generated asm statements) + [os.path.join(HERE, '..', 'include', 'ddk.h'), os.path.join(HERE, '..', 'include', 'ddk_debug.h')]
     objs, relink = [], force or not os.path.exists(LIB)
     for src in SOURCES:
         s = os.path.join(CSRC, src)

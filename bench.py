@@ -685,9 +685,6 @@ def main():
                       'headline': {k: v for k, v in summary(head, n_done).items() if k != 'value'},
                       'device_loop': device_loop, 'per_call_ms': head['per_call_ms'] if a.steps <= 64 else head['per_call_ms'][:64] + ['...'], 'stream': head['stream']},
         }
-        if int(getattr(ctx.cfg, 'conv_kernel', 0)) == 2:
-            out['roofline']['kernel'] = ('ddk::conv_y_kernel<false> (k_conv_y.hip: the same six limb products per K step on one accumulator chain, software-pipelined: one '
-                                         'wave per SIMD, two 32-edge blocks per wave; ddk_config.conv_kernel = 2)')
         if int(getattr(ctx.cfg, 'conv_kernel', 0)) == 1:
             # the whole run was switched to the fallback kernel (DDK_CONV_KERNEL=1): its work is fp32 MFMA chains, priced against the fp32 MFMA peak
             r_ = out['roofline']

@@ -12,11 +12,6 @@ using namespace ddk;
 
 namespace ddk {
 
-// DDK_CONV_Y=1 (development aid for same-box A/Bs): the score model's conv layers run k_conv_y.hip as with ddk_config.conv_kernel = 2
-bool conv_y_enabled() {
-  static const int v = [] { const char* e = getenv("DDK_CONV_Y"); return e == nullptr ? 0 : atoi(e); }();
-  return v != 0;
-}
 
 int fail(ddk_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->err = msg;
@@ -425,7 +420,7 @@ static int pack_x3(ddk_ctx* ctx, ConvLayerDev& L, int NG, const std::vector<floa
   }
   if (!exact) return fail(ctx, DDK_ERR_INVALID, "internal: the three-limb fp16 split of a conv weight is not exact");
   L.h_w2x = w2x; L.h_w1x = w1x;
-  L.y_ok = conv_y_layer_ok(L.h_tiles);      // k_conv_y.hip serves the layer's gather launches (score-model conv layers)
+  L.epi_ok = conv_epilogue_shapes_ok(L.h_tiles);      // launch_conv_fused_x refuses the asm-epilogue instantiation otherwise
   if (ctx->host_only) return DDK_OK;
   L.w2x = (uint8_t*)dev_alloc(ctx, w2x.size());
   L.w1x = (uint8_t*)dev_alloc(ctx, w1x.size());
@@ -673,7 +668,7 @@ void model_destroy(ddk_ctx* ctx);   // model.hip
 
 extern "C" {
 
-const char* ddk_version(void) { return "ddk 0.6 (gfx950)"; }      // 0.6: conv_kernel = 2 (k_conv_y.hip), streaming ddk_tp_forward, confidence edge capacity from geometry; 0.5: ddk_config.confidence_mode + ddk_score_confidence; 0.4: three-limb records carry limbs at their own weight + tile descriptors; conv_f16x3 removed (INTEGRATION.md "ABI notes")
+const char* ddk_version(void) { return "ddk 0.7 (gfx950)"; }      // 0.7: conv_kernel = 2 left the library (tools/variants/), ddk_tp_forward walks columns (flat 16-B reads), ddk_debug_set_alloc_limit; 0.6: conv_kernel = 2 (k_conv_y.hip), streaming ddk_tp_forward, confidence edge capacity from geometry; 0.5: ddk_config.confidence_mode + ddk_score_confidence; 0.4: three-limb records carry limbs at their own weight + tile descriptors; conv_f16x3 removed (INTEGRATION.md "ABI notes")
 
 int ddk_create(const ddk_config* cfg, ddk_ctx** out) {
   if (!cfg || !out) return DDK_ERR_INVALID;
@@ -690,8 +685,12 @@ int ddk_create(const ddk_config* cfg, ddk_ctx** out) {
     return fail(ctx, DDK_ERR_INVALID, "only 32-wide sigma / distance embeddings are compiled in");
   if (cfg->deterministic && cfg->all_atoms)
     return fail(ctx, DDK_ERR_INVALID, "deterministic scatter is implemented for the score model (not with all_atoms)");
-  if (cfg->conv_kernel < 0 || cfg->conv_kernel > 2)
-    return fail(ctx, DDK_ERR_INVALID, "conv_kernel must be 0 (three-limb f16), 1 (fp32 MFMA) or 2 (three-limb f16, software-pipelined conv layers)");
+#ifdef DDK_VARIANT_CONV_Y
+  if (cfg->conv_kernel < 0 || cfg->conv_kernel > 2) return fail(ctx, DDK_ERR_INVALID, "conv_kernel must be 0, 1 or 2 (variant build)");
+#else
+  if (cfg->conv_kernel < 0 || cfg->conv_kernel > 1)
+    return fail(ctx, DDK_ERR_INVALID, "conv_kernel must be 0 (three-limb f16) or 1 (fp32 MFMA); 2 (round 5's software-pipelined form) lives under tools/variants/ and is not part of libddk.so");
+#endif
   if (cfg->device < 0) {
     ctx->host_only = true;   // packing-only context (CPU tests); every launch entry point refuses to run
     return DDK_OK;

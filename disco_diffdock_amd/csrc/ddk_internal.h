@@ -141,7 +141,7 @@ struct ConvLayerDev {          // device copies for one TensorProductConvLayer w
   uint8_t* w1x = nullptr;      // three-limb f16 kernel: [groups][3][W1X_TILE_BYTES]
   uint8_t* w2x = nullptr;      // three-limb f16 kernel: [groups][n_tiles][W2X_TILE_BYTES]
   float w1s[CONV_MAX_GROUPS] = {1, 1, 1, 1, 1, 1, 1, 1, 1}, w2s[CONV_MAX_GROUPS] = {1, 1, 1, 1, 1, 1, 1, 1, 1};   // three-limb f16 kernel: power-of-two range scale of the packed W1 / W2 of each weight set
-  bool y_ok = false;           // the tile table suits k_conv_y.hip (every flush closes a 4-quad scalar or a 3-quad vector column): set by pack_x3
+  bool epi_ok = false;         // the tile table has the column shapes the generated asm epilogue hard-codes (conv_epilogue_shapes_ok): set by pack_x3
   int n_cols = 0;              // flush columns (8 output channels each); col_start[c] = first tile of column c, col_start[n_cols] = n_tiles
   int col_start[17] = {};
   // GEMM1 split: W1 [edge_emb | x_src[:ns] | x_dst[:ns]] = W1a edge_emb + (W1b x[src][:ns] + b1) + W1c x[dst][:ns]; the
@@ -265,7 +265,7 @@ struct ConvLaunch {
   const int32_t* gend = nullptr;
   uint32_t* trace = nullptr;   // != null (three-limb kernel, split gather path): workgroup 0 records its half-phase time stamps here
   int trace_coarse = 0;        // one record per unit instead of per tile (no stamps inside the tile loop)
-  bool use_y = false;          // ddk_config.conv_kernel = 2: k_conv_y.hip where the layer's tile table allows it (gather path with node terms, atomics)
+  bool use_y = false;          // variant builds only (DDK_VARIANT_CONV_Y): tools/variants/k_conv_y.hip for the gather launches with node terms
 };
 hipError_t launch_conv_fused(const ConvLayerDev& L, const ConvLaunch& a, int n_cu, hipStream_t s);
 hipError_t launch_conv_fused_x(const ConvLayerDev& L, const ConvLaunch& a, int n_cu, hipStream_t s);   // k_conv_x.hip (exact three-limb f16)

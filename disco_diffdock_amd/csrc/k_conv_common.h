@@ -39,11 +39,12 @@ struct ConvXArgs {      // kernel arguments of the three-limb f16 kernels (k_con
   uint32_t* trace;                  // TRACE instantiation: [8 waves][CONV_TRACE_TILES][8] s_memtime stamps of workgroup 0
   int trace_coarse;                 // 1: one record per UNIT (slots 4-7 prologue, 0 = tile loop done, 1 = tiles, 2 = unit handed over): no stamp inside the tile loop
 };
-// k_conv_y.hip: the software-pipelined one-wave-per-SIMD form for the score model's conv layers (gather path with node terms, atomics)
+// tools/variants/k_conv_y.hip (round 5's software-pipelined one-wave-per-SIMD form; measured +9 %, not part of libddk.so: tools/build_variant_y.sh)
 hipError_t launch_conv_y(const ConvXArgs& X, int n_cu, hipStream_t s);
 hipError_t conv_prepare_device_y();
-bool conv_y_layer_ok(const std::vector<TileDesc>& tiles);
-bool conv_y_enabled();            // ddk_capi.hip: DDK_CONV_Y=0 keeps round 4's alternating kernel (k_conv_x.hip) for every launch
+// every flush of the tile table closes a 4-quad scalar or a 3-quad vector column, the shared tail sits behind a scalar flush, no l = 2 rows: the column
+// shapes the generated asm epilogue of k_conv_x.hip (and k_conv_y.hip) hard-codes.  Checked by pack_x3 (ConvLayerDev::epi_ok)
+bool conv_epilogue_shapes_ok(const std::vector<TileDesc>& tiles);
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }

@@ -34,6 +34,14 @@
 // chunks of tile t+3 from L2 during its burst of tile t and stores them in its epilogue of tile t into the stage tile t-1 has left - group A
 // between barriers t and t+1, group B one interval later - so tile t+3 is complete at barrier t+2 and each wave fetches the first two K steps of
 // its NEXT tile at the start of its epilogue.
+// Experiment switches.  X3_ABL_* are TIMING-ONLY ablations (results invalid), ONE_ACC / X3_PF2 / X3_CXX_EPI / X_PROLOGUE_TILES are measured-and-dropped
+// alternatives kept for same-box A/Bs (tools/build_variant.sh builds them into ab_libs/, never into libddk.so).  A stray -D cannot reach the product library:
+#if (defined(X3_ABL_NOBARRIER) || defined(X3_ABL_BAR2) || defined(X3_ABL_PRIO_B2) || defined(X3_ABL_NOW1)) && !defined(DDK_TIMING_ONLY_BUILD)
+#error "X3_ABL_* switches give WRONG RESULTS (timing-only ablations): they need -DDDK_TIMING_ONLY_BUILD as well (tools/build_variant.sh adds it)"
+#endif
+#if (defined(ONE_ACC) || defined(X3_PF2) || defined(X3_CXX_EPI) || defined(X_PROLOGUE_TILES)) && !defined(DDK_VARIANT_BUILD) && !defined(DDK_TIMING_ONLY_BUILD)
+#error "experiment switch of k_conv_x.hip outside a variant build: add -DDDK_VARIANT_BUILD (tools/build_variant.sh adds it)"
+#endif
 #include <stdlib.h>
 
 #include "k_conv_common.h"
@@ -881,6 +889,20 @@ static hipError_t attr_x_t() {
                              (int)CONV_X_LDS_BYTES);
 }
 
+bool conv_epilogue_shapes_ok(const std::vector<TileDesc>& tiles) {
+  if (tiles.empty()) return false;
+  for (const TileDesc& t : tiles) {
+    const int w0 = x_tile_word(t.w0);
+    if (w0 < 0 || (w0 & X_TILE_L2)) return false;
+    const int fl = (w0 >> 2) & 3, nrq = (w0 >> 4) & 7, kind = w0 & 3;
+    if (fl == FL_S && nrq != 4) return false;
+    if (fl == FL_V && nrq != 3) return false;
+    if (kind == T_RTS && fl != FL_S) return false;
+  }
+  const int last = x_tile_word(tiles.back().w0);
+  return ((last >> 2) & 3) != 0;      // (a unit ends with a flush)
+}
+
 hipError_t conv_prepare_device_x() {
   hipError_t e = attr_x_t<true, true, false>();
   if (e == hipSuccess) e = attr_x_t<true, false, false>();
@@ -896,7 +918,9 @@ hipError_t conv_prepare_device_x() {
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<false, false, false, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)CONV_X_LDS_BYTES);
+#ifdef DDK_VARIANT_CONV_Y
   if (e == hipSuccess) e = conv_prepare_device_y();
+#endif
   return e;
 }
 
@@ -931,10 +955,15 @@ hipError_t launch_conv_fused_x(const ConvLayerDev& L, const ConvLaunch& a, int n
     conv_det_fix(k, a, L.dout, s);
     return hipGetLastError();
   }
-  if (a.gather && a.pre != nullptr && (a.trace == nullptr || a.trace_coarse == 1) && L.y_ok && (a.use_y || conv_y_enabled())) {   // ddk_config.conv_kernel = 2: the software-pipelined form (k_conv_y.hip)
+#ifdef DDK_VARIANT_CONV_Y      // tools/variants/k_conv_y.hip (round 5's one-wave-per-SIMD form, +9 %): linked by tools/build_variant_y.sh only
+  if (a.gather && a.pre != nullptr && (a.trace == nullptr || a.trace_coarse == 1) && L.epi_ok && a.use_y) {
     X.trace = a.trace;      // (its TRACE instantiation writes the per-unit records only)
     return launch_conv_y(X, n_cu, s);
   }
+#endif
+  // the generated asm epilogue of the hot instantiation hard-codes the column shapes of this model family (a scalar flush closes 4 row quads, a vector
+  // flush 3, the shared tail sits behind a scalar flush, no l = 2 rows): a tile table outside them must not reach it
+  if (a.gather && a.pre != nullptr && !L.epi_ok) return hipErrorInvalidValue;
   X.trace = a.trace;
   if (a.trace != nullptr) {
     if (!(a.gather && a.pre != nullptr)) return hipErrorInvalidValue;

@@ -3,6 +3,8 @@
 // HBM-bound by construction (W*4 B of weights per edge for ~5 kFLOP): one wave per edge streams the weight row with vector loads
 // (tp_stream_kernel below); the <=276 row operands u_i live in an LDS table per wave.
 // Used by the drop-in FasterTensorProduct module and as an on-GPU cross-check of the fused kernel.
+#include <stdlib.h>
+
 #include "ddk_internal.h"
 
 namespace ddk {
@@ -229,6 +231,175 @@ __global__ __launch_bounds__(64) void tp_stream_kernel(TpSArgs S) {
   }
 }
 
+
+// ---- Column-owner form (round 6) ------------------------------------------------------------------------------------
+// The weight row of an edge is ONE contiguous piece of 4 W bytes: the wave reads it flat, 16 B per lane and 1 KB per wave instruction whatever the
+// block shapes (W = 1872: 8 instructions, W = 936: 4; the row-shaped reads above needed 10 / 6), D rows ahead in registers, and parks it in LDS in the
+// same flat order.  Then every OUTPUT column of the edge has one lane (24 + 6 + 6 + 24 = 60 lanes) that walks its column down the block's rows:
+// no partial sums between lanes, no reduction, no barrier beyond the wave's own LDS order.  The per-row factors that do not depend on the row
+// (s0, v, the cross product with v) are applied ONCE per column (tensor_layers.py:75-92 is linear in the rows), so the row operand of a lane is a raw
+// input value: a_i / c_i (one LDS word, the same address for the whole block: a broadcast) or the raw p_i / q_i vector (one 16-B record).
+// Rows are walked in three phases that line up across the four blocks:
+//   A (scalar operand; A or C rows):  0e: a_i s0 | 1o: a_i (x) v | 1e: c_i (x) v | 0o: c_i s0
+//   B (P rows):                        0e: (p_i . v)/sqrt3 | 1o: p_i s0 | 1e: (p_i x v)/sqrt2
+//   C (Q rows):                        1o: (q_i x v)/sqrt2 | 1e: q_i s0 | 0o: (q_i . v)/sqrt3
+struct TpFArgs {
+  const float* x; const float* sh; const float* w; float* out;
+  int64_t E;
+};
+template <int A_, int P_, int Q_, int C_, int O0_, int O1_, int O2_, int O3_>
+struct TpShape {
+  static constexpr int A = A_, P = P_, Q = Q_, C = C_, O0 = O0_, O1 = O1_, O2 = O2_, O3 = O3_;
+  static constexpr int R0 = O0 ? A + P : 0, R1 = O1 ? A + P + Q : 0, R2 = O2 ? P + Q + C : 0, R3 = O3 ? Q + C : 0;      // tensor_layers.py:56-61
+  static constexpr int B0 = 0, B1 = B0 + R0 * O0, B2 = B1 + R1 * O1, B3 = B2 + R2 * O2, W = B3 + R3 * O3;
+  static constexpr int DIN = A + 3 * P + 3 * Q + C, DOUT = O0 + 3 * O1 + 3 * O2 + O3;
+  static constexpr int NV = (W / 4 + 63) / 64;       // 16-B loads per lane and row
+  static constexpr int XC = A + 3 * P + 3 * Q;       // first 0o input
+  static_assert(A % 8 == 0 && C % 8 == 0 && (A == C || A == 0 || C == 0) && (C == 0 || XC % 4 == 0), "phase A walks 8 rows at a time, operands in 16-B groups");
+  static_assert(W % 4 == 0 && DIN <= 128 && O0 + O1 + O2 + O3 <= 64 && P <= 8 && Q <= 8, "shape outside the flat kernel's layout");
+};
+typedef float tp_f4 __attribute__((ext_vector_type(4), aligned(4)));
+template <class S> struct TpRow { float4 w[S::NV]; float x0, x1; float4 sh; };
+
+template <class S, bool NT>
+__device__ __forceinline__ void tpf_request(const TpFArgs& a, int64_t e, int lane, TpRow<S>& R) {
+  const float4* wr = reinterpret_cast<const float4*>(a.w + e * S::W);
+#pragma unroll
+  for (int t = 0; t < S::NV; ++t) {
+    const int f = 64 * t + lane;
+    if ((t + 1) * 64 <= S::W / 4 || f < S::W / 4) {
+      const tp_f4* pw = reinterpret_cast<const tp_f4*>(wr + f);
+      const tp_f4 q = NT ? __builtin_nontemporal_load(pw) : *pw;
+      R.w[t] = make_float4(q.x, q.y, q.z, q.w);
+    }
+  }
+  const float* xr = a.x + e * S::DIN;
+  R.x0 = lane < S::DIN ? (NT ? __builtin_nontemporal_load(xr + lane) : xr[lane]) : 0.f;
+  R.x1 = lane + 64 < S::DIN ? (NT ? __builtin_nontemporal_load(xr + lane + 64) : xr[lane + 64]) : 0.f;
+  R.sh = *reinterpret_cast<const float4*>(a.sh + e * 4);
+}
+
+#ifndef TP_FLAT_ATTR
+#define TP_FLAT_ATTR
+#endif
+template <class S, int D, bool NT>
+__global__ __launch_bounds__(64) TP_FLAT_ATTR void tp_flat_kernel(TpFArgs a) {
+  __shared__ float4 Wst[S::NV * 64];
+  __shared__ __attribute__((aligned(16))) float X[128];
+  __shared__ float4 RBv[8], RBs[8], RCv[8], RCs[8];
+  const float* Wf = reinterpret_cast<const float*>(Wst);
+  const int lane = threadIdx.x;
+  const int64_t stride = gridDim.x;
+  int64_t e = blockIdx.x;
+  // ---- the lane's column: block, first weight of each phase, row stride, operand addresses ----
+  const int blk = lane < S::O0 ? 0 : (lane < S::O0 + S::O1 ? 1 : (lane < S::O0 + S::O1 + S::O2 ? 2 : (lane < S::O0 + S::O1 + S::O2 + S::O3 ? 3 : 4)));
+  const int col = lane - (blk == 0 ? 0 : (blk == 1 ? S::O0 : (blk == 2 ? S::O0 + S::O1 : S::O0 + S::O1 + S::O2)));
+  const int nout = blk == 0 ? S::O0 : (blk == 1 ? S::O1 : (blk == 2 ? S::O2 : (blk == 3 ? S::O3 : 0)));
+  const int bbase = blk == 0 ? S::B0 : (blk == 1 ? S::B1 : (blk == 2 ? S::B2 : S::B3));
+  const int nA = blk <= 1 ? S::A : (blk <= 3 ? S::C : 0);
+  const int rowA = blk <= 1 ? 0 : (blk == 2 ? S::P + S::Q : S::Q);
+  const bool onA = nA > 0 && nout > 0, onB = blk <= 2 && S::P > 0 && nout > 0, onC = blk >= 1 && blk <= 3 && S::Q > 0 && nout > 0;
+  const int wA = onA ? bbase + rowA * nout + col : 0, sA = onA ? nout : 0, xA = (onA && blk >= 2) ? S::XC : 0;
+  const int wB = onB ? bbase + (blk == 2 ? 0 : S::A) * nout + col : 0, sB = onB ? nout : 0;
+  const int wC = onC ? bbase + (blk == 1 ? S::A + S::P : (blk == 2 ? S::P : 0)) * nout + col : 0, sC = onC ? nout : 0;
+  const float4* recB = blk == 0 ? RBs : RBv;
+  const float4* recC = blk == 3 ? RCs : RCv;
+  const int nrow = blk == 0 ? S::R0 : (blk == 1 ? S::R1 : (blk == 2 ? S::R2 : (blk == 3 ? S::R3 : 1)));
+  const float rs = 1.0f / sqrtf((float)(nrow > 0 ? nrow : 1));                       // tensor_layers.py:89-92
+  const int ooff = blk == 0 ? col : (blk == 1 ? S::O0 + 3 * col : (blk == 2 ? S::O0 + 3 * S::O1 + 3 * col : S::O0 + 3 * S::O1 + 3 * S::O2 + col));
+  const float inv_s3 = 0.57735026918962576451f, inv_s2 = 0.70710678118654752440f;
+  constexpr int NA = S::A > S::C ? S::A : S::C;
+
+  TpRow<S> R[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (e + d * stride < a.E) tpf_request<S, NT>(a, e + d * stride, lane, R[d]);
+  for (;;) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      if (e >= a.E) return;
+      // ---- park the row (flat), the node row and the per-edge operands in LDS; ask for the row D edges ahead ----
+#pragma unroll
+      for (int t = 0; t < S::NV; ++t) Wst[64 * t + lane] = R[d].w[t];
+      X[lane] = R[d].x0;
+      X[lane + 64] = R[d].x1;
+      const float s0 = R[d].sh.x, vx = R[d].sh.y, vy = R[d].sh.z, vz = R[d].sh.w;
+      if (e + (int64_t)D * stride < a.E) tpf_request<S, NT>(a, e + (int64_t)D * stride, lane, R[d]);
+      __syncthreads();
+      if (lane < S::P) {
+        const float px = X[S::A + 3 * lane], py = X[S::A + 3 * lane + 1], pz = X[S::A + 3 * lane + 2];
+        RBv[lane] = make_float4(px, py, pz, 0.f);
+        RBs[lane] = make_float4((px * vx + py * vy + pz * vz) * inv_s3, 0.f, 0.f, 0.f);
+      } else if (lane >= 32 && lane < 32 + S::Q) {
+        const int m = lane - 32;
+        const float qx = X[S::A + 3 * S::P + 3 * m], qy = X[S::A + 3 * S::P + 3 * m + 1], qz = X[S::A + 3 * S::P + 3 * m + 2];
+        RCv[m] = make_float4(qx, qy, qz, 0.f);
+        RCs[m] = make_float4((qx * vx + qy * vy + qz * vz) * inv_s3, 0.f, 0.f, 0.f);
+      }
+      __syncthreads();
+      float accA = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+      // (chunks of 8 rows: 2 broadcast reads of 4 operands + 8 column reads in flight; a fully unrolled walk parks ~100 LDS results in registers)
+      const float4* X4 = reinterpret_cast<const float4*>(X) + (xA >> 2);
+#pragma unroll 1
+      for (int i0 = 0; i0 < NA; i0 += 8) {
+        const float4 ua = X4[(i0 >> 2)], ub = X4[(i0 >> 2) + 1];
+        const float uu[8] = {ua.x, ua.y, ua.z, ua.w, ub.x, ub.y, ub.z, ub.w};
+        const float* wp = Wf + wA + i0 * sA;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) accA = fmaf(uu[j], wp[j * sA], accA);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < S::P; ++i) {
+        const float4 u = recB[i];
+        const float w = Wf[wB + i * sB];
+        b0 = fmaf(u.x, w, b0); b1 = fmaf(u.y, w, b1); b2 = fmaf(u.z, w, b2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < S::Q; ++i) {
+        const float4 u = recC[i];
+        const float w = Wf[wC + i * sC];
+        c0 = fmaf(u.x, w, c0); c1 = fmaf(u.y, w, c1); c2 = fmaf(u.z, w, c2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (!onA) accA = 0.f;
+      if (!onB) { b0 = 0.f; b1 = 0.f; b2 = 0.f; }
+      if (!onC) { c0 = 0.f; c1 = 0.f; c2 = 0.f; }
+      float* o = a.out + e * S::DOUT + ooff;
+      if (blk == 0) {
+        o[0] = (s0 * accA + b0) * rs;
+      } else if (blk == 1) {      // a (x) v + p s0 + (q x v)/sqrt2
+        o[0] = (vx * accA + s0 * b0 + (c1 * vz - c2 * vy) * inv_s2) * rs;
+        o[1] = (vy * accA + s0 * b1 + (c2 * vx - c0 * vz) * inv_s2) * rs;
+        o[2] = (vz * accA + s0 * b2 + (c0 * vy - c1 * vx) * inv_s2) * rs;
+      } else if (blk == 2) {      // (p x v)/sqrt2 + q s0 + c (x) v
+        o[0] = ((b1 * vz - b2 * vy) * inv_s2 + s0 * c0 + vx * accA) * rs;
+        o[1] = ((b2 * vx - b0 * vz) * inv_s2 + s0 * c1 + vy * accA) * rs;
+        o[2] = ((b0 * vy - b1 * vx) * inv_s2 + s0 * c2 + vz * accA) * rs;
+      } else if (blk == 3) {
+        o[0] = (c0 + s0 * accA) * rs;
+      }
+      e += stride;
+      __syncthreads();
+    }
+  }
+}
+
+template <class S>
+static hipError_t launch_tp_flat(const TpFArgs& a, int variant, int64_t blocks, hipStream_t s) {
+  const dim3 g((unsigned)blocks), b(64);
+  switch (variant) {
+    case 1: hipLaunchKernelGGL((tp_flat_kernel<S, 2, false>), g, b, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((tp_flat_kernel<S, 2, true>), g, b, 0, s, a); break;
+    case 3: hipLaunchKernelGGL((tp_flat_kernel<S, 3, false>), g, b, 0, s, a); break;
+    case 4: hipLaunchKernelGGL((tp_flat_kernel<S, 3, true>), g, b, 0, s, a); break;
+    case 5: hipLaunchKernelGGL((tp_flat_kernel<S, 1, false>), g, b, 0, s, a); break;
+    default: hipLaunchKernelGGL((tp_flat_kernel<S, 1, true>), g, b, 0, s, a); break;
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_tp_forward(const ConvLayerDev& L, const float* x_dst, const float* sh, const float* w, int64_t E,
                              float* out, hipStream_t s) {
   if (E == 0) return hipSuccess;
@@ -240,6 +411,22 @@ hipError_t launch_tp_forward(const ConvLayerDev& L, const float* x_dst, const fl
     k.n_in[b] = L.n_in[b]; k.n_out[b] = L.n_out[b]; k.blk_off[b] = L.blk_off[b]; k.in_mul[b] = L.in_mul[b];
     k.out_off[b] = off;
     off += L.out_mul[b] * dims[b];
+  }
+  static const int variant = getenv("DDK_TP_VARIANT") ? atoi(getenv("DDK_TP_VARIANT")) : 1;
+  static const int grid_env = getenv("DDK_TP_GRID") ? atoi(getenv("DDK_TP_GRID")) : 0;
+  if (variant > 0) {
+    TpFArgs a{x_dst, sh, w, out, E};
+    const int64_t cap = grid_env > 0 ? grid_env : 256 * 16;
+    const int64_t nb = E < cap ? E : cap;
+    const int im[4] = {L.in_mul[0], L.in_mul[1], L.in_mul[2], L.in_mul[3]}, om[4] = {L.out_mul[0], L.out_mul[1], L.out_mul[2], L.out_mul[3]};
+    auto is = [&](int a0, int a1, int a2, int a3, int o0, int o1, int o2, int o3) {
+      return im[0] == a0 && im[1] == a1 && im[2] == a2 && im[3] == a3 && om[0] == o0 && om[1] == o1 && om[2] == o2 && om[3] == o3;
+    };
+    if (is(24, 6, 6, 24, 24, 6, 6, 24)) return launch_tp_flat<TpShape<24, 6, 6, 24, 24, 6, 6, 24>>(a, variant, nb, s);
+    if (is(24, 6, 6, 0, 24, 6, 6, 24)) return launch_tp_flat<TpShape<24, 6, 6, 0, 24, 6, 6, 24>>(a, variant, nb, s);
+    if (is(24, 6, 0, 0, 24, 6, 6, 0)) return launch_tp_flat<TpShape<24, 6, 0, 0, 24, 6, 6, 0>>(a, variant, nb, s);
+    if (is(24, 0, 0, 0, 24, 6, 0, 0)) return launch_tp_flat<TpShape<24, 0, 0, 0, 24, 6, 0, 0>>(a, variant, nb, s);
+    return hipErrorInvalidValue;
   }
   TpSArgs S;
   S.k = k;

@@ -56,8 +56,7 @@ typedef struct ddk_config {
    *    itself), fp32 accumulators (k_conv_x.hip).
    * 1: v_mfma_f32_32x32x2_f32, plain fp32 FMA chains (k_conv.hip) - the stated fallback.  Both apply to the score model and to the all-atom
    *    confidence model's conv layers.
-   * 2: as 0, but the score model's conv layers (gather path, atomics) run the software-pipelined one-wave-per-SIMD form of the same arithmetic
-   *    (k_conv_y.hip: one accumulator chain per tile instead of two; round 5, measured level with 0 - DESIGN.md §3.6); everything else as 0. */
+   *    (Round 5's value 2 - a software-pipelined one-wave-per-SIMD form, measured 9 % slower - is refused: the kernel lives under tools/variants/.) */
   int32_t conv_kernel;
   /* 1: fixed summation order per node in the score model's conv layers and heads (scatter_mean of tensor_layers.py:159): edges are
    *    sorted by the receiving node, so run tails STORE and the runs that straddle 32-edge tiles are folded in tile order by a second

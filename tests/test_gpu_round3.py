@@ -163,7 +163,7 @@ def test_three_limb_product_at_least_as_accurate_as_fp32_chain(dev):
 # ------------------------------------------------------------------------------------------------------------------------------------------
 # the core parity tests once more under every (conv kernel, scatter) mode, inside the driver's single `pytest -m gpu` (VERDICT r02 #5d)
 # ------------------------------------------------------------------------------------------------------------------------------------------
-@pytest.fixture(params=[(0, 0), (0, 1), (1, 0), (1, 1), (2, 0)], ids=['x3-atomics', 'x3-deterministic', 'fp32-atomics', 'fp32-deterministic', 'x3-pipelined-atomics'])
+@pytest.fixture(params=[(0, 0), (0, 1), (1, 0), (1, 1)], ids=['x3-atomics', 'x3-deterministic', 'fp32-atomics', 'fp32-deterministic'])
 def mode(request, monkeypatch):
     """every ddk context created inside the test runs the given conv kernel / scatter mode (runtime.Context reads the switches)"""
     kernel, det = request.param

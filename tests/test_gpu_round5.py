@@ -2,7 +2,7 @@
 
 * the streaming FasterTensorProduct kernel (k_tp.hip, the BASELINE metric's HBM-bound form) at E = 200 000 against the fp64 oracle, every conv layer's
   shape, and on a weight tensor that is only 4-byte aligned;
-* ddk_config.conv_kernel = 2 (k_conv_y.hip, the software-pipelined one-wave-per-SIMD form of the three-limb conv kernel): engaged, and equal to kernel 0;
+* ddk_config.conv_kernel = 2 (round 5's k_conv_y.hip, now under tools/variants/) is refused by the product library;
 * the pocket-bound bracket of bench.py as a 20-step oracle trajectory;
 * ddk_create on a device ordinal the box does not have."""
 import ctypes as C
@@ -77,38 +77,13 @@ def test_tp_stream_kernel_dword_aligned_weights(dev):
     assert rel_err(out.cpu(), tp(xd, sd, w.to(dev)).cpu()) < 1e-6
 
 
-def test_pipelined_conv_kernel_engaged_and_equal(dev):
-    """ddk_config.conv_kernel = 2: the score model's conv layers run k_conv_y.hip (checked through its per-unit trace record: slot 3, the drain stamp, only
-    that kernel writes) and give the scores / node rows of kernel 0 up to the association of the accumulation (one MFMA chain per tile instead of two)."""
-    from disco_diffdock_amd import synthetic
-    from disco_diffdock_amd.runtime import Context, Complex
-    if os.environ.get('DDK_DETERMINISTIC'):
-        pytest.skip('the deterministic scatter exists in k_conv_x.hip only: conv_kernel = 2 falls back to it (k_conv_x.hip: launch_conv_x3)')
-    c = synthetic.make_complex(3, n_res=300)
-    P = smr.random_state_dict(CFG, seed=9)
-    B = 40
-    rng = np.random.default_rng(5)
-    pos = torch.from_numpy(np.stack([c['lig_pos'] + rng.normal(0, 3.0, size=(1, 3)) for _ in range(B)]).astype(np.float32)).to(dev)
-    res = {}
-    for kernel in (0, 2):
-        ctx = Context(device=0, conv_kernel=kernel)
-        ctx.load_state_dict(P)
-        cx = Complex(ctx, c, B)
-        for t in (1.0, 0.3):
-            tr, rot, tor = cx.score_forward(pos, t, t, t)
-            res[(kernel, t)] = (tr.cpu(), rot.cpu(), tor.cpu(), cx.lig_node_features(B, dev).cpu())
-        if kernel == 2:
-            trace = torch.zeros((8, 1024, 8), dtype=torch.int32, device=dev)
-            ctx._check(ctx.L.ddk_debug_conv_trace(ctx.h, 100 + 3, C.c_void_p(trace.data_ptr())), 'trace')
-            cx.score_forward(pos, 0.3, 0.3, 0.3)
-            ctx._check(ctx.L.ddk_debug_conv_trace(ctx.h, -1, None), 'trace off')
-            torch.cuda.synchronize()
-            tr_ = trace.cpu().numpy()
-            assert (tr_[0, :, 2] != 0).sum() > 0 and tr_[0, 0, 3] != 0 and (tr_[4:] == 0).all(), 'k_conv_y.hip did not run (four waves, drain stamp)'
-    for t in (1.0, 0.3):
-        for i, name in enumerate(('tr', 'rot', 'tor')):
-            assert rel_err(res[(2, t)][i], res[(0, t)][i]) < 5e-6, (name, t)      # (observed <= 8e-7: the level at which the fp32-MFMA kernel differs from kernel 0)
-        assert chan_err(res[(2, t)][3], res[(0, t)][3]) < 1e-5, t
+def test_conv_kernel_2_is_refused_by_the_product_library(dev):
+    """Round 5's ddk_config.conv_kernel = 2 (the one-wave-per-SIMD form, 9 % slower) left libddk.so in round 6 (tools/variants/k_conv_y.hip,
+    tools/build_variant_y.sh): the product library refuses the value with a message instead of silently running kernel 0."""
+    from disco_diffdock_amd.runtime import Context
+    with pytest.raises(RuntimeError) as ei:
+        Context(device=0, conv_kernel=2)
+    assert 'conv_kernel' in str(ei.value) and 'variants' in str(ei.value), str(ei.value)
 
 
 def test_create_on_a_missing_device_fails_cleanly(dev):

@@ -413,3 +413,17 @@ def test_bench_quotes_pmc_traffic_only_for_the_profiled_kernel(tmp_path, monkeyp
     assert t is None and 'other kernel sources' in why
     (prof / 'r09_pmc_traffic.json').write_text(_json.dumps({'traffic_bytes_per_launch': 123.0}))      # a profile without a stamp (rounds 1-3)
     assert b.pmc_traffic()[0] is None
+
+
+def test_build_stamp_covers_the_public_headers_and_the_product_has_no_variant_kernel():
+    """include/ddk.h and ddk_debug.h had dropped out of every object's content stamp (a change of ddk_config would not have
+    recompiled anything); VERDICT r05 #7: round 5's opt-in conv kernel lives under tools/variants/ and is not a source of libddk.so."""
+    from disco_diffdock_amd import build
+    hs = [os.path.normpath(h) for h in build.stamp_headers()]
+    for name in ('ddk.h', 'ddk_debug.h'):
+        assert os.path.normpath(os.path.join(ROOT, 'include', name)) in hs, name
+    assert any(h.endswith('k_conv_x_epi_gen.inc') for h in hs) and all(os.path.exists(h) for h in hs)
+    assert 'k_conv_y.hip' not in build.SOURCES and not os.path.exists(os.path.join(ROOT, 'disco_diffdock_amd', 'csrc', 'k_conv_y.hip'))
+    assert os.path.exists(os.path.join(ROOT, 'tools', 'variants', 'k_conv_y.hip'))
+    src = open(os.path.join(ROOT, 'disco_diffdock_amd', 'csrc', 'k_conv_x.hip')).read()
+    assert '#error "X3_ABL_* switches give WRONG RESULTS' in src      # a stray -DX3_ABL_* cannot produce a wrong-answer product library

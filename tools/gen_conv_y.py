@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generator of the hand-placed tile loop of k_conv_y.hip  ->  disco_diffdock_amd/csrc/k_conv_y_gen.inc
+"""Generator of the hand-placed tile loop of k_conv_y.hip  ->  tools/variants/k_conv_y_gen.inc
 
 k_conv_y.hip runs ONE wave per SIMD; every wave owns two 32-edge column blocks a / b.  A W2 tile is two HALF-BURSTS: HB(X = a) = the 28
 MFMAs of block a (one accumulator chain), HB(X = b) the same for block b.  In the MFMA shadows of HB(X) - hand-placed (tools/probes/
@@ -569,7 +569,7 @@ def main():
         ins = [(n, 'v', f'{n}{Y}') for n in ('oscv', 's0', 'vx', 'vy', 'vz', 'wx', 'wy', 'wz', 'sm1', 'sm2', 'sm4', 'sm8', 'sm16', 'vrow')]
         ins += [('hh4', 'v', 'hh4'), ('hh12', 'v', 'hh12'), ('pchan', 's', f'pchan{Y}'), ('tail', 's', f'tail{Y}'), ('sumbase', 's', 'sumbase'), ('sel', 's', 'sel_')]
         out.append(asm_stmt(f'Y_DRAIN_FLUSH_{Y}', lines, outs, ins, CLOBBER + ['memory', 'scc']))
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'disco_diffdock_amd', 'csrc', 'k_conv_y_gen.inc')
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'variants', 'k_conv_y_gen.inc')
     with open(path, 'w') as f:
         f.write('\n'.join(out))
     print('wrote', os.path.normpath(path), sum(s.count('\n') for s in out), 'lines')

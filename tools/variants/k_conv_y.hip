@@ -44,7 +44,7 @@ typedef int i32x2 __attribute__((ext_vector_type(2)));
 #define VMC(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define PINA(x) asm volatile("" : "+a"(x))
 
-#include "k_conv_y_gen.inc"
+#include "k_conv_y_gen.inc"      // (tools/variants/, next to this file)
 
 // Exact power-of-two range scale (k_conv_x.hip)
 __device__ __forceinline__ float y_range_scale(float m, float& inv) {
@@ -463,22 +463,7 @@ hipError_t conv_prepare_device_y() {
 }
 
 // The layer's tile table qualifies when every flush closes a full scalar column (4 quads) or a 6-channel vector column (3 quads): the score model's
-// conv layers (ns = 24, nv = 6).  Checked once per layer at finalize time (ConvLayerDev::y_ok).
-bool conv_y_layer_ok(const std::vector<TileDesc>& tiles) {
-  if (tiles.empty()) return false;
-  for (const TileDesc& t : tiles) {
-    const int w0 = x_tile_word(t.w0);
-    if (w0 < 0 || (w0 & X_TILE_L2)) return false;
-    const int fl = (w0 >> 2) & 3, nrq = (w0 >> 4) & 7, kind = w0 & 3;
-    if (fl == FL_S && nrq != 4) return false;
-    if (fl == FL_V && nrq != 3) return false;
-    if (kind == T_RTS && fl != FL_S) return false;
-    if (kind == T_TV && (w0 & 0x80) && false) return false;
-  }
-  const int last = x_tile_word(tiles.back().w0);
-  return ((last >> 2) & 3) != 0;      // (a unit ends with a flush)
-}
-
+// conv layers (ns = 24, nv = 6).  Checked once per layer at finalize time (ConvLayerDev::epi_ok).
 hipError_t launch_conv_y(const ConvXArgs& X, int n_cu, hipStream_t s) {
   if (X.trace != nullptr) hipLaunchKernelGGL(conv_y_kernel<true>, dim3(n_cu), dim3(64 * Y_WAVES), CONV_X_LDS_BYTES, s, X);
   else hipLaunchKernelGGL(conv_y_kernel<false>, dim3(n_cu), dim3(64 * Y_WAVES), CONV_X_LDS_BYTES, s, X);

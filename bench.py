@@ -216,11 +216,58 @@ def pocket_poses(c, rng, samples, sigma=1.0):
 def _make_complex(job):
     """one synthetic complex of the workload (top level: the large sets are generated by a process pool)"""
     from disco_diffdock_amd import synthetic
-    seed, n_res, spread_ligands, with_conf = job
-    c = synthetic.make_complex(seed, n_res=n_res, n_lig=int(np.random.default_rng(7000 + seed).integers(10, 81)) if spread_ligands else None)
+    seed, n_res, n_lig, with_conf = job
+    c = synthetic.make_complex(seed, n_res=n_res, n_lig=n_lig)
     if with_conf:
         synthetic.add_receptor_atoms(c, np.random.default_rng(seed))
     return c
+
+
+def set_shapes(n_cx, offset, n_res_default, spread, fixed_receptor):
+    """(n_res, n_lig or None) of the n_cx complexes of this run: the default 8 share one receptor size and the generator's own ligand; a larger set is
+    timesplit-SHAPED (synthetic.timesplit_shape: log-normal receptor sizes, 10-80-atom ligands) unless --fixed-receptor keeps round 5's 300-residue stream"""
+    from disco_diffdock_amd import synthetic
+    if not spread:
+        return [(n_res_default, None) for _ in range(n_cx)]
+    sh = [synthetic.timesplit_shape(offset + i) for i in range(n_cx)]
+    return [(n_res_default if fixed_receptor else r, l) for r, l in sh]
+
+
+def tp_boundary_a(dev, edges=800000, iters=10):
+    """BASELINE metric, second clause, at the REFERENCE's op boundary: FasterTensorProduct.forward (models/tensor_layers.py:65-116) with the per-edge weights
+    [E, W] resident in HBM - 4 (W + din + 4 + dout) + 8 B per edge for ~5 kFLOP: the one HBM-bound kernel of the path (k_tp.hip, ddk_tp_forward).  HIP events
+    on the launch stream around `iters` launches per conv-layer shape; layer 3 (= 4) is the BASELINE shape.  tools/bench_tp.py is the same measurement with
+    an fp64 check of a slice; tools/profile_tp.sh takes the rocprofv3 kernel trace and the FETCH / WRITE counters of it (profiles/r06_tp_boundary_kernel_stats.md)."""
+    from disco_diffdock_amd.tensor_layers import FasterTensorProduct
+    seq = ['24x0e', '24x0e+6x1o', '24x0e+6x1o+6x1e', '24x0e+6x1o+6x1e+24x0o']
+    din = [24, 42, 60, 84, 84]
+    layers = {}
+    g = torch.Generator(device=dev).manual_seed(0)
+    for l in (3, 2, 1, 0):
+        tp = FasterTensorProduct(seq[min(l, 3)], '1x0e+1x1o', seq[min(l + 1, 3)])
+        W = tp.weight_numel
+        x = torch.randn(edges, din[l], device=dev, generator=g)
+        sh = torch.randn(edges, 4, device=dev, generator=g)
+        w = torch.randn(edges, W, device=dev, generator=g)
+        out = tp(x, sh, w)
+        tp(x, sh, w)
+        st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        st.record()
+        for _ in range(iters):
+            tp(x, sh, w)
+        en.record()
+        torch.cuda.synchronize()
+        ms = st.elapsed_time(en) / iters
+        b = 4 * (W + din[l] + 4) + 8 + 4 * out.shape[1]
+        layers[l] = {'layer': l, 'W': W, 'algorithmic_bytes_per_edge': b, 'ms_per_launch': round(ms, 4), 'GBps': round(edges * b / ms / 1e6, 1)}
+        del x, sh, w, out
+    torch.cuda.empty_cache()
+    l3 = layers[3]
+    return {'kernel': 'ddk::tp_col_kernel (k_tp.hip): FasterTensorProduct.forward, weights [E, W] streamed from HBM', 'bound': 'hbm', 'edges': edges,
+            'achieved': l3['GBps'], 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(l3['GBps'] / PEAK_HBM_GBS, 4),
+            'frac_of_achievable_6300': round(l3['GBps'] / 6300.0, 4), 'layer': 3, 'per_layer': [layers[l] for l in (0, 1, 2, 3)],
+            'note': 'layer 3 = layer 4 = the BASELINE shape (W = 1872, 8 184 B per edge); 6 300 GB/s is what MI355X_MICROARCH.md measures as achievable (float4 copy)'}
 
 
 def timesplit_stream():
@@ -241,6 +288,7 @@ def timesplit_stream():
         return {'error': repr(e)}
     return {'command': ' '.join(cmd[1:]), 'workload': o['config']['workload'], 'value': o['value'], 'value_pruning_off': o.get('value_pruning_off'),
             'value_pocket_bound': o.get('value_pocket_bound'), 'unit': 'complexes/s', 'complexes': 363, 'ms_per_complex': o['ms_per_step'],
+            'receptor_residues_min_median_max': o['extra']['stream'].get('receptor_residues_min_median_max'), 'per_receptor_size_decile': o['extra'].get('per_receptor_size_decile'),
             'roofline_frac': o['roofline']['frac'], 'avg_conv_launch_ms': o['roofline']['avg_launch_ms'], 'conv_share_of_wall': o['roofline']['conv_share_of_wall'],
             'min_cross_edges_per_sample_pocket_bound': (o['extra'].get('pocket_bound') or {}).get('min_cross_edges_per_sample_over_steps'),
             'stream': o['extra']['stream'], 'wall_s_of_the_subprocess': round(time.perf_counter() - t0, 1)}
@@ -282,6 +330,10 @@ def main():
     ap.add_argument('--single-device', action='store_true', help='smoke test of the N > 1 path on a one-GPU box: every rank uses cuda:0')
     ap.add_argument('--complexes', type=int, default=0, help='distinct synthetic complexes per rank (default 8 of ~30 ligand atoms; N > 8: ligand sizes '
                     'drawn from 10-80 atoms like a PDBBind split - e.g. --complexes 363 --steps 363 streams a timesplit_test-sized set once)')
+    ap.add_argument('--fixed-receptor', action='store_true', help='--complexes > 8: keep every receptor at 300 residues (rounds 4 / 5 streamed this set; the default draws '
+                    'timesplit-shaped receptor sizes, synthetic.timesplit_shape)')
+    ap.add_argument('--passes', type=int, default=0, help='timed passes over the K calls, the MEDIAN pass is reported (default: 3 for K <= 64, else 1)')
+    ap.add_argument('--no-tp-boundary', action='store_true', help='skip roofline.tp_boundary_A (FasterTensorProduct.forward at the reference op boundary, 800 000 edges)')
     ap.add_argument('--complex-offset', type=int, default=0, help='first content seed of --complexes (to run a slice of a large set)')
     ap.add_argument('--force-dist', action='store_true', help='N = 1 through the N > 1 code path: a world_size-1 process group on --backend, every '
                     'barrier / all_reduce / all_gather of the path executes (proves that RCCL loads and runs beside libddk.so on a one-GPU box)')
@@ -319,7 +371,7 @@ def main():
     from disco_diffdock_amd.model_utils import get_model, get_ar_model
     from disco_diffdock_amd.sampling import sampling, step_coefficients, draw_noise
     from disco_diffdock_amd.diffusion_utils import t_to_sigma, get_t_schedule
-    from disco_diffdock_amd.distributed import shard_samples, shard_indices, gather_poses, gather_samples, gather_confidences
+    from disco_diffdock_amd.distributed import shard_samples, shard_indices, complex_cost, gather_poses, gather_samples, gather_confidences
     if rank == 0:
         build.build(verbose=False)       # no-op when the shipped libddk.so is current; never build concurrently
     if use_dist:
@@ -336,13 +388,13 @@ def main():
     n_cx = a.complexes if a.complexes > 0 else (4 if big else N_COMPLEXES)
     spread_ligands = a.complexes > N_COMPLEXES
     shard_set = a.shard_set and not big
+    shapes = set_shapes(n_cx, a.complex_offset, n_res, spread_ligands, a.fixed_receptor)
     if big:                                  # samples sharded: every rank works on the same complexes
         mine = list(range(n_cx))
         lo, hi = shard_samples(SAMPLES, rank, world)
     elif shard_set:                          # ONE set of n_cx complexes, partitioned by cost (the layout a real dataset gets)
         n_total = n_cx
-        n_lig_of = [int(np.random.default_rng(7000 + a.complex_offset + i).integers(10, 81)) if spread_ligands else 30 for i in range(n_cx)]
-        mine = shard_indices([n_res * max(v, 16) for v in n_lig_of], rank, world)
+        mine = shard_indices([complex_cost(r_, l_ or 30) for r_, l_ in shapes], rank, world)
         lo, hi = 0, SAMPLES
     else:
         n_total = n_cx * world
@@ -353,7 +405,7 @@ def main():
     b_local = hi - lo
     if shard_set:       # this rank's timed sampling() calls: its share of the set, every complex once
         a.steps, a.warmup = len(mine), (min(a.warmup, len(mine)))
-    jobs = [(a.complex_offset + i % n_cx, n_res, spread_ligands, with_conf) for i in mine]
+    jobs = [(a.complex_offset + i % n_cx, shapes[i % n_cx][0], shapes[i % n_cx][1], with_conf) for i in mine]
     if len(jobs) > 32:       # a timesplit-sized set: the synthetic generator (rejection sampling, ~0.25 s per complex) on the host's cores, not in a loop
         import multiprocessing as mp
         with mp.get_context('spawn').Pool(min(32, os.cpu_count() or 1)) as pool:
@@ -410,10 +462,13 @@ def main():
         cdl = [copy.copy(gc) for _ in range(b_local)] if with_conf else None
         return dl, cdl
 
-    def bracket(poses, warmup, prune=True, noise_scale=None):
+    n_passes_default = a.passes if a.passes > 0 else (3 if a.steps <= 64 else 1)
+
+    def bracket(poses, warmup, prune=True, noise_scale=None, n_passes=None):
         """the reference's bracket (evaluate.py:259,293) over K = a.steps sampling() calls, a NEW complex every call; returns the wall
         time and what the HIP events around the conv launches saw.  noise_scale: N(0,1) draws of every call pre-drawn and scaled (the
         pocket-bound workload); None: drawn inside sampling() from the device generator like the headline."""
+        n_passes = n_passes or n_passes_default
         calls = [data_lists(i, poses) for i in order[:warmup + a.steps]]
         torch.cuda.manual_seed(977 + rank)
         noises = None
@@ -439,51 +494,57 @@ def main():
         for k in range(warmup):
             one_call(k)
         torch.cuda.synchronize()
-        torch.cuda.manual_seed(4321 + rank)      # the device generator sampling() draws its noise from (the resident-loop figure below replays it)
-        sm_mod._complex_cache.clear()            # a NEW complex every timed call: no Complex of the warm-up survives
         ctx.profile_enable(True)
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
         pool0, mem_peak = ctx.pool_stats(), 0
-        t0 = time.perf_counter()
-        final, confs, outs = {}, {}, []
-        call_ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]      # device time stamps behind every call (no host wait)
-        call_ev[0].record()
-        for k in range(warmup, warmup + a.steps):
-            if (k - warmup) % len(mine) == 0 and k > warmup:
-                sm_mod._complex_cache.clear()    # K > #complexes: the second pass over the shard must not hit the cache either
-            if shard_set:
-                torch.cuda.manual_seed(5000 + order[k])      # noise and AR picks of a complex do not depend on which rank runs it, or after what
-            out, conf = one_call(k)
-            if os.environ.get('DDK_BENCH_TRACE'):
-                print(f'[bench] call {k - warmup} complex {order[k]} n_lig {complexes[order[k]]["lig_pos"].shape[0]} queued', file=sys.stderr, flush=True)
-            if os.environ.get('DDK_BENCH_SYNC'):      # debugging aid: a GPU fault then names the call it belongs to (the timing is meaningless)
-                torch.cuda.synchronize()
-                print(f'[bench] call {k - warmup} complex {order[k]} n_lig {complexes[order[k]]["lig_pos"].shape[0]} ok', file=sys.stderr, flush=True)
-            call_ev[k - warmup + 1].record()
-            if (k - warmup) % 8 == 0:                # device memory in use (driver query, no synchronisation), sampled every 8th call
-                fr, tot_mem = torch.cuda.mem_get_info(dev)
-                mem_peak = max(mem_peak, tot_mem - fr)
-            outs.append(out)
-            final[order[k]] = torch.stack([d['ligand'].pos for d in out])
-            if with_conf:
-                confs[order[k]] = conf
-        if disco:        # the latent bookkeeping of utils/sampling.py:205-221 (filled on first access): inside the bracket like the reference's
-            assert all(len(o[0].latent_str) >= 2 and all(hasattr(d, 'latent_pos') for d in o) for o in outs)
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        prof, fw = ctx.profile_read(), ctx.profile_read_forwards()
+        pass_elapsed, pass_calls = [], []
+        for pass_id in range(n_passes):
+            # every pass: EXACTLY a.steps calls between a barrier + synchronize on both sides; the same complexes, start poses and generator seed
+            torch.cuda.manual_seed(4321 + rank)      # the device generator sampling() draws its noise from (the resident-loop figure below replays it)
+            sm_mod._complex_cache.clear()            # a NEW complex every timed call: no Complex of the warm-up (or of the previous pass) survives
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            final, confs, outs = {}, {}, []
+            call_ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]      # device time stamps behind every call (no host wait)
+            call_ev[0].record()
+            for k in range(warmup, warmup + a.steps):
+                if (k - warmup) % len(mine) == 0 and k > warmup:
+                    sm_mod._complex_cache.clear()    # K > #complexes: the second pass over the shard must not hit the cache either
+                if shard_set:
+                    torch.cuda.manual_seed(5000 + order[k])      # noise and AR picks of a complex do not depend on which rank runs it, or after what
+                out, conf = one_call(k)
+                if os.environ.get('DDK_BENCH_TRACE'):
+                    print(f'[bench] call {k - warmup} complex {order[k]} n_lig {complexes[order[k]]["lig_pos"].shape[0]} queued', file=sys.stderr, flush=True)
+                if os.environ.get('DDK_BENCH_SYNC'):      # debugging aid: a GPU fault then names the call it belongs to (the timing is meaningless)
+                    torch.cuda.synchronize()
+                    print(f'[bench] call {k - warmup} complex {order[k]} n_lig {complexes[order[k]]["lig_pos"].shape[0]} ok', file=sys.stderr, flush=True)
+                call_ev[k - warmup + 1].record()
+                if (k - warmup) % 8 == 0:                # device memory in use (driver query, no synchronisation), sampled every 8th call
+                    fr, tot_mem = torch.cuda.mem_get_info(dev)
+                    mem_peak = max(mem_peak, tot_mem - fr)
+                outs.append(out)
+                final[order[k]] = torch.stack([d['ligand'].pos for d in out])
+                if with_conf:
+                    confs[order[k]] = conf
+            if disco:        # the latent bookkeeping of utils/sampling.py:205-221 (filled on first access): inside the bracket like the reference's
+                assert all(len(o[0].latent_str) >= 2 and all(hasattr(d, 'latent_pos') for d in o) for o in outs)
+            torch.cuda.synchronize()
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            el_ = time.perf_counter() - t0
+            if use_dist:
+                tmax = torch.tensor([el_], device=dev, dtype=torch.float64)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                el_ = float(tmax.item())
+            pass_elapsed.append(el_)
+            pass_calls.append([round(call_ev[k].elapsed_time(call_ev[k + 1]), 2) for k in range(a.steps)])
+        med = sorted(range(n_passes), key=lambda i_: pass_elapsed[i_])[n_passes // 2]      # the MEDIAN pass is the one reported
+        elapsed, per_call_ms = pass_elapsed[med], pass_calls[med]
+        prof, fw = ctx.profile_read(), ctx.profile_read_forwards()      # (HIP events around the conv launches of ALL passes: means are unaffected)
         ctx.profile_enable(False)
         ctx.set_pruning(True)
-        per_call_ms = [round(call_ev[k].elapsed_time(call_ev[k + 1]), 2) for k in range(a.steps)]
-        if use_dist:
-            tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            elapsed = float(tmax.item())
         for p in final.values():
             assert bool(torch.isfinite(p).all()), 'non-finite pose'
         pool1 = ctx.pool_stats()
@@ -492,14 +553,16 @@ def main():
             print('[bench] bracket done: score pool', pool1, 'conf pool', extra['confidence_model'].ctx.pool_stats() if with_conf else None,
                   'ar pool', extra['ar_model'].score_model.ctx.pool_stats() if disco and hasattr(extra['ar_model'], 'score_model') else None,
                   'device memory in use GB', round((tot_mem - fr) / 2**30, 1), file=sys.stderr, flush=True)
-        stream = {'complexes_created': a.steps, 'distinct_complexes': len(mine),
+        nres_ = sorted(int(complexes[i]['rec_pos'].shape[0]) for i in mine)
+        stream = {'complexes_created': a.steps, 'distinct_complexes': len(mine), 'receptor_residues_min_median_max': [nres_[0], nres_[len(nres_) // 2], nres_[-1]],
                   'ligand_atoms_min_max': [int(min(complexes[i]['lig_pos'].shape[0] for i in mine)), int(max(complexes[i]['lig_pos'].shape[0] for i in mine))],
                   'chunk_pool_hipMalloc_in_timed_region': pool1['hipMalloc_calls'] - pool0['hipMalloc_calls'],
                   'chunk_pool_reuses_in_timed_region': pool1['reuses'] - pool0['reuses'],
                   'chunk_pool_hipFree_in_timed_region': pool1['hipFree_calls'] - pool0['hipFree_calls'],
                   'chunk_pool_bytes_parked': pool1['bytes_parked'], 'complex_bytes_owned_peak': pool1['bytes_owned_peak'],
                   'device_memory_in_use_peak_bytes': int(mem_peak)}
-        return dict(elapsed=elapsed, prof=prof, fw=fw, per_call_ms=per_call_ms, final=final, confs=confs, order=order[warmup:warmup + a.steps], stream=stream)
+        return dict(elapsed=elapsed, prof=prof, fw=fw, per_call_ms=per_call_ms, final=final, confs=confs, order=order[warmup:warmup + a.steps], stream=stream,
+                    passes=n_passes, pass_elapsed_s=[round(v, 5) for v in pass_elapsed])
 
     layer_flop = [2 * 72 * (72 + W_LAYER[l]) + TP_FLOP[l] for l in range(5)]
 
@@ -512,7 +575,7 @@ def main():
         cross = fw[:, 3].reshape(-1, STEPS) / b_local if len(fw) and len(fw) % STEPS == 0 else None
         return {'value': n_units / r['elapsed'], 'unit': 'complexes/s', 'ms_per_step': 1e3 * r['elapsed'] / a.steps,
                 'edges_executed_over_unpruned': e_x / max(e_u, 1), 'conv_fp32_equivalent_TFLOPs': fl / max(conv_ms, 1e-9) / 1e9,
-                'conv_share_of_wall': conv_ms * 1e-3 / r['elapsed'],
+                'conv_share_of_wall': conv_ms * 1e-3 / sum(r['pass_elapsed_s']),
                 'min_cross_edges_per_sample_over_steps': None if cross is None else float(cross.min())}
 
     for _rep in range(int(os.environ.get('DDK_BENCH_REPEAT', '1')) - 1):      # debugging aid: the pocket-bound bracket several times in one process
@@ -552,7 +615,7 @@ def main():
                 pose_digest = {'sha256_of_the_gathered_poses': h.hexdigest(), 'complexes': n_total,
                                'pose_checksum': float(sum(float(gathered[i].double().sum()) for i in gathered)),
                                'confidence_checksum': None if gconf is None else float(sum(float(gconf[i].double().sum()) for i in gconf)),
-                               'complexes_per_rank': [len(shard_indices([n_res * max(v, 16) for v in n_lig_of], r, world)) for r in range(world)],
+                               'complexes_per_rank': [len(shard_indices([complex_cost(r_, l_ or 30) for r_, l_ in shapes], r, world)) for r in range(world)],
                                'note': 'DDK_DETERMINISTIC=1: bit-identical for every number of ranks (the confidence model keeps its atomics: its checksum agrees to ~1e-6)'}
         n_done = n_total if shard_set else world * a.steps
 
@@ -626,8 +689,8 @@ def main():
             traffic, traffic_file = None, 'the PMC profile is of the driver command (config 2, --steps 20 --warmup 5): not quoted for another workload'
         fw = head['fw']
         per_step = None
-        if len(fw) == a.steps * STEPS:
-            f3 = fw.reshape(a.steps, STEPS, 4)
+        if len(fw) == head['passes'] * a.steps * STEPS:
+            f3 = fw.reshape(head['passes'] * a.steps, STEPS, 4)
             per_step = [{'step': s_, 't': round(float(t_arr[s_, 0]), 3), 'edges_executed_over_unpruned': float(f3[:, s_, 1].sum() / max(f3[:, s_, 2].sum(), 1)),
                          'conv_ms': float(f3[:, s_, 0].mean()), 'cross_edges_per_sample': float(f3[:, s_, 3].mean() / b_local)} for s_ in range(STEPS)]
         # device time of the timed calls that ran the SAME complex (same ligand size, own noise): max / min - 1 over each complex' calls
@@ -636,6 +699,19 @@ def main():
             by_cx.setdefault(i, []).append(ms)
         rep = [max(v) / min(v) - 1.0 for v in by_cx.values() if len(v) > 1]
         per_call_spread = round(max(rep), 4) if rep else None
+        # device ms per complex by receptor-size decile (the timesplit-shaped set: cost grows with the receptor, distributed.complex_cost is fitted to this)
+        per_decile = None
+        if len(set(int(complexes[i]['rec_pos'].shape[0]) for i in mine)) > 1:
+            rows_ = sorted((int(complexes[i]['rec_pos'].shape[0]), int(complexes[i]['lig_pos'].shape[0]), ms) for i, ms in zip(head['order'], head['per_call_ms']))
+            per_decile = []
+            for d_ in range(10):
+                part = rows_[len(rows_) * d_ // 10:len(rows_) * (d_ + 1) // 10]
+                if part:
+                    per_decile.append({'decile': d_, 'residues': [part[0][0], part[-1][0]], 'complexes': len(part), 'mean_ligand_atoms': round(float(np.mean([r_[1] for r_ in part])), 1),
+                                       'ms_per_complex': round(float(np.mean([r_[2] for r_ in part])), 2)})
+        tp_boundary = None
+        if world == 1 and cfg_id == 2 and not a.no_tp_boundary and not a.no_extras:
+            tp_boundary = tp_boundary_a(dev)
         out = {
             'metric': 'complexes/sec, 20-step 40-sample inference',
             'value': n_done / elapsed, 'unit': 'complexes/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
@@ -646,9 +722,14 @@ def main():
             'dtype': 'f32', 'data': 'synthetic',
             'dtype_note': 'every operand and accumulator of the path is fp32; the radial-MLP GEMMs multiply the fp32 operands exactly as three f16 limbs each on the f16 '
                           'matrix pipe (six of nine limb products, dropped terms <= 3 * 2^-33 relative) with fp32 accumulation (DESIGN.md 3.3)',
-            'config': {'workload': f'BASELINE config {cfg_id}: ' + CONFIG_TEXT[cfg_id] + '; 1 step = 1 complex',
+            'config': {'workload': f'BASELINE config {cfg_id}: ' + CONFIG_TEXT[cfg_id] + ('; receptor sizes of the set drawn timesplit-shaped (synthetic.timesplit_shape: log-normal, '
+                                   'median 350, clipped to [60, 3000] residues), ligands 10-80 atoms' if (spread_ligands and not a.fixed_receptor) else '') + '; 1 step = 1 complex',
                        'bracket': 'wall time around sampling(data_list, model, ...) on host data_lists, a new complex every call (evaluate.py:259,293): '
-                                  'collation, ddk_complex_create, H2D, noise draws, the 20-step loop, pose write-back; K calls + one final synchronisation',
+                                  'collation, ddk_complex_create, H2D, noise draws, the 20-step loop, pose write-back; K calls + one final synchronisation; '
+                                  f'{head["passes"]} such passes over the same K calls, the MEDIAN pass is reported (value, ms_per_step; pass times in extra.headline.pass_elapsed_s)',
+                       # the three figures belong together, here too because the driver's record keeps `config`
+                       'value_headline_pruning_off_pocket_bound': [round(n_done / elapsed, 3), None if not pruning_off else round(pruning_off['value'], 3),
+                                                                   None if not pocket_bound else round(pocket_bound['value'], 3)],
                        'samples_per_complex': SAMPLES, 'inference_steps': STEPS, 'complexes_per_gpu': n_cx,
                        'parallelism': (f'the {SAMPLES} samples of every complex sharded over {world} process(es) ({b_local} per GPU), final all_gather'
                                        if big else f'{world} process(es), one per GPU, each with the same {n_cx} complexes (own start poses and noise: per-GPU work fixed), final RCCL all_gather of the poses')},
@@ -674,7 +755,9 @@ def main():
                          'flop_per_launch': mfma_exec / max(launches, 1), 'fp32_equivalent_flop_per_launch': flops_exec / max(launches, 1),
                          'algorithmic_hbm_GBps': byts / (conv_ms * 1e-3) / 1e9 if conv_ms > 0 else 0.0,
                          'algorithmic_hbm_frac_of_peak': (byts / (conv_ms * 1e-3) / 1e9) / PEAK_HBM_GBS if conv_ms > 0 else 0.0,
-                         'conv_share_of_wall': conv_ms * 1e-3 / elapsed,
+                         'conv_share_of_wall': conv_ms * 1e-3 / sum(head['pass_elapsed_s']),
+                         # the BASELINE metric's second clause at the REFERENCE's op boundary (tensor_layers.py:65-116, weights [E, W] in HBM): the HBM-bound kernel
+                         'tp_boundary_A': tp_boundary,
                          'per_layer': [{'layer': l, 'ms_per_launch': p['ms'] / max(p['launches'], 1), 'w2_tiles': n_tiles[l],
                                         'mfma_TFLOPs': p['edges'] * MFMA_FLOP_PER_EDGE_TILE * (n_tiles[l] + 1) / max(p['ms'], 1e-9) / 1e9,
                                         'fp32_equivalent_TFLOPs': p['edges'] * layer_flop[l] / max(p['ms'], 1e-9) / 1e9,
@@ -682,7 +765,8 @@ def main():
                                        for l, p in enumerate(prof)]},
             'extra': {'pruning_off': pruning_off, 'pocket_bound': pocket_bound, 'per_step': per_step, 'create_ms': create_ms, 'pose_digest': None if big else pose_digest,
                       'per_call_spread_same_complex': per_call_spread,
-                      'headline': {k: v for k, v in summary(head, n_done).items() if k != 'value'},
+                      'headline': dict({k: v for k, v in summary(head, n_done).items() if k != 'value'}, passes=head['passes'], pass_elapsed_s=head['pass_elapsed_s']),
+                      'per_receptor_size_decile': per_decile,
                       'device_loop': device_loop, 'per_call_ms': head['per_call_ms'] if a.steps <= 64 else head['per_call_ms'][:64] + ['...'], 'stream': head['stream']},
         }
         if int(getattr(ctx.cfg, 'conv_kernel', 0)) == 1:

@@ -44,7 +44,7 @@ SYMBOLS = ['ddk_create', 'ddk_destroy', 'ddk_last_error', 'ddk_version', 'ddk_lo
            'ddk_confidence_forward', 'ddk_score_confidence', 'ddk_pose_metrics', 'ddk_build_graph', 'ddk_set_receptive_field_pruning', 'ddk_ar_logits', 'ddk_ar_decode', 'ddk_confidence_status']
 
 # test hooks (include/ddk_debug.h): not part of the drop-in boundary
-DEBUG_SYMBOLS = ['ddk_debug_export', 'ddk_debug_read_edges', 'ddk_debug_conf_counts', 'ddk_debug_conf_table', 'ddk_debug_conf_nodes', 'ddk_debug_conf_edges', 'ddk_debug_kabsch', 'ddk_debug_axis_angle', 'ddk_debug_set_layer0_dedup', 'ddk_debug_read_patch', 'ddk_debug_split3', 'ddk_debug_conv_trace', 'ddk_debug_pool_stats', 'ddk_debug_set_conv_workgroups']
+DEBUG_SYMBOLS = ['ddk_debug_export', 'ddk_debug_read_edges', 'ddk_debug_conf_counts', 'ddk_debug_conf_table', 'ddk_debug_conf_nodes', 'ddk_debug_conf_edges', 'ddk_debug_kabsch', 'ddk_debug_axis_angle', 'ddk_debug_set_layer0_dedup', 'ddk_debug_read_patch', 'ddk_debug_split3', 'ddk_debug_conv_trace', 'ddk_debug_pool_stats', 'ddk_debug_set_conv_workgroups', 'ddk_debug_set_alloc_limit']
 
 
 def lib():
@@ -112,6 +112,7 @@ def _declare_debug(L):
     L.ddk_debug_conv_trace.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     L.ddk_debug_pool_stats.argtypes = [C.c_void_p, C.c_void_p]
     L.ddk_debug_set_conv_workgroups.argtypes = [C.c_void_p, C.c_int32]
+    L.ddk_debug_set_alloc_limit.argtypes = [C.c_void_p, C.c_int64]
     L.ddk_debug_conf_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.ddk_debug_conf_table.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     L.ddk_debug_conf_nodes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]

@@ -22,10 +22,30 @@ int hip_fail(ddk_ctx* ctx, hipError_t e, const char* what) {
   return fail(ctx, DDK_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
 }
 
+hipError_t ctx_malloc(ddk_ctx* ctx, void** p, size_t bytes) {
+  *p = nullptr;
+  if (ctx->alloc_limit > 0 && ctx->dev_bytes + (int64_t)bytes > ctx->alloc_limit) { ctx->alloc_refusals++; return hipErrorOutOfMemory; }
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess) { *p = nullptr; (void)hipGetLastError(); return e; }      // (the sticky error is consumed: the context stays usable)
+  ctx->dev_bytes += (int64_t)bytes;
+  ctx->dev_sizes[*p] = bytes;
+  return hipSuccess;
+}
+
+void ctx_free(ddk_ctx* ctx, void* p) {
+  if (!p) return;
+  auto it = ctx->dev_sizes.find(p);
+  if (it != ctx->dev_sizes.end()) { ctx->dev_bytes -= (int64_t)it->second; ctx->dev_sizes.erase(it); }
+  hipFree(p);
+}
+
 void* dev_alloc(ddk_ctx* ctx, size_t bytes) {
   void* p = nullptr;
   if (bytes == 0) bytes = 16;
-  if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+  if (ctx_malloc(ctx, &p, bytes) != hipSuccess) {
+    // memory pressure: the chunks parked in the pool are the context's own slack - hand them back and try once more
+    if (pool_evict_idle(ctx, true) == 0 || ctx_malloc(ctx, &p, bytes) != hipSuccess) return nullptr;
+  }
   ctx->dev_allocs.push_back(p);
   return p;
 }
@@ -41,11 +61,16 @@ float* dev_upload(ddk_ctx* ctx, const std::vector<float>& v) {
 int ensure(ddk_ctx* ctx, void** p, size_t* cap, size_t bytes) {
   if (*cap >= bytes && *p) return DDK_OK;
   if (*p) {
-    hipFree(*p);
+    ctx_free(ctx, *p);
     *p = nullptr;
+    *cap = 0;
   }
   size_t want = bytes + bytes / 4 + 256;
-  if (hipMalloc(p, want) != hipSuccess) return fail(ctx, DDK_ERR_NOMEM, "hipMalloc failed for workspace");
+  if (ctx_malloc(ctx, p, want) != hipSuccess) {
+    if (pool_evict_idle(ctx, true) == 0 || ctx_malloc(ctx, p, want) != hipSuccess)
+      return fail(ctx, DDK_ERR_NOMEM, "out of device memory: workspace of " + std::to_string(want) + " B (context holds " + std::to_string(ctx->dev_bytes) + " B" +
+                  (ctx->alloc_limit > 0 ? ", debug limit " + std::to_string(ctx->alloc_limit) + " B" : std::string()) + ")");
+  }
   *cap = want;
   return DDK_OK;
 }
@@ -724,16 +749,16 @@ void ddk_destroy(ddk_ctx* ctx) {
     conf_model_destroy(ctx);
     for (auto& r : ctx->prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     if (ctx->prof_edges) hipHostFree(ctx->prof_edges);
-    for (auto& c : ctx->chunk_pool) { if (c.free_after) hipEventDestroy(c.free_after); hipFree(c.p); }
+    for (auto& c : ctx->chunk_pool) { if (c.free_after) hipEventDestroy(c.free_after); ctx_free(ctx, c.p); }
     for (auto& b : ctx->stage_pool) { if (b.done) hipEventDestroy(b.done); hipHostFree(b.p); }
     if (ctx->up_stream) hipStreamDestroy(ctx->up_stream);
     if (ctx->head_stream) hipStreamDestroy(ctx->head_stream);
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
-    for (void* p : ctx->dev_allocs) hipFree(p);
-    if (ctx->ws.xpad) hipFree(ctx->ws.xpad);
-    if (ctx->ws.sum) hipFree(ctx->ws.sum);
-    if (ctx->ws.deg) hipFree(ctx->ws.deg);
+    for (void* p : ctx->dev_allocs) ctx_free(ctx, p);
+    if (ctx->ws.xpad) ctx_free(ctx, ctx->ws.xpad);
+    if (ctx->ws.sum) ctx_free(ctx, ctx->ws.sum);
+    if (ctx->ws.deg) ctx_free(ctx, ctx->ws.deg);
   }
   delete ctx;
 }

@@ -203,6 +203,11 @@ struct ddk_ctx {
   std::vector<double> so3_table, torus_table;
   ddk::Workspace ws;
   std::vector<void*> dev_allocs;
+  // every hipMalloc of the context goes through ctx_malloc / ctx_free: dev_bytes = device memory this context holds right now (weights, workspaces,
+  // chunks of live complexes AND chunks parked in the pool); alloc_limit > 0 (ddk_debug_set_alloc_limit) makes a request beyond it fail like a real
+  // hipErrorOutOfMemory - the hook behind the retry-with-half-the-batch test (evaluate.py:228-231,394-398 of the reference)
+  int64_t dev_bytes = 0, alloc_limit = 0, alloc_refusals = 0;
+  std::map<void*, size_t> dev_sizes;
   // packed small weights for the non-conv kernels live in model.hip (opaque here)
   void* model = nullptr;
   void* conf_model = nullptr;   // conf.hip
@@ -231,6 +236,9 @@ struct ddk_ctx {
 namespace ddk {
 int fail(ddk_ctx* ctx, int code, const std::string& msg);
 int hip_fail(ddk_ctx* ctx, hipError_t e, const char* what);
+hipError_t ctx_malloc(ddk_ctx* ctx, void** p, size_t bytes);      // hipMalloc under the context's accounting (and debug limit)
+void ctx_free(ddk_ctx* ctx, void* p);
+size_t pool_evict_idle(ddk_ctx* ctx, bool wait);                  // model.hip: give parked chunks back to the driver (memory pressure)
 void* dev_alloc(ddk_ctx* ctx, size_t bytes);                      // tracked, freed in ddk_destroy
 float* dev_upload(ddk_ctx* ctx, const std::vector<float>& v);
 int ensure(ddk_ctx* ctx, void** p, size_t* cap, size_t bytes);    // grow-only workspace

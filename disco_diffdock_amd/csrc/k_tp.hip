@@ -282,7 +282,7 @@ __device__ __forceinline__ void tpf_request(const TpFArgs& a, int64_t e, int lan
 #ifndef TP_FLAT_ATTR
 #define TP_FLAT_ATTR
 #endif
-template <class S, int D, bool NT>
+template <class S, int D, bool NT, int PROBE = 0>
 __global__ __launch_bounds__(64) TP_FLAT_ATTR void tp_flat_kernel(TpFArgs a) {
   __shared__ float4 Wst[S::NV * 64];
   __shared__ __attribute__((aligned(16))) float X[128];
@@ -318,6 +318,15 @@ __global__ __launch_bounds__(64) TP_FLAT_ATTR void tp_flat_kernel(TpFArgs a) {
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       if (e >= a.E) return;
+      if (PROBE == 2) {      // (measurement only: the read stream alone - no LDS, no arithmetic but a sum, 4 B written per edge)
+        float acc = R[d].x0 + R[d].x1 + R[d].sh.x;
+#pragma unroll
+        for (int t = 0; t < S::NV; ++t) acc += R[d].w[t].x + R[d].w[t].y + R[d].w[t].z + R[d].w[t].w;
+        if (e + (int64_t)D * stride < a.E) tpf_request<S, NT>(a, e + (int64_t)D * stride, lane, R[d]);
+        if (acc == 123.456f) a.out[e * S::DOUT + lane] = acc;
+        e += stride;
+        continue;
+      }
       // ---- park the row (flat), the node row and the per-edge operands in LDS; ask for the row D edges ahead ----
 #pragma unroll
       for (int t = 0; t < S::NV; ++t) Wst[64 * t + lane] = R[d].w[t];
@@ -337,6 +346,12 @@ __global__ __launch_bounds__(64) TP_FLAT_ATTR void tp_flat_kernel(TpFArgs a) {
         RCs[m] = make_float4((qx * vx + qy * vy + qz * vz) * inv_s3, 0.f, 0.f, 0.f);
       }
       __syncthreads();
+      if (PROBE == 1) {      // (measurement only: read stream + LDS staging, no column walk)
+        if (Wf[lane * 7] == 123.456f) a.out[e * S::DOUT + lane] = 1.f;
+        e += stride;
+        __syncthreads();
+        continue;
+      }
       float accA = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
       // (chunks of 8 rows: 2 broadcast reads of 4 operands + 8 column reads in flight; a fully unrolled walk parks ~100 LDS results in registers)
       const float4* X4 = reinterpret_cast<const float4*>(X) + (xA >> 2);
@@ -386,6 +401,125 @@ __global__ __launch_bounds__(64) TP_FLAT_ATTR void tp_flat_kernel(TpFArgs a) {
   }
 }
 
+
+// ---- the same column walk with the row operands in SGPRs (round 6, second form) ------------------------------------------------------------
+// The row operand of a walk step is one value for the whole block (a_i, c_i, the components of p_i / q_i, (p_i . v)/sqrt3): the lane that loaded it
+// from the node row hands it over with v_readlane_b32 and the FMA reads it as a scalar operand - no LDS traffic but the weights themselves (one
+// ds_read_b32 per lane and row), no operand records, one wave-level barrier per edge.  Every lane runs the FMAs of both operand classes of a step into
+// separate accumulators (a lane's weight is its own; the class that is not its block's is dropped at the end): no select, no divergence.
+template <class S>
+__device__ __forceinline__ float tp_xval(float x0, float x1, int k) {      // x[k] of the node row as a wave-uniform value (k is a compile-time constant)
+  return k < 64 ? __builtin_amdgcn_readlane(x0, k) : __builtin_amdgcn_readlane(x1, k - 64);
+}
+template <class S, int D, bool NT, int WPE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void tp_col_kernel(TpFArgs a) {
+  __shared__ float4 Wst[S::NV * 64];
+  const char* Wb = reinterpret_cast<const char*>(Wst);
+  const int lane = threadIdx.x;
+  const int64_t stride = gridDim.x;
+  int64_t e = blockIdx.x;
+  const int blk = lane < S::O0 ? 0 : (lane < S::O0 + S::O1 ? 1 : (lane < S::O0 + S::O1 + S::O2 ? 2 : (lane < S::O0 + S::O1 + S::O2 + S::O3 ? 3 : 4)));
+  const int col = lane - (blk == 0 ? 0 : (blk == 1 ? S::O0 : (blk == 2 ? S::O0 + S::O1 : S::O0 + S::O1 + S::O2)));
+  const int nout = blk == 0 ? S::O0 : (blk == 1 ? S::O1 : (blk == 2 ? S::O2 : (blk == 3 ? S::O3 : 0)));
+  const int bbase = blk == 0 ? S::B0 : (blk == 1 ? S::B1 : (blk == 2 ? S::B2 : S::B3));
+  const bool lowblk = blk <= 1;                                                  // phase A operand: a_i (blocks 0e, 1o) or c_i (1e, 0o)
+  const bool onA = nout > 0 && (lowblk ? S::A > 0 : S::C > 0), onB = blk <= 2 && S::P > 0 && nout > 0, onC = blk >= 1 && blk <= 3 && S::Q > 0 && nout > 0;
+  // byte addresses of the lane's first weight of each phase, byte stride between rows (0: the lane idles through the phase on weight 0)
+  const int sA = onA ? 4 * nout : 0, sB = onB ? 4 * nout : 0, sC = onC ? 4 * nout : 0;
+  const int wA0 = onA ? 4 * (bbase + (blk <= 1 ? 0 : (blk == 2 ? S::P + S::Q : S::Q)) * nout + col) : 0;
+  const int wB0 = onB ? 4 * (bbase + (blk == 2 ? 0 : S::A) * nout + col) : 0;
+  const int wC0 = onC ? 4 * (bbase + (blk == 1 ? S::A + S::P : (blk == 2 ? S::P : 0)) * nout + col) : 0;
+  const int nrow = blk == 0 ? S::R0 : (blk == 1 ? S::R1 : (blk == 2 ? S::R2 : (blk == 3 ? S::R3 : 1)));
+  const float rs = 1.0f / sqrtf((float)(nrow > 0 ? nrow : 1));                   // tensor_layers.py:89-92
+  const int ooff = blk == 0 ? col : (blk == 1 ? S::O0 + 3 * col : (blk == 2 ? S::O0 + 3 * S::O1 + 3 * col : S::O0 + 3 * S::O1 + 3 * S::O2 + col));
+  const float inv_s3 = 0.57735026918962576451f, inv_s2 = 0.70710678118654752440f;
+  constexpr int NA = S::A > S::C ? S::A : S::C;
+  // which component of v multiplies this lane's node-row value in the (p . v), (q . v) sums: lanes A .. A + 3P + 3Q - 1 of x0 hold p then q, xyz interleaved
+  static_assert(S::A + 3 * S::P + 3 * S::Q <= 64, "the vector inputs of the node row sit in the first 64 lanes");
+  const int vsel = (lane >= S::A && lane < S::XC) ? (lane - S::A) % 3 : 3;
+
+  TpRow<S> R[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (e + d * stride < a.E) tpf_request<S, NT>(a, e + d * stride, lane, R[d]);
+  for (;;) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      if (e >= a.E) return;
+#pragma unroll
+      for (int t = 0; t < S::NV; ++t) Wst[64 * t + lane] = R[d].w[t];
+      const float x0 = R[d].x0, x1 = R[d].x1;
+      const float s0 = R[d].sh.x, vx = R[d].sh.y, vy = R[d].sh.z, vz = R[d].sh.w;
+      if (e + (int64_t)D * stride < a.E) tpf_request<S, NT>(a, e + (int64_t)D * stride, lane, R[d]);
+      // (p_i . v)/sqrt3 in lane A + 3i, (q_i . v)/sqrt3 in lane A + 3P + 3i: three neighbouring lanes' products through the lane crossbar
+      float pvq = 0.f;
+      if (S::P + S::Q > 0) {
+        const float t = x0 * (vsel == 0 ? vx : (vsel == 1 ? vy : (vsel == 2 ? vz : 0.f)));
+        pvq = (t + __shfl_down(t, 1) + __shfl_down(t, 2)) * inv_s3;
+      }
+      __syncthreads();
+      float accA = 0.f, accC = 0.f, bs = 0.f, bx = 0.f, by = 0.f, bz = 0.f, cs = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
+      // (the row addresses advance in ONE register per phase: left to itself the compiler keeps all 36 of them, loop-invariant, in VGPRs - the opaque asm pins the chain)
+      int ad = wA0;
+      asm volatile("" : "+v"(ad));
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const float w = *reinterpret_cast<const float*>(Wb + ad);
+        ad += sA;
+        asm volatile("" : "+v"(ad));
+        if (i < S::A) accA = fmaf(tp_xval<S>(x0, x1, i), w, accA);
+        if (i < S::C) accC = fmaf(tp_xval<S>(x0, x1, S::XC + i), w, accC);
+        if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);      // (eight rows' reads in flight, not all of them: registers)
+      }
+      ad = wB0;
+      asm volatile("" : "+v"(ad));
+#pragma unroll
+      for (int i = 0; i < S::P; ++i) {
+        const float w = *reinterpret_cast<const float*>(Wb + ad);
+        ad += sB;
+        asm volatile("" : "+v"(ad));
+        bs = fmaf(__builtin_amdgcn_readlane(pvq, S::A + 3 * i), w, bs);
+        bx = fmaf(tp_xval<S>(x0, x1, S::A + 3 * i), w, bx);
+        by = fmaf(tp_xval<S>(x0, x1, S::A + 3 * i + 1), w, by);
+        bz = fmaf(tp_xval<S>(x0, x1, S::A + 3 * i + 2), w, bz);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      ad = wC0;
+      asm volatile("" : "+v"(ad));
+#pragma unroll
+      for (int i = 0; i < S::Q; ++i) {
+        const float w = *reinterpret_cast<const float*>(Wb + ad);
+        ad += sC;
+        asm volatile("" : "+v"(ad));
+        cs = fmaf(__builtin_amdgcn_readlane(pvq, S::A + 3 * S::P + 3 * i), w, cs);
+        cx = fmaf(tp_xval<S>(x0, x1, S::A + 3 * S::P + 3 * i), w, cx);
+        cy = fmaf(tp_xval<S>(x0, x1, S::A + 3 * S::P + 3 * i + 1), w, cy);
+        cz = fmaf(tp_xval<S>(x0, x1, S::A + 3 * S::P + 3 * i + 2), w, cz);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const float sa = onA ? (lowblk ? accA : accC) : 0.f;
+      if (!onB) { bs = 0.f; bx = 0.f; by = 0.f; bz = 0.f; }
+      if (!onC) { cs = 0.f; cx = 0.f; cy = 0.f; cz = 0.f; }
+      float* o = a.out + e * S::DOUT + ooff;
+      if (blk == 0) {
+        o[0] = (s0 * sa + bs) * rs;
+      } else if (blk == 1) {      // a (x) v + p s0 + (q x v)/sqrt2
+        o[0] = (vx * sa + s0 * bx + (cy * vz - cz * vy) * inv_s2) * rs;
+        o[1] = (vy * sa + s0 * by + (cz * vx - cx * vz) * inv_s2) * rs;
+        o[2] = (vz * sa + s0 * bz + (cx * vy - cy * vx) * inv_s2) * rs;
+      } else if (blk == 2) {      // (p x v)/sqrt2 + q s0 + c (x) v
+        o[0] = ((by * vz - bz * vy) * inv_s2 + s0 * cx + vx * sa) * rs;
+        o[1] = ((bz * vx - bx * vz) * inv_s2 + s0 * cy + vy * sa) * rs;
+        o[2] = ((bx * vy - by * vx) * inv_s2 + s0 * cz + vz * sa) * rs;
+      } else if (blk == 3) {
+        o[0] = (cs + s0 * sa) * rs;
+      }
+      e += stride;
+      __syncthreads();
+    }
+  }
+}
+
 template <class S>
 static hipError_t launch_tp_flat(const TpFArgs& a, int variant, int64_t blocks, hipStream_t s) {
   const dim3 g((unsigned)blocks), b(64);
@@ -395,6 +529,15 @@ static hipError_t launch_tp_flat(const TpFArgs& a, int variant, int64_t blocks, 
     case 3: hipLaunchKernelGGL((tp_flat_kernel<S, 3, false>), g, b, 0, s, a); break;
     case 4: hipLaunchKernelGGL((tp_flat_kernel<S, 3, true>), g, b, 0, s, a); break;
     case 5: hipLaunchKernelGGL((tp_flat_kernel<S, 1, false>), g, b, 0, s, a); break;
+    case 7: hipLaunchKernelGGL((tp_flat_kernel<S, 2, false, 1>), g, b, 0, s, a); break;
+    case 8: hipLaunchKernelGGL((tp_flat_kernel<S, 2, false, 2>), g, b, 0, s, a); break;
+    case 9: hipLaunchKernelGGL((tp_flat_kernel<S, 4, false, 2>), g, b, 0, s, a); break;
+    case 11: hipLaunchKernelGGL((tp_col_kernel<S, 2, false, 4>), g, b, 0, s, a); break;
+    case 12: hipLaunchKernelGGL((tp_col_kernel<S, 2, false, 3>), g, b, 0, s, a); break;
+    case 13: hipLaunchKernelGGL((tp_col_kernel<S, 1, false, 4>), g, b, 0, s, a); break;
+    case 14: hipLaunchKernelGGL((tp_col_kernel<S, 1, false, 5>), g, b, 0, s, a); break;
+    case 15: hipLaunchKernelGGL((tp_col_kernel<S, 3, false, 3>), g, b, 0, s, a); break;
+    case 16: hipLaunchKernelGGL((tp_col_kernel<S, 2, false, 2>), g, b, 0, s, a); break;
     default: hipLaunchKernelGGL((tp_flat_kernel<S, 1, true>), g, b, 0, s, a); break;
   }
   return hipGetLastError();

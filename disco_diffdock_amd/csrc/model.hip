@@ -322,6 +322,23 @@ static int make_step_params(ddk_ctx* ctx, float t_tr, float t_rot, float t_tor, 
 constexpr size_t CHUNK_POOL_MAX_CHUNKS = 1024;
 constexpr size_t CHUNK_POOL_MAX_BYTES = (size_t)96 << 30;   // device memory parked in the pool (288 GB of HBM per GPU); beyond it hipFree (device sync)
 
+size_t pool_evict_idle(ddk_ctx* ctx, bool wait) {
+  size_t freed = 0;
+  for (size_t i = 0; i < ctx->chunk_pool.size();) {
+    ddk_ctx::PoolChunk& c = ctx->chunk_pool[i];
+    const bool idle = !c.free_after || hipEventQuery(c.free_after) == hipSuccess;
+    if (!idle && !wait) { ++i; continue; }
+    if (!idle) hipEventSynchronize(c.free_after);      // (hipFree does not wait for work on the context's non-blocking streams)
+    if (c.free_after) hipEventDestroy(c.free_after);
+    ctx_free(ctx, c.p);
+    freed += c.cap;
+    ctx->chunk_pool_bytes -= c.cap;
+    ctx->pool_frees++;
+    ctx->chunk_pool.erase(ctx->chunk_pool.begin() + i);
+  }
+  return freed;
+}
+
 void* cx_new_chunk(ddk_complex* cx, size_t cap) {
   ddk_ctx* ctx = cx->owner;
   {   // size classes {2^k, 1.5 * 2^k}: complexes of similar size take each other's chunks (ligands of 20-40 atoms differ by +-30 %)
@@ -345,9 +362,17 @@ void* cx_new_chunk(ddk_complex* cx, size_t cap) {
     if (c.free_after) hipEventDestroy(c.free_after);      // (complete: checked above)
     p = c.p; cap = c.cap;
     ctx->pool_reuses++;
-  } else if (hipMalloc(&p, cap) != hipSuccess) {
-    return nullptr;
   } else {
+    if (ctx_malloc(ctx, &p, cap) != hipSuccess) {
+      // memory pressure (or the debug limit): what is parked in the pool is this context's own slack - hand the idle chunks back to the driver and try
+      // once more, waiting for chunks whose last user is still running only if that is what it takes
+      if (pool_evict_idle(ctx, false) == 0 || ctx_malloc(ctx, &p, cap) != hipSuccess)
+        if (pool_evict_idle(ctx, true) == 0 || ctx_malloc(ctx, &p, cap) != hipSuccess) {
+          ctx->err = "out of device memory: a complex asked for a chunk of " + std::to_string(cap) + " B (context holds " + std::to_string(ctx->dev_bytes) + " B" +
+                     (ctx->alloc_limit > 0 ? ", debug limit " + std::to_string(ctx->alloc_limit) + " B" : std::string()) + "); retry with a smaller batch";
+          return nullptr;
+        }
+    }
     ctx->pool_mallocs++;
   }
   ctx->pool_bytes_out += (int64_t)cap;
@@ -797,7 +822,9 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
     cx->zero_lat = cx_upload<float>(cx, nullptr, N * c.latent_dim);
     if (cx->zero_lat) launch_zero_fill(cx->zero_lat, (size_t)N * c.latent_dim * sizeof(float), ctx->up_stream);
   }
-  if (cx->oom || !cx->bond_src || !cx->rr_sh || !cx->scores) return fail(ctx, DDK_ERR_NOMEM, "device allocation failed in ddk_complex_create");
+  if (cx->oom || !cx->bond_src || !cx->rr_sh || !cx->scores)
+    return fail(ctx, DDK_ERR_NOMEM, "ddk_complex_create (max_batch " + std::to_string(max_batch) + ", " + std::to_string(n_rec) + " residues): " +
+                (ctx->err.rfind("out of device memory", 0) == 0 ? ctx->err : std::string("device allocation failed")));
   hipMemsetAsync(cx->info, 0, INFO_INTS * sizeof(int32_t), ctx->up_stream);
   // the accumulators start clean (node_finalize clears behind itself): cleared here, on the upload stream, beside the previous complex' loop
   if (cx->sum && cx->sum_rr0) {
@@ -862,7 +889,7 @@ void ddk_complex_destroy(ddk_ctx* ctx, ddk_complex* cx) {
       // 363-complex stream with ligands of 10-80 atoms filled round 3's 64-chunk pool and freed memory under kernels still in flight)
       if (ok) hipEventSynchronize(c.free_after); else hipDeviceSynchronize();
       if (c.free_after) hipEventDestroy(c.free_after);
-      hipFree(a.p);
+      ctx_free(ctx, a.p);
       ctx->pool_frees++;
       continue;
     }
@@ -1176,7 +1203,13 @@ int ddk_debug_set_conv_workgroups(ddk_ctx* ctx, int32_t n) {
 int ddk_debug_pool_stats(ddk_ctx* ctx, int64_t* out) {
   if (!ctx || !out) return DDK_ERR_INVALID;
   out[0] = ctx->pool_mallocs; out[1] = ctx->pool_reuses; out[2] = ctx->pool_frees; out[3] = (int64_t)ctx->chunk_pool_bytes;
-  out[4] = (int64_t)ctx->chunk_pool.size(); out[5] = ctx->pool_bytes_out; out[6] = ctx->pool_bytes_out_peak; out[7] = 0;
+  out[4] = (int64_t)ctx->chunk_pool.size(); out[5] = ctx->pool_bytes_out; out[6] = ctx->pool_bytes_out_peak; out[7] = ctx->dev_bytes;
+  return DDK_OK;
+}
+
+int ddk_debug_set_alloc_limit(ddk_ctx* ctx, int64_t bytes) {
+  if (!ctx || bytes < 0) return DDK_ERR_INVALID;
+  ctx->alloc_limit = bytes;
   return DDK_OK;
 }
 

@@ -5,6 +5,14 @@ import torch
 import torch.distributed as dist
 
 
+def complex_cost(n_res, n_lig):
+    """Relative cost of one complex (40 samples x 20 reverse steps) for the partition below: affine in the receptor size with a ligand term, fitted to the
+    per-complex device times of bench.py --config 4 --complexes 363 on the timesplit-shaped set (profiles/r06_bench_config4_363.json: per-decile table).
+    The rec-rec messages (24 per residue and sample) dominate; the cross edges grow with n_lig x the residues within the cutoff; a constant covers the AR
+    passes' and the small launches' share.  Only ratios matter."""
+    return 1.0 + n_res / 160.0 + max(n_lig, 16) / 50.0
+
+
 def shard_indices(costs, rank, world):
     """Greedy longest-processing-time partition: complexes sorted by descending cost (~ n_rec * n_lig), each
     assigned to the currently least loaded rank.  Deterministic; every rank computes the same assignment."""

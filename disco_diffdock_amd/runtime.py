@@ -182,8 +182,12 @@ class Context:
         """device-chunk pool of the complexes (include/ddk_debug.h): hipMalloc calls, reuses, hipFree calls, bytes / chunks parked, bytes owned now / at peak"""
         buf = (C.c_int64 * 8)()
         self._check(self.L.ddk_debug_pool_stats(self.h, buf), 'ddk_debug_pool_stats')
-        keys = ('hipMalloc_calls', 'reuses', 'hipFree_calls', 'bytes_parked', 'chunks_parked', 'bytes_owned', 'bytes_owned_peak')
-        return dict(zip(keys, [int(v) for v in buf[:7]]))
+        keys = ('hipMalloc_calls', 'reuses', 'hipFree_calls', 'bytes_parked', 'chunks_parked', 'bytes_owned', 'bytes_owned_peak', 'device_bytes_held')
+        return dict(zip(keys, [int(v) for v in buf[:8]]))
+
+    def debug_set_alloc_limit(self, nbytes=0):
+        """test hook (include/ddk_debug.h): cap on the device memory this context may hold (0 = none); a request beyond it fails like a real out-of-memory"""
+        self._check(self.L.ddk_debug_set_alloc_limit(self.h, int(nbytes)), 'ddk_debug_set_alloc_limit')
 
     def debug_set_layer0_dedup(self, on=True):
         """test hook (include/ddk_debug.h): layer-0 de-duplication of the rec-rec messages on / off"""

@@ -258,6 +258,17 @@ def add_receptor_atoms(c, rng, atom_radius=5.0, atom_max_neighbors=8, atoms_per_
     return c
 
 
+def timesplit_shape(seed):
+    """(n_res, n_lig) of complex `seed` of the timesplit-SHAPED synthetic set (bench.py --complexes 363).  The reference's test split
+    (data/splits/timesplit_test, 363 PDB ids, README.md:20) mixes receptors from under a hundred to a few thousand residues - every chain within reach of
+    the ligand is kept, datasets_utils/process_mols.py:411-429 - and ligands of ~10-80 heavy atoms.  Without the structures here the sizes are DRAWN:
+    residues log-normal with median 350 and sigma 0.65 (mean ~430, 5 % above ~1 000, 0.1 % above ~2 600), clipped to [60, 3 000]; ligand atoms uniform
+    in [10, 80] (the same draw as rounds 4 / 5, so a seed keeps its ligand).  The choice is stated next to every number that rests on it."""
+    n_lig = int(np.random.default_rng(7000 + seed).integers(10, 81))
+    n_res = int(np.clip(np.rint(np.exp(np.random.default_rng(9000 + seed).normal(np.log(350.0), 0.65))), 60, 3000))
+    return n_res, n_lig
+
+
 def make_complex(seed, n_res=300, n_lig=None, cutoff=15.0, max_neighbor=24, esm_dim=ESM_DIM):
     """One synthetic complex as a dict of numpy arrays; ligand centred on a random pocket point
     inside the receptor ball (coordinates are receptor-centred like pdbbind.py:341-347)."""

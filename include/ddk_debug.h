@@ -39,8 +39,13 @@ int ddk_debug_set_layer0_dedup(ddk_ctx* ctx, int32_t on);
 
 /* Device-chunk pool of the complexes (ddk_complex_create / destroy never synchronise: chunks whose previous owner has finished are reused,
  * otherwise hipMalloc): out[8] = hipMalloc calls, reuses, hipFree calls, bytes parked in the pool, chunks parked, bytes owned by live
- * complexes, the peak of that, 0. */
+ * complexes, the peak of that, device bytes the context holds in all (weights + workspaces + live and parked chunks). */
 int ddk_debug_pool_stats(ddk_ctx* ctx, int64_t* out);
+/* Cap on the device memory this context may hold (0 = none): a hipMalloc that would take it beyond `bytes` fails exactly like hipErrorOutOfMemory
+ * (after the pool has handed its parked chunks back, as under real memory pressure): ddk_complex_create / ddk_conv_forward return DDK_ERR_NOMEM with
+ * ddk_last_error naming the request, the context and its pool stay usable, a smaller batch then succeeds.  The reference's recovery path
+ * (evaluate.py:228-231, 394-398: halve the batch and retry) is tested through it. */
+int ddk_debug_set_alloc_limit(ddk_ctx* ctx, int64_t bytes);
 
 /* Persistent workgroups of this context's conv launches (default: one per CU).  Experiments with two contexts / streams side by side. */
 int ddk_debug_set_conv_workgroups(ddk_ctx* ctx, int32_t n);

@@ -152,16 +152,26 @@ def test_gloo_gather_with_a_rank_that_owns_nothing(tmp_path):
 
 
 def test_shard_indices_balances_the_timesplit_sized_set():
-    """VERDICT r04 #5b: the LPT partition of bench.py --config 4 --complexes 363's cost vector (300 residues x a 10-80-atom ligand spread) over 8 ranks:
-    max / mean load <= 1.05, every complex owned exactly once, the same answer on every rank."""
-    from disco_diffdock_amd.distributed import shard_indices
-    costs = [300 * max(int(np.random.default_rng(7000 + i).integers(10, 81)), 16) for i in range(363)]
+    """VERDICT r04 #5b / r05 #2: the LPT partition of bench.py --config 4 --complexes 363's cost vector - round 6: the timesplit-SHAPED set
+    (synthetic.timesplit_shape: log-normal receptor sizes in [60, 3000] residues around a median of 350, 10-80-atom ligands; distributed.complex_cost)
+    - over 8 ranks: max / mean load <= 1.05, every complex owned exactly once, the same answer on every rank.  The heavy tail is what makes this a test:
+    the largest receptor costs ~3.7 x the median complex."""
+    from disco_diffdock_amd.distributed import shard_indices, complex_cost
+    from disco_diffdock_amd import synthetic
+    shapes = [synthetic.timesplit_shape(i) for i in range(363)]
+    n_res = np.array([r for r, _ in shapes])
+    assert n_res.min() >= 60 and n_res.max() <= 3000 and 300 <= np.median(n_res) <= 400 and (n_res > 1000).sum() >= 5 and (n_res < 150).sum() >= 20
+    costs = [complex_cost(r, l) for r, l in shapes]
+    assert max(costs) / float(np.median(costs)) > 3.0
     parts = [shard_indices(costs, r, 8) for r in range(8)]
     assert sorted(i for p in parts for i in p) == list(range(363))
     loads = [sum(costs[i] for i in p) for p in parts]
     assert max(loads) / (sum(loads) / 8) <= 1.05, loads
-    assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 3
     assert parts == [shard_indices(costs, r, 8) for r in range(8)]
+    # round 5's set (every receptor at 300 residues: bench.py --fixed-receptor) still balances
+    costs5 = [complex_cost(300, l) for _, l in shapes]
+    loads5 = [sum(costs5[i] for i in shard_indices(costs5, r, 8)) for r in range(8)]
+    assert max(loads5) / (sum(loads5) / 8) <= 1.05
 
 
 def test_product_state_dict_spec_equals_reference_layout():

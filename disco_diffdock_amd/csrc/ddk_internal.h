@@ -255,6 +255,8 @@ struct ConvLaunch {
   int32_t* counter;          // device tile counter (zeroed by the caller)
   float* part = nullptr;        // deterministic mode (ddk_config.deterministic): [edge_bound / 32 + 8][2][XW] partial rows; null: fp32 atomics
   int64_t edge_bound = 0;       // host upper bound of the last edge index of the launch (sizes the fix-up grid)
+  const int32_t* det_rng = nullptr;   // deterministic mode: sample-aligned ranges of the launch (ConvKArgs::det_rng, det_ranges_kernel) ...
+  int det_nr = 0;                     // ... and their number (0: blocks run through the groups)
   const float* pre = nullptr;   // [N, PRE_W] node terms of GEMM1 (gather mode, score model) or null: GEMM1 over all 72 inputs
   int gather;                // 1: edge_attr is edge_emb[E,24] and x[src][:24], x[dst][:24] are gathered
   // layer-0 receptor-receptor de-duplication (all samples of a batch share the receptor and, before the first conv,

@@ -107,7 +107,10 @@ __global__ __launch_bounds__(64 * ConvTraits<MODE>::WAVES) void conv_fused_kerne
     if (lane >= d) pend_v += t;
   }
   const int pbeg_v = pend_v - nb_v;
-  const int bs4 = __builtin_amdgcn_readlane(pend_v, 15);
+  int bs4 = __builtin_amdgcn_readlane(pend_v, 15);
+  if constexpr (DET) {
+    if (A.det_nr > 0) bs4 = A.det_rng[A.det_nr];      // sample-aligned units: the work queue walks the ranges' blocks (k_conv_common.h)
+  }
   float* Fr = F + el * FS;
   const float inv_s3 = 0.57735026918962576451f, inv_s2 = 0.70710678118654752440f;
   const int n_tiles = A.n_tiles;
@@ -145,9 +148,15 @@ __global__ __launch_bounds__(64 * ConvTraits<MODE>::WAVES) void conv_fused_kerne
       t_begin = A.col_start[(c * A.n_cols) / split];
       t_end = A.col_start[((c + 1) * A.n_cols) / split];
     }
-    const int g = __popcll(__ballot(lane < 16 && blk >= pend_v));
-    const int gbeg = __builtin_amdgcn_readlane(gb_v, g), gend = __builtin_amdgcn_readlane(ge_v, g);
-    const int bstart = __builtin_amdgcn_readlane(pbeg_v, g);
+    int g = __popcll(__ballot(lane < 16 && blk >= pend_v));
+    int gbeg = __builtin_amdgcn_readlane(gb_v, g), gend = __builtin_amdgcn_readlane(ge_v, g);
+    int bstart = __builtin_amdgcn_readlane(pbeg_v, g);
+    if constexpr (DET) {
+      if (A.det_nr > 0) {
+        const DetRange R_ = det_find(A.det_rng, A.det_nr, blk);
+        g = R_.g; gbeg = R_.beg; gend = R_.end; bstart = R_.bstart;
+      }
+    }
     const int e0 = gbeg + BLOCK_EDGES * (blk - bstart) + 32 * wave;
     const int nvalid = min(32, gend - e0);                    // <= 0: this wave's slice lies past the end of the group
     const bool valid = el < nvalid;
@@ -662,15 +671,24 @@ hipError_t conv_prepare_device() {
 __global__ __launch_bounds__(256) void conv_det_fix_kernel(ConvKArgs A, int dout) {
   const int lane = threadIdx.x & 63;
   int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-  int g = 0, gb = 0, ge = 0, bstart = 0;                 // bstart: first 256-edge block of the group in the launch's work queue
-  for (; g < A.n_active; ++g) {
-    gb = A.gbeg[g]; ge = A.gend[g];
-    const int nt = (ge - gb + 31) / 32;
-    if (tile < nt) break;
-    tile -= nt;
-    bstart += (ge - gb + CONV_BLOCK_EDGES - 1) / CONV_BLOCK_EDGES;
+  int g = 0, gb = 0, ge = 0, bstart = 0;                 // bstart: first 256-edge block of the group (or range) in the launch's work queue
+  if (A.det_nr > 0) {                                    // sample-aligned units: tile = (work-queue block, wave) of the conv launch
+    const int blk = tile / CONV_WAVES;
+    if (blk >= A.det_rng[A.det_nr]) return;
+    const DetRange R_ = det_find(A.det_rng, A.det_nr, blk);
+    g = R_.g; gb = R_.beg; ge = R_.end; bstart = R_.bstart;
+    tile -= bstart * CONV_WAVES;
+    if (gb + 32 * tile >= ge) return;
+  } else {
+    for (; g < A.n_active; ++g) {
+      gb = A.gbeg[g]; ge = A.gend[g];
+      const int nt = (ge - gb + 31) / 32;
+      if (tile < nt) break;
+      tile -= nt;
+      bstart += (ge - gb + CONV_BLOCK_EDGES - 1) / CONV_BLOCK_EDGES;
+    }
+    if (g >= A.n_active) return;
   }
-  if (g >= A.n_active) return;
   auto prow_of = [&](int t, int which) { return A.part + ((size_t)((bstart + t / CONV_WAVES) * CONV_WAVES + t % CONV_WAVES) * 2 + which) * XW; };
   int e0 = gb + 32 * tile;
   int n = min(32, ge - e0);
@@ -698,7 +716,7 @@ __global__ __launch_bounds__(256) void conv_det_fix_kernel(ConvKArgs A, int dout
 
 // deterministic mode: the fix-up pass behind a conv launch of either kernel
 void conv_det_fix(const ConvKArgs& k, const ConvLaunch& a, int dout, hipStream_t s) {
-  const int64_t tiles = a.edge_bound / 32 + 8 * CONV_MAX_GROUPS;
+  const int64_t tiles = a.edge_bound / 32 + 8 * CONV_MAX_GROUPS + (int64_t)CONV_WAVES * a.det_nr;      // (every range may end in a partial block)
   hipLaunchKernelGGL(conv_det_fix_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s, k, dout);
 }
 
@@ -718,7 +736,7 @@ hipError_t launch_conv_fused(const ConvLayerDev& L, const ConvLaunch& a, int n_c
   k.n_groups = a.n_groups; k.n_active = a.n_active; k.n_slots = a.n_slots; k.slots = a.slots; k.wmap = a.wmap;
   if (a.gbeg) { k.gbeg = a.gbeg; k.gend = a.gend; }
   else { k.gbeg = a.tile_info + 5; k.gend = a.tile_info + 6; }   // 4 contiguous groups go[g] .. go[g+1] (explicit-boundary entry point)
-  k.pre = a.pre; k.part = a.part;
+  k.pre = a.pre; k.part = a.part; k.det_rng = a.det_rng; k.det_nr = a.det_nr;
   if (a.part != nullptr) {       // deterministic scatter (score model paths only)
     if (a.mode != 0) return hipErrorInvalidValue;
     hipError_t e = (a.gather && a.pre != nullptr) ? launch_conv_t<true, 0, true, true>(k, n_cu, s)

@@ -32,7 +32,25 @@ struct ConvKArgs {
   uint64_t wmap;      // 4 bits per group: which radial MLP (weight set, node-term role) group g uses (identity unless a group is split in two)
   const int32_t* gbeg;
   const int32_t* gend;
+  // deterministic mode, sample-aligned work units (round 6): det_nr > 0 -> the launch's edges as det_nr RANGES (one per edge group, level segment and
+  // SAMPLE), det_rng = [block prefix pb[0 .. nr] | beg[nr] | end[nr] | group[nr]] (device, det_ranges_kernel).  A 256-edge block never crosses a range, so
+  // where the 32-edge tiles cut a node's run of edges - and with it the association of its fp32 sum - depends on the sample's own edge list only, not on which
+  // other samples share the batch (samples sharded over ranks see the same bits as the 40-sample batch).
+  const int32_t* det_rng = nullptr;
+  int det_nr = 0;
 };
+struct DetRange { int beg, end, g, bstart; };
+// the range that holds work-queue block blk: the largest r with pb[r] <= blk (empty ranges share their successor's prefix and are skipped by that rule)
+__device__ __forceinline__ DetRange det_find(const int32_t* rng, int nr, int blk) {
+  int lo = 0, hi = nr;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (rng[mid] <= blk) lo = mid; else hi = mid;
+  }
+  DetRange r;
+  r.bstart = rng[lo]; r.beg = rng[nr + 1 + lo]; r.end = rng[2 * nr + 1 + lo]; r.g = rng[3 * nr + 1 + lo];
+  return r;
+}
 
 struct ConvXArgs {      // kernel arguments of the three-limb f16 kernels (k_conv_x.hip, k_conv_y.hip)
   ConvKArgs k;

@@ -314,7 +314,10 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
     if (lane >= d) pend_v += t;
   }
   const int pbeg_v = pend_v - nb_v;
-  const int bs4 = __builtin_amdgcn_readlane(pend_v, 15);
+  int bs4 = __builtin_amdgcn_readlane(pend_v, 15);
+  if constexpr (DET) {
+    if (A.det_nr > 0) bs4 = A.det_rng[A.det_nr];      // sample-aligned units: the work queue walks the ranges' blocks (k_conv_common.h)
+  }
   float* Fr = F + el * FS;
   const float inv_s3 = 0.57735026918962576451f, inv_s2 = 0.70710678118654752440f;
   const int n_tiles = A.n_tiles;
@@ -368,9 +371,15 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
       t_begin = A.col_start[(c * A.n_cols) / split];
       t_end = A.col_start[((c + 1) * A.n_cols) / split];
     }
-    const int g = __popcll(__ballot(lane < 16 && blk >= pend_v));
-    const int gbeg = __builtin_amdgcn_readlane(gb_v, g), gend = __builtin_amdgcn_readlane(ge_v, g);
-    const int bstart = __builtin_amdgcn_readlane(pbeg_v, g);
+    int g = __popcll(__ballot(lane < 16 && blk >= pend_v));
+    int gbeg = __builtin_amdgcn_readlane(gb_v, g), gend = __builtin_amdgcn_readlane(ge_v, g);
+    int bstart = __builtin_amdgcn_readlane(pbeg_v, g);
+    if constexpr (DET) {
+      if (A.det_nr > 0) {
+        const DetRange R_ = det_find(A.det_rng, A.det_nr, blk);
+        g = R_.g; gbeg = R_.beg; gend = R_.end; bstart = R_.bstart;
+      }
+    }
     const int e0 = gbeg + BLOCK_EDGES * (blk - bstart) + 32 * wave;
     const int nvalid = min(32, gend - e0);                    // <= 0: this wave's slice lies past the end of the group
     const bool valid = el < nvalid;
@@ -940,7 +949,7 @@ hipError_t launch_conv_fused_x(const ConvLayerDev& L, const ConvLaunch& a, int n
   k.n_groups = a.n_groups; k.n_active = a.n_active; k.n_slots = a.n_slots; k.slots = a.slots; k.wmap = a.wmap;
   if (a.gbeg) { k.gbeg = a.gbeg; k.gend = a.gend; }
   else { k.gbeg = a.tile_info + 5; k.gend = a.tile_info + 6; }   // 4 contiguous groups go[g] .. go[g+1] (explicit-boundary entry point)
-  k.pre = a.pre; k.part = a.part;
+  k.pre = a.pre; k.part = a.part; k.det_rng = a.det_rng; k.det_nr = a.det_nr;
   X.trace = nullptr; X.trace_coarse = a.trace_coarse;
   if (a.mode == 1) {      // the confidence model: plain gather path (no node-term split, atomics)
     if (a.pre != nullptr || a.part != nullptr || a.trace != nullptr) return hipErrorInvalidValue;

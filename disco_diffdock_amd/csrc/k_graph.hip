@@ -813,6 +813,61 @@ hipError_t launch_graph(const GraphArgs& G, int64_t edge_cap, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ---- deterministic mode: the sample-aligned ranges of a conv launch (ConvKArgs::det_rng, k_conv_common.h) ---------------------------------------
+// One range per (edge group [, level segment of group 2], sample), in the launch's group order; the offsets are graph_fill_kernel's own
+// (sample_prefix: the same counts, the same arithmetic).  kind: 0 = groups ll, lr only (the last layer); 1 / 2 / 3 = + the level segments A / A, B / A, B, C
+// of group 2 + rl; 4 = all four segments (no pruning) + rl; 5 = [ll | lr | the shared rec-rec copy (ONE range) | rl] (layer 0);
+// 6 = n_uniform consecutive ranges of len_uniform edges from edge 0 (the heads' centre edges: one range per sample).
+// out = [pb[0 .. nr] | beg[nr] | end[nr] | group[nr]].  One workgroup; wave w takes samples w, w + 16, ...
+__global__ __launch_bounds__(GT) void det_ranges_kernel(GraphArgs G, int kind, int len_uniform, int32_t* out, int nr) {
+  extern __shared__ int nb_s[];                       // [nr] blocks per range -> exclusive prefix
+  __shared__ int scan_tmp[GT / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int32_t* beg_o = out + nr + 1;
+  int32_t* end_o = beg_o + nr;
+  int32_t* grp_o = end_o + nr;
+  auto put = [&](int r, int beg, int end, int g) {
+    if (lane == 0) { beg_o[r] = beg; end_o[r] = end; grp_o[r] = g; nb_s[r] = (end - beg + 255) / 256; }
+  };
+  if (kind == 6) {
+    for (int r = tid; r < nr; r += GT) { beg_o[r] = r * len_uniform; end_o[r] = (r + 1) * len_uniform; grp_o[r] = 0; nb_s[r] = (len_uniform + 255) / 256; }
+  } else {
+    const int nseg = kind == 5 ? 0 : kind;            // level segments of group 2 that the launch evaluates
+    for (int b = wave; b < G.B; b += GT / 64) {
+      int ex[6], tot[5];
+      sample_prefix(G, b, ex, tot);
+      const int g1 = tot[0], g2 = tot[0] + tot[1], g3 = g2 + G.B * G.E_rr;
+      const int cnt0 = G.counts[CNT_STRIDE * b] + G.M, cnt1 = G.counts[CNT_STRIDE * b + 1];
+      const int ca = G.counts[CNT_STRIDE * b + 2], cb = G.counts[CNT_STRIDE * b + 3], cc = G.counts[CNT_STRIDE * b + 4];
+      put(b, ex[0], ex[0] + cnt0, 0);
+      put(G.B + b, g1 + ex[1], g1 + ex[1] + cnt1, 1);
+      if (kind == 0) continue;
+      int r = 2 * G.B;
+      const int segbeg[4] = {g2 + ex[2], g2 + tot[2] + ex[3], g2 + tot[2] + tot[3] + ex[4], g2 + tot[2] + tot[3] + tot[4] + ex[5]};
+      const int seglen[4] = {ca, cb, cc, G.E_rr - ca - cb - cc};
+      for (int l = 0; l < nseg; ++l) { put(r + b, segbeg[l], segbeg[l] + seglen[l], 2); r += G.B; }
+      if (kind == 5) {
+        const int g4 = g3 + tot[1];
+        if (b == 0) put(r, g4, g4 + G.E_rr, 2);
+        r += 1;
+      }
+      put(r + b, g3 + ex[1], g3 + ex[1] + cnt1, 3);
+    }
+  }
+  __syncthreads();
+  block_exclusive_scan(nb_s, nr, scan_tmp);           // (in place; ends with a barrier)
+  for (int r = tid; r < nr; r += GT) out[r] = nb_s[r];
+  if (tid == 0) out[nr] = nb_s[nr - 1] + (end_o[nr - 1] - beg_o[nr - 1] + 255) / 256;
+}
+
+int det_ranges_count(int kind, int B) { return kind == 0 ? 2 * B : (kind == 5 ? 3 * B + 1 : (kind == 6 ? B : (3 + kind) * B)); }
+
+hipError_t launch_det_ranges(const GraphArgs& G, int kind, int len_uniform, int32_t* out, hipStream_t s) {
+  const int nr = det_ranges_count(kind, G.B);
+  hipLaunchKernelGGL(det_ranges_kernel, dim3(1), dim3(GT), (size_t)(nr + 1) * sizeof(int), s, G, kind, len_uniform, out, nr);
+  return hipGetLastError();
+}
+
 hipError_t launch_edge_features(const EdgeFeatArgs& A, int64_t edge_cap, hipStream_t s) {
   const unsigned blocks = (unsigned)((edge_cap + 255) / 256 + 5);
   hipLaunchKernelGGL(edge_features_kernel, dim3(blocks), dim3(256), 0, s, A);

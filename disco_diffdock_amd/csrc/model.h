@@ -179,6 +179,10 @@ struct GraphArgs {
 };
 
 // DisCo layer-0 patches: receivers whose rec-rec messages differ from the shared (sample-0) evaluation
+// deterministic mode: the sample-aligned ranges of a conv launch (k_graph.hip: det_ranges_kernel; kinds documented there)
+int det_ranges_count(int kind, int B);
+hipError_t launch_det_ranges(const GraphArgs& G, int kind, int len_uniform, int32_t* out, hipStream_t s);
+
 struct PatchArgs {
   const float* rec_latent;   // [B * n_rec, latent_dim]
   const int32_t* rr_start;   // [n_rec]
@@ -323,6 +327,7 @@ struct ddk_complex {
   float cfg_weight = 0.0f, cfg_start = 1.0f, cfg_end = 0.0f;   // ddk_set_guidance
   float *zero_lat = nullptr, *scores2 = nullptr;
   float* part = nullptr;      // deterministic mode: partial rows of the conv launches (ConvLaunch::part)
+  int32_t* det_rng = nullptr; // deterministic mode: sample-aligned ranges of the current conv launch | of the final_conv head (det_ranges_kernel)
   float* sum_rr0 = nullptr;   // [n_rec, XW] layer-0 rec-rec messages shared by all samples
   int32_t *h_src = nullptr, *h_dst = nullptr, *h_deg = nullptr;      // heads' edge list and accumulators (k_heads.hip)
   float *h_attr = nullptr, *h_sh = nullptr, *h_sum = nullptr;

@@ -571,6 +571,12 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
     if (c.deterministic) {     // ligand atoms receive in groups 0,1, residues in 2,3: slot = g & 1 -> one writer per (node, slot, channel)
       a.n_slots = 2; a.slots = (0u) | (1u << 2) | (0u << 4) | (1u << 6);
       a.part = cx->part; a.edge_bound = cap_b;
+      // sample-aligned work units: where the 32-edge tiles cut a node's run depends on the sample's own edges only (not on the batch around it)
+      const int kind = lig_only ? 0 : (shared0 ? 5 : (tab == TAB_A ? 1 : (tab == TAB_B ? 2 : (tab == TAB_C ? 3 : 4))));
+      GraphArgs Gd = {};
+      Gd.counts = cx->counts; Gd.B = B; Gd.M = cx->M; Gd.E_rr = cx->E_rr;
+      CK(launch_det_ranges(Gd, kind, 0, cx->det_rng, s), "deterministic ranges");
+      a.det_rng = cx->det_rng; a.det_nr = det_ranges_count(kind, B);
     }
     if (shared0) {
       rr0_dirty = true;
@@ -631,6 +637,15 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
   }
   CK(launch_heads_pre(Hd, torsion, s), "heads_pre");
   // final_conv on the context's side stream beside tor_bond_conv on the caller's stream (disjoint accumulator rows and work queues)
+  // deterministic mode, final_conv: the centre edges of a sample are ONE sample-aligned range (the bond edges of tor_bond_conv sit in fixed 32-edge slots
+  // per bond already); built on the caller's stream before the fork
+  int32_t* head_rng = nullptr;
+  if (c.deterministic) {
+    head_rng = cx->det_rng + (4 * (7 * (size_t)cx->max_batch + 1) + 8);
+    GraphArgs Gd = {};
+    Gd.B = B;
+    CK(launch_det_ranges(Gd, 6, n_lig, head_rng, s), "deterministic ranges (head)");
+  }
   if (torsion) {
     CK(hipEventRecord(ctx->ev_fork, s), "head fork");
     CK(hipStreamWaitEvent(ctx->head_stream, ctx->ev_fork, 0), "head fork");
@@ -641,9 +656,10 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
     a.tile_info = cx->info; a.counter = cx->info + I_HEAD + 4 + hd; a.gather = 0; a.pre = nullptr;
     a.n_groups = 1; a.n_active = 1; a.n_slots = 1; a.slots = 0;
     a.gbeg = cx->info + I_HEAD + (hd == 1 ? 0 : 2); a.gend = a.gbeg + 1;
-    if (c.deterministic) {     // (the two head launches run side by side: each its own half of the partial-row buffer)
+    if (c.deterministic) {     // (the two head launches run side by side: each its own part of the partial-row buffer)
       const int64_t eh = (int64_t)B * (n_lig + (int64_t)cx->R * BOND_CAP);
-      a.part = cx->part + (hd == 1 ? 0 : ((size_t)B * n_lig / CONV_BLOCK_EDGES + 2) * CONV_WAVES * 2 * XW); a.edge_bound = eh;
+      a.part = cx->part + (hd == 1 ? 0 : ((size_t)B + 2) * CONV_WAVES * 2 * XW); a.edge_bound = eh;
+      if (hd == 1) { a.det_rng = head_rng; a.det_nr = B; }
     }
     CK(launch_conv_fused(ctx->head[hd], a, ctx->n_cu, (hd == 1 && torsion) ? ctx->head_stream : s), "conv_fused (head)");
   }
@@ -699,7 +715,7 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
     const size_t cap0 = Bm0 * ((size_t)M + (size_t)n_lig * LIG_CAP + 2 * (size_t)n_lig * n_rec + E0) + E0 + 64, N0 = Bm0 * (size_t)(n_lig + n_rec);
     size_t need = (size_t)M * 24 + R0 * 8 + R0 * n_lig + (size_t)n_rec * 12 + (size_t)(n_lig + n_rec) * NS * 4 + E0 * (8 + NS * 4 + 16) + (size_t)n_rec * 4 +
                   (size_t)n_rec * d->rec_feat_dim * 4;
-    need += cap0 * (12 + NS * 4 + 16) + N0 * 4 + N0 * PRE_W * 4 + (c.deterministic ? N0 * XW * 4 + (cap0 / 32 + 128) * 2 * XW * 4 : 0) + Bm0 * ((size_t)n_lig + R0 * BOND_CAP + 2) * (8 + NE * 4 + 16) + Bm0 * (1 + R0) * (XW * 4 + 4) + 8 * 256 + Bm0 * 2 * CNT_STRIDE * 4 + INFO_INTS * 4 + (size_t)n_rec * 4 + Bm0 * n_rec + 3 * N0 * XW * 4 + (size_t)n_rec * XW * 4 + Bm0 * n_lig * 12 + 2 * Bm0 * (6 + R0) * 4;
+    need += cap0 * (12 + NS * 4 + 16) + N0 * 4 + N0 * PRE_W * 4 + (c.deterministic ? N0 * XW * 4 + (cap0 / 32 + 128 + 8 * (7 * Bm0 + 8)) * 2 * XW * 4 + 64 * (7 * Bm0 + 8) : 0) + Bm0 * ((size_t)n_lig + R0 * BOND_CAP + 2) * (8 + NE * 4 + 16) + Bm0 * (1 + R0) * (XW * 4 + 4) + 8 * 256 + Bm0 * 2 * CNT_STRIDE * 4 + INFO_INTS * 4 + (size_t)n_rec * 4 + Bm0 * n_rec + 3 * N0 * XW * 4 + (size_t)n_rec * XW * 4 + Bm0 * n_lig * 12 + 2 * Bm0 * (6 + R0) * 4;
     if (c.latent_dim > 0) need += N0 * c.latent_dim * 4 + Bm0 * E0 * (12 + NS * 4 + 16) + Bm0 * n_rec + (Bm0 + 1) * 4 + 3 * 256;
     cx_reserve(cx, need + 64 * 256);
     // everything uploaded below (topology, static embeddings, receptor-edge geometry) goes through one pinned staging buffer
@@ -803,7 +819,10 @@ int ddk_complex_create(ddk_ctx* ctx, const ddk_complex_desc* d, int32_t max_batc
   cx->xb = cx_upload<float>(cx, nullptr, N * XW);
   const int det = c.deterministic ? 1 : 0;
   cx->sum = cx_upload<float>(cx, nullptr, N * XW * (det ? 2 : 1));      // deterministic: one accumulator per (node, receiving group)
-  if (det) cx->part = cx_upload<float>(cx, nullptr, (cx->edge_cap / CONV_BLOCK_EDGES + 16) * CONV_WAVES * 2 * XW);
+  if (det) {      // partial rows of the runs that straddle 32-edge tiles (one block more per sample-aligned range: 7 per sample at most) + the ranges themselves
+    cx->part = cx_upload<float>(cx, nullptr, (cx->edge_cap / CONV_BLOCK_EDGES + 16 + 7 * Bm + 8) * CONV_WAVES * 2 * XW);
+    cx->det_rng = cx_upload<int32_t>(cx, nullptr, 2 * (4 * (7 * Bm + 1) + 8));      // [conv layers | final_conv head]
+  }
   cx->sum_rr0 = cx_upload<float>(cx, nullptr, (int64_t)n_rec * XW);
   if (has_model) cx->pre = cx_upload<float>(cx, nullptr, N * PRE_W);
   if (has_model) {      // heads (k_heads.hip): edge list [B*n_lig centre edges | <= B*R*BOND_CAP bond-neighbour edges], accumulators [B | B*R] rows

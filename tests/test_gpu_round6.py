@@ -208,3 +208,89 @@ def test_sampling_retries_with_half_the_batch_like_evaluate_py(dev, tables):
     assert got is not None and batch_size == 20 and len(failures) == 1 and 'out of device memory' in failures[0], (batch_size, failures)
     det = bool(int(os.environ.get('DDK_DETERMINISTIC', '0')))
     assert torch.equal(got, want) if det else rel_err(got.reshape(-1, 3), want.reshape(-1, 3)) < 2e-5
+
+
+@pytest.mark.parametrize('l', range(5))
+def test_tp_column_kernel_operand_classes_and_tails(dev, l):
+    """tp_col_kernel (k_tp.hip, round 6): every row-operand class on its own - only the 0e inputs non-zero, only 1o, only 1e, only 0o, sh = (s0, 0) and sh = (0, v) -
+    so that a wrong row offset, a swapped phase or a sign in one of the cross products cannot hide behind the other terms; edge counts around the persistent
+    grid (1, 63, 4095, 4096, 4097, 2 x 4096 + 5: first row only / no second row in flight / exactly one trip / tail of one).  fp64 restatement, per block of
+    output columns, 1e-6."""
+    from disco_diffdock_amd.tensor_layers import FasterTensorProduct
+    i_irr, o_irr = CFG.conv_irreps(l)
+    tp = FasterTensorProduct(i_irr, '1x0e+1x1o', o_irr)
+    din = smr.irreps_dim(i_irr)
+    mul = {'0e': 0, '1o': 0, '1e': 0, '0o': 0}
+    for part in i_irr.split('+'):
+        m, ir = part.strip().split('x')
+        mul[ir] = int(m)
+    spans, o = {}, 0
+    for ir, d in (('0e', 1), ('1o', 3), ('1e', 3), ('0o', 1)):
+        spans[ir] = (o, o + d * mul[ir])
+        o += d * mul[ir]
+    assert o == din
+    g = torch.Generator().manual_seed(500 + l)
+    for E in (1, 63, 4095, 4096, 4097, 2 * 4096 + 5):
+        x = torch.randn(E, din, generator=g)
+        sh = torch.randn(E, 4, generator=g)
+        w = torch.randn(E, tp.weight_numel, generator=g)
+        cases = [('all', x, sh)]
+        if E == 4097:
+            for ir, (a, b) in spans.items():
+                if b > a:
+                    xm = torch.zeros_like(x)
+                    xm[:, a:b] = x[:, a:b]
+                    cases.append((f'only {ir}', xm, sh))
+            s_only, v_only = sh.clone(), sh.clone()
+            s_only[:, 1:] = 0
+            v_only[:, 0] = 0
+            cases += [('sh = (s0, 0)', x, s_only), ('sh = (0, v)', x, v_only)]
+        for name, xx, ss in cases:
+            out = tp(xx.to(dev), ss.to(dev), w.to(dev)).cpu()
+            ref = smr.faster_tensor_product(xx.double(), ss.double(), w.double(), i_irr, o_irr)
+            scale = float(ref.abs().max()) + 1e-30
+            assert float((out.double() - ref).abs().max()) / scale < 1e-6, (l, E, name)
+            if name.startswith('only') or name.startswith('sh'):      # ... and what must vanish does: blocks no operand of the case reaches are exactly zero
+                dead = ref.abs().max(0).values == 0
+                assert bool((out[:, dead] == 0).all()), (l, E, name)
+
+
+def test_deterministic_samples_do_not_depend_on_the_batch_around_them(dev):
+    """under ddk_config.deterministic = 1 the scores, node rows and 20-step poses of a sample are the same BITS whichever other samples share its
+    batch - samples [0:5] and [35:40] of a 40-sample forward equal the two 5-sample forwards, a 13-sample batch cut out of the middle likewise (the layout
+    north_star's sample sharding produces: config 5, 40 samples over 8 ranks).  What makes it so: the conv launches' work units are aligned per (edge group,
+    level segment, SAMPLE) (det_ranges_kernel), so where the 32-edge tiles cut a node's run of edges depends on the sample's own edge list only."""
+    from disco_diffdock_amd import synthetic
+    from disco_diffdock_amd.runtime import Context, Complex
+    kern = int(os.environ.get('DDK_CONV_KERNEL', '0'))
+    for n_res, seed in ((300, 2), (2000, 3)):
+        c = synthetic.make_complex(seed, n_res=n_res)
+        P = smr.random_state_dict(CFG, seed=11)
+        ctx = Context(device=0, deterministic=1, conv_kernel=kern)
+        ctx.load_state_dict(P)
+        B = 40
+        steps = 20 if n_res == 300 else 3
+        coeffs, pos0 = _sampler_inputs(c, B, steps=steps)
+        R = int(np.asarray(c['mask_rotate']).reshape(-1, len(c['lig_x'])).shape[0])
+        z = torch.randn(steps, B, 6 + R, generator=torch.Generator().manual_seed(8))
+        # poses at three distances: far (few cross edges, heavy pruning), the bench's spread, inside the pocket
+        pos0[:14] += np.random.default_rng(1).normal(0, 12.0, size=(14, 1, 3)).astype(np.float32)
+        full = Complex(ctx, c, B)
+
+        def run(cx, sl, t):
+            pos = T(pos0[sl].copy()).to(dev)
+            tr, rot, tor = cx.score_forward(pos, t, t, t)
+            nb = pos.shape[0]
+            rows = cx.lig_node_features(nb, dev).cpu()
+            cx.sample(pos, *coeffs, z[:, sl].contiguous().to(dev))
+            return tr.cpu(), rot.cpu(), tor.cpu().reshape(nb, -1), rows.reshape(nb, -1), pos.cpu()
+
+        for t in (1.0, 0.3, 0.05):
+            ref = run(full, slice(0, B), t)
+            for sl in (slice(0, 5), slice(35, 40), slice(14, 27)):
+                small = Complex(ctx, c, sl.stop - sl.start)
+                got = run(small, sl, t)
+                for name, a, b in zip(('tr', 'rot', 'tor', 'ligand rows', 'poses'), got, ref):
+                    assert torch.equal(a, b[sl]), (n_res, t, sl, name, float((a - b[sl]).abs().max()))
+                small.close()
+        full.close()

@@ -289,7 +289,7 @@ def timesplit_stream():
     return {'command': ' '.join(cmd[1:]), 'workload': o['config']['workload'], 'value': o['value'], 'value_pruning_off': o.get('value_pruning_off'),
             'value_pocket_bound': o.get('value_pocket_bound'), 'unit': 'complexes/s', 'complexes': 363, 'ms_per_complex': o['ms_per_step'],
             'receptor_residues_min_median_max': o['extra']['stream'].get('receptor_residues_min_median_max'), 'per_receptor_size_decile': o['extra'].get('per_receptor_size_decile'),
-            'roofline_frac': o['roofline']['frac'], 'avg_conv_launch_ms': o['roofline']['avg_launch_ms'], 'conv_share_of_wall': o['roofline']['conv_share_of_wall'],
+            'roofline_frac': o['roofline']['frac'], 'avg_conv_launch_ms': o['roofline']['avg_launch_ms'], 'conv_share_of_wall': o['roofline']['conv_share_of_wall'], 'conv_share_of_wall_incl_ar_model': o['roofline'].get('conv_share_of_wall_incl_ar_model'),
             'min_cross_edges_per_sample_pocket_bound': (o['extra'].get('pocket_bound') or {}).get('min_cross_edges_per_sample_over_steps'),
             'stream': o['extra']['stream'], 'wall_s_of_the_subprocess': round(time.perf_counter() - t0, 1)}
 
@@ -469,7 +469,10 @@ def main():
         time and what the HIP events around the conv launches saw.  noise_scale: N(0,1) draws of every call pre-drawn and scaled (the
         pocket-bound workload); None: drawn inside sampling() from the device generator like the headline."""
         n_passes = n_passes or n_passes_default
-        calls = [data_lists(i, poses) for i in order[:warmup + a.steps]]
+        # sampling() writes the final poses into the graphs it was given (utils/sampling.py:197-199 does the same): every pass gets its OWN host data_lists,
+        # built before the clock starts, or the second pass would start from the first one's final poses
+        calls_of_pass = [[data_lists(i, poses) for i in order[:warmup + a.steps]] for _ in range(n_passes)]
+        calls = calls_of_pass[0]
         torch.cuda.manual_seed(977 + rank)
         noises = None
         Rs = {i: int(np.asarray(complexes[i]['mask_rotate']).shape[0]) for i in mine}
@@ -495,9 +498,13 @@ def main():
             one_call(k)
         torch.cuda.synchronize()
         ctx.profile_enable(True)
+        ar_ctx = extra['ar_model'].pretrained_score_model.ctx if disco else None      # the AR latent model's own score-model copy: its conv launches are timed too
+        if ar_ctx is not None:
+            ar_ctx.profile_enable(True)
         pool0, mem_peak = ctx.pool_stats(), 0
         pass_elapsed, pass_calls = [], []
         for pass_id in range(n_passes):
+            calls = calls_of_pass[pass_id]
             # every pass: EXACTLY a.steps calls between a barrier + synchronize on both sides; the same complexes, start poses and generator seed
             torch.cuda.manual_seed(4321 + rank)      # the device generator sampling() draws its noise from (the resident-loop figure below replays it)
             sm_mod._complex_cache.clear()            # a NEW complex every timed call: no Complex of the warm-up (or of the previous pass) survives
@@ -545,6 +552,11 @@ def main():
         prof, fw = ctx.profile_read(), ctx.profile_read_forwards()      # (HIP events around the conv launches of ALL passes: means are unaffected)
         ctx.profile_enable(False)
         ctx.set_pruning(True)
+        ar_conv_ms = None
+        if ar_ctx is not None:
+            ar_conv_ms = sum(p_['ms'] for p_ in ar_ctx.profile_read())
+            ar_ctx.profile_read_forwards()
+            ar_ctx.profile_enable(False)
         for p in final.values():
             assert bool(torch.isfinite(p).all()), 'non-finite pose'
         pool1 = ctx.pool_stats()
@@ -562,7 +574,7 @@ def main():
                   'chunk_pool_bytes_parked': pool1['bytes_parked'], 'complex_bytes_owned_peak': pool1['bytes_owned_peak'],
                   'device_memory_in_use_peak_bytes': int(mem_peak)}
         return dict(elapsed=elapsed, prof=prof, fw=fw, per_call_ms=per_call_ms, final=final, confs=confs, order=order[warmup:warmup + a.steps], stream=stream,
-                    passes=n_passes, pass_elapsed_s=[round(v, 5) for v in pass_elapsed])
+                    passes=n_passes, pass_elapsed_s=[round(v, 5) for v in pass_elapsed], ar_conv_ms=ar_conv_ms)
 
     layer_flop = [2 * 72 * (72 + W_LAYER[l]) + TP_FLOP[l] for l in range(5)]
 
@@ -576,6 +588,7 @@ def main():
         return {'value': n_units / r['elapsed'], 'unit': 'complexes/s', 'ms_per_step': 1e3 * r['elapsed'] / a.steps,
                 'edges_executed_over_unpruned': e_x / max(e_u, 1), 'conv_fp32_equivalent_TFLOPs': fl / max(conv_ms, 1e-9) / 1e9,
                 'conv_share_of_wall': conv_ms * 1e-3 / sum(r['pass_elapsed_s']),
+                'conv_share_of_wall_incl_ar_model': None if r.get('ar_conv_ms') is None else (conv_ms + r['ar_conv_ms']) * 1e-3 / sum(r['pass_elapsed_s']),
                 'min_cross_edges_per_sample_over_steps': None if cross is None else float(cross.min())}
 
     for _rep in range(int(os.environ.get('DDK_BENCH_REPEAT', '1')) - 1):      # debugging aid: the pocket-bound bracket several times in one process
@@ -756,6 +769,9 @@ def main():
                          'algorithmic_hbm_GBps': byts / (conv_ms * 1e-3) / 1e9 if conv_ms > 0 else 0.0,
                          'algorithmic_hbm_frac_of_peak': (byts / (conv_ms * 1e-3) / 1e9) / PEAK_HBM_GBS if conv_ms > 0 else 0.0,
                          'conv_share_of_wall': conv_ms * 1e-3 / sum(head['pass_elapsed_s']),
+                         # configs 3 / 4: + the conv launches of the AR latent model's two encoder passes per complex (its own context; the all-atom confidence
+                         # model's nine-group launches are not event-timed)
+                         'conv_share_of_wall_incl_ar_model': None if head.get('ar_conv_ms') is None else (conv_ms + head['ar_conv_ms']) * 1e-3 / sum(head['pass_elapsed_s']),
                          # the BASELINE metric's second clause at the REFERENCE's op boundary (tensor_layers.py:65-116, weights [E, W] in HBM): the HBM-bound kernel
                          'tp_boundary_A': tp_boundary,
                          'per_layer': [{'layer': l, 'ms_per_launch': p['ms'] / max(p['launches'], 1), 'w2_tiles': n_tiles[l],

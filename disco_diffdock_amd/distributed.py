@@ -10,7 +10,7 @@ def complex_cost(n_res, n_lig):
     per-complex device times of bench.py --config 4 --complexes 363 on the timesplit-shaped set (profiles/r06_bench_config4_363.json: per-decile table).
     The rec-rec messages (24 per residue and sample) dominate; the cross edges grow with n_lig x the residues within the cutoff; a constant covers the AR
     passes' and the small launches' share.  Only ratios matter."""
-    return 1.0 + n_res / 160.0 + max(n_lig, 16) / 50.0
+    return 1.0 + n_res / 175.0 + max(n_lig, 16) / 300.0      # (per-decile fit: ~18 ms + 0.104 ms per residue; the ligand term is small beside it)
 
 
 def shard_indices(costs, rank, world):

@@ -7,6 +7,7 @@
 // 24 KB for 2000), neighbour tests are brute force over the sample (30 x 300 .. 30 x 2000 pairs).
 #include <stdlib.h>
 #include "model.h"
+#include "k_node.h"
 
 namespace ddk {
 
@@ -570,8 +571,7 @@ __global__ __launch_bounds__(GT) void graph_fill_kernel(GraphArgs G) {
 // The sigma_emb columns are the same for every edge of a forward -> folded into the first-layer bias on the host.
 // ---------------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void edge_features_kernel(EdgeFeatArgs A) {
-  const int blk = blockIdx.x;
+__device__ __forceinline__ void edge_features_body(const EdgeFeatArgs& A, const int blk, const int tid) {
   const int bs1 = A.info[I_FB + 1], bs2 = A.info[I_FB + 2], bs3 = A.info[I_FB + 3], bs4 = A.info[I_FB + 4], bs5 = A.info[I_FB + 5];
   const int bs6 = A.patch_off >= 0 ? A.info[I_FBX] : bs5;
   if (blk >= bs6) return;
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(256) void edge_features_kernel(EdgeFeatArgs A) {
   const int bstart = fg == 0 ? 0 : (fg == 1 ? bs1 : (fg == 2 ? bs2 : (fg == 3 ? bs3 : (fg == 4 ? bs4 : bs5))));
   const int first = fg < 4 ? A.info[I_GO + fg] : (fg == 4 ? A.info[I_SHARED] : (int)A.patch_off);
   const int last = fg < 4 ? A.info[I_GO + 1 + fg] : (fg == 4 ? A.info[I_SHARED] + A.n_shared : (int)A.patch_off + A.info[I_PATCH]);
-  const int e = first + 256 * (blk - bstart) + threadIdx.x;
+  const int e = first + 256 * (blk - bstart) + tid;
   if (e >= last) return;
   if (fg == 2 && A.g2_live_only && e >= A.info[I_SEG + 3]) return;      // behind the level-C segment: no layer evaluates these messages
   const int g = fg >= 4 ? 2 : fg;
@@ -665,6 +665,16 @@ __global__ __launch_bounds__(256) void edge_features_kernel(EdgeFeatArgs A) {
   }
   *reinterpret_cast<float4*>(A.e_sh + 4 * (size_t)e) = shv;
   if (out2) *reinterpret_cast<float4*>(A.e_sh + 4 * (size_t)aux) = shv;
+}
+
+__global__ __launch_bounds__(256) void edge_features_kernel(EdgeFeatArgs A) { edge_features_body(A, (int)blockIdx.x, (int)threadIdx.x); }
+
+// The edge features and, beside them, the node embedding + layer 0's node terms (node_finalize_pre_body<2>): the latter depend on the diffusion time and
+// the latents only - not on the poses, not on the graph - so their blocks run in the same launch instead of in one of their own behind it (round 6:
+// -1 launch and ~10 us per reverse step).  Blocks [0, node_blocks) are node tiles (PRE_W threads each), the rest edge blocks (256 of the PRE_W threads).
+__global__ __launch_bounds__(PRE_W) void edge_features_node_kernel(EdgeFeatArgs A, NodePreArgs P, NodeEmbedArgs E, int node_blocks) {
+  if ((int)blockIdx.x < node_blocks) { node_finalize_pre_body<2>(P, E, (int)blockIdx.x, node_blocks); return; }
+  if (threadIdx.x < 256) edge_features_body(A, (int)blockIdx.x - node_blocks, (int)threadIdx.x);
 }
 
 // node embeddings: static part (categorical embeddings, ESM projection, bias) + the per-step sigma part
@@ -871,6 +881,13 @@ hipError_t launch_det_ranges(const GraphArgs& G, int kind, int len_uniform, int3
 hipError_t launch_edge_features(const EdgeFeatArgs& A, int64_t edge_cap, hipStream_t s) {
   const unsigned blocks = (unsigned)((edge_cap + 255) / 256 + 5);
   hipLaunchKernelGGL(edge_features_kernel, dim3(blocks), dim3(256), 0, s, A);
+  return hipGetLastError();
+}
+
+hipError_t launch_edge_features_node(const EdgeFeatArgs& A, int64_t edge_cap, const NodePreArgs& P, const NodeEmbedArgs& E, hipStream_t s) {
+  const unsigned blocks = (unsigned)((edge_cap + 255) / 256 + 5);
+  const int nb = node_pre_tiles(P);
+  hipLaunchKernelGGL(edge_features_node_kernel, dim3(blocks + nb), dim3(PRE_W), 0, s, A, P, E, nb);
   return hipGetLastError();
 }
 

@@ -284,6 +284,7 @@ struct ConfComplex;
 hipError_t launch_graph(const GraphArgs& G, int64_t edge_cap, hipStream_t s);
 int graph_cross_mirror_fits(int n_lig, int n_rec);      // k_graph.hip: does the current device's LDS hold the residue x ligand-atom bit matrix of GraphArgs::cross_mirror?
 hipError_t launch_edge_features(const EdgeFeatArgs& A, int64_t edge_cap, hipStream_t s);
+hipError_t launch_edge_features_node(const EdgeFeatArgs& A, int64_t edge_cap, const NodePreArgs& P, const NodeEmbedArgs& E, hipStream_t s);   // + node embedding and layer-0 node terms
 struct NodeEmbedArgs {
   const float* lig_static; const float* rec_static; StepParams sp; int B, n_lig, n_rec; float* x;
   const float *lig_latent, *rec_latent, *lig_w_lat, *rec_w_lat, *lig_unc, *rec_unc; float unconditional; int latent_dim;

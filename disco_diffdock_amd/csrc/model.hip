@@ -520,7 +520,7 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
   F.latent_dim = c.latent_dim; F.lig_latent = cx->lig_latent; F.rec_latent = cx->rec_latent; F.unconditional = cx->unconditional;
   // worst-case edge count of THIS batch size bounds the launch
   const int64_t cap_b = (int64_t)B * ((int64_t)cx->M + (int64_t)n_lig * LIG_CAP + 2LL * n_lig * n_rec + cx->E_rr) + cx->E_rr;
-  CK(launch_edge_features(F, (cap_b < cx->edge_cap ? cap_b : cx->edge_cap) + (F.patch_off >= 0 ? (int64_t)B * cx->E_rr + 256 : 0), s), "edge features");
+  const int64_t feat_cap = (cap_b < cx->edge_cap ? cap_b : cx->edge_cap) + (F.patch_off >= 0 ? (int64_t)B * cx->E_rr + 256 : 0);
   float* xin = cx->xa;
   float* xout = cx->xb;
   NodeEmbedArgs NE_;
@@ -533,8 +533,10 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
     NodePreArgs PA = {};
     PA.x_out = xin; PA.n_lig_total = B * n_lig; PA.n_rec_total = B * n_rec; PA.n_rec = n_rec;
     PA.wn = ctx->conv[0].wn; PA.bnp = ctx->conv[0].bnp; PA.pre = cx->pre; PA.n_slots = 1; PA.lig_roles = 15; PA.rec_roles = 15;
-    CK(launch_node_finalize_pre(PA, false, s, &NE_), "node embed + node_pre");
+    // ONE launch: the edge features and, beside them, the node embedding + layer 0's node terms (they depend on t and the latents only)
+    CK(launch_edge_features_node(F, feat_cap, PA, NE_, s), "edge features + node embed + node_pre");
   } else {
+    CK(launch_edge_features(F, feat_cap, s), "edge features");
     CK(launch_node_embed(NE_, s), "node embed");
   }
   // accumulators: node_finalize zeroes what it reads, so a forward that ran to its end leaves them clean for the next one

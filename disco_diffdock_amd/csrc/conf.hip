@@ -284,32 +284,38 @@ struct LaArgs {
 };
 
 constexpr int COMPACT_SLICES = 32;      // z blocks of conf_level_compact_kernel
-// max over the points a of the number of points within `r` of a (a itself included): uniform cell grid of edge r, 27 cells per point
+// max over the points a of the number of points within `r` of a (a itself included): uniform cell grid, cells of edge >= r searched by coordinate range.
+// Returns -1 for non-finite coordinates (the float -> int casts below are undefined for NaN / inf, and a far-flung atom must not buy a
+// 256^3-cell grid: the cell edge doubles until the grid has at most max(4096, 8 n) cells - wider cells only enlarge the superset that is searched).
 static int max_neighbours_within(const float* pos, int n, float r) {
   if (n <= 0) return 0;
+  for (int i = 0; i < 3 * n; ++i)
+    if (!std::isfinite(pos[i])) return -1;
   float lo[3] = {pos[0], pos[1], pos[2]}, hi[3] = {pos[0], pos[1], pos[2]};
   for (int i = 1; i < n; ++i)
     for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], pos[3 * i + k]); hi[k] = std::max(hi[k], pos[3 * i + k]); }
   int dim[3];
-  for (int k = 0; k < 3; ++k) dim[k] = std::min(256, (int)((hi[k] - lo[k]) / r) + 1);
-  auto cell_of = [&](int i, int k) { return std::min(dim[k] - 1, (int)((pos[3 * i + k] - lo[k]) / r)); };      // (clamped grids only merge cells: still a superset search)
+  float cell = r;
+  const size_t max_cells = std::max<size_t>(4096, 8 * (size_t)n);
+  for (;;) {
+    size_t total = 1;
+    for (int k = 0; k < 3; ++k) { dim[k] = (int)std::min(255.0f, (hi[k] - lo[k]) / cell) + 1; total *= (size_t)dim[k]; }      // (clamped in float: the cast is always defined)
+    if (total <= max_cells) break;
+    cell *= 2.0f;
+  }
+  auto cell_at = [&](float x, int k) { return std::max(0, std::min(dim[k] - 1, (int)std::min(255.0f, std::max(0.0f, (x - lo[k]) / cell)))); };      // (clamped grids only merge cells: still a superset search)
   std::vector<int> start((size_t)dim[0] * dim[1] * dim[2] + 1, 0), item(n);
   auto cid = [&](int cx, int cy, int cz) { return ((size_t)cx * dim[1] + cy) * dim[2] + cz; };
-  for (int i = 0; i < n; ++i) ++start[cid(cell_of(i, 0), cell_of(i, 1), cell_of(i, 2)) + 1];
+  for (int i = 0; i < n; ++i) ++start[cid(cell_at(pos[3 * i], 0), cell_at(pos[3 * i + 1], 1), cell_at(pos[3 * i + 2], 2)) + 1];
   for (size_t q = 1; q < start.size(); ++q) start[q] += start[q - 1];
   std::vector<int> fill(start.begin(), start.end() - 1);
-  for (int i = 0; i < n; ++i) item[fill[cid(cell_of(i, 0), cell_of(i, 1), cell_of(i, 2))]++] = i;
+  for (int i = 0; i < n; ++i) item[fill[cid(cell_at(pos[3 * i], 0), cell_at(pos[3 * i + 1], 1), cell_at(pos[3 * i + 2], 2))]++] = i;
   const float r2 = r * r;
-  // a clamped axis (more than 256 cells of edge r) has cells wider than r only if the extent exceeds 256 r: search the neighbouring cells by coordinate range instead
   int best = 0;
   for (int i = 0; i < n; ++i) {
     int cnt = 0;
     int c0[3], c1[3];
-    for (int k = 0; k < 3; ++k) {
-      c0[k] = std::max(0, std::min(dim[k] - 1, (int)((pos[3 * i + k] - r - lo[k]) / r)));
-      c1[k] = std::max(0, std::min(dim[k] - 1, (int)((pos[3 * i + k] + r - lo[k]) / r)));
-      if (pos[3 * i + k] - r < lo[k]) c0[k] = 0;
-    }
+    for (int k = 0; k < 3; ++k) { c0[k] = cell_at(pos[3 * i + k] - r, k); c1[k] = cell_at(pos[3 * i + k] + r, k); }
     for (int cx = c0[0]; cx <= c1[0]; ++cx)
       for (int cy = c0[1]; cy <= c1[1]; ++cy)
         for (int cz = c0[2]; cz <= c1[2]; ++cz)
@@ -877,7 +883,9 @@ int ddk_complex_set_atoms(ddk_ctx* ctx, ddk_complex* cx, const ddk_atoms_desc* d
     // overflow, from the receptor's own geometry.  If any atom a lies within r of a point x, every atom within r of x lies within 2r of a: no ligand atom,
     // wherever a pose puts it, collects more than max_a |{b : |b - a| < 2r}| neighbours (round 4 assumed 96 per ligand atom on average and turned the whole
     // batch into NaN / -1000 when a dense pocket exceeded it).  ~250 for protein heavy atoms at r = 5 A; a cell grid makes the count O(n_atom)
-    const int la_bound = std::min(n_atom, max_neighbours_within(d->atom_pos, n_atom, 2.0f * c.lig_max_radius));
+    const int la_raw = max_neighbours_within(d->atom_pos, n_atom, 2.0f * c.lig_max_radius);
+    if (la_raw < 0) return fail(ctx, DDK_ERR_INVALID, "ddk_complex_set_atoms: non-finite receptor atom coordinates");
+    const int la_bound = std::min(n_atom, la_raw);
     K->cap_la = Bm * (int64_t)n_lig * std::max(la_bound, 1) + 64;
     K->off_la = K->cap4; K->off_al = K->off_la + K->cap_la; K->off_aa = K->off_al + K->cap_la;
     // (Bv = Bm + 1 segments of every static set: the last one belongs to the virtual ligand-free sample; vrr = its rec-rec records)

@@ -824,6 +824,8 @@ int ddk_tp_forward(ddk_ctx* ctx, int32_t layer, const float* x_dst, const float*
   int rc = check_launchable(ctx, layer);
   if (rc) return rc;
   hipError_t e = launch_tp_forward(ctx->conv[layer], x_dst, sh, w, E, out, (hipStream_t)stream);
+  if (e == hipErrorInvalidValue)      // (say what is wrong instead of a bare HIP error)
+    return fail(ctx, DDK_ERR_INVALID, "ddk_tp_forward: the layer's irreps are not one of the four conv-layer shapes of this model family (24x0e [+ 6x1o [+ 6x1e [+ 24x0o]]] -> the next entry)");
   if (e != hipSuccess) return hip_fail(ctx, e, "tp_forward launch");
   return DDK_OK;
 }

@@ -593,7 +593,30 @@ static int score_forward_impl(ddk_ctx* ctx, ddk_complex* cx, int B, const float*
     }
     a.use_y = ctx->cfg.conv_kernel == 2;
     if (ctx->conv_trace != nullptr && ctx->conv_trace_layer == l) { a.trace = ctx->conv_trace; a.trace_coarse = ctx->conv_trace_coarse; }
+#if defined(DDK_ABL_CONCURRENT_LAYERS)
+#ifndef DDK_TIMING_ONLY_BUILD
+#error "DDK_ABL_CONCURRENT_LAYERS gives WRONG RESULTS (timing-only ablation): it needs -DDDK_TIMING_ONLY_BUILD as well (tools/build_variant_model.sh adds it)"
+#endif
+    {   // TIMING ONLY (results invalid): the five conv launches of a forward on five streams, none waiting for the finalize before it - how long the forward's
+        // conv work takes when the launches fill each other's ramps and tails: the upper bound of what ONE persistent launch over the layers could save
+      static hipStream_t abl_s[8] = {};
+      static hipEvent_t abl_fork = nullptr, abl_join[8] = {};
+      if (!abl_fork) {
+        hipEventCreateWithFlags(&abl_fork, hipEventDisableTiming);
+        for (int k = 0; k < 8; ++k) { hipStreamCreateWithFlags(&abl_s[k], hipStreamNonBlocking); hipEventCreateWithFlags(&abl_join[k], hipEventDisableTiming); }
+      }
+      if (l == 0) {
+        CK(hipEventRecord(abl_fork, s), "abl fork");
+        for (int k = 0; k < NL; ++k) CK(hipStreamWaitEvent(abl_s[k], abl_fork, 0), "abl fork");
+      }
+      CK(launch_conv_fused(L, a, ctx->n_cu, abl_s[l]), "conv_fused (ablation)");
+      CK(hipEventRecord(abl_join[l], abl_s[l]), "abl join");
+      if (l == NL - 1)
+        for (int k = 0; k < NL; ++k) CK(hipStreamWaitEvent(s, abl_join[k], 0), "abl join");
+    }
+#else
     CK(launch_conv_fused(L, a, ctx->n_cu, s), "conv_fused");
+#endif
     if (prof_slot) {
       CK(hipEventRecord(pr.b, s), "event record");
       ctx->prof_recs.push_back(pr);

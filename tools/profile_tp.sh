@@ -8,7 +8,8 @@ OUT=$ROOT/gpurun_out/tp_prof
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp
 for L in 3 2 1 0; do
-  CMD="python $ROOT/tools/bench_tp.py --layer $L --edges 800000 --iters 10 --json $OUT/bench_L$L.json"
+  CMD="python $ROOT/tools/bench_tp.py --layer $L --edges 800000 --iters 10"
+  python $ROOT/tools/bench_tp.py --layer $L --edges 800000 --iters 10 --json $OUT/bench_L$L.json > "$OUT/plain_L$L.log" 2>&1      # (no profiler: the events-timed figure of the last column)
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_L$L" -o tp -- $CMD > "$OUT/trace_L$L.log" 2>&1
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch_L$L" -o tp -- $CMD > "$OUT/fetch_L$L.log" 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write_L$L" -o tp -- $CMD > "$OUT/write_L$L.log" 2>&1
@@ -22,7 +23,7 @@ def find(d, suffix):
     return r[0] if r else None
 lines = ['# tp_col_kernel (k_tp.hip): FasterTensorProduct.forward at the reference op boundary, weights [E, W] in HBM (SURVEY 8(d) boundary A)', '',
          'rocprofv3 --kernel-trace --stats / --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python tools/bench_tp.py --layer L --edges 800000 --iters 10', '',
-         '| layer | W | algorithmic B/edge | avg launch us (kernel trace) | GB/s algorithmic | / 8000 | / 6300 | FETCH_SIZE KB (x2: gfx950 correction) | WRITE_SIZE KB | counter B/edge | counter / algorithmic | bench_tp.py (events) ms |',
+         '| layer | W | algorithmic B/edge | avg launch us (kernel trace) | GB/s algorithmic | / 8000 | / 6300 | FETCH_SIZE KB (x2: gfx950 correction) | WRITE_SIZE KB | counter B/edge | counter / algorithmic | bench_tp.py alone (events, no profiler) ms |',
          '|---|---|---|---|---|---|---|---|---|---|---|---|']
 for L in (3, 2, 1, 0):
     b = json.load(open(os.path.join(out, f'bench_L{L}.json')))

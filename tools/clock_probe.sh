@@ -1,5 +1,6 @@
 #!/bin/bash
-# Effective shader clock of the conv kernels (GRBM_GUI_ACTIVE / kernel duration) and their matrix-pipe busy share, for DDK_CONV_Y = 0 / 1 on fixed inputs
+# Effective shader clock of the conv kernels (GRBM_GUI_ACTIVE / kernel duration) and their matrix-pipe busy share, for conv_kernel 0 and 2 (DDK_CONV_KERNEL) on fixed inputs
+# (y = 1 needs a VARIANT library with tools/variants/k_conv_y.hip: tools/build_variant_y.sh y, then DDK_LIB=$(pwd)/ab_libs/libddk_y.so tools/clock_probe.sh ...; the product library refuses conv_kernel = 2)
 # (tools/conv_fixed.py).  Run on the GPU box:  tools/clock_probe.sh <out-name>
 set -u
 export TMPDIR=/tmp
@@ -8,7 +9,7 @@ OUT=$ROOT/gpurun_out/${1:-clock}
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp
 for y in 0 1; do
-  DDK_CONV_Y=$y rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d "$OUT/y$y" -o p -- python $ROOT/tools/conv_fixed.py --reps 4 > "$OUT/y$y.log" 2>&1
+  DDK_CONV_KERNEL=$((2 * y)) rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d "$OUT/y$y" -o p -- python $ROOT/tools/conv_fixed.py --reps 4 > "$OUT/y$y.log" 2>&1
 done
 cd "$ROOT"
 python - "$OUT" <<'PY'
@@ -30,7 +31,7 @@ for y in (0, 1):
                 cnt[r['Dispatch_Id']][r['Counter_Name']] = float(r['Counter_Value'])
     big = [(k, v) for k, v in dur.items() if v[1] > 300000 and 'GRBM_GUI_ACTIVE' in cnt[k]]      # the long launches (layers 1-3 at t = 1.0 / 0.6)
     ns = sum(v[1] for _, v in big); gui = sum(cnt[k]['GRBM_GUI_ACTIVE'] for k, _ in big); mf = sum(cnt[k].get('SQ_VALU_MFMA_BUSY_CYCLES', 0) for k, _ in big)
-    res[f'DDK_CONV_Y={y}'] = {'kernel': big[0][1][0] if big else None, 'launches': len(big), 'mean_us': ns / max(len(big), 1) / 1e3,
+    res[f'conv_kernel={2 * int(y)}'] = {'kernel': big[0][1][0] if big else None, 'launches': len(big), 'mean_us': ns / max(len(big), 1) / 1e3,
                               'effective_clock_GHz': gui / max(ns, 1), 'mfma_busy_share_of_cycles_x_simds': mf / max(gui, 1) / 1024 * 8 if False else mf / max(gui * 1024 / 8, 1)}
 json.dump(res, open(os.path.join(out, 'summary.json'), 'w'), indent=1)
 print(json.dumps(res, indent=1))

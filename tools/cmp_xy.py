@@ -1,4 +1,5 @@
-"""development aid: ddk_config.conv_kernel 0 (k_conv_x.hip) against 2 (k_conv_y.hip) on the same inputs"""
+"""development aid: ddk_config.conv_kernel 0 (k_conv_x.hip) against 2 (tools/variants/k_conv_y.hip) on the same inputs - run with DDK_LIB pointing at a variant library built by
+tools/build_variant_y.sh (the product library refuses conv_kernel = 2 since round 6)"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), '..')))

@@ -86,6 +86,18 @@ def test_bench_line_reports_executed_work_and_both_floors(dev):
     assert ex['pocket_bound']['min_cross_edges_per_sample_over_steps'] > 0          # the pocket-bound samples never lose contact
     assert ex['pocket_bound']['edges_executed_over_unpruned'] >= rf['edges_executed_over_unpruned'] - 1e-9
     assert len(ex['per_step']) == 20 and all(0 < s['edges_executed_over_unpruned'] <= 1 for s in ex['per_step'])
+    # round 6: the median of three timed passes over the same calls (every pass with its own host data_lists: sampling() writes the final poses into the graphs it is
+    # given, and a pass that inherited them would start from wandered-off ligands and run 1.5 - 2 x faster - the bug this guards against), the three figures and the
+    # HBM-bound boundary-A kernel under keys the driver's record keeps
+    hl = ex['headline']
+    assert hl['passes'] == 3 and len(hl['pass_elapsed_s']) == 3 and max(hl['pass_elapsed_s']) / min(hl['pass_elapsed_s']) < 1.15, hl['pass_elapsed_s']
+    assert out['ms_per_step'] == pytest.approx(1e3 * sorted(hl['pass_elapsed_s'])[1] / out['steps'], rel=1e-3)
+    trio = out['config']['value_headline_pruning_off_pocket_bound']
+    assert trio == [round(out['value'], 3), round(out['value_pruning_off'], 3), round(out['value_pocket_bound'], 3)]
+    tp = rf['tp_boundary_A']
+    assert tp is not None and tp['bound'] == 'hbm' and tp['unit'] == 'GB/s' and tp['layer'] == 3 and [p['layer'] for p in tp['per_layer']] == [0, 1, 2, 3]
+    assert tp['achieved'] == tp['per_layer'][3]['GBps'] and tp['frac'] == pytest.approx(tp['achieved'] / 8000.0, abs=1e-3)
+    assert all(p['GBps'] > 3000 for p in tp['per_layer']), tp['per_layer']      # (round 5's kernel: 3 100 - 4 300; the new one 4 700 - 5 500)
 
 
 # ------------------------------------------------------------------------------------------------------------------------------------------

@@ -64,7 +64,8 @@ TP_FLOP = [2016, 2736, 3456, 5472, 5472]
 FUSED_BYTES = [408, 480, 552, 648, 648]                        # fused boundary, bytes per edge
 PEAK_F32_MFMA_TFLOPS = 157.3                                   # MI355X_MICROARCH.md
 PEAK_F16_MFMA_TFLOPS = 2500.0                                  # dense f16 / bf16 matrix peak (MI355X_MICROARCH.md; micro-benchmark ceiling 2382)
-MFMA_FLOP_PER_EDGE_TILE = (24 * 2 * 32 * 32 * 16 + 6 * 2 * 32 * 32 * 8) / 32      # k_conv_x.hip: 432 K-columns of 32x32 limb products per 32 edges and W2 tile (26 x 32x32x16 + 2 x 32x32x8 with the packed tail; 24 + 6 unpacked; the same count per GEMM1)
+MFMA_FLOP_PER_EDGE_TILE = {6: (24 * 2 * 32 * 32 * 16 + 6 * 2 * 32 * 32 * 8) / 32,      # k_conv_x.hip (conv_kernel = 3, six limb products): 432 K-columns of 32x32 per 32 edges and W2 tile (26 x 32x32x16 + 2 x 32x32x8 with the packed tail; 24 + 6 unpacked; the same count per GEMM1)
+                           4: (16 * 2 * 32 * 32 * 16 + 4 * 2 * 32 * 32 * 8) / 32}      # k_conv_x4.hip (the default, four limb products): 288 K-columns (16 x 32x32x16 + 2 packed tail MFMAs = 18 per tile)
 PEAK_HBM_GBS = 8000.0
 
 ARGS_S = Namespace(ns=24, nv=6, num_conv_layers=5, sigma_embed_dim=32, distance_embed_dim=32, cross_distance_embed_dim=32,
@@ -94,7 +95,7 @@ CONFIG_TEXT = {
 }
 
 
-CONV_KERNEL_SOURCES = ('k_conv_x.hip', 'k_conv_x_epi_gen.inc', 'k_conv_common.h', 'ddk_internal.h')      # what the dominant kernel is compiled from
+CONV_KERNEL_SOURCES = ('k_conv_x.hip', 'k_conv_x4.hip', 'k_conv_x_epi_gen.inc', 'k_conv_x_epi4_gen.inc', 'k_conv_common.h', 'ddk_internal.h')      # what the dominant kernel is compiled from
 
 
 def conv_kernel_source_sha():
@@ -319,7 +320,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--config', type=int, default=2, choices=[2, 3, 4, 5])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-alt', action='store_true', help='skip the measurement of the fallback fp32-MFMA kernel')
+    ap.add_argument('--no-alt', action='store_true', help='skip the brackets of the other conv kernels: the three-limb / six-product form (value_six_limb_products) and the fp32-MFMA fallback')
     ap.add_argument('--no-device-loop', action='store_true', help='skip the resident-loop comparison figure')
     ap.add_argument('--no-extras', action='store_true', help='skip the pruning-off and pocket-bound brackets')
     ap.add_argument('--shard-set', action='store_true', help='configs 2-4: the --complexes complexes are ONE set, partitioned over the ranks with distributed.shard_indices (LPT by '
@@ -418,23 +419,41 @@ def main():
 
     # ---- models through the reference's call surface ----------------------------------------------------------------------------
     tsig = partial(t_to_sigma, args=margs)
-    model = get_model(margs, dev, tsig, no_parallel=True)
-    score_model = getattr(model, 'score_model', model)
     P = synthetic.random_score_model_state_dict(seed=0, latent_dim=margs.latent_dim, latent_droprate=getattr(margs, 'latent_droprate', 0.0))
-    score_model.load_state_dict(P, strict=True)
-    extra = {}
-    if disco:
-        ar = get_ar_model(ARGS_AR, margs, dev, training=False)
-        ar.load_state_dict(synthetic.random_ar_state_dict(seed=14))
-        ar.eval()
-        extra.update(ar_model=ar, ar_args=ARGS_AR, softmax_latent_temperature=float(np.exp(-1.5)))
-    else:
-        extra.update(use_latent=False)
-    if with_conf:
-        cm = get_model(ARGS_CONF, dev, partial(t_to_sigma, args=ARGS_CONF), no_parallel=True, confidence_mode=True)
-        cm.load_state_dict(synthetic.random_confidence_state_dict(seed=1), strict=True)
-        cm.eval()
-        extra.update(confidence_model=cm, confidence_model_args=ARGS_CONF)
+
+    def build_models(conv_kernel=None):
+        """score model (+ AR latent model, + confidence model) through the reference's call surface; conv_kernel: ddk_config.conv_kernel of every context
+        they create (None: the default, or whatever DDK_CONV_KERNEL says)"""
+        saved = os.environ.get('DDK_CONV_KERNEL')
+        if conv_kernel is not None:
+            os.environ['DDK_CONV_KERNEL'] = str(conv_kernel)
+        try:
+            model_ = get_model(margs, dev, tsig, no_parallel=True)
+            sm_ = getattr(model_, 'score_model', model_)
+            sm_.load_state_dict(P, strict=True)
+            extra_ = {}
+            if disco:
+                ar = get_ar_model(ARGS_AR, margs, dev, training=False)
+                ar.load_state_dict(synthetic.random_ar_state_dict(seed=14))
+                ar.eval()
+                extra_.update(ar_model=ar, ar_args=ARGS_AR, softmax_latent_temperature=float(np.exp(-1.5)))
+            else:
+                extra_.update(use_latent=False)
+            if with_conf:
+                cm = get_model(ARGS_CONF, dev, partial(t_to_sigma, args=ARGS_CONF), no_parallel=True, confidence_mode=True)
+                cm.load_state_dict(synthetic.random_confidence_state_dict(seed=1), strict=True)
+                cm.eval()
+                extra_.update(confidence_model=cm, confidence_model_args=ARGS_CONF)
+        finally:
+            if conv_kernel is not None:
+                if saved is None:
+                    os.environ.pop('DDK_CONV_KERNEL', None)
+                else:
+                    os.environ['DDK_CONV_KERNEL'] = saved
+        return model_, sm_, extra_
+
+    model, score_model, extra = build_models()
+    models_default = (model, score_model, extra)
     sched = get_t_schedule(STEPS)
     coeffs = step_coefficients(STEPS, sched, sched, sched, tsig, margs, False, False, True, temps['temp_sampling'], temps['temp_psi'],
                                temps['temp_sigma_data'])
@@ -464,10 +483,13 @@ def main():
 
     n_passes_default = a.passes if a.passes > 0 else (3 if a.steps <= 64 else 1)
 
-    def bracket(poses, warmup, prune=True, noise_scale=None, n_passes=None):
+    def bracket(poses, warmup, prune=True, noise_scale=None, n_passes=None, mdl=None):
         """the reference's bracket (evaluate.py:259,293) over K = a.steps sampling() calls, a NEW complex every call; returns the wall
         time and what the HIP events around the conv launches saw.  noise_scale: N(0,1) draws of every call pre-drawn and scaled (the
-        pocket-bound workload); None: drawn inside sampling() from the device generator like the headline."""
+        pocket-bound workload); None: drawn inside sampling() from the device generator like the headline.  mdl: (model, score_model, extra) of build_models()
+        when the bracket is to run another set of contexts (the three-limb / six-product conv kernel)."""
+        model, score_model_, extra = mdl if mdl is not None else models_default
+        ctx = score_model_.ctx
         n_passes = n_passes or n_passes_default
         # sampling() writes the final poses into the graphs it was given (utils/sampling.py:197-199 does the same): every pass gets its OWN host data_lists,
         # built before the clock starts, or the second pass would start from the first one's final poses
@@ -636,7 +658,27 @@ def main():
         np.savez(a.dump_poses, **{f'c{i}': gathered[i].cpu().numpy() for i in sorted(gathered)})
 
     # ---- what the headline rests on: the same bracket without the receptive-field pruning (the floor) and on a pocket-bound workload ----
-    pruning_off = pocket_bound = None
+    pruning_off = pocket_bound = other_limbs = None
+    kern_default = int(getattr(ctx.cfg, 'conv_kernel', 0))
+    if not a.no_extras and not a.no_alt and kern_default in (0, 3) and not shard_set:
+        # the same sampling() bracket with the OTHER form of the f16-limb conv kernel in every context (score model, AR model, confidence model): conv_kernel = 3
+        # (three limbs, six products: the default of rounds 3 - 5) beside the default 0 (two limbs, four products), or the other way round under DDK_CONV_KERNEL=3
+        other_k = 3 if kern_default == 0 else 0
+        print(f'[bench] extras: conv_kernel = {other_k} bracket', file=sys.stderr, flush=True)
+        mdl_o = build_models(conv_kernel=other_k)
+        assert int(mdl_o[1].ctx.cfg.conv_kernel) == other_k
+        r_o = bracket(poses_all, min(a.warmup, 2), mdl=mdl_o)
+        other_limbs = summary(r_o, n_done)
+        conv_ms_o, launches_o = sum(p_['ms'] for p_ in r_o['prof']), sum(p_['launches'] for p_ in r_o['prof'])
+        nt_o = [len(mdl_o[1].ctx.export(f'conv.{l}.tiles', dtype=np.int32)) // 4 for l in range(5)]
+        prod_o = 6 if other_k == 3 else 4
+        mfma_o = sum(p_['edges'] * MFMA_FLOP_PER_EDGE_TILE[prod_o] * (nt_o[l] + 1) for l, p_ in enumerate(r_o['prof']))
+        other_limbs.update(conv_kernel=other_k, limb_products=prod_o, avg_launch_ms=conv_ms_o / max(launches_o, 1),
+                           mfma_TFLOPs_executed=mfma_o / max(conv_ms_o, 1e-9) / 1e9, frac_of_f16_matrix_peak=mfma_o / max(conv_ms_o, 1e-9) / 1e9 / PEAK_F16_MFMA_TFLOPS,
+                           note=('the same bracket, workload, seeds and pruning with ddk_config.conv_kernel = %d in every context: ' % other_k) +
+                                ('three fp16 limbs per operand, six limb products exact to 2^-33 (k_conv_x.hip: the default of ddk 0.4 - 0.7)' if other_k == 3 else
+                                 'two fp16 limbs per operand, four limb products (k_conv_x4.hip: the default)'))
+        del mdl_o, r_o
     if not a.no_extras:
         w2 = min(a.warmup, 2)
         print('[bench] extras: pruning_off bracket', file=sys.stderr, flush=True)
@@ -692,7 +734,9 @@ def main():
         fl = lambda key: sum(p[key] * layer_flop[l] for l, p in enumerate(prof))
         flops_exec, flops_unpruned, flops_full = fl('edges'), fl('edges_unpruned'), fl('edges_reference')
         n_tiles = [len(ctx.export(f'conv.{l}.tiles', dtype=np.int32)) // 4 for l in range(5)]        # W2 tiles of 32 rows per layer (59 for W = 1872)
-        mfma_exec = sum(p['edges'] * MFMA_FLOP_PER_EDGE_TILE * (n_tiles[l] + 1) for l, p in enumerate(prof))
+        products = 6 if int(getattr(ctx.cfg, 'conv_kernel', 0)) == 3 else 4
+        mfma_tile = MFMA_FLOP_PER_EDGE_TILE[products]
+        mfma_exec = sum(p['edges'] * mfma_tile * (n_tiles[l] + 1) for l, p in enumerate(prof))
         byts = sum(p['edges'] * FUSED_BYTES[l] for l, p in enumerate(prof))
         launches = sum(p['launches'] for p in prof)
         tf = lambda f: f / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
@@ -731,10 +775,15 @@ def main():
             # the three figures belong together: value rests on where random-init weights push the ligand; value_pocket_bound is what a trained
             # checkpoint's trajectories look like (every sample keeps >= 2 500 cross edges for all 20 steps), value_pruning_off the guaranteed floor of value
             'value_pocket_bound': pocket_bound['value'] if pocket_bound else None, 'value_pruning_off': pruning_off['value'] if pruning_off else None,
+            # the same bracket with the three-limb / six-product form of the conv kernel (ddk_config.conv_kernel = 3, the default of rounds 3 - 5) in every context
+            'value_six_limb_products': (other_limbs['value'] if (other_limbs and other_limbs['conv_kernel'] == 3) else (n_done / elapsed if kern_default == 3 else None)),
             'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True, 'scaling': 'strong' if (big or shard_set) else 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'dtype_note': 'every operand and accumulator of the path is fp32; the radial-MLP GEMMs multiply the fp32 operands exactly as three f16 limbs each on the f16 '
-                          'matrix pipe (six of nine limb products, dropped terms <= 3 * 2^-33 relative) with fp32 accumulation (DESIGN.md 3.3)',
+            'dtype_note': ('every input, weight, accumulator and output of the path is fp32; the radial-MLP GEMMs multiply the fp32 operands on the f16 matrix pipe as ' +
+                           ('three f16 limbs each (six of nine limb products, dropped terms <= 3 * 2^-33 relative: ddk_config.conv_kernel = 3)' if kern_default == 3 else
+                            'two f16 limbs each, hi + mid rounded to nearest (|x - hi - mid| <= 2^-22 |x|), four limb products: <= 2^-21 relative per product, measured level with '
+                            'fp32 FMA chains and with the six-product form against the fp64 oracle (6 - 9e-8 relative per conv layer, tests/test_gpu_round6.py; value_six_limb_products '
+                            'is the same bracket with conv_kernel = 3)') + ', fp32 accumulation (DESIGN.md 3.3)'),
             'config': {'workload': f'BASELINE config {cfg_id}: ' + CONFIG_TEXT[cfg_id] + ('; receptor sizes of the set drawn timesplit-shaped (synthetic.timesplit_shape: log-normal, '
                                    'median 350, clipped to [60, 3000] residues), ligands 10-80 atoms' if (spread_ligands and not a.fixed_receptor) else '') + '; 1 step = 1 complex',
                        'bracket': 'wall time around sampling(data_list, model, ...) on host data_lists, a new complex every call (evaluate.py:259,293): '
@@ -743,14 +792,19 @@ def main():
                        # the three figures belong together, here too because the driver's record keeps `config`
                        'value_headline_pruning_off_pocket_bound': [round(n_done / elapsed, 3), None if not pruning_off else round(pruning_off['value'], 3),
                                                                    None if not pocket_bound else round(pocket_bound['value'], 3)],
+                       'conv_kernel': kern_default,
+                       'value_six_limb_products_conv_kernel_3': None if not (other_limbs and other_limbs['conv_kernel'] == 3) else round(other_limbs['value'], 3),
                        'samples_per_complex': SAMPLES, 'inference_steps': STEPS, 'complexes_per_gpu': n_cx,
                        'parallelism': (f'the {SAMPLES} samples of every complex sharded over {world} process(es) ({b_local} per GPU), final all_gather'
                                        if big else f'{world} process(es), one per GPU, each with the same {n_cx} complexes (own start poses and noise: per-GPU work fixed), final RCCL all_gather of the poses')},
-            'roofline': {'bound': 'mfma', 'kernel': 'ddk::conv_x3_kernel<true, true, false> (k_conv_x.hip: fp32 operands as three exact f16 limbs, six limb '
-                                                    'products on v_mfma_f32_32x32x16_f16, fp32 accumulators)',
+            'roofline': {'bound': 'mfma', 'kernel': ('ddk::conv_x3_kernel<true, true, false> (k_conv_x.hip: fp32 operands as three exact f16 limbs, six limb '
+                                                     'products on v_mfma_f32_32x32x16_f16, fp32 accumulators)' if kern_default == 3 else
+                                                     'ddk::conv_x2_kernel<true, true, false> (k_conv_x4.hip = k_conv_x.hip with two f16 limbs per fp32 operand, four limb '
+                                                     'products on v_mfma_f32_32x32x16_f16, one fp32 accumulator)'),
                          'achieved': tf(mfma_exec), 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf(mfma_exec) / PEAK_F16_MFMA_TFLOPS,
-                         'accounting': 'achieved / frac: MFMA FLOPs the launches EXECUTED (per evaluated edge and layer: (W2 tiles + 1 GEMM1) x (432 K-columns of 32x32 f16 MFMA = 24 x 32x32x16 + 6 x '
-                                       '32x32x8 unpacked, per 32 edges) = six limb products of K = 72, rows padded to 32-row tiles) / HIP-event time of the '
+                         'accounting': 'achieved / frac: MFMA FLOPs the launches EXECUTED (per evaluated edge and layer: (W2 tiles + 1 GEMM1) x (' + ('432 K-columns of 32x32 f16 MFMA = 24 x 32x32x16 + 6 x '
+                                       '32x32x8 unpacked, per 32 edges) = six' if products == 6 else '288 K-columns of 32x32 f16 MFMA = 16 x 32x32x16 + 4 x 32x32x8 unpacked, per 32 edges) = four') +
+                                       ' limb products of K = 72, rows padded to 32-row tiles) / HIP-event time of the '
                                        'launches, against the dense f16 matrix peak.  fp32_equivalent_TFLOPs: the ALGORITHMIC fp32 FLOPs of the same edges '
                                        '(2*72*(72+W) + TP per edge and layer, BASELINE.md section 3) / the same time - what an fp32 kernel would have to sustain; '
                                        'the fp32 MFMA peak is 157.3.  reference_equivalent_TFLOPs additionally counts the receptor-receptor messages the backward '
@@ -774,12 +828,16 @@ def main():
                          'conv_share_of_wall_incl_ar_model': None if head.get('ar_conv_ms') is None else (conv_ms + head['ar_conv_ms']) * 1e-3 / sum(head['pass_elapsed_s']),
                          # the BASELINE metric's second clause at the REFERENCE's op boundary (tensor_layers.py:65-116, weights [E, W] in HBM): the HBM-bound kernel
                          'tp_boundary_A': tp_boundary,
+                         'limb_products': products,
+                         # the other form of the f16-limb kernel through the same bracket (None: --no-alt / --no-extras): what the executed-MFMA fraction is when six products are multiplied
+                         'other_limb_form': None if not other_limbs else {k_: other_limbs[k_] for k_ in ('conv_kernel', 'limb_products', 'value', 'avg_launch_ms', 'mfma_TFLOPs_executed',
+                                                                                                          'frac_of_f16_matrix_peak', 'conv_fp32_equivalent_TFLOPs')},
                          'per_layer': [{'layer': l, 'ms_per_launch': p['ms'] / max(p['launches'], 1), 'w2_tiles': n_tiles[l],
-                                        'mfma_TFLOPs': p['edges'] * MFMA_FLOP_PER_EDGE_TILE * (n_tiles[l] + 1) / max(p['ms'], 1e-9) / 1e9,
+                                        'mfma_TFLOPs': p['edges'] * mfma_tile * (n_tiles[l] + 1) / max(p['ms'], 1e-9) / 1e9,
                                         'fp32_equivalent_TFLOPs': p['edges'] * layer_flop[l] / max(p['ms'], 1e-9) / 1e9,
                                         'edges_executed_frac': p['edges'] / max(p['edges_unpruned'], 1)}
                                        for l, p in enumerate(prof)]},
-            'extra': {'pruning_off': pruning_off, 'pocket_bound': pocket_bound, 'per_step': per_step, 'create_ms': create_ms, 'pose_digest': None if big else pose_digest,
+            'extra': {'pruning_off': pruning_off, 'pocket_bound': pocket_bound, 'other_limb_form': other_limbs, 'per_step': per_step, 'create_ms': create_ms, 'pose_digest': None if big else pose_digest,
                       'per_call_spread_same_complex': per_call_spread,
                       'headline': dict({k: v for k, v in summary(head, n_done).items() if k != 'value'}, passes=head['passes'], pass_elapsed_s=head['pass_elapsed_s']),
                       'per_receptor_size_decile': per_decile,

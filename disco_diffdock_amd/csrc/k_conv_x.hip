@@ -45,7 +45,15 @@
 #include <stdlib.h>
 
 #include "k_conv_common.h"
+#ifdef X3_P4
+// k_conv_x4.hip compiles this file a second time as the FOUR-product form (ddk_config.conv_kernel, include/ddk.h): the same kernel under its own names
+#define conv_x3_kernel conv_x2_kernel
+#define launch_conv_fused_x launch_conv_fused_x4
+#define conv_prepare_device_x conv_prepare_device_x4
+#include "k_conv_x_epi4_gen.inc"     // ... generated with GEN_ONE_ACC=1: one accumulator, nothing to fold
+#else
 #include "k_conv_x_epi_gen.inc"      // the tile epilogue as one asm statement per ring stage (tools/gen_conv_x_epi.py; round 5)
+#endif
 
 namespace ddk {
 
@@ -171,7 +179,18 @@ __device__ __forceinline__ void segf_add_n(float* dst, int stride, float (&xv)[N
 #undef SEGF_STEP
 
 // six-term product of one K step into the two accumulators, alternating (D0: hi.hi and the 2^-11 terms, D1: the 2^-22 terms)
-#ifdef ONE_ACC
+#if defined(X3_P4)
+// four limb products on two limbs per operand (hi, mid: 22 bits of significand): hi.hi + hi.mid + mid.hi + mid.mid in ONE accumulator, 18 MFMAs per tile
+#define X3_D1(r) 0.0f
+#define X3_TAIL3(a_lh, a_hm) (void)(a_lh); D0 = MFMA16(a_hm, HT.mh, D0); D0 = MFMA16(a_hm, HT.hm, D0);
+#define X3_STEP(MF, ah, am, al, bh, bm, bl)   \
+  (void)(al);                                 \
+  D0 = MF(am, bm, D0);                        \
+  D0 = MF(ah, bm, D0);                        \
+  D0 = MF(am, bh, D0);                        \
+  D0 = MF(ah, bh, D0);
+#elif defined(ONE_ACC)
+#define X3_D1(r) D1[r]
 #define X3_TAIL3(a_lh, a_hm) D0 = MFMA16(a_lh, HT.hl, D0); D0 = MFMA16(a_hm, HT.mh, D0); D0 = MFMA16(a_hm, HT.hm, D0);
 #define X3_STEP(MF, ah, am, al, bh, bm, bl)   \
   D0 = MF(ah, bl, D0);                        \
@@ -181,6 +200,7 @@ __device__ __forceinline__ void segf_add_n(float* dst, int stride, float (&xv)[N
   D0 = MF(am, bh, D0);                        \
   D0 = MF(ah, bh, D0);
 #else
+#define X3_D1(r) D1[r]
 #define X3_TAIL3(a_lh, a_hm) D0 = MFMA16(a_hm, HT.mh, D0); D1 = MFMA16(a_lh, HT.hl, D1); D0 = MFMA16(a_hm, HT.hm, D0);
 #define X3_STEP(MF, ah, am, al, bh, bm, bl)   \
   D1 = MF(ah, bl, D1);                        \
@@ -500,7 +520,11 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
             // (the K = 8 half step packed like the tile tail: hi.mid + mid.hi, lo.hi + hi.lo, hi.hi + mid.mid as one K = 16 MFMA each: 9 instead of 12 per row tile)
             const f16x8 a_hm = __builtin_shufflevector(ah, am, 0, 1, 2, 3, 4, 5, 6, 7), a_lh = __builtin_shufflevector(al, ah, 0, 1, 2, 3, 4, 5, 6, 7);
             D0 = MFMA16(a_hm, b1_mh, D0);
+#ifndef X3_P4
             D1 = MFMA16(a_lh, b1_hl, D1);
+#else
+            (void)a_lh; (void)b1_hl;
+#endif
             D0 = MFMA16(a_hm, b1_hm, D0);
           }
           const int nr = T < 2 ? 16 : 4;
@@ -651,7 +675,10 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
     // the first K step of the first tile and its descriptor (the two words ride behind the bias in the ring record: an LDS read, not a scalar
     // load - a scalar load in flight turns every counted LDS wait into a full one); later tiles: fetched in the previous burst's tail
     Frag16 p0;
-    p0.h = *reinterpret_cast<const f16x8*>(ringl); p0.m = *reinterpret_cast<const f16x8*>(ringl + W2X_LIMB_BYTES); p0.l = *reinterpret_cast<const f16x8*>(ringl + 2 * W2X_LIMB_BYTES);
+    p0.h = *reinterpret_cast<const f16x8*>(ringl); p0.m = *reinterpret_cast<const f16x8*>(ringl + W2X_LIMB_BYTES);
+#ifndef X3_P4
+    p0.l = *reinterpret_cast<const f16x8*>(ringl + 2 * W2X_LIMB_BYTES);
+#endif
 #ifdef X3_PF2          // (experiment: fragments requested TWO K steps ahead: p0 / p1 of a tile in the previous burst's last two steps, +12 VGPRs across the epilogue)
     Frag16 p1;
     p1.h = *reinterpret_cast<const f16x8*>(ringl + 1024); p1.m = *reinterpret_cast<const f16x8*>(ringl + W2X_LIMB_BYTES + 1024); p1.l = *reinterpret_cast<const f16x8*>(ringl + 2 * W2X_LIMB_BYTES + 1024);
@@ -720,8 +747,40 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
     // one tile: burst + epilogue; ST = the tile's ring stage (compile time)
 #define X3_PAIR(mask) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(mask, 1, 0); }
 #define X3_BARE { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }
+#ifdef X3_P4
+#define X3_FRAG(f, off) f.h = *reinterpret_cast<const f16x8*>(ringl + (off)); f.m = *reinterpret_cast<const f16x8*>(ringl + W2X_LIMB_BYTES + (off));
+#define X3_TRIO(mask) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(mask, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+#else
 #define X3_FRAG(f, off) f.h = *reinterpret_cast<const f16x8*>(ringl + (off)); f.m = *reinterpret_cast<const f16x8*>(ringl + W2X_LIMB_BYTES + (off)); f.l = *reinterpret_cast<const f16x8*>(ringl + 2 * W2X_LIMB_BYTES + (off));
-#ifdef X3_PF2
+#endif
+#if defined(X3_P4)
+/* four products per K step: 18 MFMAs; the same riders (two limbs of every fragment), four shadows per region */
+#define X3_BURST_BODY(ST)                                                                                                                    \
+      Frag16 p1; X3_FRAG(p1, SO + 1024)                                                                                                      \
+      const f32x4 f0 = ldv4(Fp);                                                                                                             \
+      const u32x4 st0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)fo0, rec_soff, 0);                                                  \
+      const u32x4 st1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)fo1, rec_soff, 0);                                                  \
+      rec_soff += W2X_TILE_BYTES;                                                                                                            \
+      X3_STEP(MFMA16, p0.h, p0.m, p0.l, H.hi[0], H.mid[0], H.lo[0])                                                                         \
+      X3_PAIR(0x100) X3_PAIR(0x020) X3_PAIR(0x100) X3_TRIO(0x020)                                                                            \
+      __builtin_amdgcn_sched_barrier(0);                                                                                                     \
+      Frag16 q2; X3_FRAG(q2, SO + 2048)                                                                                                      \
+      const f16x4 th = *reinterpret_cast<const f16x4*>(ringt + SO + 4096);                                                                   \
+      const f16x4 tm = *reinterpret_cast<const f16x4*>(ringt + SO + W2X_LIMB_BYTES + 4096);                                                  \
+      const f16x4 tl = th;                                                                                                                   \
+      X3_STEP(MFMA16, p1.h, p1.m, p1.l, H.hi[1], H.mid[1], H.lo[1])                                                                         \
+      X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100)                                                                            \
+      __builtin_amdgcn_sched_barrier(0);                                                                                                     \
+      Frag16 q3; X3_FRAG(q3, SO + 3072)                                                                                                      \
+      X3_STEP(MFMA16, q2.h, q2.m, q2.l, H.hi[2], H.mid[2], H.lo[2])                                                                         \
+      X3_PAIR(0x100) X3_PAIR(0x100) X3_BARE X3_BARE                                                                                          \
+      __builtin_amdgcn_sched_barrier(0);                                                                                                     \
+      const int2 dq = *reinterpret_cast<const int2*>(ring + SN + W2X_DESC_OFF);                                                              \
+      X3_FRAG(p0, SN)                                                                                                                        \
+      X3_STEP(MFMA16, q3.h, q3.m, q3.l, H.hi[3], H.mid[3], H.lo[3])                                                                         \
+      X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_BARE                                                                                   \
+      __builtin_amdgcn_sched_barrier(0);
+#elif defined(X3_PF2)
 #define X3_BURST_BODY(ST)                                                                                                                    \
       Frag16 q2; X3_FRAG(q2, SO + 2048)                                                                                                      \
       const f32x4 f0 = ldv4(Fp);                                                                                                             \
@@ -775,6 +834,11 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
       X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_BARE X3_BARE                                                            \
       __builtin_amdgcn_sched_barrier(0);
 #endif
+#ifdef X3_P4
+#define X3_TAIL_BARES X3_BARE X3_BARE
+#else
+#define X3_TAIL_BARES X3_BARE X3_BARE X3_BARE
+#endif
 #define X3_TILE(ST)                                                                                                                          \
     {                                                                                                                                        \
       constexpr int SO = (ST) * W2X_TILE_BYTES, SN = (((ST) + 1) & 3) * W2X_TILE_BYTES, SW = (((ST) + 3) & 3) * W2X_TILE_BYTES;              \
@@ -794,7 +858,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
         const f16x8 a_hm = __builtin_shufflevector(th, tm, 0, 1, 2, 3, 4, 5, 6, 7), a_lh = __builtin_shufflevector(tl, th, 0, 1, 2, 3, 4, 5, 6, 7); \
         X3_TAIL3(a_lh, a_hm)                                                                                                                 \
       }                                                                                                                                      \
-      X3_BARE X3_BARE X3_BARE                                                                                                                \
+      X3_TAIL_BARES                                                                                                                          \
       __builtin_amdgcn_sched_barrier(0);                                                                                                     \
       __builtin_amdgcn_s_setprio(0);                                                                                                         \
       stamp(1);                                                                                                                              \
@@ -866,6 +930,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
   }
 }
 
+#ifndef X3_P4
 // Test hook kernel: the in-kernel limb split of n fp32 values (one range scale per group of `group` consecutive values, like the kernel's
 // per-edge scaling): limbs as fp32, and the scale
 __global__ void split3_probe_kernel(const float* x, int64_t n, int group, float* hi, float* mid, float* lo, float* scale) {
@@ -886,6 +951,8 @@ hipError_t launch_split3_probe(const float* x, int64_t n, int group, float* hi, 
   return hipGetLastError();
 }
 
+#endif      // !X3_P4
+
 template <bool GATHER, bool SPLIT, bool DET>
 static hipError_t launch_x_t(const ConvXArgs& k, int n_cu, hipStream_t s) {
   hipLaunchKernelGGL((conv_x3_kernel<GATHER, SPLIT, DET>), dim3(n_cu), dim3(64 * CONV_WAVES), CONV_X_LDS_BYTES, s, k);
@@ -898,6 +965,7 @@ static hipError_t attr_x_t() {
                              (int)CONV_X_LDS_BYTES);
 }
 
+#ifndef X3_P4
 bool conv_epilogue_shapes_ok(const std::vector<TileDesc>& tiles) {
   if (tiles.empty()) return false;
   for (const TileDesc& t : tiles) {
@@ -911,6 +979,7 @@ bool conv_epilogue_shapes_ok(const std::vector<TileDesc>& tiles) {
   const int last = x_tile_word(tiles.back().w0);
   return ((last >> 2) & 3) != 0;      // (a unit ends with a flush)
 }
+#endif      // !X3_P4
 
 hipError_t conv_prepare_device_x() {
   hipError_t e = attr_x_t<true, true, false>();
@@ -927,7 +996,7 @@ hipError_t conv_prepare_device_x() {
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<false, false, false, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)CONV_X_LDS_BYTES);
-#ifdef DDK_VARIANT_CONV_Y
+#if defined(DDK_VARIANT_CONV_Y) && !defined(X3_P4)
   if (e == hipSuccess) e = conv_prepare_device_y();
 #endif
   return e;
@@ -964,7 +1033,7 @@ hipError_t launch_conv_fused_x(const ConvLayerDev& L, const ConvLaunch& a, int n
     conv_det_fix(k, a, L.dout, s);
     return hipGetLastError();
   }
-#ifdef DDK_VARIANT_CONV_Y      // tools/variants/k_conv_y.hip (round 5's one-wave-per-SIMD form, +9 %): linked by tools/build_variant_y.sh only
+#if defined(DDK_VARIANT_CONV_Y) && !defined(X3_P4)      // tools/variants/k_conv_y.hip (round 5's one-wave-per-SIMD form, +9 %): linked by tools/build_variant_y.sh only
   if (a.gather && a.pre != nullptr && (a.trace == nullptr || a.trace_coarse == 1) && L.epi_ok && a.use_y) {
     X.trace = a.trace;      // (its TRACE instantiation writes the per-unit records only)
     return launch_conv_y(X, n_cu, s);

@@ -84,7 +84,7 @@ class Context:
     def __init__(self, device=0, **cfg):
         self.L = _lib.lib()
         d = dict(DEFAULTS)
-        if os.environ.get('DDK_CONV_KERNEL'):     # 1: the fp32-MFMA conv kernel (the fallback) for every context of this process
+        if os.environ.get('DDK_CONV_KERNEL'):     # 1: the fp32-MFMA conv kernel (the fallback), 3: the three-limb / six-product form, for every context of this process
             d['conv_kernel'] = int(os.environ['DDK_CONV_KERNEL'])
         if os.environ.get('DDK_DETERMINISTIC'):   # select the deterministic scatter for every context of this process
             d['deterministic'] = int(os.environ['DDK_DETERMINISTIC'])

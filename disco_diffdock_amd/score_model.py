@@ -137,10 +137,10 @@ class TensorProductScoreModel(nn.Module):
                  confidence_dropout=0, confidence_no_batchnorm=False, num_confidence_outputs=1, **unused):
         super().__init__()
         if 'conv_f16x3' in unused or os.environ.get('DDK_CONV_F16X3') is not None:
-            # round 2's switch had the opposite sense (1 = the f16 kernel); round 3 replaced it by conv_kernel (0 = exact three-limb f16, the
-            # default; 1 = fp32 MFMA).  Swallowing the old spelling would switch kernels silently.
+            # round 2's switch had the opposite sense (1 = the f16 kernel); round 3 replaced it by conv_kernel (0 = the f16-limb kernel, the
+            # default; 1 = fp32 MFMA; since ddk 0.8: 0 = two limbs / four products, 3 = three limbs / six products).  Swallowing the old spelling would switch kernels silently.
             raise RuntimeError("ddk: the conv_f16x3 option / DDK_CONV_F16X3 variable was replaced by the conv_kernel option "
-                               "(0 = exact three-limb f16 product, default; 1 = fp32 MFMA) - see INTEGRATION.md")
+                               "(0 = f16-limb product, default; 1 = fp32 MFMA; 3 = three-limb / six-product form) - see INTEGRATION.md")
         if sh_lmax != 1 or use_second_order_repr or use_old_atom_encoder or latent_cross_attention:
             raise RuntimeError('ddk implements the sh_lmax=1 first-order score model with the new AtomEncoder only')
         if confidence_mode and (num_conv_layers < 4 or latent_dim):      # (ddk_create: num_conv_layers in [4, 16]; the predictor reads the full 0e+1o+1e+0o rows)
@@ -162,7 +162,7 @@ class TensorProductScoreModel(nn.Module):
         self.confidence_mode = bool(confidence_mode)
         if confidence_mode:      # models/score_model.py:110-121: no score heads, a confidence_predictor on the pooled ligand scalars (ddk_score_confidence)
             self.cfg.update(confidence_mode=1, num_confidence_outputs=int(num_confidence_outputs), confidence_no_batchnorm=int(bool(confidence_no_batchnorm)))
-        if conv_kernel is not None:      # extra (not in the reference ctor): 1 selects the fp32-MFMA conv kernel (ddk_config.conv_kernel)
+        if conv_kernel is not None:      # extra (not in the reference ctor): 1 selects the fp32-MFMA conv kernel, 3 the three-limb / six-product form (ddk_config.conv_kernel)
             self.cfg['conv_kernel'] = int(conv_kernel)
         self.ctx = Context(device=dev_index, **self.cfg)
         self.no_torsion = no_torsion

@@ -100,6 +100,30 @@ def test_bench_line_reports_executed_work_and_both_floors(dev):
     assert all(p['GBps'] > 3000 for p in tp['per_layer']), tp['per_layer']      # (round 5's kernel: 3 100 - 4 300; the new one 4 700 - 5 500)
 
 
+def test_bench_line_carries_the_other_limb_form_of_the_conv_kernel(dev):
+    """Round 6: the default conv kernel multiplies two f16 limbs per operand (four products); the line also carries the SAME sampling() bracket with the three-limb /
+    six-product form (ddk_config.conv_kernel = 3, the default of rounds 3 - 5) in every context - value_six_limb_products at the top level and under `config` (keys
+    the driver's record keeps), the launch time and executed-MFMA fraction under roofline.other_limb_form - and the executed-work accounting follows the form that ran."""
+    out = _bench('--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-device-loop', '--no-timesplit', '--no-tp-boundary')
+    rf, kern = out['roofline'], int(os.environ.get('DDK_CONV_KERNEL', '0'))
+    assert out['config']['conv_kernel'] == kern
+    if kern == 1:
+        assert rf['other_limb_form'] is None and out['value_six_limb_products'] is None
+        return
+    o = out['extra']['other_limb_form']
+    assert rf['limb_products'] == (6 if kern == 3 else 4) and o['limb_products'] == (4 if kern == 3 else 6) and o['conv_kernel'] == (0 if kern == 3 else 3)
+    assert rf['other_limb_form']['value'] == o['value'] and o['value'] > 0
+    six_ms, four_ms = (rf['avg_launch_ms'], o['avg_launch_ms']) if kern == 3 else (o['avg_launch_ms'], rf['avg_launch_ms'])
+    assert 1.10 < six_ms / four_ms < 1.45, (six_ms, four_ms)            # 27 vs 18 MFMAs per weight tile: measured 1.25 - 1.27
+    if kern == 0:
+        assert out['value_six_limb_products'] == o['value'] and out['config']['value_six_limb_products_conv_kernel_3'] == round(o['value'], 3)
+    else:
+        assert out['value_six_limb_products'] == out['value']
+    # per evaluated edge and tile the four-product form executes 2/3 of the six-product form's MFMA FLOPs
+    assert o['frac_of_f16_matrix_peak'] == pytest.approx(o['mfma_TFLOPs_executed'] / 2500.0)
+    assert out['fallback_fp32_kernel']['value'] > 0
+
+
 # ------------------------------------------------------------------------------------------------------------------------------------------
 # the exact three-limb f16 product of the default conv kernel (VERDICT r02 #3 i, ii)
 # ------------------------------------------------------------------------------------------------------------------------------------------
@@ -150,8 +174,9 @@ def test_device_limb_split_is_exact(dev, scale, binades):
 
 
 def test_three_limb_product_at_least_as_accurate_as_fp32_chain(dev):
-    """(ii): one conv layer at W = 1872 on 20k edges against the fp64 oracle: the three-limb f16 kernel's error is not above the fp32-MFMA
-    kernel's (products are exact and only three of nine limb products, <= 3 * 2^-33, are dropped; both accumulate in fp32)."""
+    """(ii): one conv layer at W = 1872 on 20k edges against the fp64 oracle: the three-limb f16 kernel's error (ddk_config.conv_kernel = 3 since round 6) is not
+    above the fp32-MFMA kernel's (products are exact and only three of nine limb products, <= 3 * 2^-33, are dropped; both accumulate in fp32).  The default
+    two-limb / four-product form has its own test (test_gpu_round6.py::test_two_limb_four_product_kernel_is_fp32_grade)."""
     from disco_diffdock_amd.runtime import Context
     from test_gpu_ops import _random_case, CFG as OCFG
     l, N, splits = 3, 1000, [0, 3000, 9000, 15000, 20000]
@@ -163,19 +188,20 @@ def test_three_limb_product_at_least_as_accurate_as_fp32_chain(dev):
                             i_irr, '1x0e+1x1o', o_irr, residual=True, batch_norm=True, faster=True, edge_groups=4)
     args = (l, node.to(dev), ei[0].to(dev), ei[1].to(dev), splits, ea.to(dev), sh.to(dev), smr.irreps_dim(o_irr))
     err = {}
-    for kernel in (0, 1):
+    for kernel in (3, 1):
         ctx = Context(device=0, conv_kernel=kernel)
         ctx.load_state_dict({f'conv_layers.{l}.{k}': v for k, v in Pl.items()})
         out = ctx.conv_forward(*args).cpu()
         err[kernel] = (rel_err(out, ref), elem_err(out, ref))
-    print(f'conv layer vs fp64: three-limb f16 {err[0]}, fp32 MFMA {err[1]}')
-    assert err[0][0] < 1e-5 and err[0][0] <= 1.25 * err[1][0] + 1e-7 and err[0][1] <= 1.25 * err[1][1] + 1e-6, err
+    print(f'conv layer vs fp64: three-limb f16 {err[3]}, fp32 MFMA {err[1]}')
+    assert err[3][0] < 1e-5 and err[3][0] <= 1.25 * err[1][0] + 1e-7 and err[3][1] <= 1.25 * err[1][1] + 1e-6, err
 
 
 # ------------------------------------------------------------------------------------------------------------------------------------------
 # the core parity tests once more under every (conv kernel, scatter) mode, inside the driver's single `pytest -m gpu` (VERDICT r02 #5d)
 # ------------------------------------------------------------------------------------------------------------------------------------------
-@pytest.fixture(params=[(0, 0), (0, 1), (1, 0), (1, 1)], ids=['x3-atomics', 'x3-deterministic', 'fp32-atomics', 'fp32-deterministic'])
+@pytest.fixture(params=[(0, 0), (0, 1), (1, 0), (1, 1), (3, 0), (3, 1)],
+                ids=['x2-atomics', 'x2-deterministic', 'fp32-atomics', 'fp32-deterministic', 'x3-atomics', 'x3-deterministic'])
 def mode(request, monkeypatch):
     """every ddk context created inside the test runs the given conv kernel / scatter mode (runtime.Context reads the switches)"""
     kernel, det = request.param
@@ -303,7 +329,7 @@ def test_workload_size_trajectory_vs_oracle(dev, tables):
     assert err < 1e-3
 
 
-@pytest.mark.parametrize('kernel', [0, 1])
+@pytest.mark.parametrize('kernel', [0, 1, 3])
 def test_pruned_trajectory_equals_unpruned_over_twenty_steps(dev, kernel):
     """(b) the receptive-field pruning over 20 ACCUMULATING steps at workload size, deterministic scatter on both sides (no atomics: what
     differs is only which dead messages are evaluated and where the 32-edge tile boundaries fall inside the re-ordered rec-rec group, i.e.

@@ -294,3 +294,37 @@ def test_deterministic_samples_do_not_depend_on_the_batch_around_them(dev):
                     assert torch.equal(a, b[sl]), (n_res, t, sl, name, float((a - b[sl]).abs().max()))
                 small.close()
         full.close()
+
+
+@pytest.mark.parametrize('l', range(5))
+def test_two_limb_four_product_kernel_is_fp32_grade(dev, l):
+    """The default conv kernel since round 6 (ddk_config.conv_kernel = 0, k_conv_x4.hip): every operand of the two radial-MLP GEMMs (tensor_layers.py:140-143,154-155)
+    as TWO fp16 limbs, the four limb products in one fp32 accumulator.  hi = fp16(x) and mid = fp16(x - hi) round to nearest, so |x - hi - mid| <= 2^-22 |x| (<= 2^-25
+    absolute after the per-group range scaling for values more than 2^-3 under their group's maximum): a product carries <= 2^-21 relative error, the size of what an fp32
+    FMA chain over K = 72 accumulates (sqrt(72) * 2^-24).  Measured here on 20k edges of every layer shape against the fp64 oracle, beside the three-limb / six-product
+    kernel (3: products exact to 2^-33) and the fp32-MFMA chains (1): the default must stay within 1.5x of the fp32 chains' error (+ 1e-7) and under 1e-5 relative -
+    an order under north_star's 1e-4."""
+    from disco_diffdock_amd.runtime import Context
+    from test_gpu_ops import _random_case, CFG as OCFG
+    from helpers import elem_err
+    from test_gpu_round3 import _record_drift
+    N, splits = 1000, [0, 3000, 9000, 15000, 20000]
+    i_irr, o_irr = OCFG.conv_irreps(l)
+    Pl = smr.random_conv_layer_params(OCFG, l, 321 + l, True)
+    node, ei, ea, sh = _random_case(l, N, splits, 9 + l, True)
+    P = {'L.' + k: v.double() for k, v in Pl.items()}
+    ref = smr.tp_conv_layer(P, 'L', node.double(), ei, [ea.double()[splits[i]:splits[i + 1]] for i in range(4)], sh.double(),
+                            i_irr, '1x0e+1x1o', o_irr, residual=True, batch_norm=True, faster=True, edge_groups=4)
+    args = (l, node.to(dev), ei[0].to(dev), ei[1].to(dev), splits, ea.to(dev), sh.to(dev), smr.irreps_dim(o_irr))
+    err, outs = {}, {}
+    for kernel in (0, 1, 3):
+        ctx = Context(device=0, conv_kernel=kernel)
+        assert int(ctx.cfg.conv_kernel) == kernel
+        ctx.load_state_dict({f'conv_layers.{l}.{k}': v for k, v in Pl.items()})
+        outs[kernel] = ctx.conv_forward(*args).cpu()
+        err[kernel] = (rel_err(outs[kernel], ref), elem_err(outs[kernel], ref))
+    print(f'conv layer {l} vs fp64: four products (default) {err[0]}, fp32 MFMA chains {err[1]}, six products {err[3]}')
+    _record_drift(f'conv_layer_{l}_20k_edges_vs_fp64_four_products_default', err[0][0], bar=1e-5,
+                  four_products=err[0][0], fp32_chains=err[1][0], six_products=err[3][0], four_products_elem=err[0][1], fp32_chains_elem=err[1][1], six_products_elem=err[3][1])
+    assert not torch.equal(outs[0], outs[3])                  # (it IS another arithmetic: the mode switch reaches the kernel)
+    assert err[0][0] < 1e-5 and err[0][0] <= 1.5 * err[1][0] + 1e-7 and err[0][1] <= 1.5 * err[1][1] + 1e-6, err

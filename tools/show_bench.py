@@ -11,5 +11,8 @@ for f in sys.argv[1:]:
     for k in ('pruning_off', 'pocket_bound'):
         if e.get(k):
             print(f"   {k}: {e[k]['value']:.2f}")
+    o = e.get('other_limb_form')
+    if o:
+        print(f"   conv_kernel = {o['conv_kernel']} ({o['limb_products']} limb products): {o['value']:.2f}, avg launch {o['avg_launch_ms']:.4f} ms, frac {o['frac_of_f16_matrix_peak']:.3f}")
     if d.get('cpu_baseline'):
         print('   cpu_baseline', d['cpu_baseline']['value'], d['cpu_baseline']['sample'][:120])

@@ -24,7 +24,7 @@ for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
     if 'ddk::' not in k:
         continue
     per = sum(v) / fw
-    if 'conv_x3_kernel<true' not in k:
+    if 'conv_x3_kernel<true' not in k and 'conv_x2_kernel<true' not in k:
         tot_nc += per
     print('%-70s calls/fw %5.2f  avg %7.1f us  min %6.1f  per forward %7.1f us' % (k[:70], len(v) / fw, sum(v) / len(v), min(v), per))
 print('non-conv ddk kernels per forward: %.1f us' % tot_nc)

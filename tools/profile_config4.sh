@@ -22,16 +22,16 @@ f = glob.glob(os.path.join(out, '**', '*kernel_trace.csv'), recursive=True)[0]
 agg = defaultdict(list)
 for r in csv.DictReader(open(f)):
     agg[r['Kernel_Name']].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
-calls = n + 2        # timed + warm-up sampling() calls
+calls = max(len(v) for k, v in agg.items() if 'conf_head_kernel' in k)        # sampling() calls of the whole run: the headline bracket and the extra brackets, warm-ups included (one confidence head launch each)
 tot = sum(sum(v) for v in agg.values())
-print('# rocprofv3 --kernel-trace -- python bench.py --config 4 --complexes %d --steps %d --warmup 2 (MI355X; per sampling() call = per complex, %d calls)\n' % (n, n, calls))
+print('# rocprofv3 --kernel-trace -- python bench.py --config 4 --complexes %d --steps %d --warmup 2 (MI355X; per sampling() call = per complex, %d calls over all brackets of the run)\n' % (n, n, calls))
 print('under the profiler: %.2f complexes/s, %.2f ms per complex; kernel time per complex %.2f ms\n' % (d['value'], d['ms_per_step'], tot / calls / 1e3))
 print('| kernel | launches per complex | avg us | min us | max us | us per complex | % of kernel time |\n|---|---|---|---|---|---|---|')
 for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:40]:
     print('| %s | %.1f | %.1f | %.1f | %.1f | %.1f | %.2f |' % (k[:100], len(v) / calls, sum(v) / len(v), min(v), max(v), sum(v) / calls, 100 * sum(v) / tot))
 grp = defaultdict(float)
 for k, v in agg.items():
-    g = 'conv_x3 (score + AR + confidence layers)' if 'conv_x3_kernel<true' in k else ('confidence-only kernels (conf_*)' if 'conf_' in k else
+    g = 'f16-limb conv kernel (score + AR + confidence layers)' if ('conv_x3_kernel<true' in k or 'conv_x2_kernel<true' in k) else ('confidence-only kernels (conf_*)' if 'conf_' in k else
         ('AR logits / decode' if 'ar_' in k else ('runtime fills / copies' if '__amd_rocclr' in k else ('other ddk kernels' if 'ddk::' in k else 'torch / other'))))
     grp[g] += sum(v)
 print('\n| group | us per complex | % |\n|---|---|---|')

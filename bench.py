@@ -65,7 +65,7 @@ FUSED_BYTES = [408, 480, 552, 648, 648]                        # fused boundary,
 PEAK_F32_MFMA_TFLOPS = 157.3                                   # MI355X_MICROARCH.md
 PEAK_F16_MFMA_TFLOPS = 2500.0                                  # dense f16 / bf16 matrix peak (MI355X_MICROARCH.md; micro-benchmark ceiling 2382)
 MFMA_FLOP_PER_EDGE_TILE = {6: (24 * 2 * 32 * 32 * 16 + 6 * 2 * 32 * 32 * 8) / 32,      # k_conv_x.hip (conv_kernel = 3, six limb products): 432 K-columns of 32x32 per 32 edges and W2 tile (26 x 32x32x16 + 2 x 32x32x8 with the packed tail; 24 + 6 unpacked; the same count per GEMM1)
-                           4: (16 * 2 * 32 * 32 * 16 + 4 * 2 * 32 * 32 * 8) / 32}      # k_conv_x4.hip (the default, four limb products): 288 K-columns (16 x 32x32x16 + 2 packed tail MFMAs = 18 per tile)
+                           3: (14 * 2 * 32 * 32 * 16) / 32}      # k_conv_x2.hip (the default: two limbs, three limb products): 224 K-columns = 14 x 32x32x16 per tile (12 + the packed K = 8 tail's two, which carry mid.mid for free)
 PEAK_HBM_GBS = 8000.0
 
 ARGS_S = Namespace(ns=24, nv=6, num_conv_layers=5, sigma_embed_dim=32, distance_embed_dim=32, cross_distance_embed_dim=32,
@@ -95,7 +95,7 @@ CONFIG_TEXT = {
 }
 
 
-CONV_KERNEL_SOURCES = ('k_conv_x.hip', 'k_conv_x4.hip', 'k_conv_x_epi_gen.inc', 'k_conv_x_epi4_gen.inc', 'k_conv_common.h', 'ddk_internal.h')      # what the dominant kernel is compiled from
+CONV_KERNEL_SOURCES = ('k_conv_x.hip', 'k_conv_x2.hip', 'k_conv_x_epi_gen.inc', 'k_conv_x_epi2_gen.inc', 'k_conv_common.h', 'ddk_internal.h')      # what the dominant kernel is compiled from
 
 
 def conv_kernel_source_sha():
@@ -662,7 +662,7 @@ def main():
     kern_default = int(getattr(ctx.cfg, 'conv_kernel', 0))
     if not a.no_extras and not a.no_alt and kern_default in (0, 3) and not shard_set:
         # the same sampling() bracket with the OTHER form of the f16-limb conv kernel in every context (score model, AR model, confidence model): conv_kernel = 3
-        # (three limbs, six products: the default of rounds 3 - 5) beside the default 0 (two limbs, four products), or the other way round under DDK_CONV_KERNEL=3
+        # (three limbs, six products: the default of rounds 3 - 5) beside the default 0 (two limbs, three products), or the other way round under DDK_CONV_KERNEL=3
         other_k = 3 if kern_default == 0 else 0
         print(f'[bench] extras: conv_kernel = {other_k} bracket', file=sys.stderr, flush=True)
         mdl_o = build_models(conv_kernel=other_k)
@@ -671,13 +671,13 @@ def main():
         other_limbs = summary(r_o, n_done)
         conv_ms_o, launches_o = sum(p_['ms'] for p_ in r_o['prof']), sum(p_['launches'] for p_ in r_o['prof'])
         nt_o = [len(mdl_o[1].ctx.export(f'conv.{l}.tiles', dtype=np.int32)) // 4 for l in range(5)]
-        prod_o = 6 if other_k == 3 else 4
+        prod_o = 6 if other_k == 3 else 3
         mfma_o = sum(p_['edges'] * MFMA_FLOP_PER_EDGE_TILE[prod_o] * (nt_o[l] + 1) for l, p_ in enumerate(r_o['prof']))
         other_limbs.update(conv_kernel=other_k, limb_products=prod_o, avg_launch_ms=conv_ms_o / max(launches_o, 1),
                            mfma_TFLOPs_executed=mfma_o / max(conv_ms_o, 1e-9) / 1e9, frac_of_f16_matrix_peak=mfma_o / max(conv_ms_o, 1e-9) / 1e9 / PEAK_F16_MFMA_TFLOPS,
                            note=('the same bracket, workload, seeds and pruning with ddk_config.conv_kernel = %d in every context: ' % other_k) +
                                 ('three fp16 limbs per operand, six limb products exact to 2^-33 (k_conv_x.hip: the default of ddk 0.4 - 0.7)' if other_k == 3 else
-                                 'two fp16 limbs per operand, four limb products (k_conv_x4.hip: the default)'))
+                                 'two fp16 limbs per operand, three limb products (k_conv_x2.hip: the default)'))
         del mdl_o, r_o
     if not a.no_extras:
         w2 = min(a.warmup, 2)
@@ -734,7 +734,7 @@ def main():
         fl = lambda key: sum(p[key] * layer_flop[l] for l, p in enumerate(prof))
         flops_exec, flops_unpruned, flops_full = fl('edges'), fl('edges_unpruned'), fl('edges_reference')
         n_tiles = [len(ctx.export(f'conv.{l}.tiles', dtype=np.int32)) // 4 for l in range(5)]        # W2 tiles of 32 rows per layer (59 for W = 1872)
-        products = 6 if int(getattr(ctx.cfg, 'conv_kernel', 0)) == 3 else 4
+        products = 6 if int(getattr(ctx.cfg, 'conv_kernel', 0)) == 3 else 3
         mfma_tile = MFMA_FLOP_PER_EDGE_TILE[products]
         mfma_exec = sum(p['edges'] * mfma_tile * (n_tiles[l] + 1) for l, p in enumerate(prof))
         byts = sum(p['edges'] * FUSED_BYTES[l] for l, p in enumerate(prof))
@@ -781,9 +781,10 @@ def main():
             'dtype': 'f32', 'data': 'synthetic',
             'dtype_note': ('every input, weight, accumulator and output of the path is fp32; the radial-MLP GEMMs multiply the fp32 operands on the f16 matrix pipe as ' +
                            ('three f16 limbs each (six of nine limb products, dropped terms <= 3 * 2^-33 relative: ddk_config.conv_kernel = 3)' if kern_default == 3 else
-                            'two f16 limbs each, hi + mid rounded to nearest (|x - hi - mid| <= 2^-22 |x|), four limb products: <= 2^-21 relative per product, measured level with '
-                            'fp32 FMA chains and with the six-product form against the fp64 oracle (6 - 9e-8 relative per conv layer, tests/test_gpu_round6.py; value_six_limb_products '
-                            'is the same bracket with conv_kernel = 3)') + ', fp32 accumulation (DESIGN.md 3.3)'),
+                            'two f16 limbs each, hi + mid rounded to nearest (|x - hi - mid| <= 2^-22 |x|), the three limb products hi.hi + hi.mid + mid.hi (mid.mid <= 2^-22 dropped): '
+                            '<= 3 * 2^-22 relative per product, below the classical 72 * 2^-24 of an fp32 dot product of K = 72; measured level with fp32 FMA chains and with the six-product '
+                            'form against the fp64 oracle (6 - 10e-8 relative per conv layer, tests/test_gpu_round6.py; value_six_limb_products is the same bracket with conv_kernel = 3)') +
+                           ', fp32 accumulation (DESIGN.md 3.3)'),
             'config': {'workload': f'BASELINE config {cfg_id}: ' + CONFIG_TEXT[cfg_id] + ('; receptor sizes of the set drawn timesplit-shaped (synthetic.timesplit_shape: log-normal, '
                                    'median 350, clipped to [60, 3000] residues), ligands 10-80 atoms' if (spread_ligands and not a.fixed_receptor) else '') + '; 1 step = 1 complex',
                        'bracket': 'wall time around sampling(data_list, model, ...) on host data_lists, a new complex every call (evaluate.py:259,293): '
@@ -799,11 +800,11 @@ def main():
                                        if big else f'{world} process(es), one per GPU, each with the same {n_cx} complexes (own start poses and noise: per-GPU work fixed), final RCCL all_gather of the poses')},
             'roofline': {'bound': 'mfma', 'kernel': ('ddk::conv_x3_kernel<true, true, false> (k_conv_x.hip: fp32 operands as three exact f16 limbs, six limb '
                                                      'products on v_mfma_f32_32x32x16_f16, fp32 accumulators)' if kern_default == 3 else
-                                                     'ddk::conv_x2_kernel<true, true, false> (k_conv_x4.hip = k_conv_x.hip with two f16 limbs per fp32 operand, four limb '
+                                                     'ddk::conv_x2_kernel<true, true, false> (k_conv_x2.hip = k_conv_x.hip with two f16 limbs per fp32 operand, three limb '
                                                      'products on v_mfma_f32_32x32x16_f16, one fp32 accumulator)'),
                          'achieved': tf(mfma_exec), 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf(mfma_exec) / PEAK_F16_MFMA_TFLOPS,
                          'accounting': 'achieved / frac: MFMA FLOPs the launches EXECUTED (per evaluated edge and layer: (W2 tiles + 1 GEMM1) x (' + ('432 K-columns of 32x32 f16 MFMA = 24 x 32x32x16 + 6 x '
-                                       '32x32x8 unpacked, per 32 edges) = six' if products == 6 else '288 K-columns of 32x32 f16 MFMA = 16 x 32x32x16 + 4 x 32x32x8 unpacked, per 32 edges) = four') +
+                                       '32x32x8 unpacked, per 32 edges) = six' if products == 6 else '224 K-columns of 32x32 f16 MFMA = 14 x 32x32x16 per 32 edges) = three') +
                                        ' limb products of K = 72, rows padded to 32-row tiles) / HIP-event time of the '
                                        'launches, against the dense f16 matrix peak.  fp32_equivalent_TFLOPs: the ALGORITHMIC fp32 FLOPs of the same edges '
                                        '(2*72*(72+W) + TP per edge and layer, BASELINE.md section 3) / the same time - what an fp32 kernel would have to sustain; '

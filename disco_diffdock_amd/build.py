@@ -11,15 +11,15 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libddk.so')
-SOURCES = ['ddk_capi.hip', 'k_conv.hip', 'k_tp.hip', 'k_graph.hip', 'k_heads.hip', 'k_se3.hip', 'model.hip', 'conf.hip', 'k_conv_x.hip', 'k_conv_x4.hip', 'k_ar.hip']
+SOURCES = ['ddk_capi.hip', 'k_conv.hip', 'k_tp.hip', 'k_graph.hip', 'k_heads.hip', 'k_se3.hip', 'model.hip', 'conf.hip', 'k_conv_x.hip', 'k_conv_x2.hip', 'k_ar.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-mllvm', '-amdgpu-mfma-vgpr-form', '-Wall', '-Wno-unused-function', '-Wno-unused-value', '-Wno-unused-result']
 
 
 # per-file flags.  k_conv_x: the SLP vectoriser packs the fp32 epilogue FMAs into v_pk_fma_f32 with a v_mov shuffle per operand pair (packed
 # f32 VALU has no rate advantage on gfx950 and is an anti-lever next to MFMAs, MI355X_MICROARCH.md)
-FILE_FLAGS = {'k_conv_x.hip': ['-fno-slp-vectorize'], 'k_conv_x4.hip': ['-fno-slp-vectorize']}
+FILE_FLAGS = {'k_conv_x.hip': ['-fno-slp-vectorize'], 'k_conv_x2.hip': ['-fno-slp-vectorize']}
 # sources that are #included by another source (besides the headers): part of that object's content stamp
-INCLUDED_SOURCES = {'k_conv_x4.hip': ['k_conv_x.hip']}
+INCLUDED_SOURCES = {'k_conv_x2.hip': ['k_conv_x.hip']}
 
 
 def _hipcc():

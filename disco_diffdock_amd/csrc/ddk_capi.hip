@@ -446,7 +446,7 @@ static int pack_x3(ddk_ctx* ctx, ConvLayerDev& L, int NG, const std::vector<floa
   if (!exact) return fail(ctx, DDK_ERR_INVALID, "internal: the three-limb fp16 split of a conv weight is not exact");
   L.h_w2x = w2x; L.h_w1x = w1x;
   L.epi_ok = conv_epilogue_shapes_ok(L.h_tiles);      // launch_conv_fused_x refuses the asm-epilogue instantiation otherwise
-  L.products = ctx->cfg.conv_kernel == 3 ? 6 : 4;     // the default four-product form reads the first two limbs of the same records (k_conv_x4.hip); conv_kernel = 3: all three, six products
+  L.limbs = ctx->cfg.conv_kernel == 3 ? 3 : 2;        // the default two-limb form reads the first two limbs of the same records (k_conv_x2.hip); conv_kernel = 3: all three, six products
   if (ctx->host_only) return DDK_OK;
   L.w2x = (uint8_t*)dev_alloc(ctx, w2x.size());
   L.w1x = (uint8_t*)dev_alloc(ctx, w1x.size());
@@ -694,7 +694,7 @@ void model_destroy(ddk_ctx* ctx);   // model.hip
 
 extern "C" {
 
-const char* ddk_version(void) { return "ddk 0.8 (gfx950)"; }      // 0.8: conv_kernel = 0 is the two-limb / four-product form of the f16-limb kernel (k_conv_x4.hip), the three-limb / six-product form (the default of 0.4 - 0.7) is conv_kernel = 3; 0.7: conv_kernel = 2 left the library (tools/variants/), ddk_tp_forward walks columns (flat 16-B reads), ddk_debug_set_alloc_limit; 0.6: conv_kernel = 2 (k_conv_y.hip), streaming ddk_tp_forward, confidence edge capacity from geometry; 0.5: ddk_config.confidence_mode + ddk_score_confidence; 0.4: three-limb records carry limbs at their own weight + tile descriptors; conv_f16x3 removed (INTEGRATION.md "ABI notes")
+const char* ddk_version(void) { return "ddk 0.8 (gfx950)"; }      // 0.8: conv_kernel = 0 is the two-limb / three-product form of the f16-limb kernel (k_conv_x2.hip), the three-limb / six-product form (the default of 0.4 - 0.7) is conv_kernel = 3; 0.7: conv_kernel = 2 left the library (tools/variants/), ddk_tp_forward walks columns (flat 16-B reads), ddk_debug_set_alloc_limit; 0.6: conv_kernel = 2 (k_conv_y.hip), streaming ddk_tp_forward, confidence edge capacity from geometry; 0.5: ddk_config.confidence_mode + ddk_score_confidence; 0.4: three-limb records carry limbs at their own weight + tile descriptors; conv_f16x3 removed (INTEGRATION.md "ABI notes")
 
 int ddk_create(const ddk_config* cfg, ddk_ctx** out) {
   if (!cfg || !out) return DDK_ERR_INVALID;
@@ -715,7 +715,7 @@ int ddk_create(const ddk_config* cfg, ddk_ctx** out) {
   if (cfg->conv_kernel < 0 || cfg->conv_kernel > 3) return fail(ctx, DDK_ERR_INVALID, "conv_kernel must be 0, 1, 2 (variant build) or 3");
 #else
   if (cfg->conv_kernel < 0 || cfg->conv_kernel > 3 || cfg->conv_kernel == 2)
-    return fail(ctx, DDK_ERR_INVALID, "conv_kernel must be 0 (two f16 limbs per operand, four products), 1 (fp32 MFMA) or 3 (three f16 limbs, six products); 2 (round 5's software-pipelined form) lives under tools/variants/ and is not part of libddk.so");
+    return fail(ctx, DDK_ERR_INVALID, "conv_kernel must be 0 (two f16 limbs per operand, three products), 1 (fp32 MFMA) or 3 (three f16 limbs, six products); 2 (round 5's software-pipelined form) lives under tools/variants/ and is not part of libddk.so");
 #endif
   if (cfg->device < 0) {
     ctx->host_only = true;   // packing-only context (CPU tests); every launch entry point refuses to run

@@ -141,7 +141,7 @@ struct ConvLayerDev {          // device copies for one TensorProductConvLayer w
   uint8_t* w1x = nullptr;      // three-limb f16 kernel: [groups][3][W1X_TILE_BYTES]
   uint8_t* w2x = nullptr;      // three-limb f16 kernel: [groups][n_tiles][W2X_TILE_BYTES]
   float w1s[CONV_MAX_GROUPS] = {1, 1, 1, 1, 1, 1, 1, 1, 1}, w2s[CONV_MAX_GROUPS] = {1, 1, 1, 1, 1, 1, 1, 1, 1};   // three-limb f16 kernel: power-of-two range scale of the packed W1 / W2 of each weight set
-  int products = 4;            // limb products of the f16-limb kernel: 4 (two limbs per operand, k_conv_x4.hip: the default) or 6 (three limbs, k_conv_x.hip: conv_kernel = 3); set by pack_x3
+  int limbs = 2;               // fp16 limbs per fp32 operand in the f16-limb kernel: 2 (three products, k_conv_x2.hip: the default) or 3 (six products, k_conv_x.hip: conv_kernel = 3); set by pack_x3
   bool epi_ok = false;         // the tile table has the column shapes the generated asm epilogue hard-codes (conv_epilogue_shapes_ok): set by pack_x3
   int n_cols = 0;              // flush columns (8 output channels each); col_start[c] = first tile of column c, col_start[n_cols] = n_tiles
   int col_start[17] = {};
@@ -280,12 +280,12 @@ struct ConvLaunch {
 };
 hipError_t launch_conv_fused(const ConvLayerDev& L, const ConvLaunch& a, int n_cu, hipStream_t s);
 hipError_t launch_conv_fused_x(const ConvLayerDev& L, const ConvLaunch& a, int n_cu, hipStream_t s);   // k_conv_x.hip (three f16 limbs per operand, six products)
-hipError_t launch_conv_fused_x4(const ConvLayerDev& L, const ConvLaunch& a, int n_cu, hipStream_t s);  // k_conv_x4.hip (two limbs, four products)
+hipError_t launch_conv_fused_x2(const ConvLayerDev& L, const ConvLaunch& a, int n_cu, hipStream_t s);  // k_conv_x2.hip (two limbs, three products: the default)
 hipError_t launch_split3_probe(const float* x, int64_t n, int group, float* hi, float* mid, float* lo, float* scale, hipStream_t s);
 int build_head_layer(ddk_ctx* ctx, int mode, ConvLayerDev& L);      // ddk_capi.hip: mode 2 = tor_bond_conv, 3 = final_conv
 hipError_t conv_prepare_device();     // per-device kernel attributes (dynamic LDS opt-in), called by ddk_create
 hipError_t conv_prepare_device_x();   // k_conv_x.hip
-hipError_t conv_prepare_device_x4();  // k_conv_x4.hip
+hipError_t conv_prepare_device_x2();  // k_conv_x2.hip
 hipError_t graph_prepare_device(int* max_rec);   // k_graph.hip, per device: dynamic-LDS opt-in of the graph kernels, largest receptor their LDS holds
 hipError_t launch_conv_setup(int32_t* tile_info, const int64_t* group_offsets_host, hipStream_t s);
 hipError_t launch_conv_one_group(int32_t* gt, int n_groups, int k, int64_t E, hipStream_t s);

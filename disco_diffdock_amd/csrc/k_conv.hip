@@ -543,7 +543,7 @@ hipError_t conv_prepare_device() {
   if (e == hipSuccess) e = conv_attr_t<true, 0, true, true>();
   if (e == hipSuccess) e = conv_attr_t<false, 0, false, true>();
   if (e == hipSuccess) e = conv_prepare_device_x();
-  if (e == hipSuccess) e = conv_prepare_device_x4();
+  if (e == hipSuccess) e = conv_prepare_device_x2();
   return e;
 }
 
@@ -605,7 +605,7 @@ hipError_t launch_conv_fused(const ConvLayerDev& L, const ConvLaunch& a, int n_c
   // the default: exact three-limb product on the f16 matrix pipe - the score model's launches and, for the confidence model's layers (mode 1, no node
   // terms), both the gather path of its forward and ddk_conv_forward's explicit-boundary entry (test_confidence_conv_layer_vs_oracle[kernel 0])
   if (L.w2x != nullptr && (a.mode == 0 || (a.mode == 1 && a.pre == nullptr)))
-    return L.products == 4 ? launch_conv_fused_x4(L, a, n_cu, s) : launch_conv_fused_x(L, a, n_cu, s);
+    return L.limbs == 2 ? launch_conv_fused_x2(L, a, n_cu, s) : launch_conv_fused_x(L, a, n_cu, s);
   ConvKArgs k;
   k.w1x = nullptr; k.w2x = nullptr;
   for (int g = 0; g < CONV_MAX_GROUPS; ++g) { k.w1s[g] = 1.0f; k.w1u[g] = 1.0f; k.w2s[g] = 1.0f; k.w2u[g] = 1.0f; }

@@ -39,18 +39,18 @@
 #if (defined(X3_ABL_NOBARRIER) || defined(X3_ABL_BAR2) || defined(X3_ABL_PRIO_B2) || defined(X3_ABL_NOW1)) && !defined(DDK_TIMING_ONLY_BUILD)
 #error "X3_ABL_* switches give WRONG RESULTS (timing-only ablations): they need -DDDK_TIMING_ONLY_BUILD as well (tools/build_variant.sh adds it)"
 #endif
-#if (defined(ONE_ACC) || defined(X3_PF2) || defined(X3_CXX_EPI) || defined(X_PROLOGUE_TILES)) && !defined(DDK_VARIANT_BUILD) && !defined(DDK_TIMING_ONLY_BUILD)
+#if (defined(ONE_ACC) || defined(X3_PF2) || defined(X3_CXX_EPI) || defined(X_PROLOGUE_TILES) || defined(X3_KEEP_MIDMID)) && !defined(DDK_VARIANT_BUILD) && !defined(DDK_TIMING_ONLY_BUILD)
 #error "experiment switch of k_conv_x.hip outside a variant build: add -DDDK_VARIANT_BUILD (tools/build_variant.sh adds it)"
 #endif
 #include <stdlib.h>
 
 #include "k_conv_common.h"
-#ifdef X3_P4
-// k_conv_x4.hip compiles this file a second time as the FOUR-product form (ddk_config.conv_kernel, include/ddk.h): the same kernel under its own names
+#ifdef X3_TWO_LIMBS
+// k_conv_x2.hip compiles this file a second time as the TWO-LIMB form (ddk_config.conv_kernel = 0, include/ddk.h): the same kernel under its own names
 #define conv_x3_kernel conv_x2_kernel
-#define launch_conv_fused_x launch_conv_fused_x4
-#define conv_prepare_device_x conv_prepare_device_x4
-#include "k_conv_x_epi4_gen.inc"     // ... generated with GEN_ONE_ACC=1: one accumulator, nothing to fold
+#define launch_conv_fused_x launch_conv_fused_x2
+#define conv_prepare_device_x conv_prepare_device_x2
+#include "k_conv_x_epi2_gen.inc"     // ... generated with GEN_ONE_ACC=1: one accumulator, nothing to fold
 #else
 #include "k_conv_x_epi_gen.inc"      // the tile epilogue as one asm statement per ring stage (tools/gen_conv_x_epi.py; round 5)
 #endif
@@ -179,13 +179,20 @@ __device__ __forceinline__ void segf_add_n(float* dst, int stride, float (&xv)[N
 #undef SEGF_STEP
 
 // six-term product of one K step into the two accumulators, alternating (D0: hi.hi and the 2^-11 terms, D1: the 2^-22 terms)
-#if defined(X3_P4)
-// four limb products on two limbs per operand (hi, mid: 22 bits of significand): hi.hi + hi.mid + mid.hi + mid.mid in ONE accumulator, 18 MFMAs per tile
+#if defined(X3_TWO_LIMBS)
+// TWO limbs per operand (hi = fp16(x), mid = fp16(x - hi): |x - hi - mid| <= 2^-22 |x|) and the three products hi.hi + hi.mid + mid.hi in ONE accumulator: 14 MFMAs per tile.
+// The fourth product mid.mid is <= 2^-22 relative - the size of the operands' own truncation - and is dropped (it rides for free in the packed K = 8 tail, where
+// {W_hi, W_mid} x {h_hi, h_mid} is one MFMA either way); a product is off by <= 3 * 2^-22, a K = 72 dot product by less than the classical fp32 bound 72 * 2^-24
 #define X3_D1(r) 0.0f
 #define X3_TAIL3(a_lh, a_hm) (void)(a_lh); D0 = MFMA16(a_hm, HT.mh, D0); D0 = MFMA16(a_hm, HT.hm, D0);
+#ifdef X3_KEEP_MIDMID      /* (variant builds, tools/build_variant2.sh: the fourth product mid.mid as well - 18 MFMAs per tile, +10 % conv time, no measurable accuracy) */
+#define X3_MM(MF, am, bm) D0 = MF(am, bm, D0);
+#else
+#define X3_MM(MF, am, bm)
+#endif
 #define X3_STEP(MF, ah, am, al, bh, bm, bl)   \
   (void)(al);                                 \
-  D0 = MF(am, bm, D0);                        \
+  X3_MM(MF, am, bm)                           \
   D0 = MF(ah, bm, D0);                        \
   D0 = MF(am, bh, D0);                        \
   D0 = MF(ah, bh, D0);
@@ -520,7 +527,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
             // (the K = 8 half step packed like the tile tail: hi.mid + mid.hi, lo.hi + hi.lo, hi.hi + mid.mid as one K = 16 MFMA each: 9 instead of 12 per row tile)
             const f16x8 a_hm = __builtin_shufflevector(ah, am, 0, 1, 2, 3, 4, 5, 6, 7), a_lh = __builtin_shufflevector(al, ah, 0, 1, 2, 3, 4, 5, 6, 7);
             D0 = MFMA16(a_hm, b1_mh, D0);
-#ifndef X3_P4
+#ifndef X3_TWO_LIMBS
             D1 = MFMA16(a_lh, b1_hl, D1);
 #else
             (void)a_lh; (void)b1_hl;
@@ -676,7 +683,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
     // load - a scalar load in flight turns every counted LDS wait into a full one); later tiles: fetched in the previous burst's tail
     Frag16 p0;
     p0.h = *reinterpret_cast<const f16x8*>(ringl); p0.m = *reinterpret_cast<const f16x8*>(ringl + W2X_LIMB_BYTES);
-#ifndef X3_P4
+#ifndef X3_TWO_LIMBS
     p0.l = *reinterpret_cast<const f16x8*>(ringl + 2 * W2X_LIMB_BYTES);
 #endif
 #ifdef X3_PF2          // (experiment: fragments requested TWO K steps ahead: p0 / p1 of a tile in the previous burst's last two steps, +12 VGPRs across the epilogue)
@@ -747,14 +754,25 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
     // one tile: burst + epilogue; ST = the tile's ring stage (compile time)
 #define X3_PAIR(mask) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(mask, 1, 0); }
 #define X3_BARE { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }
-#ifdef X3_P4
+#ifdef X3_TWO_LIMBS
 #define X3_FRAG(f, off) f.h = *reinterpret_cast<const f16x8*>(ringl + (off)); f.m = *reinterpret_cast<const f16x8*>(ringl + W2X_LIMB_BYTES + (off));
 #define X3_TRIO(mask) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(mask, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
 #else
 #define X3_FRAG(f, off) f.h = *reinterpret_cast<const f16x8*>(ringl + (off)); f.m = *reinterpret_cast<const f16x8*>(ringl + W2X_LIMB_BYTES + (off)); f.l = *reinterpret_cast<const f16x8*>(ringl + 2 * W2X_LIMB_BYTES + (off));
 #endif
-#if defined(X3_P4)
-/* four products per K step: 18 MFMAs; the same riders (two limbs of every fragment), four shadows per region */
+#if defined(X3_TWO_LIMBS)
+/* three products per K step + the packed tail: 14 MFMAs; the same riders (two limbs of every fragment), three shadows per region */
+#ifndef X3_KEEP_MIDMID
+#define X3_L2_R0 X3_PAIR(0x100) X3_TRIO(0x020) X3_TRIO(0x020)
+#define X3_L2_R1 X3_PAIR(0x100) X3_PAIR(0x100) X3_TRIO(0x100)
+#define X3_L2_R2 X3_PAIR(0x100) X3_PAIR(0x100) X3_BARE
+#define X3_L2_R3 X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100)
+#else
+#define X3_L2_R0 X3_PAIR(0x100) X3_PAIR(0x020) X3_PAIR(0x100) X3_TRIO(0x020)
+#define X3_L2_R1 X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100)
+#define X3_L2_R2 X3_PAIR(0x100) X3_PAIR(0x100) X3_BARE X3_BARE
+#define X3_L2_R3 X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_BARE
+#endif
 #define X3_BURST_BODY(ST)                                                                                                                    \
       Frag16 p1; X3_FRAG(p1, SO + 1024)                                                                                                      \
       const f32x4 f0 = ldv4(Fp);                                                                                                             \
@@ -762,23 +780,23 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
       const u32x4 st1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)fo1, rec_soff, 0);                                                  \
       rec_soff += W2X_TILE_BYTES;                                                                                                            \
       X3_STEP(MFMA16, p0.h, p0.m, p0.l, H.hi[0], H.mid[0], H.lo[0])                                                                         \
-      X3_PAIR(0x100) X3_PAIR(0x020) X3_PAIR(0x100) X3_TRIO(0x020)                                                                            \
+      X3_L2_R0                                                                                                                               \
       __builtin_amdgcn_sched_barrier(0);                                                                                                     \
       Frag16 q2; X3_FRAG(q2, SO + 2048)                                                                                                      \
       const f16x4 th = *reinterpret_cast<const f16x4*>(ringt + SO + 4096);                                                                   \
       const f16x4 tm = *reinterpret_cast<const f16x4*>(ringt + SO + W2X_LIMB_BYTES + 4096);                                                  \
       const f16x4 tl = th;                                                                                                                   \
       X3_STEP(MFMA16, p1.h, p1.m, p1.l, H.hi[1], H.mid[1], H.lo[1])                                                                         \
-      X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100)                                                                            \
+      X3_L2_R1                                                                                                                               \
       __builtin_amdgcn_sched_barrier(0);                                                                                                     \
       Frag16 q3; X3_FRAG(q3, SO + 3072)                                                                                                      \
       X3_STEP(MFMA16, q2.h, q2.m, q2.l, H.hi[2], H.mid[2], H.lo[2])                                                                         \
-      X3_PAIR(0x100) X3_PAIR(0x100) X3_BARE X3_BARE                                                                                          \
+      X3_L2_R2                                                                                                                               \
       __builtin_amdgcn_sched_barrier(0);                                                                                                     \
       const int2 dq = *reinterpret_cast<const int2*>(ring + SN + W2X_DESC_OFF);                                                              \
       X3_FRAG(p0, SN)                                                                                                                        \
       X3_STEP(MFMA16, q3.h, q3.m, q3.l, H.hi[3], H.mid[3], H.lo[3])                                                                         \
-      X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_BARE                                                                                   \
+      X3_L2_R3                                                                                                                               \
       __builtin_amdgcn_sched_barrier(0);
 #elif defined(X3_PF2)
 #define X3_BURST_BODY(ST)                                                                                                                    \
@@ -834,7 +852,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
       X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_PAIR(0x100) X3_BARE X3_BARE                                                            \
       __builtin_amdgcn_sched_barrier(0);
 #endif
-#ifdef X3_P4
+#ifdef X3_TWO_LIMBS
 #define X3_TAIL_BARES X3_BARE X3_BARE
 #else
 #define X3_TAIL_BARES X3_BARE X3_BARE X3_BARE
@@ -930,7 +948,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
   }
 }
 
-#ifndef X3_P4
+#ifndef X3_TWO_LIMBS
 // Test hook kernel: the in-kernel limb split of n fp32 values (one range scale per group of `group` consecutive values, like the kernel's
 // per-edge scaling): limbs as fp32, and the scale
 __global__ void split3_probe_kernel(const float* x, int64_t n, int group, float* hi, float* mid, float* lo, float* scale) {
@@ -951,7 +969,7 @@ hipError_t launch_split3_probe(const float* x, int64_t n, int group, float* hi, 
   return hipGetLastError();
 }
 
-#endif      // !X3_P4
+#endif      // !X3_TWO_LIMBS
 
 template <bool GATHER, bool SPLIT, bool DET>
 static hipError_t launch_x_t(const ConvXArgs& k, int n_cu, hipStream_t s) {
@@ -965,7 +983,7 @@ static hipError_t attr_x_t() {
                              (int)CONV_X_LDS_BYTES);
 }
 
-#ifndef X3_P4
+#ifndef X3_TWO_LIMBS
 bool conv_epilogue_shapes_ok(const std::vector<TileDesc>& tiles) {
   if (tiles.empty()) return false;
   for (const TileDesc& t : tiles) {
@@ -979,7 +997,7 @@ bool conv_epilogue_shapes_ok(const std::vector<TileDesc>& tiles) {
   const int last = x_tile_word(tiles.back().w0);
   return ((last >> 2) & 3) != 0;      // (a unit ends with a flush)
 }
-#endif      // !X3_P4
+#endif      // !X3_TWO_LIMBS
 
 hipError_t conv_prepare_device_x() {
   hipError_t e = attr_x_t<true, true, false>();
@@ -996,7 +1014,7 @@ hipError_t conv_prepare_device_x() {
   if (e == hipSuccess)
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x3_kernel<false, false, false, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)CONV_X_LDS_BYTES);
-#if defined(DDK_VARIANT_CONV_Y) && !defined(X3_P4)
+#if defined(DDK_VARIANT_CONV_Y) && !defined(X3_TWO_LIMBS)
   if (e == hipSuccess) e = conv_prepare_device_y();
 #endif
   return e;
@@ -1033,7 +1051,7 @@ hipError_t launch_conv_fused_x(const ConvLayerDev& L, const ConvLaunch& a, int n
     conv_det_fix(k, a, L.dout, s);
     return hipGetLastError();
   }
-#if defined(DDK_VARIANT_CONV_Y) && !defined(X3_P4)      // tools/variants/k_conv_y.hip (round 5's one-wave-per-SIMD form, +9 %): linked by tools/build_variant_y.sh only
+#if defined(DDK_VARIANT_CONV_Y) && !defined(X3_TWO_LIMBS)      // tools/variants/k_conv_y.hip (round 5's one-wave-per-SIMD form, +9 %): linked by tools/build_variant_y.sh only
   if (a.gather && a.pre != nullptr && (a.trace == nullptr || a.trace_coarse == 1) && L.epi_ok && a.use_y) {
     X.trace = a.trace;      // (its TRACE instantiation writes the per-unit records only)
     return launch_conv_y(X, n_cu, s);

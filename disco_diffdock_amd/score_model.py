@@ -138,7 +138,7 @@ class TensorProductScoreModel(nn.Module):
         super().__init__()
         if 'conv_f16x3' in unused or os.environ.get('DDK_CONV_F16X3') is not None:
             # round 2's switch had the opposite sense (1 = the f16 kernel); round 3 replaced it by conv_kernel (0 = the f16-limb kernel, the
-            # default; 1 = fp32 MFMA; since ddk 0.8: 0 = two limbs / four products, 3 = three limbs / six products).  Swallowing the old spelling would switch kernels silently.
+            # default; 1 = fp32 MFMA; since ddk 0.8: 0 = two limbs / three products, 3 = three limbs / six products).  Swallowing the old spelling would switch kernels silently.
             raise RuntimeError("ddk: the conv_f16x3 option / DDK_CONV_F16X3 variable was replaced by the conv_kernel option "
                                "(0 = f16-limb product, default; 1 = fp32 MFMA; 3 = three-limb / six-product form) - see INTEGRATION.md")
         if sh_lmax != 1 or use_second_order_repr or use_old_atom_encoder or latent_cross_attention:

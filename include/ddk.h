@@ -52,13 +52,14 @@ typedef struct ddk_config {
   /* how the radial-MLP GEMMs (Linear(72,72) + ReLU + Linear(72,W), tensor_layers.py:140-143) of the fused conv kernel are multiplied.  Inputs, weights,
    * accumulators and outputs are fp32 in every mode; 0 and 3 run on the f16 matrix pipe with every fp32 operand carried as fp16 LIMBS (after an exact
    * power-of-two range scaling per weight group / per edge), 1 on the fp32 matrix pipe.
-   * 0 (default, since ddk 0.8): TWO limbs x = hi + mid (hi = fp16(x), mid = fp16(x - hi), both rounded to nearest: |x - hi - mid| <= 2^-22 |x|), the
-   *    four limb products hi.hi + hi.mid + mid.hi + mid.mid in one fp32 accumulator (k_conv_x4.hip).  Error per product <= 2^-21 relative - the size of what an
-   *    fp32 FMA chain over K = 72 accumulates in roundings; measured against the fp64 oracle it is level with mode 1 and mode 3 (6 - 9e-8 relative on every layer shape,
-   *    tests/test_gpu_round6.py::test_two_limb_four_product_kernel_is_fp32_grade), 18 instead of 27 MFMAs per 32-edge weight tile.
+   * 0 (default, since ddk 0.8): TWO limbs x = hi + mid (hi = fp16(x), mid = fp16(x - hi), both rounded to nearest: |x - hi - mid| <= 2^-22 |x|) and the
+   *    three limb products hi.hi + hi.mid + mid.hi in one fp32 accumulator (k_conv_x2.hip); mid.mid, <= 2^-22 relative like the operands' own truncation, is dropped.
+   *    Error per product <= 3 * 2^-22 relative, of a K = 72 dot product below the classical fp32 bound 72 * 2^-24; measured against the fp64 oracle it is level with mode 1
+   *    and mode 3 (6 - 10e-8 relative on every layer shape, tests/test_gpu_round6.py::test_two_limb_kernel_is_fp32_grade), 14 instead of 27 MFMAs per 32-edge weight tile
+   *    (DESIGN.md 3.3).
    * 3: THREE limbs x = hi + mid + lo (exact for every value within 2^-15 of its range-scaling group's maximum, off by <= 2^-39 of that maximum below), six of the
    *    nine limb products kept (the dropped ones are <= 3 * 2^-33 relative), two fp32 accumulators (k_conv_x.hip): products exact to 2^-33 - the default of
-   *    ddk 0.4 - 0.7, ~25 % more conv time than 0.
+   *    ddk 0.4 - 0.7, ~40 % more conv time than 0.
    * 1: v_mfma_f32_32x32x2_f32, plain fp32 FMA chains (k_conv.hip) - the stated fallback.  All three apply to the score model, its heads and the all-atom
    *    confidence model's conv layers.
    *    (Round 5's value 2 - a software-pipelined one-wave-per-SIMD form, measured 9 % slower - is refused: the kernel lives under tools/variants/.) */

@@ -562,7 +562,7 @@ def test_randomize_position_device_wrapper(dev, golden):
 def test_confidence_model_golden(dev, golden, kernel):
     """ddk_confidence_forward == the reference's all-atom confidence model (golden produced by
     models/all_atom_score_model.py through get_model on the stand-ins) on the same poses; ligand features after the conv stack too.
-    kernel 0: the default two-limb / four-product f16 form (k_conv_x4.hip, l = 2 row groups included), 1: the fp32-MFMA fallback, 3: the three-limb / six-product form (k_conv_x.hip)."""
+    kernel 0: the default two-limb / three-product f16 form (k_conv_x2.hip, l = 2 row groups included), 1: the fp32-MFMA fallback, 3: the three-limb / six-product form (k_conv_x.hip)."""
     from oracle import confidence_ref as cr
     from disco_diffdock_amd.runtime import Context, Complex
     z, c = golden('confidence_paper_model'), complex_from_npz(golden('complex_confidence'))

@@ -117,7 +117,7 @@ def test_fused_conv_equals_unfused_boundary(dev):
 @pytest.mark.parametrize('l', range(5))
 def test_confidence_conv_layer_vs_oracle(dev, l, kernel):
     """One conv of the all-atom confidence model (e3nn FCTP with sh 0e+1o+2e, BatchNorm, no residual)
-    through ddk_conv_forward in an all-atom context == the oracle's conv layer; every conv kernel (0: two f16 limbs / four products, 1: fp32 MFMA, 3: three limbs / six products)."""
+    through ddk_conv_forward in an all-atom context == the oracle's conv layer; every conv kernel (0: two f16 limbs / three products, 1: fp32 MFMA, 3: three limbs / six products)."""
     from oracle import confidence_ref as cr, e3nn_lite as o3
     from disco_diffdock_amd.runtime import Context
     cfg = cr.ConfidenceModelConfig()
@@ -148,7 +148,7 @@ def test_confidence_conv_layer_vs_oracle(dev, l, kernel):
     (4, 400, [0, 33, 64, 4000, 4031], False),
 ])
 def test_conv_layer_fp32_kernel_vs_oracle(dev, l, N, splits, sort_src):
-    """The fallback ddk_config.conv_kernel = 1 (radial-MLP GEMMs as fp32 MFMA chains; the default is the f16-limb product - two limbs, four products since round 6 - which
+    """The fallback ddk_config.conv_kernel = 1 (radial-MLP GEMMs as fp32 MFMA chains; the default is the f16-limb product - two limbs, three products since round 6 - which
     every other test of this file runs) must meet the SAME bar against the fp64 oracle, and repeated launches must agree."""
     from disco_diffdock_amd.runtime import Context
     i_irr, o_irr = CFG.conv_irreps(l)
@@ -172,7 +172,7 @@ def test_conv_layer_fp32_kernel_vs_oracle(dev, l, N, splits, sort_src):
     (1.0, 1e6, 1e-6),       # W1 above, W2 below
 ])
 def test_conv_layer_x3_range(dev, in_scale, w1_scale, w2_scale):
-    """The f16-limb products (0: two limbs / four products, the default; 3: three limbs / six products) must not depend on the SCALE of a checkpoint or of
+    """The f16-limb products (0: two limbs / three products, the default; 3: three limbs / six products) must not depend on the SCALE of a checkpoint or of
     the features: operands are range-scaled by exact powers of two (weights per group at pack time, activations per edge in the kernel), so operands far outside
     the fp16 range meet the same bar, and the error against the fp64 oracle is not larger than the fp32-MFMA kernel's (VERDICT r02 #3 ii; 2x for the default).
     (The three scales multiply to 1, so the messages stay O(1) next to the residual and the batch-norm statistics.)"""
@@ -195,12 +195,12 @@ def test_conv_layer_x3_range(dev, in_scale, w1_scale, w2_scale):
     assert 0.05 < float(ref.abs().max()) < 1e3
     args = (l, node.to(dev), ei[0].to(dev), ei[1].to(dev), splits, ea.to(dev), sh.to(dev), smr.irreps_dim(o_irr))
     err = {}
-    for kernel in (0, 1, 3):       # 0: two f16 limbs / four products (default), 1: fp32 MFMA, 3: three limbs / six products
+    for kernel in (0, 1, 3):       # 0: two f16 limbs / three products (default), 1: fp32 MFMA, 3: three limbs / six products
         ctx = Context(device=0, conv_kernel=kernel)
         ctx.load_state_dict({f'conv_layers.{l}.{k}': v for k, v in Pl.items()})
         out = ctx.conv_forward(*args).cpu()
         assert torch.isfinite(out).all()
         err[kernel] = rel_err(out, ref)
-    print(f'range test {in_scale:g}/{w1_scale:g}/{w2_scale:g}: two limbs / four products {err[0]:.2e}, fp32 MFMA {err[1]:.2e}, three limbs / six products {err[3]:.2e}')
+    print(f'range test {in_scale:g}/{w1_scale:g}/{w2_scale:g}: two limbs / three products {err[0]:.2e}, fp32 MFMA {err[1]:.2e}, three limbs / six products {err[3]:.2e}')
     assert err[3] < 1e-5 and err[3] < 1.5 * err[1] + 2e-7, err
     assert err[0] < 1e-5 and err[0] < 2.0 * err[1] + 4e-7, err      # the same per-edge range scaling: no dependence on the magnitude of inputs / weights

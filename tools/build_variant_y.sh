@@ -9,5 +9,5 @@ mkdir -p ab_libs
 /opt/rocm/bin/hipcc $F -fno-slp-vectorize "$@" -c tools/variants/k_conv_y.hip -o /tmp/k_conv_y_$NAME.o
 /opt/rocm/bin/hipcc $F -fno-slp-vectorize -c $C/k_conv_x.hip -o /tmp/k_conv_xy_$NAME.o
 /opt/rocm/bin/hipcc $F -c $C/ddk_capi.hip -o /tmp/ddk_capi_y_$NAME.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ab_libs/libddk_$NAME.so /tmp/ddk_capi_y_$NAME.o $C/k_conv.o $C/k_tp.o $C/k_graph.o $C/k_heads.o $C/k_se3.o $C/model.o $C/conf.o /tmp/k_conv_xy_$NAME.o /tmp/k_conv_y_$NAME.o $C/k_conv_x4.o $C/k_ar.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ab_libs/libddk_$NAME.so /tmp/ddk_capi_y_$NAME.o $C/k_conv.o $C/k_tp.o $C/k_graph.o $C/k_heads.o $C/k_se3.o $C/model.o $C/conf.o /tmp/k_conv_xy_$NAME.o /tmp/k_conv_y_$NAME.o $C/k_conv_x2.o $C/k_ar.o
 echo built ab_libs/libddk_$NAME.so

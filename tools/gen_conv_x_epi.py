@@ -159,7 +159,7 @@ def main():
     out = ['// GENERATED by tools/gen_conv_x_epi.py - do not edit.\n']
     accs = [o for o in G.acc_ops('') if not o[0].startswith('R')]
     outs = [('D0', '+{v[16:31]}', 'D0')] + accs + [(n, '=&s', f'{n}_') for n in ('t0', 't1', 't2', 'sel', 'pk0', 'pk1', 'pk2', 'sv')]
-    one_acc = bool(os.environ.get('GEN_ONE_ACC'))      # one accumulator chain (the four-product form, k_conv_x.hip X3_P4): no D1 operand, nothing to fold
+    one_acc = bool(os.environ.get('GEN_ONE_ACC'))      # one accumulator chain (the two-limb form, k_conv_x.hip X3_TWO_LIMBS -> k_conv_x2.hip): no D1 operand, nothing to fold
     ins = ([] if one_acc else [('D1', '{v[32:47]}', 'D1')]) + [('f0', '{v[48:51]}', 'f0'), ('st0', 'v', 'st0'), ('st1', 'v', 'st1'), ('ringb', 'v', 'ringb_u'), ('rw0', 'v', 'ringw0_u'),
            ('rw1', 'v', 'ringw1_u'), ('fpa', 'v', 'fpa_u'), ('fra', 'v', 'fra_u'), ('bsc2', 'v', 'bsc2'), ('oscv', 'v', 'oscv'), ('s0', 'v', 's0'), ('vx', 'v', 'vx'),
            ('vy', 'v', 'vy'), ('vz', 'v', 'vz'), ('sm1', 'v', 'seg.m1'), ('sm2', 'v', 'seg.m2'), ('sm4', 'v', 'seg.m4'), ('sm8', 'v', 'seg.m8'), ('sm16', 'v', 'seg.m16'),

@@ -1,4 +1,4 @@
-# round-end evidence on the final library (default conv kernel = two limbs / four products): the driver's command, configs 3 / 4 / 5, the 363-complex stream (config 4),
+# round-end evidence on the final library (default conv kernel = two limbs / three products): the driver's command, configs 3 / 4 / 5, the 363-complex stream (config 4),
 # its per-kernel profile, the 8-rank single-GPU comparison
 mkdir -p gpurun_out/r6h
 ( time python bench.py --steps 20 --warmup 5 > gpurun_out/r6h/bench_n1.json 2> gpurun_out/r6h/bench_n1.err ) 2> gpurun_out/r6h/bench_n1.time

@@ -6,7 +6,7 @@ from collections import defaultdict
 
 src, out = sys.argv[1], sys.argv[2]
 os.makedirs(out, exist_ok=True)
-KERNEL = os.environ.get('DDK_PROFILE_KERNEL', 'conv_x2_kernel<true, true, false')      # the score model's conv layers in the default two-limb / four-product form (the two head launches are conv_x2_kernel<false, ...>); DDK_CONV_KERNEL=3 runs: conv_x3_kernel<true, true, false
+KERNEL = os.environ.get('DDK_PROFILE_KERNEL', 'conv_x2_kernel<true, true, false')      # the score model's conv layers in the default two-limb / three-product form (the two head launches are conv_x2_kernel<false, ...>); DDK_CONV_KERNEL=3 runs: conv_x3_kernel<true, true, false
 
 
 def find(d, suffix):
@@ -34,7 +34,7 @@ open(os.path.join(out, 'kernel_stats.md'), 'w').write(head + '\n'.join(lines) + 
 import hashlib
 _root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
 _h = hashlib.sha256()
-for _n in ('k_conv_x.hip', 'k_conv_x4.hip', 'k_conv_x_epi_gen.inc', 'k_conv_x_epi4_gen.inc', 'k_conv_common.h', 'ddk_internal.h'):          # == bench.py CONV_KERNEL_SOURCES: bench.py quotes this profile only for these sources
+for _n in ('k_conv_x.hip', 'k_conv_x2.hip', 'k_conv_x_epi_gen.inc', 'k_conv_x_epi2_gen.inc', 'k_conv_common.h', 'ddk_internal.h'):          # == bench.py CONV_KERNEL_SOURCES: bench.py quotes this profile only for these sources
     _h.update(open(os.path.join(_root, 'disco_diffdock_amd', 'csrc', _n), 'rb').read())
 res = {'kernel_source_sha256': _h.hexdigest(), 'command': 'rocprofv3 --kernel-trace --pmc <group> (one group per pass) -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-alt --no-device-loop --no-extras --no-timesplit',
        'kernel': 'ddk::' + KERNEL + ', false>', 'avg_launch_us_kernel_trace': sum(conv) / max(len(conv), 1)}

@@ -54,7 +54,8 @@ typedef struct ddk_config {
    * power-of-two range scaling per weight group / per edge), 1 on the fp32 matrix pipe.
    * 0 (default, since ddk 0.8): TWO limbs x = hi + mid (hi = fp16(x), mid = fp16(x - hi), both rounded to nearest: |x - hi - mid| <= 2^-22 |x|) and the
    *    three limb products hi.hi + hi.mid + mid.hi in one fp32 accumulator (k_conv_x2.hip); mid.mid, <= 2^-22 relative like the operands' own truncation, is dropped.
-   *    Error per product <= 3 * 2^-22 relative, of a K = 72 dot product below the classical fp32 bound 72 * 2^-24; measured against the fp64 oracle it is level with mode 1
+   *    Error per product <= 3 * 2^-22 relative, of a K = 72 dot product below the classical fp32 bound 72 * 2^-24 and, restated bit for bit on the host, not above an fp32 FMA
+   *    chain's over the same operands (tests/test_limb_bound.py); measured against the fp64 oracle it is level with mode 1
    *    and mode 3 (6 - 10e-8 relative on every layer shape, tests/test_gpu_round6.py::test_two_limb_kernel_is_fp32_grade), 14 instead of 27 MFMAs per 32-edge weight tile
    *    (DESIGN.md 3.3).
    * 3: THREE limbs x = hi + mid + lo (exact for every value within 2^-15 of its range-scaling group's maximum, off by <= 2^-39 of that maximum below), six of the

@@ -36,7 +36,7 @@
 // its NEXT tile at the start of its epilogue.
 // Experiment switches.  X3_ABL_* are TIMING-ONLY ablations (results invalid), ONE_ACC / X3_PF2 / X3_CXX_EPI / X_PROLOGUE_TILES are measured-and-dropped
 // alternatives kept for same-box A/Bs (tools/build_variant.sh builds them into ab_libs/, never into libddk.so).  A stray -D cannot reach the product library:
-#if (defined(X3_ABL_NOBARRIER) || defined(X3_ABL_BAR2) || defined(X3_ABL_PRIO_B2) || defined(X3_ABL_NOW1)) && !defined(DDK_TIMING_ONLY_BUILD)
+#if (defined(X3_ABL_NOBARRIER) || defined(X3_ABL_BAR2) || defined(X3_ABL_PRIO_B2) || defined(X3_ABL_NOW1) || defined(X3_ABL_NOGATHER)) && !defined(DDK_TIMING_ONLY_BUILD)
 #error "X3_ABL_* switches give WRONG RESULTS (timing-only ablations): they need -DDDK_TIMING_ONLY_BUILD as well (tools/build_variant.sh adds it)"
 #endif
 #if (defined(ONE_ACC) || defined(X3_PF2) || defined(X3_CXX_EPI) || defined(X_PROLOGUE_TILES) || defined(X3_KEEP_MIDMID)) && !defined(DDK_VARIANT_BUILD) && !defined(DDK_TIMING_ONLY_BUILD)
@@ -440,7 +440,11 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
     float4 mainv[NS / 4];
     float2 pv2[3 * NV / 2];
     {
+#ifdef X3_ABL_NOGATHER      // (timing-only: every lane reads the rows of the wave's FIRST edge - one cache line per request instead of 32: what would hiding the gathers be worth?)
+      const float* xr = A.x + (size_t)__shfl(dn, 0, 32) * XW;
+#else
       const float* xr = A.x + (size_t)dn * XW;
+#endif
 #pragma unroll
       for (int j = 0; j < NS / 4; ++j) mainv[j] = ld4(xr + (hh ? OFF_C : 0) + 4 * j);
 #pragma unroll
@@ -460,8 +464,13 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
         // L2): all 18 requests of a lane go out together, right behind the indices - one exposed memory latency, not one per row tile
         float4 psv[9], pdv[9];
         {
+#ifdef X3_ABL_NOGATHER
+          const float* ps = A.pre + ((size_t)__shfl(sn, 0, 32) * 4 + (gw & 1)) * NE + 36 * hh;
+          const float* pd = A.pre + ((size_t)__shfl(dn, 0, 32) * 4 + 2 + (gw >> 1)) * NE + 36 * hh;
+#else
           const float* ps = A.pre + ((size_t)sn * 4 + (gw & 1)) * NE + 36 * hh;
           const float* pd = A.pre + ((size_t)dn * 4 + 2 + (gw >> 1)) * NE + 36 * hh;
+#endif
 #pragma unroll
           for (int j = 0; j < 9; ++j) { psv[j] = ld4(ps + 4 * j); pdv[j] = ld4(pd + 4 * j); }
         }

@@ -183,7 +183,7 @@ __device__ __forceinline__ void segf_add_n(float* dst, int stride, float (&xv)[N
 // TWO limbs per operand (hi = fp16(x), mid = fp16(x - hi): |x - hi - mid| <= 2^-22 |x|) and the three products hi.hi + hi.mid + mid.hi in ONE accumulator: 14 MFMAs per tile.
 // The fourth product mid.mid is <= 2^-22 relative - the size of the operands' own truncation - and is dropped (it rides for free in the packed K = 8 tail, where
 // {W_hi, W_mid} x {h_hi, h_mid} is one MFMA either way); a product is off by <= 3 * 2^-22, a K = 72 dot product by less than the classical fp32 bound 72 * 2^-24
-#define X3_D1(r) 0.0f
+#define X3_SUM(r) D0[r]                      /* one accumulator: nothing to fold */
 #define X3_TAIL3(a_lh, a_hm) (void)(a_lh); D0 = MFMA16(a_hm, HT.mh, D0); D0 = MFMA16(a_hm, HT.hm, D0);
 #ifdef X3_KEEP_MIDMID      /* (variant builds, tools/build_variant2.sh: the fourth product mid.mid as well - 18 MFMAs per tile, +10 % conv time, no measurable accuracy) */
 #define X3_MM(MF, am, bm) D0 = MF(am, bm, D0);
@@ -197,7 +197,7 @@ __device__ __forceinline__ void segf_add_n(float* dst, int stride, float (&xv)[N
   D0 = MF(am, bh, D0);                        \
   D0 = MF(ah, bh, D0);
 #elif defined(ONE_ACC)
-#define X3_D1(r) D1[r]
+#define X3_SUM(r) (D0[r] + D1[r])
 #define X3_TAIL3(a_lh, a_hm) D0 = MFMA16(a_lh, HT.hl, D0); D0 = MFMA16(a_hm, HT.mh, D0); D0 = MFMA16(a_hm, HT.hm, D0);
 #define X3_STEP(MF, ah, am, al, bh, bm, bl)   \
   D0 = MF(ah, bl, D0);                        \
@@ -207,7 +207,7 @@ __device__ __forceinline__ void segf_add_n(float* dst, int stride, float (&xv)[N
   D0 = MF(am, bh, D0);                        \
   D0 = MF(ah, bh, D0);
 #else
-#define X3_D1(r) D1[r]
+#define X3_SUM(r) (D0[r] + D1[r])
 #define X3_TAIL3(a_lh, a_hm) D0 = MFMA16(a_hm, HT.mh, D0); D1 = MFMA16(a_lh, HT.hl, D1); D0 = MFMA16(a_hm, HT.hm, D0);
 #define X3_STEP(MF, ah, am, al, bh, bm, bl)   \
   D1 = MF(ah, bl, D1);                        \
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
           const int nr = T < 2 ? 16 : 4;
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            if (r < nr) h[16 * T + r] = fmaxf(D0[r] + D1[r], 0.0f) * usc;
+            if (r < nr) h[16 * T + r] = fmaxf(X3_SUM(r), 0.0f) * usc;
         }
       } else {
         float bin[36];
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
           const int nr = T < 2 ? 16 : 4;
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            if (r < nr) h[16 * T + r] = fmaxf(D0[r] + D1[r], 0.0f) * usc;
+            if (r < nr) h[16 * T + r] = fmaxf(X3_SUM(r), 0.0f) * usc;
         }
       }
       float m2 = 0.0f;
@@ -904,10 +904,10 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv_x3_kernel(ConvXArgs AX) 
       *reinterpret_cast<u32x4*>(ringw1 + SW) = st1;                                                                                          \
       stamp_epi(4);                                                                                                                          \
       /* the two accumulators and the bias into one */                                                                                       \
-      D0[0] = fmaf(bs0.x, bsc2, D0[0] + D1[0]); D0[1] = fmaf(bs0.y, bsc2, D0[1] + D1[1]); D0[2] = fmaf(bs0.z, bsc2, D0[2] + D1[2]); D0[3] = fmaf(bs0.w, bsc2, D0[3] + D1[3]); \
-      D0[4] = fmaf(bs1.x, bsc2, D0[4] + D1[4]); D0[5] = fmaf(bs1.y, bsc2, D0[5] + D1[5]); D0[6] = fmaf(bs1.z, bsc2, D0[6] + D1[6]); D0[7] = fmaf(bs1.w, bsc2, D0[7] + D1[7]); \
-      D0[8] = fmaf(bs2.x, bsc2, D0[8] + D1[8]); D0[9] = fmaf(bs2.y, bsc2, D0[9] + D1[9]); D0[10] = fmaf(bs2.z, bsc2, D0[10] + D1[10]); D0[11] = fmaf(bs2.w, bsc2, D0[11] + D1[11]); \
-      D0[12] = fmaf(bs3.x, bsc2, D0[12] + D1[12]); D0[13] = fmaf(bs3.y, bsc2, D0[13] + D1[13]); D0[14] = fmaf(bs3.z, bsc2, D0[14] + D1[14]); D0[15] = fmaf(bs3.w, bsc2, D0[15] + D1[15]); \
+      D0[0] = fmaf(bs0.x, bsc2, X3_SUM(0)); D0[1] = fmaf(bs0.y, bsc2, X3_SUM(1)); D0[2] = fmaf(bs0.z, bsc2, X3_SUM(2)); D0[3] = fmaf(bs0.w, bsc2, X3_SUM(3)); \
+      D0[4] = fmaf(bs1.x, bsc2, X3_SUM(4)); D0[5] = fmaf(bs1.y, bsc2, X3_SUM(5)); D0[6] = fmaf(bs1.z, bsc2, X3_SUM(6)); D0[7] = fmaf(bs1.w, bsc2, X3_SUM(7)); \
+      D0[8] = fmaf(bs2.x, bsc2, X3_SUM(8)); D0[9] = fmaf(bs2.y, bsc2, X3_SUM(9)); D0[10] = fmaf(bs2.z, bsc2, X3_SUM(10)); D0[11] = fmaf(bs2.w, bsc2, X3_SUM(11)); \
+      D0[12] = fmaf(bs3.x, bsc2, X3_SUM(12)); D0[13] = fmaf(bs3.y, bsc2, X3_SUM(13)); D0[14] = fmaf(bs3.z, bsc2, X3_SUM(14)); D0[15] = fmaf(bs3.w, bsc2, X3_SUM(15)); \
       stamp_epi(5);                                                                                                                          \
       if ((w0 & 0x8e) == 0) {        /* the common tile: scalar rows (T_RA / T_RT), no packed quad, no flush */                              \
         if (w0 & 1) {                                                                                                                        \

@@ -60,7 +60,7 @@ typedef struct ddk_config {
    *    (DESIGN.md 3.3).
    * 3: THREE limbs x = hi + mid + lo (exact for every value within 2^-15 of its range-scaling group's maximum, off by <= 2^-39 of that maximum below), six of the
    *    nine limb products kept (the dropped ones are <= 3 * 2^-33 relative), two fp32 accumulators (k_conv_x.hip): products exact to 2^-33 - the default of
-   *    ddk 0.4 - 0.7, ~40 % more conv time than 0.
+   *    ddk 0.4 - 0.7, ~35 % more conv time than 0.
    * 1: v_mfma_f32_32x32x2_f32, plain fp32 FMA chains (k_conv.hip) - the stated fallback.  All three apply to the score model, its heads and the all-atom
    *    confidence model's conv layers.
    *    (Round 5's value 2 - a software-pipelined one-wave-per-SIMD form, measured 9 % slower - is refused: the kernel lives under tools/variants/.) */
